@@ -1,0 +1,147 @@
+/* libsivae_hip — C ABI of the MI355X (gfx950 / CDNA4) Soft-IntroVAE training kernels.
+ *
+ * The reference (taldatech/soft-intro-vae-pytorch) has NO native layer: its hot path is a chain of
+ * ATen ops issued from soft_intro_vae/train_soft_intro_vae.py.  This header is the drop-in boundary a
+ * replacement shared library must export; each entry point names the reference op (file:line, all
+ * relative to the reference checkout) whose arithmetic it reproduces.
+ *
+ * Conventions (all functions):
+ *   - return int: 0 = ok; >0 = hipError_t of the launch; <0 = argument error (SIVAE_ERR_*).
+ *   - never allocate, never synchronise, never touch global state: re-entrant, one stream per call.
+ *   - all tensors are caller-owned device buffers, fp32, contiguous NCHW (or [rows][cols] where said).
+ *   - scratch memory is passed as (workspace, workspace_bytes); sizes come from *_workspace_bytes().
+ *   - `stream` is a hipStream_t (void* here so that the header needs no HIP include).
+ */
+#ifndef SIVAE_HIP_H
+#define SIVAE_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIVAE_OK 0
+#define SIVAE_ERR_NULL -1      /* a required pointer is null */
+#define SIVAE_ERR_SHAPE -2     /* unsupported / inconsistent shape */
+#define SIVAE_ERR_KSIZE -3     /* kernel size not in {1,3,5} */
+#define SIVAE_ERR_WORKSPACE -4 /* workspace missing or too small */
+#define SIVAE_ERR_RANGE -5     /* tensor too large for the kernels' 32-bit addressing */
+#define SIVAE_ERR_MODE -6      /* unknown mode / flag value */
+
+typedef void* sivae_stream_t;
+
+/* ---- probes ---------------------------------------------------------------------------------- */
+int sivae_abi_version(void);
+const char* sivae_arch(void); /* "gfx950" */
+int sivae_device_count(void);
+
+/* ---- convolution (stride 1, padding k/2, k in {1,3,5}) ------------------------------------------
+ * nn.Conv2d call sites: ResidualBlock conv_expand/conv1/conv2 train_soft_intro_vae.py:51-61, Encoder
+ * stem :89, Decoder predict :159; nn.Linear :109,:146 run through ks = 1 with H = W = 1.
+ * Weights are consumed in a packed GEMM layout produced by sivae_pack_conv_weight:
+ *   mode 0 = forward operand, mode 1 = data-gradient operand (transposed + 180-degree flipped). */
+int sivae_conv_ck(int ks);
+int sivae_conv_ci_pad(int ks, int ci);
+int sivae_conv_co_pad(int co);
+size_t sivae_pack_conv_weight_bytes(int Co, int Ci, int ks, int mode);
+int sivae_pack_conv_weight(const float* w /*[Co][Ci][ks][ks]*/, float* wp, int Co, int Ci, int ks, int mode,
+                           sivae_stream_t stream);
+
+/* y[B][Co][H][W] (+)= conv(x', wp) + bias.
+ *   x' = x, or LeakyReLU((x-pro_mean[c])*pro_invstd[c]*pro_gamma[c]+pro_beta[c], pro_slope) when
+ *        pro_mean != NULL (producer BatchNorm2d + LeakyReLU fused into the load, :58-59,:90-91);
+ *   upsample != 0: x is [B][Ci][H/2][W/2] and is read through nn.Upsample(2,'nearest') (:155);
+ *   stats_partial != NULL: per-pixel-tile per-channel {sum, sumsq} of y, [n_px_tiles][Co][2], for the
+ *        consumer BatchNorm2d (see sivae_bn_stats_from_conv);
+ *   accumulate != 0: y += result (used to sum the two branches of the residual data gradient).
+ * The data gradient of the same conv is this function on dy with the mode-1 pack (Ci/Co swapped):
+ * aten::convolution_backward (input half). */
+int sivae_conv2d_fwd_num_px_tiles(int B, int Co, int H, int W);
+int sivae_conv2d_fwd(const float* x, const float* wp, float* y, const float* bias, const float* pro_mean,
+                     const float* pro_invstd, const float* pro_gamma, const float* pro_beta, float pro_slope,
+                     float* stats_partial, int B, int Ci, int Co, int H, int W, int ks, int upsample,
+                     int accumulate, sivae_stream_t stream);
+
+/* dw[Co][Ci][ks][ks] = weight gradient (aten::convolution_backward, weight half); x is read with the
+ * same optional prologue / upsample addressing as the forward. Deterministic split-K. */
+size_t sivae_conv2d_wgrad_workspace_bytes(int B, int Ci, int Co, int H, int W, int ks);
+int sivae_conv2d_wgrad(const float* x, const float* dy, float* dw, const float* pro_mean,
+                       const float* pro_invstd, const float* pro_gamma, const float* pro_beta, float pro_slope,
+                       int B, int Ci, int Co, int H, int W, int ks, int upsample, void* workspace,
+                       size_t workspace_bytes, sivae_stream_t stream);
+
+/* ---- BatchNorm2d (training mode) + LeakyReLU + residual add ----------------------------------------
+ * nn.BatchNorm2d(eps 1e-5, momentum 0.1) :58,:62,:90 ; nn.LeakyReLU(0.2) :59,:63,:91 ; torch.add :74.
+ * running_var gets the unbiased variance, num_batches_tracked (int64, device) is incremented. */
+size_t sivae_bn_workspace_bytes(int B, int C, int HW);
+int sivae_bn_stats(const float* x, int B, int C, int HW, float eps, float momentum, float* running_mean,
+                   float* running_var, long long* num_batches_tracked, float* mean_out, float* invstd_out,
+                   void* workspace, size_t workspace_bytes, sivae_stream_t stream);
+int sivae_bn_stats_from_conv(const float* partials, int n_tiles, int B, int C, int HW, float eps, float momentum,
+                             float* running_mean, float* running_var, long long* num_batches_tracked,
+                             float* mean_out, float* invstd_out, sivae_stream_t stream);
+/* y = LeakyReLU((x-mean[c])*invstd[c]*gamma[c]+beta[c] (+ res), slope); slope = 1 -> identity act. */
+int sivae_bn_apply_act(const float* x, const float* res, const float* mean, const float* invstd,
+                       const float* gamma, const float* beta, float slope, float* y, int B, int C, int HW,
+                       sivae_stream_t stream);
+/* backward of the above: dz = dy*(y>0?1:slope) (y = saved OUTPUT, may be NULL for no activation);
+ * dx = BN backward of dz; dz_out (optional) = gradient of the residual branch; dgamma/dbeta optional. */
+int sivae_bn_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                 const float* gamma, float slope, float* dx, float* dz_out, float* dgamma, float* dbeta, int B,
+                 int C, int HW, void* workspace, size_t workspace_bytes, sivae_stream_t stream);
+/* out[c] = sum over (B, HW) — bias gradient of Decoder.predict (:159). Workspace as sivae_bn_workspace_bytes. */
+int sivae_channel_sum(const float* x, float* out, int B, int C, int HW, void* workspace, size_t workspace_bytes,
+                      sivae_stream_t stream);
+
+/* ---- pooling / upsampling / ReLU --------------------------------------------------------------------
+ * nn.AvgPool2d(2) :92,:98 (floor semantics for odd sizes); nn.Upsample(scale_factor=2, 'nearest') :155;
+ * nn.ReLU(True) :147. rows = B*C. */
+int sivae_avgpool2_fwd(const float* x, float* y, int rows, int Hin, int Win, sivae_stream_t stream);
+int sivae_avgpool2_bwd(const float* dy, float* dx, int rows, int Hin, int Win, sivae_stream_t stream);
+int sivae_upsample2_fwd(const float* x, float* y, int rows, int H, int W, sivae_stream_t stream);
+int sivae_upsample2_bwd(const float* dy, float* dx, int rows, int H, int W, sivae_stream_t stream);
+int sivae_relu_fwd(const float* x, float* y, size_t n, sivae_stream_t stream);
+int sivae_relu_bwd(const float* dy, const float* y, float* dx, size_t n, sivae_stream_t stream);
+int sivae_add_inplace(float* y, const float* x, size_t n, sivae_stream_t stream);
+
+/* ---- sampler and losses -------------------------------------------------------------------------------
+ * reparameterize :254-265 ; calc_kl :231-251 ; calc_reconstruction_loss :268-294 ; expELBO :580-581.
+ * mu / logvar are [B][Z] with leading dimension ld (the two halves of the encoder fc output). */
+int sivae_reparam_fwd(const float* mu, const float* logvar, int ld, const float* eps, float* z, int B, int Z,
+                      sivae_stream_t stream);
+int sivae_reparam_bwd(const float* dz, const float* logvar, int ld, const float* eps, float* dmu, float* dlogvar,
+                      int ldg, int B, int Z, sivae_stream_t stream);
+int sivae_kl_fwd(const float* logvar, const float* mu, int ld, float mu_o, float logvar_o, float* out /*[B]*/,
+                 int B, int Z, sivae_stream_t stream);
+int sivae_kl_bwd(const float* g, int g_per_sample, float g_scale, const float* logvar, const float* mu, int ld,
+                 float mu_o, float logvar_o, float* dlogvar, float* dmu, int ldg, int B, int Z,
+                 sivae_stream_t stream);
+/* loss_type: 0 mse, 1 l1, 2 bce.  rowsum: out[b] = sum_i term(x[b,i], recon[b,i]). */
+size_t sivae_recon_workspace_bytes(int B, int D);
+int sivae_recon_rowsum_fwd(const float* x, const float* recon, int loss_type, float* out, int B, int D,
+                           void* workspace, size_t workspace_bytes, sivae_stream_t stream);
+/* g_mode 0: g[B] per sample, 1: scalar g[0], 2: per element g[B*D]; effective grad = g * g_scale. */
+int sivae_recon_bwd(const float* x, const float* recon, int loss_type, const float* g, int g_mode, float g_scale,
+                    float* d_recon, float* d_x, int B, int D, sivae_stream_t stream);
+int sivae_recon_elem_fwd(const float* x, const float* recon, int loss_type, float* out, size_t numel,
+                         sivae_stream_t stream);
+int sivae_vec_sum(const float* v, int n, float scale, float* out, sivae_stream_t stream);
+/* e[b] = exp(-2*scale*(beta_rec*L[b] + beta_neg*KL[b])), out[0] = mean_b e[b]. */
+int sivae_expelbo_fwd(const float* L, const float* KL, float scale, float beta_rec, float beta_neg, int B,
+                      float* e, float* out, sivae_stream_t stream);
+int sivae_expelbo_bwd(const float* gout, const float* e, float scale, float beta_rec, float beta_neg, int B,
+                      float* dL, float* dKL, sivae_stream_t stream);
+/* Philox4x32-10 standard normals (replaces torch.randn / randn_like :264,:547 in fast mode). */
+int sivae_randn(float* out, size_t n, unsigned long long seed, unsigned long long offset, sivae_stream_t stream);
+
+/* ---- optimizer ------------------------------------------------------------------------------------------
+ * torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) :450-451, one launch over a flat parameter buffer. */
+int sivae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                    float step_size /* lr / (1 - beta1^t) */, float beta1, float beta2, float eps,
+                    float bias_correction2_sqrt /* sqrt(1 - beta2^t) */, float grad_scale,
+                    sivae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIVAE_HIP_H */

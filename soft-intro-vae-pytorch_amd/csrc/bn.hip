@@ -1,0 +1,411 @@
+// Training-mode BatchNorm2d (+ LeakyReLU, + residual add) for NCHW fp32 on gfx950.
+// All kernels are HBM-bound streaming kernels: float4 loads along the contiguous H*W axis, per-thread
+// fp64 accumulation, wave64 butterfly (`__shfl_xor`) + LDS block reduction, one partial per block,
+// and a tiny per-channel finalize that combines partials in a FIXED order in fp64 (reproducible).
+//
+// Reference ops being replaced: nn.BatchNorm2d (eps 1e-5, momentum 0.1, affine) + nn.LeakyReLU(0.2)
+// + torch.add as used in ResidualBlock / Encoder stem,
+// soft_intro_vae/train_soft_intro_vae.py:58-63,71-74,90-91.
+#include "common.h"
+
+namespace {
+
+// One channel's data is B runs of HW contiguous floats.  A "slice" is a contiguous range of the
+// channel-local index n = b*HW + i.
+struct SlicePlan {
+  int S;          // slices per channel
+  long long len;  // elements per slice (multiple of 4)
+};
+static SlicePlan plan_slices(long long n_per_ch, int C) {
+  SlicePlan p;
+  long long s1 = (n_per_ch + 8191) / 8192;
+  long long s2 = 2048 / C;
+  if (s2 < 1) s2 = 1;
+  long long S = s1 < s2 ? s1 : s2;
+  if (S < 1) S = 1;
+  long long len = (n_per_ch + S - 1) / S;
+  len = (len + 3) & ~3LL;
+  p.S = (int)((n_per_ch + len - 1) / len);
+  p.len = len;
+  return p;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// forward statistics
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bn_stats_partial_kernel(const float* __restrict__ x, double* __restrict__ part,
+                                                               int C, int HW, long long n_per_ch,
+                                                               long long slice_len, int S) {
+  __shared__ double red[4];
+  const int c = blockIdx.x, s = blockIdx.y;
+  const long long n0 = (long long)s * slice_len;
+  long long n1 = n0 + slice_len;
+  if (n1 > n_per_ch) n1 = n_per_ch;
+  double sum = 0.0, sq = 0.0;
+  if ((HW & 3) == 0) {
+    for (long long n = n0 + (long long)threadIdx.x * 4; n < n1; n += 1024) {
+      const long long b = n / HW;
+      const int i = (int)(n - b * HW);
+      const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)b * C + c) * HW + i);
+      sum += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+      sq += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+  } else {
+    for (long long n = n0 + threadIdx.x; n < n1; n += 256) {
+      const long long b = n / HW;
+      const int i = (int)(n - b * HW);
+      const float v = x[((size_t)b * C + c) * HW + i];
+      sum += (double)v;
+      sq += (double)v * v;
+    }
+  }
+  sum = block_sum<256>(sum, red);
+  sq = block_sum<256>(sq, red);
+  if (threadIdx.x == 0) {
+    part[((size_t)c * S + s) * 2 + 0] = sum;
+    part[((size_t)c * S + s) * 2 + 1] = sq;
+  }
+}
+
+// partials from bn_stats_partial_kernel, layout [C][S][2] doubles (S <= 2048 / C)
+__global__ void __launch_bounds__(64) bn_finalize_kernel(const double* __restrict__ part, int S, int C,
+                                                         double count, float eps,
+                                                         float momentum, float* running_mean,
+                                                         float* running_var, long long* num_batches_tracked,
+                                                         float* __restrict__ mean_out,
+                                                         float* __restrict__ invstd_out) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  if (c >= C) return;
+  double sum = 0.0, sq = 0.0;
+  for (int s = 0; s < S; ++s) {
+    const size_t o = ((size_t)c * S + s) * 2;
+    sum += part[o];
+    sq += part[o + 1];
+  }
+  const double mean = sum / count;
+  double var = sq / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  mean_out[c] = (float)mean;
+  invstd_out[c] = invstd;
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+  }
+}
+
+// Finalize for the conv-epilogue partials ([S][C][2] floats, S = number of pixel tiles, can be 10^4+):
+// one block per channel, threads stride over tiles, fixed-shape fp64 tree -> deterministic.
+__global__ void __launch_bounds__(256) bn_finalize_conv_kernel(const float* __restrict__ part, int S, int C,
+                                                               double count, float eps, float momentum,
+                                                               float* running_mean, float* running_var,
+                                                               long long* num_batches_tracked,
+                                                               float* __restrict__ mean_out,
+                                                               float* __restrict__ invstd_out) {
+  __shared__ double red[4];
+  const int c = blockIdx.x;
+  double sum = 0.0, sq = 0.0;
+  for (int s = threadIdx.x; s < S; s += 256) {
+    const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)s * C + c) * 2);
+    sum += (double)v.x;
+    sq += (double)v.y;
+  }
+  sum = block_sum<256>(sum, red);
+  sq = block_sum<256>(sq, red);
+  if (threadIdx.x != 0) return;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  const double mean = sum / count;
+  double var = sq / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  mean_out[c] = (float)mean;
+  invstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+  }
+}
+
+extern "C" size_t sivae_bn_workspace_bytes(int B, int C, int HW) {
+  if (B <= 0 || C <= 0 || HW <= 0) return 0;
+  SlicePlan p = plan_slices((long long)B * HW, C);
+  // forward: [C][S][2] doubles; backward needs the same + [C][2] coefficients
+  return ((size_t)C * p.S * 2 + (size_t)C * 2) * sizeof(double);
+}
+
+extern "C" int sivae_bn_stats(const float* x, int B, int C, int HW, float eps, float momentum,
+                              float* running_mean, float* running_var, long long* num_batches_tracked,
+                              float* mean_out, float* invstd_out, void* workspace, size_t workspace_bytes,
+                              hipStream_t stream) {
+  if (!x || !mean_out || !invstd_out) return SIVAE_ERR_NULL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return SIVAE_ERR_NULL;
+  if (B <= 0 || C <= 0 || HW <= 0) return SIVAE_ERR_SHAPE;
+  if (!workspace || workspace_bytes < sivae_bn_workspace_bytes(B, C, HW)) return SIVAE_ERR_WORKSPACE;
+  const long long n = (long long)B * HW;
+  SlicePlan p = plan_slices(n, C);
+  double* part = (double*)workspace;
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, p.S), dim3(256), 0, stream, x, part, C, HW, n, p.len, p.S);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, (const double*)part, p.S, C,
+                     (double)n, eps, momentum, running_mean, running_var, num_batches_tracked, mean_out,
+                     invstd_out);
+  return sivae_launch_status();
+}
+
+// Statistics from the per-pixel-tile partial sums the conv forward epilogue wrote ([n_tiles][C][2] floats).
+extern "C" int sivae_bn_stats_from_conv(const float* partials, int n_tiles, int B, int C, int HW, float eps,
+                                        float momentum, float* running_mean, float* running_var,
+                                        long long* num_batches_tracked, float* mean_out, float* invstd_out,
+                                        hipStream_t stream) {
+  if (!partials || !mean_out || !invstd_out) return SIVAE_ERR_NULL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return SIVAE_ERR_NULL;
+  if (B <= 0 || C <= 0 || HW <= 0 || n_tiles <= 0) return SIVAE_ERR_SHAPE;
+  hipLaunchKernelGGL(bn_finalize_conv_kernel, dim3(C), dim3(256), 0, stream, partials, n_tiles, C,
+                     (double)B * HW, eps, momentum, running_mean, running_var, num_batches_tracked, mean_out,
+                     invstd_out);
+  return sivae_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// apply:  y = LeakyReLU( (x - mean[c]) * invstd[c]*gamma[c] + beta[c]  (+ res) )
+// slope == 1 -> no activation.
+// ------------------------------------------------------------------------------------------------
+template <bool HAS_RES, bool VEC>
+__global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float slope,
+                                                       float* __restrict__ y, int C, int HW, size_t numel) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  if (VEC) {
+    const size_t n4 = numel >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+      const size_t e = i << 2;
+      const int c = (int)((e / HW) % C);
+      const float m = mean[c], g = invstd[c] * gamma[c], bt = beta[c];
+      float4 v = reinterpret_cast<const float4*>(x)[i];
+      v.x = (v.x - m) * g + bt;
+      v.y = (v.y - m) * g + bt;
+      v.z = (v.z - m) * g + bt;
+      v.w = (v.w - m) * g + bt;
+      if (HAS_RES) {
+        const float4 r = reinterpret_cast<const float4*>(res)[i];
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      v.x = lrelu(v.x, slope); v.y = lrelu(v.y, slope); v.z = lrelu(v.z, slope); v.w = lrelu(v.w, slope);
+      reinterpret_cast<float4*>(y)[i] = v;
+    }
+  } else {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < numel; e += stride) {
+      const int c = (int)((e / HW) % C);
+      float v = (x[e] - mean[c]) * (invstd[c] * gamma[c]) + beta[c];
+      if (HAS_RES) v += res[e];
+      y[e] = lrelu(v, slope);
+    }
+  }
+}
+
+extern "C" int sivae_bn_apply_act(const float* x, const float* res, const float* mean, const float* invstd,
+                                  const float* gamma, const float* beta, float slope, float* y, int B, int C,
+                                  int HW, hipStream_t stream) {
+  if (!x || !mean || !invstd || !gamma || !beta || !y) return SIVAE_ERR_NULL;
+  if (B <= 0 || C <= 0 || HW <= 0) return SIVAE_ERR_SHAPE;
+  const size_t numel = (size_t)B * C * HW;
+  const bool vec = (HW & 3) == 0;
+  long long work = vec ? (long long)(numel >> 2) : (long long)numel;
+  int nb = cdiv(work, 256);
+  if (nb > 8192) nb = 8192;
+  if (nb < 1) nb = 1;
+#define LAUNCH(R, V) \
+  hipLaunchKernelGGL((bn_apply_kernel<R, V>), dim3(nb), dim3(256), 0, stream, x, res, mean, invstd, gamma, beta, \
+                     slope, y, C, HW, numel)
+  if (res) {
+    if (vec) LAUNCH(true, true); else LAUNCH(true, false);
+  } else {
+    if (vec) LAUNCH(false, true); else LAUNCH(false, false);
+  }
+#undef LAUNCH
+  return sivae_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward of  y = LeakyReLU(BN(x) [+ res])
+//   dz = dy * (y > 0 ? 1 : slope)        (y is the saved OUTPUT; valid because slope > 0)
+//   dbeta = sum dz ; dgamma = sum dz * xhat
+//   dx = gamma*invstd * (dz - mean(dz) - xhat * mean(dz*xhat)) ;  dres = dz
+// pass 1: per-channel partial sums (fp64), pass 2: coefficients, pass 3: dx / dz.
+// If y == nullptr no activation mask is applied.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                             const float* __restrict__ x,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, float slope,
+                                                             double* __restrict__ part, int C, int HW,
+                                                             long long n_per_ch, long long slice_len, int S) {
+  __shared__ double red[4];
+  const int c = blockIdx.x, s = blockIdx.y;
+  const long long n0 = (long long)s * slice_len;
+  long long n1 = n0 + slice_len;
+  if (n1 > n_per_ch) n1 = n_per_ch;
+  const float m = mean[c], is = invstd[c];
+  double s1 = 0.0, s2 = 0.0;
+  if ((HW & 3) == 0) {
+    for (long long n = n0 + (long long)threadIdx.x * 4; n < n1; n += 1024) {
+      const long long b = n / HW;
+      const size_t o = ((size_t)b * C + c) * HW + (size_t)(n - b * HW);
+      const float4 g = *reinterpret_cast<const float4*>(dy + o);
+      const float4 xv = *reinterpret_cast<const float4*>(x + o);
+      float gz[4] = {g.x, g.y, g.z, g.w};
+      if (y) {
+        const float4 yv = *reinterpret_cast<const float4*>(y + o);
+        gz[0] = yv.x > 0.f ? gz[0] : gz[0] * slope;
+        gz[1] = yv.y > 0.f ? gz[1] : gz[1] * slope;
+        gz[2] = yv.z > 0.f ? gz[2] : gz[2] * slope;
+        gz[3] = yv.w > 0.f ? gz[3] : gz[3] * slope;
+      }
+      const float xh[4] = {(xv.x - m) * is, (xv.y - m) * is, (xv.z - m) * is, (xv.w - m) * is};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        s1 += (double)gz[k];
+        s2 += (double)gz[k] * (double)xh[k];
+      }
+    }
+  } else {
+    for (long long n = n0 + threadIdx.x; n < n1; n += 256) {
+      const long long b = n / HW;
+      const size_t o = ((size_t)b * C + c) * HW + (size_t)(n - b * HW);
+      float g = dy[o];
+      if (y) g = y[o] > 0.f ? g : g * slope;
+      s1 += (double)g;
+      s2 += (double)g * (double)((x[o] - m) * is);
+    }
+  }
+  s1 = block_sum<256>(s1, red);
+  s2 = block_sum<256>(s2, red);
+  if (threadIdx.x == 0) {
+    part[((size_t)c * S + s) * 2 + 0] = s1;
+    part[((size_t)c * S + s) * 2 + 1] = s2;
+  }
+}
+
+__global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const double* __restrict__ part, int S, int C,
+                                                             double count, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, float* __restrict__ coef) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = 0; s < S; ++s) {
+    s1 += part[((size_t)c * S + s) * 2 + 0];
+    s2 += part[((size_t)c * S + s) * 2 + 1];
+  }
+  if (dbeta) dbeta[c] = (float)s1;
+  if (dgamma) dgamma[c] = (float)s2;
+  coef[c * 2 + 0] = (float)(s1 / count);
+  coef[c * 2 + 1] = (float)(s2 / count);
+}
+
+template <bool HAS_Y, bool HAS_DZ, bool VEC>
+__global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                        const float* __restrict__ x, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ coef, float slope,
+                                                        float* __restrict__ dx, float* __restrict__ dz_out, int C,
+                                                        int HW, size_t numel) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  if (VEC) {
+    const size_t n4 = numel >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+      const size_t e = i << 2;
+      const int c = (int)((e / HW) % C);
+      const float m = mean[c], is = invstd[c], gs = gamma[c] * is, c1 = coef[c * 2], c2 = coef[c * 2 + 1];
+      const float4 g = reinterpret_cast<const float4*>(dy)[i];
+      const float4 xv = reinterpret_cast<const float4*>(x)[i];
+      float gz[4] = {g.x, g.y, g.z, g.w};
+      if (HAS_Y) {
+        const float4 yv = reinterpret_cast<const float4*>(y)[i];
+        gz[0] = yv.x > 0.f ? gz[0] : gz[0] * slope;
+        gz[1] = yv.y > 0.f ? gz[1] : gz[1] * slope;
+        gz[2] = yv.z > 0.f ? gz[2] : gz[2] * slope;
+        gz[3] = yv.w > 0.f ? gz[3] : gz[3] * slope;
+      }
+      float4 o;
+      o.x = gs * (gz[0] - c1 - (xv.x - m) * is * c2);
+      o.y = gs * (gz[1] - c1 - (xv.y - m) * is * c2);
+      o.z = gs * (gz[2] - c1 - (xv.z - m) * is * c2);
+      o.w = gs * (gz[3] - c1 - (xv.w - m) * is * c2);
+      reinterpret_cast<float4*>(dx)[i] = o;
+      if (HAS_DZ) reinterpret_cast<float4*>(dz_out)[i] = make_float4(gz[0], gz[1], gz[2], gz[3]);
+    }
+  } else {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < numel; e += stride) {
+      const int c = (int)((e / HW) % C);
+      const float m = mean[c], is = invstd[c];
+      float g = dy[e];
+      if (HAS_Y) g = y[e] > 0.f ? g : g * slope;
+      dx[e] = gamma[c] * is * (g - coef[c * 2] - (x[e] - m) * is * coef[c * 2 + 1]);
+      if (HAS_DZ) dz_out[e] = g;
+    }
+  }
+}
+
+extern "C" int sivae_bn_bwd(const float* dy, const float* y, const float* x, const float* mean,
+                            const float* invstd, const float* gamma, float slope, float* dx, float* dz_out,
+                            float* dgamma, float* dbeta, int B, int C, int HW, void* workspace,
+                            size_t workspace_bytes, hipStream_t stream) {
+  if (!dy || !x || !mean || !invstd || !gamma || !dx) return SIVAE_ERR_NULL;
+  if (B <= 0 || C <= 0 || HW <= 0) return SIVAE_ERR_SHAPE;
+  if (!workspace || workspace_bytes < sivae_bn_workspace_bytes(B, C, HW)) return SIVAE_ERR_WORKSPACE;
+  const long long n = (long long)B * HW;
+  SlicePlan p = plan_slices(n, C);
+  double* part = (double*)workspace;
+  float* coef = (float*)(part + (size_t)C * p.S * 2);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, p.S), dim3(256), 0, stream, dy, y, x, mean, invstd, slope, part,
+                     C, HW, n, p.len, p.S);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, (const double*)part, p.S, C,
+                     (double)n, dgamma, dbeta, coef);
+  const size_t numel = (size_t)B * C * HW;
+  const bool vec = (HW & 3) == 0;
+  long long work = vec ? (long long)(numel >> 2) : (long long)numel;
+  int nb = cdiv(work, 256);
+  if (nb > 8192) nb = 8192;
+  if (nb < 1) nb = 1;
+#define LAUNCH(Y, Z, V) \
+  hipLaunchKernelGGL((bn_bwd_dx_kernel<Y, Z, V>), dim3(nb), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma, \
+                     (const float*)coef, slope, dx, dz_out, C, HW, numel)
+  const bool hy = y != nullptr, hz = dz_out != nullptr;
+  if (hy && hz) { if (vec) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
+  else if (hy) { if (vec) LAUNCH(true, false, true); else LAUNCH(true, false, false); }
+  else if (hz) { if (vec) LAUNCH(false, true, true); else LAUNCH(false, true, false); }
+  else { if (vec) LAUNCH(false, false, true); else LAUNCH(false, false, false); }
+#undef LAUNCH
+  return sivae_launch_status();
+}
+
+// per-channel sum over (B, HW) — bias gradient of the `predict` conv (train_soft_intro_vae.py:159)
+__global__ void __launch_bounds__(64) channel_sum_finalize_kernel(const double* __restrict__ part, int S, int C,
+                                                                  float* __restrict__ out) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0;
+  for (int s = 0; s < S; ++s) s1 += part[((size_t)c * S + s) * 2];
+  out[c] = (float)s1;
+}
+
+extern "C" int sivae_channel_sum(const float* x, float* out, int B, int C, int HW, void* workspace,
+                                 size_t workspace_bytes, hipStream_t stream) {
+  if (!x || !out) return SIVAE_ERR_NULL;
+  if (B <= 0 || C <= 0 || HW <= 0) return SIVAE_ERR_SHAPE;
+  if (!workspace || workspace_bytes < sivae_bn_workspace_bytes(B, C, HW)) return SIVAE_ERR_WORKSPACE;
+  const long long n = (long long)B * HW;
+  SlicePlan p = plan_slices(n, C);
+  double* part = (double*)workspace;
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, p.S), dim3(256), 0, stream, x, part, C, HW, n, p.len, p.S);
+  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, (const double*)part, p.S,
+                     C, out);
+  return sivae_launch_status();
+}

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Builds libsivae_hip.so for gfx950 in-tree (next to the Python loader). Usage: csrc/build.sh [-j N]
+set -e
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+out="$here/../sivae_hip/libsivae_hip.so"
+obj="$here/build"
+mkdir -p "$obj"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc"
+pids=()
+for f in abi pack conv_fwd conv_wgrad bn eltwise loss optim; do
+  if [ ! -f "$obj/$f.o" ] || [ "$here/$f.hip" -nt "$obj/$f.o" ] || [ "$here/common.h" -nt "$obj/$f.o" ]; then
+    "$HIPCC" $FLAGS -c "$here/$f.hip" -o "$obj/$f.o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "$obj"/abi.o "$obj"/pack.o "$obj"/conv_fwd.o "$obj"/conv_wgrad.o \
+  "$obj"/bn.o "$obj"/eltwise.o "$obj"/loss.o "$obj"/optim.o
+echo "built $out"

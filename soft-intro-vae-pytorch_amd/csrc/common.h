@@ -1,0 +1,118 @@
+// Shared device/host helpers for libsivae_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+// ---- error codes (negative = argument errors defined by this library, positive = hipError_t) ----
+#define SIVAE_OK 0
+#define SIVAE_ERR_NULL -1       // a required pointer is null
+#define SIVAE_ERR_SHAPE -2      // unsupported / inconsistent shape
+#define SIVAE_ERR_KSIZE -3      // kernel size not in {1,3,5}
+#define SIVAE_ERR_WORKSPACE -4  // workspace too small
+#define SIVAE_ERR_RANGE -5      // tensor too large for 32-bit element indexing
+#define SIVAE_ERR_MODE -6       // unknown mode / flag value
+
+#define SIVAE_ABI_VERSION 1
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int sivae_launch_status() { return (int)hipGetLastError(); }
+
+static inline int ilog2_exact(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+static inline int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Tile geometry shared by the implicit-GEMM conv kernels: a pixel tile is TB images x TH rows x TW
+// cols (all powers of two, TB > 1 only when one tile covers a whole image).
+struct TileGeom {
+  int tb_log2, th_log2, tw_log2;
+  int ntb, nth, ntw;  // number of tiles along batch / rows / cols
+};
+
+static inline TileGeom make_tile_geom(int B, int H, int W, int tpx /* pixels per tile, pow2 */) {
+  TileGeom g;
+  int tw = next_pow2(W);
+  if (tw > 32) tw = 32;
+  if (tw > tpx) tw = tpx;
+  int th = next_pow2(H);
+  if (th > tpx / tw) th = tpx / tw;
+  int tb = tpx / (tw * th);
+  g.tw_log2 = ilog2_exact(tw);
+  g.th_log2 = ilog2_exact(th);
+  g.tb_log2 = ilog2_exact(tb);
+  g.ntw = cdiv(W, tw);
+  g.nth = cdiv(H, th);
+  g.ntb = cdiv(B, tb);
+  return g;
+}
+
+#ifdef __HIPCC__
+// ---- wave64 reductions (butterfly over all 64 lanes; every lane ends with the total) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over the 32 lanes that share (lane >> 5)
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum of doubles for blocks of NT threads (NT multiple of 64, <= 1024).
+// `red` must hold NT/64 doubles of LDS. Result valid in every thread.
+template <int NT>
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) t += red[i];
+  return t;
+}
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// ---- raw buffer loads: wave-uniform 128-bit descriptor + 32-bit per-lane BYTE offset + uniform
+// SGPR offset.  A per-lane offset >= num_records returns 0 without touching memory, which is how
+// every halo / out-of-image / out-of-batch element of a conv tile becomes a zero for free
+// (no per-element branches, no exec masking).  The SGPR offset is NOT range-checked.
+#define SIVAE_OOB 0xFFFFFFFFu
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned long long bytes) {
+  const unsigned n = bytes > 0xFFFFFFFEull ? 0xFFFFFFFEu : (unsigned)bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)n, 0x00020000);
+}
+__device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ float4 buf_load_f32x4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  auto q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return make_float4(__builtin_bit_cast(float, q[0]), __builtin_bit_cast(float, q[1]),
+                     __builtin_bit_cast(float, q[2]), __builtin_bit_cast(float, q[3]));
+}
+
+// exact floor(e / d) for e < 2^22, d < 2^10 with magic = floor(2^32 / d) + 1
+// magic == 0 encodes d == 1
+__device__ __forceinline__ unsigned fastdiv(unsigned e, unsigned magic) { return magic ? __umulhi(e, magic) : e; }
+#endif
+
+static inline unsigned make_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull / d) + 1ull); }

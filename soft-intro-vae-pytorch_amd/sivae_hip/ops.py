@@ -1,0 +1,344 @@
+"""Tensor-level wrappers over the libsivae_hip C ABI (no autograd here — see `functional.py`).
+
+Every function takes contiguous fp32 ROCm-device tensors, allocates the outputs, launches on torch's
+current HIP stream and returns immediately (stream-async). CPU tensors are rejected loudly: the
+product path has no CPU fallback.
+"""
+import ctypes
+
+import torch
+
+from . import lib as _lib
+
+LRELU_SLOPE = 0.2
+LOSS_TYPES = {"mse": 0, "l1": 1, "bce": 2}
+
+_workspaces = {}
+
+
+def _require(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("sivae_hip: tensor is on %s — the Soft-IntroVAE HIP kernels need a ROCm device "
+                               "tensor and have no CPU fallback" % t.device)
+        if t.dtype != torch.float32 and t.dtype != torch.int64:
+            raise TypeError("sivae_hip: expected float32, got %s" % t.dtype)
+        if not t.is_contiguous():
+            raise ValueError("sivae_hip: tensor must be contiguous")
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _s():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per (device, stream); kernels on one stream are ordered, so sharing is safe."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------------------------------------ conv
+def pack_weight(w, mode):
+    """w [Co, Ci, k, k] (or [out, in] for Linear) -> packed GEMM operand. mode 0 fwd, 1 dgrad."""
+    _require(w)
+    if w.dim() == 2:
+        Co, Ci, ks = w.shape[0], w.shape[1], 1
+    else:
+        Co, Ci, ks = w.shape[0], w.shape[1], w.shape[2]
+    L = _lib.load()
+    nbytes = L.sivae_pack_conv_weight_bytes(Co, Ci, ks, mode)
+    if nbytes == 0:
+        raise _lib.SivaeError("sivae_pack_conv_weight_bytes", -3)
+    wp = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+    _lib.call("sivae_pack_conv_weight", _p(w), _p(wp), Co, Ci, ks, mode, _s())
+    return wp
+
+
+def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=False, out=None,
+               accumulate=False):
+    """x [B, Ci, H, W] (or [B, Ci, H/2, W/2] with upsample) -> y [B, Co, H, W] (+ stats partials).
+
+    pro = (mean, invstd, gamma, beta, slope): fused producer BatchNorm + LeakyReLU on load."""
+    _require(x, wp, bias, out)
+    B, Ci, Hs, Ws = x.shape
+    H, W = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
+    y = out if out is not None else torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
+    assert y.shape == (B, Co, H, W)
+    stats = None
+    if want_stats:
+        nt = _lib.load().sivae_conv2d_fwd_num_px_tiles(B, Co, H, W)
+        stats = torch.empty((nt, Co, 2), dtype=torch.float32, device=x.device)
+    pm = pi = pg = pb = None
+    slope = 1.0
+    if pro is not None:
+        pm, pi, pg, pb, slope = pro
+        _require(pm, pi, pg, pb)
+    _lib.call("sivae_conv2d_fwd", _p(x), _p(wp), _p(y), _p(bias), _p(pm), _p(pi), _p(pg), _p(pb), float(slope),
+              _p(stats), B, Ci, Co, H, W, ks, int(bool(upsample)), int(bool(accumulate)), _s())
+    return (y, stats) if want_stats else y
+
+
+def conv2d_wgrad(x, dy, ks, pro=None, upsample=False):
+    """-> dW [Co, Ci, ks, ks]"""
+    _require(x, dy)
+    B, Ci = x.shape[0], x.shape[1]
+    _, Co, H, W = dy.shape
+    L = _lib.load()
+    nbytes = L.sivae_conv2d_wgrad_workspace_bytes(B, Ci, Co, H, W, ks)
+    ws = workspace(nbytes, x.device)
+    dw = torch.empty((Co, Ci, ks, ks), dtype=torch.float32, device=x.device)
+    pm = pi = pg = pb = None
+    slope = 1.0
+    if pro is not None:
+        pm, pi, pg, pb, slope = pro
+        _require(pm, pi, pg, pb)
+    _lib.call("sivae_conv2d_wgrad", _p(x), _p(dy), _p(dw), _p(pm), _p(pi), _p(pg), _p(pb), float(slope), B, Ci, Co,
+              H, W, ks, int(bool(upsample)), _p(ws), ws.numel(), _s())
+    return dw
+
+
+# ------------------------------------------------------------------------------------------------ BN
+def bn_stats(x, running_mean=None, running_var=None, num_batches_tracked=None, eps=1e-5, momentum=0.1):
+    _require(x, running_mean, running_var, num_batches_tracked)
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    L = _lib.load()
+    ws = workspace(L.sivae_bn_workspace_bytes(B, C, HW), x.device)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    _lib.call("sivae_bn_stats", _p(x), B, C, HW, float(eps), float(momentum), _p(running_mean), _p(running_var),
+              _p(num_batches_tracked), _p(mean), _p(invstd), _p(ws), ws.numel(), _s())
+    return mean, invstd
+
+
+def bn_stats_from_conv(partials, B, C, HW, running_mean=None, running_var=None, num_batches_tracked=None,
+                       eps=1e-5, momentum=0.1):
+    _require(partials, running_mean, running_var, num_batches_tracked)
+    mean = torch.empty(C, dtype=torch.float32, device=partials.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=partials.device)
+    _lib.call("sivae_bn_stats_from_conv", _p(partials), partials.shape[0], B, C, HW, float(eps), float(momentum),
+              _p(running_mean), _p(running_var), _p(num_batches_tracked), _p(mean), _p(invstd), _s())
+    return mean, invstd
+
+
+def bn_apply_act(x, res, mean, invstd, gamma, beta, slope=LRELU_SLOPE, out=None):
+    _require(x, res, mean, invstd, gamma, beta, out)
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    y = out if out is not None else torch.empty_like(x)
+    _lib.call("sivae_bn_apply_act", _p(x), _p(res), _p(mean), _p(invstd), _p(gamma), _p(beta), float(slope), _p(y),
+              B, C, HW, _s())
+    return y
+
+
+def bn_bwd(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_dz=False, want_param_grads=True):
+    """-> dx, dz (or None), dgamma, dbeta (or None, None)"""
+    _require(dy, y, x, mean, invstd, gamma)
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    L = _lib.load()
+    ws = workspace(L.sivae_bn_workspace_bytes(B, C, HW), x.device)
+    dx = torch.empty_like(x)
+    dz = torch.empty_like(x) if want_dz else None
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
+    _lib.call("sivae_bn_bwd", _p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), float(slope), _p(dx), _p(dz),
+              _p(dgamma), _p(dbeta), B, C, HW, _p(ws), ws.numel(), _s())
+    return dx, dz, dgamma, dbeta
+
+
+def channel_sum(x):
+    _require(x)
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    L = _lib.load()
+    ws = workspace(L.sivae_bn_workspace_bytes(B, C, HW), x.device)
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    _lib.call("sivae_channel_sum", _p(x), _p(out), B, C, HW, _p(ws), ws.numel(), _s())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ eltwise
+def avgpool2_fwd(x):
+    _require(x)
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    _lib.call("sivae_avgpool2_fwd", _p(x), _p(y), B * C, H, W, _s())
+    return y
+
+
+def avgpool2_bwd(dy, H, W):
+    _require(dy)
+    B, C = dy.shape[0], dy.shape[1]
+    dx = torch.empty((B, C, H, W), dtype=torch.float32, device=dy.device)
+    _lib.call("sivae_avgpool2_bwd", _p(dy), _p(dx), B * C, H, W, _s())
+    return dx
+
+
+def upsample2_fwd(x):
+    _require(x)
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    _lib.call("sivae_upsample2_fwd", _p(x), _p(y), B * C, H, W, _s())
+    return y
+
+
+def upsample2_bwd(dy):
+    _require(dy)
+    B, C, H2, W2 = dy.shape
+    dx = torch.empty((B, C, H2 // 2, W2 // 2), dtype=torch.float32, device=dy.device)
+    _lib.call("sivae_upsample2_bwd", _p(dy), _p(dx), B * C, H2 // 2, W2 // 2, _s())
+    return dx
+
+
+def relu_fwd(x, inplace=False):
+    _require(x)
+    y = x if inplace else torch.empty_like(x)
+    _lib.call("sivae_relu_fwd", _p(x), _p(y), x.numel(), _s())
+    return y
+
+
+def relu_bwd(dy, y):
+    _require(dy, y)
+    dx = torch.empty_like(dy)
+    _lib.call("sivae_relu_bwd", _p(dy), _p(y), _p(dx), dy.numel(), _s())
+    return dx
+
+
+def add_(y, x):
+    _require(y, x)
+    assert y.numel() == x.numel()
+    _lib.call("sivae_add_inplace", _p(y), _p(x), y.numel(), _s())
+    return y
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def _ld(t):
+    """[B, Z] view with unit inner stride -> leading dimension"""
+    assert t.dim() == 2 and t.stride(1) == 1, "mu/logvar must be [B, Z] with unit inner stride"
+    if not t.is_cuda:
+        raise RuntimeError("sivae_hip: tensor is on %s — no CPU fallback" % t.device)
+    return t.stride(0)
+
+
+def reparam_fwd(mu, logvar, eps):
+    _require(eps)
+    B, Z = mu.shape
+    ld = _ld(mu)
+    assert _ld(logvar) == ld
+    z = torch.empty((B, Z), dtype=torch.float32, device=mu.device)
+    _lib.call("sivae_reparam_fwd", _p(mu), _p(logvar), ld, _p(eps), _p(z), B, Z, _s())
+    return z
+
+
+def reparam_bwd(dz, logvar, eps):
+    _require(dz, eps)
+    B, Z = dz.shape
+    dmu = torch.empty_like(dz)
+    dlv = torch.empty_like(dz)
+    _lib.call("sivae_reparam_bwd", _p(dz), _p(logvar), _ld(logvar), _p(eps), _p(dmu), _p(dlv), Z, B, Z, _s())
+    return dmu, dlv
+
+
+def kl_fwd(logvar, mu, mu_o=0.0, logvar_o=0.0):
+    B, Z = mu.shape
+    ld = _ld(mu)
+    assert _ld(logvar) == ld
+    out = torch.empty(B, dtype=torch.float32, device=mu.device)
+    _lib.call("sivae_kl_fwd", _p(logvar), _p(mu), ld, float(mu_o), float(logvar_o), _p(out), B, Z, _s())
+    return out
+
+
+def kl_bwd(g, per_sample, g_scale, logvar, mu, mu_o=0.0, logvar_o=0.0):
+    _require(g)
+    B, Z = mu.shape
+    ld = _ld(mu)
+    dlv = torch.empty((B, Z), dtype=torch.float32, device=mu.device)
+    dmu = torch.empty((B, Z), dtype=torch.float32, device=mu.device)
+    _lib.call("sivae_kl_bwd", _p(g), int(bool(per_sample)), float(g_scale), _p(logvar), _p(mu), ld, float(mu_o),
+              float(logvar_o), _p(dlv), _p(dmu), Z, B, Z, _s())
+    return dlv, dmu
+
+
+def recon_rowsum_fwd(x, recon, loss_type):
+    _require(x, recon)
+    B = x.shape[0]
+    D = x.numel() // B
+    L = _lib.load()
+    ws = workspace(L.sivae_recon_workspace_bytes(B, D), x.device)
+    out = torch.empty(B, dtype=torch.float32, device=x.device)
+    _lib.call("sivae_recon_rowsum_fwd", _p(x), _p(recon), LOSS_TYPES[loss_type], _p(out), B, D, _p(ws), ws.numel(),
+              _s())
+    return out
+
+
+def recon_bwd(x, recon, loss_type, g, g_mode, g_scale, want_drecon=True, want_dx=False):
+    _require(x, recon, g)
+    B = x.shape[0]
+    D = x.numel() // B
+    d_r = torch.empty_like(recon) if want_drecon else None
+    d_x = torch.empty_like(x) if want_dx else None
+    _lib.call("sivae_recon_bwd", _p(x), _p(recon), LOSS_TYPES[loss_type], _p(g), int(g_mode), float(g_scale),
+              _p(d_r), _p(d_x), B, D, _s())
+    return d_r, d_x
+
+
+def recon_elem_fwd(x, recon, loss_type):
+    _require(x, recon)
+    out = torch.empty_like(x)
+    _lib.call("sivae_recon_elem_fwd", _p(x), _p(recon), LOSS_TYPES[loss_type], _p(out), x.numel(), _s())
+    return out
+
+
+def vec_sum(v, scale=1.0):
+    _require(v)
+    out = torch.empty((), dtype=torch.float32, device=v.device)
+    _lib.call("sivae_vec_sum", _p(v), v.numel(), float(scale), _p(out), _s())
+    return out
+
+
+def expelbo_fwd(L_, KL, scale, beta_rec, beta_neg):
+    _require(L_, KL)
+    B = L_.numel()
+    e = torch.empty(B, dtype=torch.float32, device=L_.device)
+    out = torch.empty((), dtype=torch.float32, device=L_.device)
+    _lib.call("sivae_expelbo_fwd", _p(L_), _p(KL), float(scale), float(beta_rec), float(beta_neg), B, _p(e), _p(out),
+              _s())
+    return out, e
+
+
+def expelbo_bwd(gout, e, scale, beta_rec, beta_neg):
+    _require(gout, e)
+    B = e.numel()
+    dL = torch.empty_like(e)
+    dKL = torch.empty_like(e)
+    _lib.call("sivae_expelbo_bwd", _p(gout), _p(e), float(scale), float(beta_rec), float(beta_neg), B, _p(dL),
+              _p(dKL), _s())
+    return dL, dKL
+
+
+def randn(shape, seed, offset, device):
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    _require(out)
+    _lib.call("sivae_randn", _p(out), out.numel(), int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset) & 0xFFFFFFFFFFFFFFFF,
+              _s())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    _require(param, grad, exp_avg, exp_avg_sq)
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    _lib.call("sivae_adam_step", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), float(lr / bc1),
+              float(beta1), float(beta2), float(eps), float(bc2 ** 0.5), float(grad_scale), _s())

@@ -1,0 +1,406 @@
+"""Kernel-level parity checks (T2): every HIP kernel vs the same op in stock torch on the CPU in fp64.
+
+Each check returns (name, err, tol) where err = max|hip - ref| / (max|ref| + 1e-30). Used by
+tests/test_kernels_gpu.py (pytest -m gpu) and by `python tests/kernel_checks.py` which prints the
+whole table without stopping at the first failure (one GPU call -> the complete picture).
+"""
+import math
+import sys
+import traceback
+
+import torch
+import torch.nn.functional as F
+
+DEV = "cuda"
+
+
+def _err(a, ref):
+    a = a.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    if a.shape != ref.shape:
+        return float("inf")
+    if not torch.isfinite(a).all():
+        return float("inf")
+    return float((a - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g, dtype=torch.float64) * scale)
+
+
+def _d(t):
+    return t.float().to(DEV).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ conv
+CONV_SHAPES = [
+    # (B, Ci, Co, H, W, ks)
+    (2, 64, 128, 32, 32, 3),
+    (2, 128, 64, 16, 16, 3),
+    (3, 64, 64, 64, 64, 3),
+    (4, 160, 136, 8, 8, 3),    # non-multiple channels
+    (8, 512, 512, 4, 4, 3),
+    (5, 16, 32, 8, 8, 3),      # Co <= 32 config
+    (2, 8, 8, 7, 7, 3),        # odd spatial
+    (2, 64, 64, 28, 28, 3),
+    (2, 64, 128, 32, 32, 1),
+    (2, 128, 64, 16, 16, 1),
+    (3, 100, 40, 8, 8, 1),
+    (3, 3, 64, 32, 32, 5),     # encoder stem
+    (2, 64, 3, 32, 32, 5),     # decoder predict
+    (2, 1, 64, 28, 28, 5),
+    (2, 64, 1, 28, 28, 5),
+    (2, 20, 130, 8, 8, 5),
+]
+
+
+def _conv_ref(x, w, b=None):
+    return F.conv2d(x, w, b, stride=1, padding=w.shape[-1] // 2)
+
+
+def check_conv_fwd(shape, bias=False, stats=False):
+    from sivae_hip import ops
+    B, Ci, Co, H, W, ks = shape
+    x = _rand(B, Ci, H, W, seed=1)
+    w = _rand(Co, Ci, ks, ks, seed=2, scale=1.0 / math.sqrt(Ci * ks * ks))
+    b = _rand(Co, seed=3) if bias else None
+    ref = _conv_ref(x, w, b)
+    wp = ops.pack_weight(_d(w), 0)
+    out = ops.conv2d_fwd(_d(x), wp, Co, ks, bias=_d(b) if bias else None, want_stats=stats)
+    res = []
+    if stats:
+        y, part = out
+        s = part.double().sum(0).cpu()
+        res.append(("conv_fwd_stats_sum%s" % (shape,), _err(s[:, 0], ref.sum((0, 2, 3))) , 2e-5))
+        res.append(("conv_fwd_stats_sq%s" % (shape,), _err(s[:, 1], (ref * ref).sum((0, 2, 3))), 2e-5))
+    else:
+        y = out
+    res.append(("conv_fwd%s%s" % (shape, "+bias" if bias else ""), _err(y, ref), 1e-5))
+    return res
+
+
+def check_conv_dgrad(shape):
+    from sivae_hip import ops
+    B, Ci, Co, H, W, ks = shape
+    x = _rand(B, Ci, H, W, seed=1).requires_grad_()
+    w = _rand(Co, Ci, ks, ks, seed=2, scale=1.0 / math.sqrt(Ci * ks * ks))
+    dy = _rand(B, Co, H, W, seed=4)
+    _conv_ref(x, w).backward(dy)
+    wpd = ops.pack_weight(_d(w), 1)
+    dx = ops.conv2d_fwd(_d(dy), wpd, Ci, ks)
+    return [("conv_dgrad%s" % (shape,), _err(dx, x.grad), 1e-5)]
+
+
+def check_conv_wgrad(shape):
+    from sivae_hip import ops
+    B, Ci, Co, H, W, ks = shape
+    x = _rand(B, Ci, H, W, seed=1)
+    w = _rand(Co, Ci, ks, ks, seed=2).requires_grad_()
+    dy = _rand(B, Co, H, W, seed=4)
+    _conv_ref(x, w).backward(dy)
+    dw = ops.conv2d_wgrad(_d(x), _d(dy), ks)
+    return [("conv_wgrad%s" % (shape,), _err(dw, w.grad), 1e-5)]
+
+
+def check_conv_fused(shape):
+    """prologue BN+LeakyReLU, nearest-2x upsample addressing, accumulate — forward and wgrad"""
+    from sivae_hip import ops
+    B, Ci, Co, H, W, ks = shape
+    res = []
+    xs = _rand(B, Ci, H // 2, W // 2, seed=5)
+    w = _rand(Co, Ci, ks, ks, seed=2, scale=1.0 / math.sqrt(Ci * ks * ks)).requires_grad_()
+    mean, invstd = _rand(Ci, seed=6), _rand(Ci, seed=7).abs() + 0.5
+    gamma, beta = _rand(Ci, seed=8), _rand(Ci, seed=9)
+    dy = _rand(B, Co, H, W, seed=4)
+    pro = (_d(mean), _d(invstd), _d(gamma), _d(beta), 0.2)
+
+    def bnact(t):
+        v = (t - mean.view(1, -1, 1, 1)) * (invstd * gamma).view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+        return F.leaky_relu(v, 0.2)
+
+    # upsample + prologue
+    xin = F.interpolate(bnact(xs), scale_factor=2, mode="nearest")
+    ref = _conv_ref(xin, w)
+    ref.backward(dy)
+    wp = ops.pack_weight(_d(w.detach()), 0)
+    y = ops.conv2d_fwd(_d(xs), wp, Co, ks, pro=pro, upsample=True)
+    res.append(("conv_fwd_pro_up%s" % (shape,), _err(y, ref), 1e-5))
+    dw = ops.conv2d_wgrad(_d(xs), _d(dy), ks, pro=pro, upsample=True)
+    res.append(("conv_wgrad_pro_up%s" % (shape,), _err(dw, w.grad), 1e-5))
+    # prologue only, full-res input, accumulate into an existing tensor
+    xf = _rand(B, Ci, H, W, seed=11)
+    base = _rand(B, Co, H, W, seed=12)
+    ref2 = _conv_ref(bnact(xf), w.detach()) + base
+    out = _d(base).clone()
+    ops.conv2d_fwd(_d(xf), wp, Co, ks, pro=pro, out=out, accumulate=True)
+    res.append(("conv_fwd_pro_acc%s" % (shape,), _err(out, ref2), 1e-5))
+    return res
+
+
+def check_linear():
+    from sivae_hip import ops
+    res = []
+    for (B, Ci, Co) in [(16, 8192, 1024), (16, 512, 8192), (7, 100, 30), (512, 2, 256)]:
+        x = _rand(B, Ci, seed=1).requires_grad_()
+        w = _rand(Co, Ci, seed=2, scale=1.0 / math.sqrt(Ci)).requires_grad_()
+        b = _rand(Co, seed=3)
+        dy = _rand(B, Co, seed=4)
+        ref = F.linear(x, w, b)
+        ref.backward(dy)
+        wp = ops.pack_weight(_d(w.detach()), 0)
+        wpd = ops.pack_weight(_d(w.detach()), 1)
+        y = ops.conv2d_fwd(_d(x.detach()).view(B, Ci, 1, 1), wp, Co, 1, bias=_d(b))
+        res.append(("linear_fwd(%d,%d,%d)" % (B, Ci, Co), _err(y.view(B, Co), ref), 1e-5))
+        dx = ops.conv2d_fwd(_d(dy).view(B, Co, 1, 1), wpd, Ci, 1)
+        res.append(("linear_dgrad(%d,%d,%d)" % (B, Ci, Co), _err(dx.view(B, Ci), x.grad), 1e-5))
+        dw = ops.conv2d_wgrad(_d(x.detach()).view(B, Ci, 1, 1), _d(dy).view(B, Co, 1, 1), 1)
+        res.append(("linear_wgrad(%d,%d,%d)" % (B, Ci, Co), _err(dw.view(Co, Ci), w.grad), 1e-5))
+    return res
+
+
+# ------------------------------------------------------------------------------------------------ BN
+BN_SHAPES = [(4, 64, 32, 32), (8, 512, 4, 4), (3, 7, 7, 7), (2, 128, 64, 64), (16, 256, 1, 1)]
+
+
+def check_bn(shape, residual):
+    from sivae_hip import ops
+    B, C, H, W = shape
+    res = []
+    x = (_rand(B, C, H, W, seed=1) * 2.0 + 0.7).requires_grad_()
+    r = _rand(B, C, H, W, seed=2).requires_grad_() if residual else None
+    gamma = (_rand(C, seed=3) * 0.5 + 1.0).requires_grad_()
+    beta = _rand(C, seed=4).requires_grad_()
+    rm, rv = _rand(C, seed=5), _rand(C, seed=6).abs() + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    dy = _rand(B, C, H, W, seed=7)
+    bn = F.batch_norm(x, rm_ref, rv_ref, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    yref = F.leaky_relu(bn + r if residual else bn, 0.2)
+    yref.backward(dy)
+    tag = "%s%s" % (shape, "+res" if residual else "")
+
+    rm_d, rv_d = _d(rm), _d(rv)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    xd = _d(x.detach())
+    mean, invstd = ops.bn_stats(xd, rm_d, rv_d, nbt)
+    xm = x.detach().mean((0, 2, 3))
+    xv = x.detach().var((0, 2, 3), unbiased=False)
+    res.append(("bn_mean%s" % tag, _err(mean, xm), 1e-6))
+    res.append(("bn_invstd%s" % tag, _err(invstd, 1.0 / torch.sqrt(xv + 1e-5)), 1e-5))
+    res.append(("bn_running_mean%s" % tag, _err(rm_d, rm_ref), 1e-6))
+    res.append(("bn_running_var%s" % tag, _err(rv_d, rv_ref), 1e-5))
+    res.append(("bn_nbt%s" % tag, 0.0 if int(nbt.item()) == 1 else float("inf"), 0.5))
+    y = ops.bn_apply_act(xd, _d(r.detach()) if residual else None, mean, invstd, _d(gamma.detach()),
+                         _d(beta.detach()), 0.2)
+    res.append(("bn_apply%s" % tag, _err(y, yref), 1e-5))
+    dx, dz, dgamma, dbeta = ops.bn_bwd(_d(dy), y, xd, mean, invstd, _d(gamma.detach()), 0.2, want_dz=residual)
+    res.append(("bn_dx%s" % tag, _err(dx, x.grad), 2e-5))
+    res.append(("bn_dgamma%s" % tag, _err(dgamma, gamma.grad), 2e-5))
+    res.append(("bn_dbeta%s" % tag, _err(dbeta, beta.grad), 2e-5))
+    if residual:
+        res.append(("bn_dres%s" % tag, _err(dz, r.grad), 1e-5))
+    return res
+
+
+def check_bn_from_conv():
+    """conv epilogue partial statistics -> finalize == stats kernel on the conv output"""
+    from sivae_hip import ops
+    res = []
+    for shape in [(4, 32, 64, 32, 32, 3), (8, 64, 256, 8, 8, 3), (2, 3, 64, 64, 64, 5)]:
+        B, Ci, Co, H, W, ks = shape
+        x = _rand(B, Ci, H, W, seed=1)
+        w = _rand(Co, Ci, ks, ks, seed=2, scale=1.0 / math.sqrt(Ci * ks * ks))
+        wp = ops.pack_weight(_d(w), 0)
+        y, part = ops.conv2d_fwd(_d(x), wp, Co, ks, want_stats=True)
+        m1, i1 = ops.bn_stats_from_conv(part, B, Co, H * W)
+        ref = _conv_ref(x, w)
+        res.append(("bn_from_conv_mean%s" % (shape,), _err(m1, ref.mean((0, 2, 3))), 1e-5))
+        res.append(("bn_from_conv_invstd%s" % (shape,),
+                    _err(i1, 1.0 / torch.sqrt(ref.var((0, 2, 3), unbiased=False) + 1e-5)), 1e-5))
+    return res
+
+
+# ------------------------------------------------------------------------------------------------ eltwise
+def check_eltwise():
+    from sivae_hip import ops
+    res = []
+    for shape in [(2, 8, 16, 16), (3, 5, 7, 7), (2, 4, 28, 28), (2, 3, 4, 4)]:
+        x = _rand(*shape, seed=1).requires_grad_()
+        ref = F.avg_pool2d(x, 2)
+        g = _rand(*ref.shape, seed=2)
+        ref.backward(g)
+        y = ops.avgpool2_fwd(_d(x.detach()))
+        res.append(("avgpool_fwd%s" % (shape,), _err(y, ref), 1e-6))
+        dx = ops.avgpool2_bwd(_d(g), shape[2], shape[3])
+        res.append(("avgpool_bwd%s" % (shape,), _err(dx, x.grad), 1e-6))
+        x2 = _rand(*shape, seed=3).requires_grad_()
+        ref2 = F.interpolate(x2, scale_factor=2, mode="nearest")
+        g2 = _rand(*ref2.shape, seed=4)
+        ref2.backward(g2)
+        y2 = ops.upsample2_fwd(_d(x2.detach()))
+        res.append(("upsample_fwd%s" % (shape,), _err(y2, ref2), 1e-7))
+        dx2 = ops.upsample2_bwd(_d(g2))
+        res.append(("upsample_bwd%s" % (shape,), _err(dx2, x2.grad), 1e-6))
+    x = _rand(1000, seed=5).requires_grad_()
+    ref = F.relu(x)
+    g = _rand(1000, seed=6)
+    ref.backward(g)
+    y = ops.relu_fwd(_d(x.detach()))
+    res.append(("relu_fwd", _err(y, ref), 1e-7))
+    res.append(("relu_bwd", _err(ops.relu_bwd(_d(g), y), x.grad), 1e-7))
+    a, b = _rand(1003, seed=7), _rand(1003, seed=8)
+    ad = _d(a)
+    ops.add_(ad, _d(b))
+    res.append(("add_inplace", _err(ad, a + b), 1e-6))
+    return res
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def check_losses():
+    from sivae_hip import ops
+    res = []
+    for (B, Z) in [(8, 128), (128, 512), (5, 2), (3, 33)]:
+        y = _rand(B, 2 * Z, seed=1)
+        yd = _d(y)
+        mu_d, lv_d = yd[:, :Z], yd[:, Z:]
+        mu = y[:, :Z].clone().requires_grad_()
+        lv = y[:, Z:].clone().requires_grad_()
+        eps = _rand(B, Z, seed=2)
+        zref = mu + eps * torch.exp(0.5 * lv)
+        g = _rand(B, Z, seed=3)
+        zref.backward(g)
+        z = ops.reparam_fwd(mu_d, lv_d, _d(eps))
+        res.append(("reparam_fwd(%d,%d)" % (B, Z), _err(z, zref), 1e-6))
+        dmu, dlv = ops.reparam_bwd(_d(g), lv_d, _d(eps))
+        res.append(("reparam_dmu(%d,%d)" % (B, Z), _err(dmu, mu.grad), 1e-6))
+        res.append(("reparam_dlv(%d,%d)" % (B, Z), _err(dlv, lv.grad), 1e-6))
+        for (mu_o, lv_o) in [(0.0, 0.0), (0.3, -0.7)]:
+            mu.grad = None
+            lv.grad = None
+            kl = -0.5 * (1 + lv - lv_o - lv.exp() / math.exp(lv_o) - (mu - mu_o).pow(2) / math.exp(lv_o)).sum(1)
+            gk = _rand(B, seed=4)
+            kl.backward(gk)
+            klh = ops.kl_fwd(lv_d, mu_d, mu_o, lv_o)
+            res.append(("kl_fwd(%d,%d,%g)" % (B, Z, mu_o), _err(klh, kl), 1e-6))
+            dlv2, dmu2 = ops.kl_bwd(_d(gk), True, 1.0, lv_d, mu_d, mu_o, lv_o)
+            res.append(("kl_dlv(%d,%d,%g)" % (B, Z, mu_o), _err(dlv2, lv.grad), 1e-6))
+            res.append(("kl_dmu(%d,%d,%g)" % (B, Z, mu_o), _err(dmu2, mu.grad), 1e-6))
+    for (B, D) in [(8, 3072), (4, 49152), (3, 101), (2, 196608)]:
+        for lt in ("mse", "l1", "bce"):
+            if lt == "bce":
+                x = torch.rand(B, D, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+                r = torch.rand(B, D, generator=torch.Generator().manual_seed(2), dtype=torch.float64) * 0.98 + 0.01
+            else:
+                x, r = _rand(B, D, seed=1), _rand(B, D, seed=2)
+            x = x.requires_grad_()
+            r = r.requires_grad_()
+            if lt == "mse":
+                el = (r - x) ** 2
+            elif lt == "l1":
+                el = (r - x).abs()
+            else:
+                el = F.binary_cross_entropy(r, x, reduction="none")
+            rows = el.sum(1)
+            g = _rand(B, seed=3)
+            rows.backward(g)
+            out = ops.recon_rowsum_fwd(_d(x.detach()), _d(r.detach()), lt)
+            res.append(("recon_rowsum_%s(%d,%d)" % (lt, B, D), _err(out, rows), 2e-6))
+            d_r, d_x = ops.recon_bwd(_d(x.detach()), _d(r.detach()), lt, _d(g), 0, 1.0, True, True)
+            res.append(("recon_drecon_%s(%d,%d)" % (lt, B, D), _err(d_r, r.grad), 1e-5))
+            res.append(("recon_dx_%s(%d,%d)" % (lt, B, D), _err(d_x, x.grad), 1e-5))
+            if D <= 3072:
+                eo = ops.recon_elem_fwd(_d(x.detach()), _d(r.detach()), lt)
+                res.append(("recon_elem_%s(%d,%d)" % (lt, B, D), _err(eo, el), 1e-6))
+    for B in (8, 128, 300):
+        L = (_rand(B, seed=1).abs() * 1000).requires_grad_()
+        KL = (_rand(B, seed=2).abs() * 50).requires_grad_()
+        scale, br, bn = 1.0 / 3072, 1.0, 256.0
+        ref = (-2 * scale * (br * L + bn * KL)).exp().mean()
+        ref.backward()
+        out, e = ops.expelbo_fwd(_d(L.detach()), _d(KL.detach()), scale, br, bn)
+        res.append(("expelbo_fwd(%d)" % B, _err(out, ref), 1e-6))
+        gout = torch.ones((), dtype=torch.float32, device=DEV)
+        dL, dKL = ops.expelbo_bwd(gout, e, scale, br, bn)
+        res.append(("expelbo_dL(%d)" % B, _err(dL, L.grad), 1e-5))
+        res.append(("expelbo_dKL(%d)" % B, _err(dKL, KL.grad), 1e-5))
+        res.append(("vec_sum(%d)" % B, _err(ops.vec_sum(_d(L.detach()), 0.5), 0.5 * L.detach().sum()), 1e-6))
+    return res
+
+
+def check_randn():
+    from sivae_hip import ops
+    a = ops.randn((1 << 20,), 1234, 0, torch.device(DEV))
+    b = ops.randn((1 << 20,), 1234, 0, torch.device(DEV))
+    c = ops.randn((1 << 20,), 1234, 1 << 18, torch.device(DEV))
+    res = [("randn_repro", float((a - b).abs().max()), 1e-12),
+           ("randn_mean", abs(float(a.mean())), 5e-3),
+           ("randn_std", abs(float(a.std()) - 1.0), 5e-3),
+           ("randn_kurt", abs(float((a ** 4).mean()) - 3.0), 5e-2),
+           ("randn_stream_indep", abs(float((a * c).mean())), 5e-3)]
+    return res
+
+
+def check_adam():
+    from sivae_hip import ops
+    n = 10007
+    p0, g1, g2 = _rand(n, seed=1).float(), _rand(n, seed=2).float(), _rand(n, seed=3).float()
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([pr], lr=2e-4)
+    pd = p0.to(DEV).clone()
+    m = torch.zeros(n, device=DEV)
+    v = torch.zeros(n, device=DEV)
+    for step, g in enumerate((g1, g2, g1), start=1):
+        pr.grad = g.clone()
+        opt.step()
+        ops.adam_step(pd, g.to(DEV), m, v, step, 2e-4)
+    return [("adam_3steps", _err(pd - p0.to(DEV), pr.detach() - p0), 1e-5)]
+
+
+def all_checks():
+    """-> list of (label, thunk) ; every thunk returns a list of (name, err, tol)"""
+    checks = []
+    for s in CONV_SHAPES:
+        checks.append(("conv_fwd%s" % (s,), lambda s=s: check_conv_fwd(s)))
+        checks.append(("conv_dgrad%s" % (s,), lambda s=s: check_conv_dgrad(s)))
+        checks.append(("conv_wgrad%s" % (s,), lambda s=s: check_conv_wgrad(s)))
+    checks.append(("conv_fwd_bias", lambda: check_conv_fwd((2, 64, 3, 32, 32, 5), bias=True)))
+    checks.append(("conv_fwd_stats", lambda: check_conv_fwd((3, 64, 128, 32, 32, 3), stats=True)
+                   + check_conv_fwd((3, 64, 64, 32, 32, 3), stats=True)
+                   + check_conv_fwd((3, 24, 40, 12, 12, 3), stats=True)))
+    for s in [(2, 64, 128, 32, 32, 3), (2, 128, 64, 16, 16, 1), (3, 64, 64, 8, 8, 3), (2, 64, 3, 16, 16, 5)]:
+        checks.append(("conv_fused%s" % (s,), lambda s=s: check_conv_fused(s)))
+    checks.append(("linear", check_linear))
+    for s in BN_SHAPES:
+        checks.append(("bn%s" % (s,), lambda s=s: check_bn(s, False)))
+        checks.append(("bn+res%s" % (s,), lambda s=s: check_bn(s, True)))
+    checks.append(("bn_from_conv", check_bn_from_conv))
+    checks.append(("eltwise", check_eltwise))
+    checks.append(("losses", check_losses))
+    checks.append(("randn", check_randn))
+    checks.append(("adam", check_adam))
+    return checks
+
+
+def main():
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "soft-intro-vae-pytorch_amd"))
+    nfail = 0
+    rows = []
+    for label, thunk in all_checks():
+        try:
+            for name, err, tol in thunk():
+                ok = err <= tol
+                nfail += (not ok)
+                rows.append("%-4s %-58s err=%.3e tol=%.1e" % ("ok" if ok else "FAIL", name, err, tol))
+        except Exception:  # noqa: BLE001
+            nfail += 1
+            rows.append("EXC  %s\n%s" % (label, traceback.format_exc(limit=3)))
+        torch.cuda.synchronize()
+    print("\n".join(rows))
+    print("kernel_checks: %d failures of %d" % (nfail, len(rows)))
+    return nfail
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main() else 0)
