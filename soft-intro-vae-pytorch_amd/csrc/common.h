@@ -105,7 +105,9 @@ __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
 __device__ __forceinline__ float4 buf_load_f32x4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  auto q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  // NOTE: the result type must be spelled out — with `auto` hipcc (ROCm 7.2) emits a ONE-dword load
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
   return make_float4(__builtin_bit_cast(float, q[0]), __builtin_bit_cast(float, q[1]),
                      __builtin_bit_cast(float, q[2]), __builtin_bit_cast(float, q[3]));
 }

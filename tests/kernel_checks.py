@@ -353,7 +353,9 @@ def check_adam():
         pr.grad = g.clone()
         opt.step()
         ops.adam_step(pd, g.to(DEV), m, v, step, 2e-4)
-    return [("adam_3steps", _err(pd - p0.to(DEV), pr.detach() - p0), 1e-5)]
+    # (the update is ~1e-3 of |p|, so compare p itself: fp32 rounding of p dominates the update error)
+    return [("adam_3steps", _err(pd, pr.detach()), 1e-6),
+            ("adam_3steps_update", _err(pd - p0.to(DEV), pr.detach() - p0), 2e-3)]
 
 
 def all_checks():
@@ -387,7 +389,10 @@ def main():
     sys.path.insert(0, os.path.join(os.path.dirname(here), "soft-intro-vae-pytorch_amd"))
     nfail = 0
     rows = []
+    filt = sys.argv[1:]
     for label, thunk in all_checks():
+        if filt and not any(f in label for f in filt):
+            continue
         try:
             for name, err, tol in thunk():
                 ok = err <= tol
