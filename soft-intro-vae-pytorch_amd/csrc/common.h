@@ -105,11 +105,13 @@ __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
 __device__ __forceinline__ float4 buf_load_f32x4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  // NOTE: the result type must be spelled out — with `auto` hipcc (ROCm 7.2) emits a ONE-dword load
+  // NOTE (hipcc / ROCm 7.2): take the result as a u32x4 and bit-cast the WHOLE vector. Per-element
+  // `__builtin_bit_cast(float, q[i])` (or an `auto` result) makes the compiler emit a ONE-dword load
+  // and leaves the other three lanes of the result undefined — verify `buffer_load_dwordx4` in the .s.
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
   const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
-  return make_float4(__builtin_bit_cast(float, q[0]), __builtin_bit_cast(float, q[1]),
-                     __builtin_bit_cast(float, q[2]), __builtin_bit_cast(float, q[3]));
+  const f32x4 f = __builtin_bit_cast(f32x4, q);
+  return make_float4(f[0], f[1], f[2], f[3]);
 }
 
 // exact floor(e / d) for e < 2^22, d < 2^10 with magic = floor(2^32 / d) + 1

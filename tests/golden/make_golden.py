@@ -1,0 +1,347 @@
+"""Generate the golden fixtures from the REAL reference (runs only where /root/reference is mounted).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference has no tests of its own, so parity is pinned by importing it here (torchvision, which the
+image lacks, is stubbed in sys.modules — only dataset/image-dump helpers use it) and recording inputs
+and outputs as plain arrays:
+
+  helpers.npz        calc_kl / calc_reconstruction_loss / reparameterize on seeded inputs
+  step_<case>.npz    one Soft-IntroVAE iteration re-sequenced from the reference's own modules and
+                     helpers: initial state_dict, inputs, the Gaussian draws, every intermediate
+                     (mu, logvar, z, rec, fake, ...), all loss scalars, selected gradients
+  loop_<case>.npz    the reference's UNMODIFIED train_soft_intro_vae() / train_soft_intro_vae_toy()
+                     run for a few iterations on synthetic data with every RNG draw and every batch
+                     recorded, plus initial and final state_dict — pins the whole E/D schedule, the
+                     detach/requires_grad semantics and the Adam updates end to end.
+
+Only narrow channel widths are used so the fixtures stay small; the layer pattern is the reference's.
+Nothing from /root/reference is copied: fixtures are inputs/outputs only.
+"""
+import importlib
+import importlib.machinery
+import os
+import sys
+import tempfile
+import types
+from unittest import mock
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _stub_torchvision():
+    for name in ["torchvision", "torchvision.utils", "torchvision.datasets", "torchvision.transforms",
+                 "torchvision.models"]:
+        m = mock.MagicMock(name=name)
+        m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+        m.__path__ = []
+        sys.modules[name] = m
+
+
+def _import_ref(subdir, module):
+    for k in [k for k in sys.modules if k in ("dataset", "metrics", module) or k.startswith("metrics.")]:
+        del sys.modules[k]
+    sys.path.insert(0, os.path.join(REF, subdir))
+    try:
+        return importlib.import_module(module)
+    finally:
+        sys.path.pop(0)
+
+
+def _np(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def _sd(model, prefix):
+    return {prefix + k: _np(v) for k, v in model.state_dict().items()}
+
+
+class RandnRecorder:
+    """records every torch.randn / torch.randn_like result (in call order) while active"""
+
+    def __init__(self):
+        self.draws = []
+        self._randn, self._randn_like = torch.randn, torch.randn_like
+
+    def __enter__(self):
+        rec = self
+
+        def randn(*a, **k):
+            out = rec._randn(*a, **k)
+            rec.draws.append(_np(out))
+            return out
+
+        def randn_like(*a, **k):
+            out = rec._randn_like(*a, **k)
+            rec.draws.append(_np(out))
+            return out
+
+        torch.randn, torch.randn_like = randn, randn_like
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn, torch.randn_like = self._randn, self._randn_like
+
+
+# --------------------------------------------------------------------------------------------------
+def make_helpers(T):
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    mu = torch.randn(6, 10, generator=g)
+    lv = torch.randn(6, 10, generator=g) * 0.5
+    out["mu"], out["logvar"] = _np(mu), _np(lv)
+    for red in ("sum", "mean", "none"):
+        out["kl_%s" % red] = _np(T.calc_kl(lv, mu, reduce=red))
+        out["kl_o_%s" % red] = _np(T.calc_kl(lv, mu, mu_o=0.3, logvar_o=-0.7, reduce=red))
+    x = torch.rand(5, 3, 4, 4, generator=g)
+    r = torch.rand(5, 3, 4, 4, generator=g) * 0.98 + 0.01
+    out["x"], out["recon"] = _np(x), _np(r)
+    for lt in ("mse", "l1", "bce"):
+        for red in ("sum", "mean", "none"):
+            out["rec_%s_%s" % (lt, red)] = _np(T.calc_reconstruction_loss(x, r, loss_type=lt, reduction=red))
+    with RandnRecorder() as rr:
+        z = T.reparameterize(mu, lv)
+    out["reparam_eps"], out["reparam_z"] = rr.draws[0], _np(z)
+    np.savez_compressed(os.path.join(OUT, "helpers.npz"), **out)
+    print("helpers.npz", len(out))
+
+
+def make_step(T, name, cdim, zdim, channels, image_size, B, hp, bootstrap=False, seed=0):
+    """One iteration re-sequenced from the reference's modules (order of train_soft_intro_vae.py:547-624)."""
+    torch.manual_seed(seed)
+    model = T.SoftIntroVAE(cdim=cdim, zdim=zdim, channels=channels, image_size=image_size)
+    model.train()
+    out = {"meta_cdim": cdim, "meta_zdim": zdim, "meta_channels": np.array(channels), "meta_image_size": image_size,
+           "meta_bootstrap": int(bootstrap)}
+    for k, v in hp.items():
+        out["hp_" + k] = v
+    out.update(_sd(model, "init/"))
+    g = torch.Generator().manual_seed(1234)
+    real = torch.rand(B, cdim, image_size, image_size, generator=g)
+    noise = torch.randn(B, zdim, generator=g)
+    out["real"], out["noise"] = _np(real), _np(noise)
+    scale = 1 / (cdim * image_size ** 2)
+    br, bk, bn, gr = hp["beta_rec"], hp["beta_kl"], hp["beta_neg"], hp["gamma_r"]
+    opt_e = torch.optim.Adam(model.encoder.parameters(), lr=hp["lr"])
+    opt_d = torch.optim.Adam(model.decoder.parameters(), lr=hp["lr"])
+    frozen = [model.decoder] + ([model.target_decoder] if bootstrap else [])
+
+    with RandnRecorder() as rr:
+        # ---- E step
+        for p in model.encoder.parameters():
+            p.requires_grad = True
+        for m in frozen:
+            for p in m.parameters():
+                p.requires_grad = False
+        fake = model.sample(noise)
+        real_mu, real_logvar = model.encode(real)
+        z = T.reparameterize(real_mu, real_logvar)
+        rec = model.decoder(z)
+        loss_rec = T.calc_reconstruction_loss(real, rec, loss_type="mse", reduction="mean")
+        kl_real = T.calc_kl(real_logvar, real_mu, reduce="mean")
+        rec_mu, rec_logvar, z_rec, rec_rec = model(rec.detach())
+        fake_mu, fake_logvar, z_fake, rec_fake = model(fake.detach())
+        kl_rec = T.calc_kl(rec_logvar, rec_mu, reduce="none")
+        kl_fake = T.calc_kl(fake_logvar, fake_mu, reduce="none")
+        l_rr = T.calc_reconstruction_loss(rec, rec_rec, loss_type="mse", reduction="none")
+        l_rf = T.calc_reconstruction_loss(fake, rec_fake, loss_type="mse", reduction="none")
+        expelbo_rec = (-2 * scale * (br * l_rr + bn * kl_rec)).exp().mean()
+        expelbo_fake = (-2 * scale * (br * l_rf + bn * kl_fake)).exp().mean()
+        lossE = scale * (br * loss_rec + bk * kl_real) + 0.25 * (expelbo_rec + expelbo_fake)
+        opt_e.zero_grad()
+        lossE.backward()
+        e_tensors = dict(fake=fake, real_mu=real_mu, real_logvar=real_logvar, z=z, rec=rec, loss_rec=loss_rec,
+                         kl_real=kl_real, rec_mu=rec_mu, rec_logvar=rec_logvar, rec_rec=rec_rec, fake_mu=fake_mu,
+                         fake_logvar=fake_logvar, rec_fake=rec_fake, kl_rec=kl_rec, kl_fake=kl_fake,
+                         expelbo_rec=expelbo_rec, expelbo_fake=expelbo_fake, lossE=lossE)
+        for k, v in e_tensors.items():
+            out["E/" + k] = _np(v)
+        for k, p in model.encoder.named_parameters():
+            out["E/grad/encoder." + k] = _np(p.grad)
+        opt_e.step()
+        # ---- D step
+        for p in model.encoder.parameters():
+            p.requires_grad = False
+        for p in model.decoder.parameters():
+            p.requires_grad = True
+        fake = model.sample(noise)
+        rec = model.decoder(z.detach())
+        loss_rec = T.calc_reconstruction_loss(real, rec, loss_type="mse", reduction="mean")
+        rec_mu, rec_logvar = model.encode(rec)
+        z_rec = T.reparameterize(rec_mu, rec_logvar)
+        fake_mu, fake_logvar = model.encode(fake)
+        z_fake = T.reparameterize(fake_mu, fake_logvar)
+        if bootstrap:
+            rec_rec = model.decode_target(z_rec)
+            rec_fake = model.decode_target(z_fake)
+            l_rr = T.calc_reconstruction_loss(rec, rec_rec, loss_type="mse", reduction="mean")
+            l_fr = T.calc_reconstruction_loss(fake, rec_fake, loss_type="mse", reduction="mean")
+        else:
+            rec_rec = model.decode(z_rec.detach())
+            rec_fake = model.decode(z_fake.detach())
+            l_rr = T.calc_reconstruction_loss(rec.detach(), rec_rec, loss_type="mse", reduction="mean")
+            l_fr = T.calc_reconstruction_loss(fake.detach(), rec_fake, loss_type="mse", reduction="mean")
+        kl_rec = T.calc_kl(rec_logvar, rec_mu, reduce="mean")
+        kl_fake = T.calc_kl(fake_logvar, fake_mu, reduce="mean")
+        lossD = scale * (loss_rec * br + (kl_rec + kl_fake) * 0.5 * bk + gr * 0.5 * br * (l_rr + l_fr))
+        opt_d.zero_grad()
+        lossD.backward()
+        d_tensors = dict(fake=fake, rec=rec, loss_rec=loss_rec, rec_mu=rec_mu, rec_logvar=rec_logvar,
+                         fake_mu=fake_mu, fake_logvar=fake_logvar, rec_rec=rec_rec, rec_fake=rec_fake,
+                         loss_rec_rec=l_rr, loss_fake_rec=l_fr, kl_rec=kl_rec, kl_fake=kl_fake, lossD=lossD)
+        for k, v in d_tensors.items():
+            out["D/" + k] = _np(v)
+        for k, p in model.decoder.named_parameters():
+            out["D/grad/decoder." + k] = _np(p.grad)
+        opt_d.step()
+    assert len(rr.draws) == 5, len(rr.draws)
+    for i, d in enumerate(rr.draws):
+        out["eps%d" % i] = d
+    out.update(_sd(model, "final/"))
+    np.savez_compressed(os.path.join(OUT, "step_%s.npz" % name), **out)
+    print("step_%s.npz" % name, "lossE=%.6g lossD=%.6g" % (float(lossE), float(lossD)))
+
+
+def make_loop(T, name, cdim, image_size, narrow_channels, zdim, B, n_batches, kwargs, bootstrap=False,
+              dataset_key="cifar10"):
+    """Run the reference's own training function, unmodified, on synthetic data; record everything."""
+    g = torch.Generator().manual_seed(99)
+    data = torch.rand(B * n_batches, cdim, image_size, image_size, generator=g)
+    labels = torch.zeros(B * n_batches, dtype=torch.long)
+    captured = {}
+    RealVAE = T.SoftIntroVAE
+
+    def narrow_factory(cdim=3, zdim=512, channels=None, image_size=256, **kw):
+        m = RealVAE(cdim=cdim, zdim=zdim, channels=narrow_channels, image_size=image_size, **kw)
+        captured["model"] = m
+        captured["init"] = {k: v.clone() for k, v in m.state_dict().items()}
+        return m
+
+    batches = []
+    RealLoader = torch.utils.data.DataLoader
+
+    class RecLoader(RealLoader):
+        def __iter__(self):
+            for b in super().__iter__():
+                batches.append(_np(b[0]))
+                yield b
+
+    ds_name = {"cifar10": "CIFAR10", "mnist": "MNIST", "svhn": "SVHN"}[dataset_key]
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            with mock.patch.object(T, "SoftIntroVAE", narrow_factory), \
+                    mock.patch.object(T, ds_name, lambda **kw: torch.utils.data.TensorDataset(data, labels)), \
+                    mock.patch.object(T, "DataLoader", RecLoader), RandnRecorder() as rr:
+                T.train_soft_intro_vae(dataset=dataset_key, z_dim=zdim, batch_size=B, num_workers=0, num_epochs=1,
+                                       device=torch.device("cpu"), **kwargs)
+        finally:
+            os.chdir(cwd)
+    model = captured["model"]
+    out = {"meta_cdim": cdim, "meta_zdim": zdim, "meta_channels": np.array(narrow_channels),
+           "meta_image_size": image_size, "meta_bootstrap": int(bootstrap), "meta_n_iters": len(batches)}
+    for k, v in kwargs.items():
+        if isinstance(v, (int, float)):
+            out["hp_" + k] = v
+    for k, v in captured["init"].items():
+        out["init/" + k] = _np(v)
+    for k, v in model.state_dict().items():
+        out["final/" + k] = _np(v)
+    for i, b in enumerate(batches):
+        out["batch%d" % i] = b
+    # per iteration: noise_batch (randn) then 5 randn_like draws; the epoch-end dump adds one more randn
+    for i, d in enumerate(rr.draws):
+        out["draw%d" % i] = d
+    out["meta_n_draws"] = len(rr.draws)
+    np.savez_compressed(os.path.join(OUT, "loop_%s.npz" % name), **out)
+    print("loop_%s.npz" % name, "iters", len(batches), "draws", len(rr.draws))
+
+
+def make_loop_2d(T2):
+    batches = []
+    RealDS = T2.ToyDataset
+
+    class RecDS(RealDS):
+        def next_batch(self, batch_size=64, device=None, sig=0.02):
+            b = super().next_batch(batch_size=batch_size, device=device, sig=sig)
+            batches.append(_np(b))
+            return b
+
+    captured = {}
+    RealVAE = T2.SoftIntroVAESimple
+
+    def factory(**kw):
+        m = RealVAE(**kw)
+        captured["init"] = {k: v.clone() for k, v in m.state_dict().items()}
+        return m
+
+    n_iter, num_vae, B = 6, 2, 64
+    kwargs = dict(z_dim=2, lr_e=2e-4, lr_d=2e-4, batch_size=B, n_iter=n_iter, num_vae=num_vae, save_interval=5000,
+                  recon_loss_type="mse", beta_kl=0.3, beta_rec=0.2, beta_neg=0.9, test_iter=5000, seed=92, scale=1,
+                  dataset="8Gaussians")
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            # the end-of-training evaluation (density plots, grid ELBO, histogram KL/JSD) is not part of the
+            # hot path: stub it out so the run only executes the training iterations
+            with mock.patch.object(T2, "ToyDataset", RecDS), mock.patch.object(T2, "SoftIntroVAESimple", factory), \
+                    mock.patch.object(T2, "plot_samples_density", lambda *a, **k: None), \
+                    mock.patch.object(T2, "plot_vae_density", lambda *a, **k: None), \
+                    mock.patch.object(T2, "calculate_sample_kl", lambda *a, **k: 0.0), \
+                    mock.patch.object(T2, "calculate_elbo_with_grid", lambda *a, **k: 0.0), \
+                    mock.patch.object(T2.plt, "savefig", lambda *a, **k: None), RandnRecorder() as rr:
+                model = T2.train_soft_intro_vae_toy(device=torch.device("cpu"), **kwargs)
+        finally:
+            os.chdir(cwd)
+    out = {"meta_n_iter": n_iter, "meta_num_vae": num_vae, "meta_B": B}
+    for k, v in kwargs.items():
+        if isinstance(v, (int, float)):
+            out["hp_" + k] = v
+    for k, v in captured["init"].items():
+        out["init/" + k] = _np(v)
+    for k, v in model.state_dict().items():
+        out["final/" + k] = _np(v)
+    # training batches are the first n_iter next_batch calls (later calls come from the plotting code)
+    for i in range(n_iter):
+        out["batch%d" % i] = batches[i]
+    for i, d in enumerate(rr.draws):
+        out["draw%d" % i] = d
+    out["meta_n_draws"] = len(rr.draws)
+    np.savez_compressed(os.path.join(OUT, "loop_2d.npz"), **out)
+    print("loop_2d.npz draws", len(rr.draws), "batches", len(batches))
+
+
+def main():
+    torch.set_num_threads(4)
+    _stub_torchvision()
+    T = _import_ref("soft_intro_vae", "train_soft_intro_vae")
+    make_helpers(T)
+    hp = dict(beta_rec=1.0, beta_kl=1.0, beta_neg=256.0, gamma_r=1e-8, lr=2e-4)
+    make_step(T, "cifar_narrow", 3, 32, [16, 32, 64], 32, 8, hp)
+    hp2 = dict(beta_rec=0.5, beta_kl=1.0, beta_neg=1024.0, gamma_r=1e-8, lr=2e-4)
+    make_step(T, "deep64_narrow", 3, 24, [8, 16, 32, 32], 64, 4, hp2, seed=1)
+    make_step(T, "mnist_narrow", 1, 8, [8, 16], 28, 6, hp, seed=2)
+    make_loop(T, "cifar_narrow", 3, 32, [8, 16, 32], 16, 8, 3,
+              dict(lr_e=2e-4, lr_d=2e-4, num_vae=0, beta_kl=1.0, beta_rec=1.0, beta_neg=256, seed=5,
+                   test_iter=1000, save_interval=50, start_epoch=0))
+    make_loop(T, "vae_branch", 3, 32, [8, 16, 32], 16, 8, 2,
+              dict(lr_e=2e-4, lr_d=2e-4, num_vae=1, beta_kl=1.0, beta_rec=1.0, beta_neg=256, seed=6,
+                   test_iter=1000, save_interval=50, start_epoch=0))
+    TB = _import_ref("soft_intro_vae_bootstrap", "train_soft_intro_vae_bootstrap")
+    hpb = dict(beta_rec=1.0, beta_kl=1.0, beta_neg=256.0, gamma_r=1.0, lr=2e-4)
+    make_step(TB, "bootstrap_narrow", 3, 32, [16, 32, 64], 32, 8, hpb, bootstrap=True, seed=3)
+    make_loop(TB, "bootstrap_narrow", 3, 32, [8, 16, 32], 16, 8, 3,
+              dict(lr_e=2e-4, lr_d=2e-4, num_vae=0, beta_kl=1.0, beta_rec=1.0, beta_neg=256, seed=7,
+                   test_iter=1000, save_interval=50, start_epoch=0, copy_to_target_freq=1), bootstrap=True)
+    T2 = _import_ref("soft_intro_vae_2d", "train_soft_intro_vae_2d")
+    make_loop_2d(T2)
+
+
+if __name__ == "__main__":
+    main()
