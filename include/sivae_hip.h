@@ -84,11 +84,14 @@ int sivae_bn_stats_from_conv(const float* partials, int n_tiles, int B, int C, i
 int sivae_bn_apply_act(const float* x, const float* res, const float* mean, const float* invstd,
                        const float* gamma, const float* beta, float slope, float* y, int B, int C, int HW,
                        sivae_stream_t stream);
-/* backward of the above: dz = dy*(y>0?1:slope) (y = saved OUTPUT, may be NULL for no activation);
- * dx = BN backward of dz; dz_out (optional) = gradient of the residual branch; dgamma/dbeta optional. */
+/* backward of the above: dz = dy*(s>0?1:slope); dx = BN backward of dz; dz_out (optional) = gradient
+ * of the residual branch; dgamma/dbeta optional.  act_mode selects where the LeakyReLU sign s comes from:
+ *   0 no activation, 1 the saved OUTPUT y (valid since slope > 0), 2 recomputed from x (needs beta; used
+ *   when the BatchNorm output was never stored because it was fused into the next conv's load). */
 int sivae_bn_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
-                 const float* gamma, float slope, float* dx, float* dz_out, float* dgamma, float* dbeta, int B,
-                 int C, int HW, void* workspace, size_t workspace_bytes, sivae_stream_t stream);
+                 const float* gamma, const float* beta, int act_mode, float slope, float* dx, float* dz_out,
+                 float* dgamma, float* dbeta, int B, int C, int HW, void* workspace, size_t workspace_bytes,
+                 sivae_stream_t stream);
 /* out[c] = sum over (B, HW) — bias gradient of Decoder.predict (:159). Workspace as sivae_bn_workspace_bytes. */
 int sivae_channel_sum(const float* x, float* out, int B, int C, int HW, void* workspace, size_t workspace_bytes,
                       sivae_stream_t stream);

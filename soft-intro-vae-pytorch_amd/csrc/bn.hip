@@ -240,10 +240,13 @@ extern "C" int sivae_bn_apply_act(const float* x, const float* res, const float*
 // pass 1: per-channel partial sums (fp64), pass 2: coefficients, pass 3: dx / dz.
 // If y == nullptr no activation mask is applied.
 // ------------------------------------------------------------------------------------------------
+template <int ACT>
 __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                              const float* __restrict__ x,
                                                              const float* __restrict__ mean,
-                                                             const float* __restrict__ invstd, float slope,
+                                                             const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float slope,
                                                              double* __restrict__ part, int C, int HW,
                                                              long long n_per_ch, long long slice_len, int S) {
   __shared__ double red[4];
@@ -252,6 +255,7 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float* __rest
   long long n1 = n0 + slice_len;
   if (n1 > n_per_ch) n1 = n_per_ch;
   const float m = mean[c], is = invstd[c];
+  const float gsc = ACT == 2 ? is * gamma[c] : 0.f, bt = ACT == 2 ? beta[c] : 0.f;
   double s1 = 0.0, s2 = 0.0;
   if ((HW & 3) == 0) {
     for (long long n = n0 + (long long)threadIdx.x * 4; n < n1; n += 1024) {
@@ -260,12 +264,17 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float* __rest
       const float4 g = *reinterpret_cast<const float4*>(dy + o);
       const float4 xv = *reinterpret_cast<const float4*>(x + o);
       float gz[4] = {g.x, g.y, g.z, g.w};
-      if (y) {
+      if (ACT == 1) {
         const float4 yv = *reinterpret_cast<const float4*>(y + o);
         gz[0] = yv.x > 0.f ? gz[0] : gz[0] * slope;
         gz[1] = yv.y > 0.f ? gz[1] : gz[1] * slope;
         gz[2] = yv.z > 0.f ? gz[2] : gz[2] * slope;
         gz[3] = yv.w > 0.f ? gz[3] : gz[3] * slope;
+      } else if (ACT == 2) {
+        gz[0] = ((xv.x - m) * gsc + bt) > 0.f ? gz[0] : gz[0] * slope;
+        gz[1] = ((xv.y - m) * gsc + bt) > 0.f ? gz[1] : gz[1] * slope;
+        gz[2] = ((xv.z - m) * gsc + bt) > 0.f ? gz[2] : gz[2] * slope;
+        gz[3] = ((xv.w - m) * gsc + bt) > 0.f ? gz[3] : gz[3] * slope;
       }
       const float xh[4] = {(xv.x - m) * is, (xv.y - m) * is, (xv.z - m) * is, (xv.w - m) * is};
 #pragma unroll
@@ -279,7 +288,8 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float* __rest
       const long long b = n / HW;
       const size_t o = ((size_t)b * C + c) * HW + (size_t)(n - b * HW);
       float g = dy[o];
-      if (y) g = y[o] > 0.f ? g : g * slope;
+      if (ACT == 1) g = y[o] > 0.f ? g : g * slope;
+      if (ACT == 2) g = ((x[o] - m) * gsc + bt) > 0.f ? g : g * slope;
       s1 += (double)g;
       s2 += (double)g * (double)((x[o] - m) * is);
     }
@@ -308,11 +318,12 @@ __global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const double* __res
   coef[c * 2 + 1] = (float)(s2 / count);
 }
 
-template <bool HAS_Y, bool HAS_DZ, bool VEC>
+template <int ACT, bool HAS_DZ, bool VEC>
 __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                         const float* __restrict__ x, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd,
                                                         const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
                                                         const float* __restrict__ coef, float slope,
                                                         float* __restrict__ dx, float* __restrict__ dz_out, int C,
                                                         int HW, size_t numel) {
@@ -326,12 +337,18 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const float* __restrict_
       const float4 g = reinterpret_cast<const float4*>(dy)[i];
       const float4 xv = reinterpret_cast<const float4*>(x)[i];
       float gz[4] = {g.x, g.y, g.z, g.w};
-      if (HAS_Y) {
+      if (ACT == 1) {
         const float4 yv = reinterpret_cast<const float4*>(y)[i];
         gz[0] = yv.x > 0.f ? gz[0] : gz[0] * slope;
         gz[1] = yv.y > 0.f ? gz[1] : gz[1] * slope;
         gz[2] = yv.z > 0.f ? gz[2] : gz[2] * slope;
         gz[3] = yv.w > 0.f ? gz[3] : gz[3] * slope;
+      } else if (ACT == 2) {
+        const float bt = beta[c];
+        gz[0] = ((xv.x - m) * gs + bt) > 0.f ? gz[0] : gz[0] * slope;
+        gz[1] = ((xv.y - m) * gs + bt) > 0.f ? gz[1] : gz[1] * slope;
+        gz[2] = ((xv.z - m) * gs + bt) > 0.f ? gz[2] : gz[2] * slope;
+        gz[3] = ((xv.w - m) * gs + bt) > 0.f ? gz[3] : gz[3] * slope;
       }
       float4 o;
       o.x = gs * (gz[0] - c1 - (xv.x - m) * is * c2);
@@ -346,7 +363,8 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const float* __restrict_
       const int c = (int)((e / HW) % C);
       const float m = mean[c], is = invstd[c];
       float g = dy[e];
-      if (HAS_Y) g = y[e] > 0.f ? g : g * slope;
+      if (ACT == 1) g = y[e] > 0.f ? g : g * slope;
+      if (ACT == 2) g = ((x[e] - m) * (is * gamma[c]) + beta[c]) > 0.f ? g : g * slope;
       dx[e] = gamma[c] * is * (g - coef[c * 2] - (x[e] - m) * is * coef[c * 2 + 1]);
       if (HAS_DZ) dz_out[e] = g;
     }
@@ -354,18 +372,24 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const float* __restrict_
 }
 
 extern "C" int sivae_bn_bwd(const float* dy, const float* y, const float* x, const float* mean,
-                            const float* invstd, const float* gamma, float slope, float* dx, float* dz_out,
-                            float* dgamma, float* dbeta, int B, int C, int HW, void* workspace,
-                            size_t workspace_bytes, hipStream_t stream) {
+                            const float* invstd, const float* gamma, const float* beta, int act_mode,
+                            float slope, float* dx, float* dz_out, float* dgamma, float* dbeta, int B, int C,
+                            int HW, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!dy || !x || !mean || !invstd || !gamma || !dx) return SIVAE_ERR_NULL;
+  if (act_mode < 0 || act_mode > 2) return SIVAE_ERR_MODE;
+  if (act_mode == 1 && !y) return SIVAE_ERR_NULL;
+  if (act_mode == 2 && !beta) return SIVAE_ERR_NULL;
   if (B <= 0 || C <= 0 || HW <= 0) return SIVAE_ERR_SHAPE;
   if (!workspace || workspace_bytes < sivae_bn_workspace_bytes(B, C, HW)) return SIVAE_ERR_WORKSPACE;
   const long long n = (long long)B * HW;
   SlicePlan p = plan_slices(n, C);
   double* part = (double*)workspace;
   float* coef = (float*)(part + (size_t)C * p.S * 2);
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, p.S), dim3(256), 0, stream, dy, y, x, mean, invstd, slope, part,
-                     C, HW, n, p.len, p.S);
+#define LAUNCHP(A) \
+  hipLaunchKernelGGL((bn_bwd_partial_kernel<A>), dim3(C, p.S), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma, \
+                     beta, slope, part, C, HW, n, p.len, p.S)
+  if (act_mode == 0) LAUNCHP(0); else if (act_mode == 1) LAUNCHP(1); else LAUNCHP(2);
+#undef LAUNCHP
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, (const double*)part, p.S, C,
                      (double)n, dgamma, dbeta, coef);
   const size_t numel = (size_t)B * C * HW;
@@ -374,14 +398,15 @@ extern "C" int sivae_bn_bwd(const float* dy, const float* y, const float* x, con
   int nb = cdiv(work, 256);
   if (nb > 8192) nb = 8192;
   if (nb < 1) nb = 1;
-#define LAUNCH(Y, Z, V) \
-  hipLaunchKernelGGL((bn_bwd_dx_kernel<Y, Z, V>), dim3(nb), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma, \
-                     (const float*)coef, slope, dx, dz_out, C, HW, numel)
-  const bool hy = y != nullptr, hz = dz_out != nullptr;
-  if (hy && hz) { if (vec) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
-  else if (hy) { if (vec) LAUNCH(true, false, true); else LAUNCH(true, false, false); }
-  else if (hz) { if (vec) LAUNCH(false, true, true); else LAUNCH(false, true, false); }
-  else { if (vec) LAUNCH(false, false, true); else LAUNCH(false, false, false); }
+#define LAUNCH(A, Z, V) \
+  hipLaunchKernelGGL((bn_bwd_dx_kernel<A, Z, V>), dim3(nb), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma, \
+                     beta, (const float*)coef, slope, dx, dz_out, C, HW, numel)
+#define LAUNCH_A(A) \
+  { if (hz) { if (vec) LAUNCH(A, true, true); else LAUNCH(A, true, false); } \
+    else { if (vec) LAUNCH(A, false, true); else LAUNCH(A, false, false); } }
+  const bool hz = dz_out != nullptr;
+  if (act_mode == 0) LAUNCH_A(0) else if (act_mode == 1) LAUNCH_A(1) else LAUNCH_A(2)
+#undef LAUNCH_A
 #undef LAUNCH
   return sivae_launch_status();
 }

@@ -1,0 +1,211 @@
+"""The Soft-IntroVAE training iteration (E-step / D-step / vanilla-VAE step) on the HIP blocks.
+
+One engine serves `train_soft_intro_vae` and `train_soft_intro_vae_bootstrap` (and bench.py):
+  reference schedule   soft_intro_vae/train_soft_intro_vae.py:542-624 (vanilla branch :512-540)
+  bootstrap deltas     soft_intro_vae_bootstrap/train_soft_intro_vae_bootstrap.py:576-652
+The pass list, detach points and requires_grad toggles are the reference's; what changes is where the
+work runs (fused HIP blocks), where the Gaussian draws come from (device Philox stream, or injected
+tensors for parity tests), that gradients live in two flat buffers (one all-reduce per network under
+data parallelism) and that all logged scalars come back in ONE device->host copy per iteration instead of
+~12 `.item()` syncs.
+"""
+import torch
+
+from . import functional as SF
+from . import rng
+
+
+# ---- reference helper surface (same names / argument meaning / errors) ------------------------------
+def reparameterize(mu, logvar, eps=None):
+    """z = mu + eps * exp(0.5 logvar); eps ~ N(0, I) from the device Philox stream unless given."""
+    if eps is None:
+        eps = rng.randn(mu.shape, mu.device)
+    return SF.reparameterize(mu, logvar, eps)
+
+
+def _as_float(v):
+    return float(v.item()) if isinstance(v, torch.Tensor) else float(v)
+
+
+def calc_kl(logvar, mu, mu_o=0.0, logvar_o=0.0, reduce="sum"):
+    """reduce in {'sum', 'mean'}; anything else returns the per-sample vector (reference :247-251)"""
+    red = reduce if reduce in ("sum", "mean") else "none"
+    return SF.kl(logvar, mu, _as_float(mu_o), _as_float(logvar_o), red)
+
+
+def calc_reconstruction_loss(x, recon_x, loss_type="mse", reduction="sum"):
+    if reduction not in ("sum", "mean", "none"):
+        raise NotImplementedError
+    if loss_type not in ("mse", "l1", "bce"):
+        raise NotImplementedError
+    B = x.size(0)
+    D = x.numel() // B
+    if loss_type == "mse":
+        if reduction == "none":
+            return SF.ReconFn.apply(x, recon_x, "mse", "rows", 1.0)
+        return SF.ReconFn.apply(x, recon_x, "mse", "total", 1.0 if reduction == "sum" else 1.0 / B)
+    if reduction == "none":
+        return SF.ReconFn.apply(x, recon_x, loss_type, "elem", 1.0).view(B, D)
+    return SF.ReconFn.apply(x, recon_x, loss_type, "total", 1.0 if reduction == "sum" else 1.0 / (B * D))
+
+
+def _per_sample(v):
+    while v.dim() > 1:
+        v = v.sum(-1)
+    return v
+
+
+STAT_NAMES = ("lossE", "lossD", "loss_rec", "kl_real", "kl_fake", "kl_rec", "expelbo_rec", "expelbo_fake")
+
+
+class SoftIntroEngine:
+    """Owns the two flat-buffer optimizers and runs iterations on a SoftIntroVAE model."""
+
+    def __init__(self, model, opt_e, opt_d, beta_kl=1.0, beta_rec=1.0, beta_neg=1.0, gamma_r=1e-8,
+                 recon_loss_type="mse", bootstrap=False, grad_sync=None):
+        self.model, self.opt_e, self.opt_d = model, opt_e, opt_d
+        self.beta_kl, self.beta_rec, self.beta_neg, self.gamma_r = beta_kl, beta_rec, beta_neg, gamma_r
+        self.loss_type = recon_loss_type
+        self.bootstrap = bootstrap
+        self.grad_sync = grad_sync  # callable(flat_grad) -> None (RCCL all-reduce mean) or None
+        self.last_z = None
+
+    # -- requires_grad toggles (reference :552-555, :592-595) -----------------------------------------
+    def _train_encoder_only(self):
+        for p in self.model.encoder.parameters():
+            p.requires_grad = True
+        for p in self.model.decoder.parameters():
+            p.requires_grad = False
+        if self.bootstrap:
+            for p in self.model.target_decoder.parameters():
+                p.requires_grad = False
+
+    def _train_decoder_only(self):
+        for p in self.model.encoder.parameters():
+            p.requires_grad = False
+        for p in self.model.decoder.parameters():
+            p.requires_grad = True
+        if self.bootstrap:
+            for p in self.model.target_decoder.parameters():
+                p.requires_grad = False
+
+    def _second_decoder(self):
+        return self.model.target_decoder if self.bootstrap else self.model.decoder
+
+    def _sync(self, opt):
+        if self.grad_sync is not None:
+            self.grad_sync(opt.flat_grad)
+
+    # -- vanilla VAE step (reference :516-533) ----------------------------------------------------------
+    def vae_step(self, real, eps=None):
+        m = self.model
+        for p in m.encoder.parameters():
+            p.requires_grad = True
+        for p in m.decoder.parameters():
+            p.requires_grad = True
+        mu, logvar = m.encode(real)
+        z = reparameterize(mu, logvar, eps)
+        rec = self._second_decoder()(z) if self.bootstrap else m.decoder(z)
+        loss_rec = calc_reconstruction_loss(real, rec, self.loss_type, "mean")
+        loss_kl = calc_kl(logvar, mu, reduce="mean")
+        loss = self.beta_rec * loss_rec + self.beta_kl * loss_kl
+        self.opt_d.zero_grad()
+        self.opt_e.zero_grad()
+        loss.backward()
+        self._sync(self.opt_e)
+        self._sync(self.opt_d)
+        self.opt_e.step()
+        self.opt_d.step()
+        return {"loss": loss.detach(), "loss_rec": loss_rec.detach(), "loss_kl": loss_kl.detach(), "rec": rec.detach()}
+
+    # -- Soft-Intro iteration (reference :547-624) --------------------------------------------------------
+    def soft_intro_step(self, real, noise=None, eps=None, keep=False):
+        """eps: optional list of the five Gaussian draws in the reference's order. Returns a dict of
+        detached device tensors (no host sync); `keep=True` also returns the image-sized intermediates."""
+        m = self.model
+        B = real.size(0)
+        scale = 1.0 / (real.size(1) * real.size(2) * real.size(3))
+        br, bk, bn, gr, lt = self.beta_rec, self.beta_kl, self.beta_neg, self.gamma_r, self.loss_type
+        if noise is None:
+            noise = rng.randn((B, m.zdim), real.device)
+        e = eps if eps is not None else [None] * 5
+        dec2 = self._second_decoder()
+        out = {}
+
+        # =========== Update E ================
+        self._train_encoder_only()
+        fake = m.sample(noise)
+        real_mu, real_logvar = m.encode(real)
+        z = reparameterize(real_mu, real_logvar, e[0])
+        rec = m.decoder(z)
+        loss_rec = calc_reconstruction_loss(real, rec, lt, "mean")
+        kl_real = calc_kl(real_logvar, real_mu, reduce="mean")
+
+        rec_mu, rec_logvar = m.encode(rec.detach())
+        z_rec = reparameterize(rec_mu, rec_logvar, e[1])
+        rec_rec = dec2(z_rec)
+        fake_mu, fake_logvar = m.encode(fake.detach())
+        z_fake = reparameterize(fake_mu, fake_logvar, e[2])
+        rec_fake = dec2(z_fake)
+
+        kl_rec = calc_kl(rec_logvar, rec_mu, reduce="none")
+        kl_fake = calc_kl(fake_logvar, fake_mu, reduce="none")
+        l_rec_rec = _per_sample(calc_reconstruction_loss(rec, rec_rec, lt, "none"))
+        l_rec_fake = _per_sample(calc_reconstruction_loss(fake, rec_fake, lt, "none"))
+        expelbo_rec = SF.expelbo(l_rec_rec, kl_rec, scale, br, bn)
+        expelbo_fake = SF.expelbo(l_rec_fake, kl_fake, scale, br, bn)
+        lossE = scale * (br * loss_rec + bk * kl_real) + 0.25 * (expelbo_rec + expelbo_fake)
+        self.opt_e.zero_grad()
+        lossE.backward()
+        self._sync(self.opt_e)
+        self.opt_e.step()
+        if keep:
+            out["E"] = dict(fake=fake.detach(), real_mu=real_mu.detach(), real_logvar=real_logvar.detach(),
+                            z=z.detach(), rec=rec.detach(), loss_rec=loss_rec.detach(), kl_real=kl_real.detach(),
+                            rec_mu=rec_mu.detach(), rec_logvar=rec_logvar.detach(), rec_rec=rec_rec.detach(),
+                            fake_mu=fake_mu.detach(), fake_logvar=fake_logvar.detach(), rec_fake=rec_fake.detach(),
+                            kl_rec=kl_rec.detach(), kl_fake=kl_fake.detach(), expelbo_rec=expelbo_rec.detach(),
+                            expelbo_fake=expelbo_fake.detach(), lossE=lossE.detach())
+        lossE_d, kl_real_d = lossE.detach(), kl_real.detach()
+        er_d, ef_d = expelbo_rec.detach(), expelbo_fake.detach()
+        z = z.detach()
+        self.last_z = z
+        del fake, rec, rec_rec, rec_fake, lossE, l_rec_rec, l_rec_fake, rec_mu, rec_logvar, fake_mu, fake_logvar
+
+        # ========= Update D ==================
+        self._train_decoder_only()
+        fake = m.sample(noise)
+        rec = m.decoder(z)
+        loss_rec = calc_reconstruction_loss(real, rec, lt, "mean")
+        rec_mu, rec_logvar = m.encode(rec)
+        z_rec = reparameterize(rec_mu, rec_logvar, e[3])
+        fake_mu, fake_logvar = m.encode(fake)
+        z_fake = reparameterize(fake_mu, fake_logvar, e[4])
+        if self.bootstrap:
+            rec_rec = dec2(z_rec)
+            rec_fake = dec2(z_fake)
+            l_rr = calc_reconstruction_loss(rec, rec_rec, lt, "mean")
+            l_fr = calc_reconstruction_loss(fake, rec_fake, lt, "mean")
+        else:
+            rec_rec = m.decode(z_rec.detach())
+            rec_fake = m.decode(z_fake.detach())
+            l_rr = calc_reconstruction_loss(rec.detach(), rec_rec, lt, "mean")
+            l_fr = calc_reconstruction_loss(fake.detach(), rec_fake, lt, "mean")
+        kl_rec = calc_kl(rec_logvar, rec_mu, reduce="mean")
+        kl_fake = calc_kl(fake_logvar, fake_mu, reduce="mean")
+        lossD = scale * (loss_rec * br + (kl_rec + kl_fake) * 0.5 * bk + gr * 0.5 * br * (l_rr + l_fr))
+        self.opt_d.zero_grad()
+        lossD.backward()
+        self._sync(self.opt_d)
+        self.opt_d.step()
+        if keep:
+            out["D"] = dict(fake=fake.detach(), rec=rec.detach(), loss_rec=loss_rec.detach(), rec_mu=rec_mu.detach(),
+                            rec_logvar=rec_logvar.detach(), fake_mu=fake_mu.detach(),
+                            fake_logvar=fake_logvar.detach(), rec_rec=rec_rec.detach(), rec_fake=rec_fake.detach(),
+                            loss_rec_rec=l_rr.detach(), loss_fake_rec=l_fr.detach(), kl_rec=kl_rec.detach(),
+                            kl_fake=kl_fake.detach(), lossD=lossD.detach())
+        # one small stats vector -> ONE device->host copy when the caller wants numbers
+        out["stats"] = torch.stack([lossE_d, lossD.detach(), loss_rec.detach(), kl_real_d, kl_fake.detach(),
+                                    kl_rec.detach(), er_d, ef_d])
+        out["fake"] = fake.detach()
+        return out

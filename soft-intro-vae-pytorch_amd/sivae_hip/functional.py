@@ -1,0 +1,371 @@
+"""Differentiable building blocks of the Soft-IntroVAE networks, composed from the HIP kernels in `ops`.
+
+Granularity is the reference's module granularity (one autograd node per ResidualBlock / stem / predict /
+fc) so that the hand-written backward controls exactly which tensors are saved and which fusions run:
+
+  forward of a residual block (train_soft_intro_vae.py:65-75)
+      idt = conv1x1(x)                                   (only if inc != outc)
+      a   = conv3x3(x)        + BatchNorm partial sums in the conv epilogue
+      c   = conv3x3(h)        with h = LeakyReLU(BN1(a)) applied while the conv stages its input tile —
+                              h is never written to HBM; + partial sums for BN2 in the epilogue
+      out = LeakyReLU(BN2(c) + idt)
+  saved for backward: x, a, c, out and 4 per-channel stat vectors (the reference graph saves x, a, h, c, out).
+  backward: the LeakyReLU sign of BN1 is recomputed from `a`; conv2's weight gradient re-applies the
+  BN1+LeakyReLU prologue on load; the two branches of dx are summed by the dgrad kernel's accumulate epilogue.
+
+Frozen networks (requires_grad=False) still run BatchNorm in training mode and update the running
+statistics, as in the reference; weight gradients are skipped per `needs_input_grad` — this is what makes
+the iteration cost 13 F_E + 19 F_D.
+"""
+import torch
+
+from . import ops
+
+SLOPE = ops.LRELU_SLOPE
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+# ---------------------------------------------------------------------------------------------------
+# packed-weight cache: one forward pack and one dgrad pack per parameter, rebuilt when the parameter
+# changes (torch's version counter for in-place updates, plus a generation counter bumped by the fused
+# optimizer which writes through raw pointers).
+# ---------------------------------------------------------------------------------------------------
+_pack_cache = {}
+
+
+def bump_generation(params):
+    for p in params:
+        p._sivae_gen = getattr(p, "_sivae_gen", 0) + 1
+
+
+def packed(w, mode):
+    key = (id(w), mode)
+    tag = (w._version, getattr(w, "_sivae_gen", 0), w.data_ptr())
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    wp = ops.pack_weight(w.detach(), mode)
+    _pack_cache[key] = (tag, wp)
+    return wp
+
+
+def clear_pack_cache():
+    _pack_cache.clear()
+
+
+class BNState:
+    """The non-differentiable part of a BatchNorm2d: buffers + mode. Passed by reference into the Functions."""
+
+    __slots__ = ("running_mean", "running_var", "num_batches_tracked", "training", "eps", "momentum")
+
+    def __init__(self, bn_module):
+        self.running_mean = bn_module.running_mean
+        self.running_var = bn_module.running_var
+        self.num_batches_tracked = bn_module.num_batches_tracked
+        self.training = bn_module.training
+        self.eps = bn_module.eps
+        self.momentum = bn_module.momentum
+
+
+def _stats(partials, B, C, HW, st):
+    """batch statistics from conv-epilogue partials (training) or the running buffers (eval)"""
+    if st.training:
+        return ops.bn_stats_from_conv(partials, B, C, HW, st.running_mean, st.running_var, st.num_batches_tracked,
+                                      st.eps, st.momentum)
+    return st.running_mean, torch.rsqrt(st.running_var + st.eps)
+
+
+def _post_fwd(out, post):
+    if post == "pool":
+        return ops.avgpool2_fwd(out)
+    if post == "up":
+        return ops.upsample2_fwd(out)
+    return out
+
+
+def _post_bwd(dy, post, shape):
+    if post == "pool":
+        return ops.avgpool2_bwd(dy, shape[2], shape[3])
+    if post == "up":
+        return ops.upsample2_bwd(dy)
+    return dy
+
+
+# ---------------------------------------------------------------------------------------------------
+class ResBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post):
+        x = x.contiguous()
+        B, Ci, H, W = x.shape
+        Cm, Co = w1.shape[0], w2.shape[0]
+        idt = x
+        if w_exp is not None:
+            idt = ops.conv2d_fwd(x, packed(w_exp, 0), Co, 1)
+        if st1.training:
+            a, p1 = ops.conv2d_fwd(x, packed(w1, 0), Cm, 3, want_stats=True)
+        else:
+            a, p1 = ops.conv2d_fwd(x, packed(w1, 0), Cm, 3), None
+        mean1, invstd1 = _stats(p1, B, Cm, H * W, st1)
+        pro1 = (mean1, invstd1, g1.detach(), b1.detach(), SLOPE)
+        if st2.training:
+            c, p2 = ops.conv2d_fwd(a, packed(w2, 0), Co, 3, pro=pro1, want_stats=True)
+        else:
+            c, p2 = ops.conv2d_fwd(a, packed(w2, 0), Co, 3, pro=pro1), None
+        mean2, invstd2 = _stats(p2, B, Co, H * W, st2)
+        out = ops.bn_apply_act(c, idt, mean2, invstd2, g2.detach(), b2.detach(), SLOPE)
+        y = _post_fwd(out, post)
+        ctx.post = post
+        ctx.has_exp = w_exp is not None
+        ctx.training = st1.training and st2.training
+        ctx.save_for_backward(x, a, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise RuntimeError("sivae_hip: backward through eval-mode BatchNorm is not supported")
+        x, a, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        need_x, need_we, need_w1, need_bn1, need_w2, need_bn2 = need[0], need[1], need[2], need[3] or need[4], \
+            need[5], need[6] or need[7]
+        Cm = w1.shape[0]
+        d_out = _post_bwd(dy.contiguous(), ctx.post, out.shape)
+        # BN2 + residual + LeakyReLU
+        dc, dz, dg2, db2 = ops.bn_bwd(d_out, out, c, mean2, invstd2, g2, SLOPE, want_dz=True,
+                                      want_param_grads=need_bn2, act_mode=1)
+        del d_out
+        pro1 = (mean1, invstd1, g1, b1, SLOPE)
+        dw2 = ops.conv2d_wgrad(a, dc, 3, pro=pro1) if need_w2 else None
+        dh = ops.conv2d_fwd(dc, packed(w2, 1), Cm, 3)
+        del dc
+        # BN1 + LeakyReLU (sign recomputed from a)
+        da, _, dg1, db1 = ops.bn_bwd(dh, None, a, mean1, invstd1, g1, SLOPE, want_dz=False,
+                                     want_param_grads=need_bn1, beta=b1, act_mode=2)
+        del dh
+        dw1 = ops.conv2d_wgrad(x, da, 3) if need_w1 else None
+        dwe = None
+        dx = None
+        if ctx.has_exp:
+            if need_we:
+                dwe = ops.conv2d_wgrad(x, dz, 1)
+            if need_x:
+                dx = ops.conv2d_fwd(da, packed(w1, 1), x.shape[1], 3)
+                ops.conv2d_fwd(dz, packed(w_exp, 1), x.shape[1], 1, out=dx, accumulate=True)
+        elif need_x:
+            dx = dz  # identity branch gradient; add the conv1 branch on top
+            ops.conv2d_fwd(da, packed(w1, 1), x.shape[1], 3, out=dx, accumulate=True)
+        return (dx, dwe, dw1, dg1 if need[3] else None, db1 if need[4] else None, dw2,
+                dg2 if need[6] else None, db2 if need[7] else None, None, None, None)
+
+
+class StemFn(torch.autograd.Function):
+    """conv5x5 -> BatchNorm -> LeakyReLU -> AvgPool2d(2)   (train_soft_intro_vae.py:88-93)"""
+
+    @staticmethod
+    def forward(ctx, x, w, g, b, st):
+        x = x.contiguous()
+        B, Ci, H, W = x.shape
+        Co = w.shape[0]
+        if st.training:
+            a, p = ops.conv2d_fwd(x, packed(w, 0), Co, 5, want_stats=True)
+        else:
+            a, p = ops.conv2d_fwd(x, packed(w, 0), Co, 5), None
+        mean, invstd = _stats(p, B, Co, H * W, st)
+        y = ops.bn_apply_act(a, None, mean, invstd, g.detach(), b.detach(), SLOPE)
+        out = ops.avgpool2_fwd(y)
+        ctx.training = st.training
+        ctx.save_for_backward(x, a, mean, invstd, w, g, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise RuntimeError("sivae_hip: backward through eval-mode BatchNorm is not supported")
+        x, a, mean, invstd, w, g, b = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dyf = ops.avgpool2_bwd(dy.contiguous(), a.shape[2], a.shape[3])
+        da, _, dg, db = ops.bn_bwd(dyf, None, a, mean, invstd, g, SLOPE, want_dz=False,
+                                   want_param_grads=need[2] or need[3], beta=b, act_mode=2)
+        del dyf
+        dw = ops.conv2d_wgrad(x, da, 5) if need[1] else None
+        dx = ops.conv2d_fwd(da, packed(w, 1), x.shape[1], 5) if need[0] else None
+        return dx, dw, dg if need[2] else None, db if need[3] else None, None
+
+
+class ConvBiasFn(torch.autograd.Function):
+    """plain conv + bias (Decoder.predict, train_soft_intro_vae.py:159)"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x = x.contiguous()
+        ks = w.shape[2]
+        y = ops.conv2d_fwd(x, packed(w, 0), w.shape[0], ks, bias=None if bias is None else bias.detach())
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dy = dy.contiguous()
+        ks = w.shape[2]
+        dw = ops.conv2d_wgrad(x, dy, ks) if need[1] else None
+        db = ops.channel_sum(dy) if (ctx.has_bias and need[2]) else None
+        dx = ops.conv2d_fwd(dy, packed(w, 1), x.shape[1], ks) if need[0] else None
+        return dx, dw, db
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b (optionally followed by ReLU) on the ks=1 path of the conv kernels (H = W = 1)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, relu):
+        x = x.contiguous()
+        B, K = x.shape
+        N = w.shape[0]
+        y = ops.conv2d_fwd(x.view(B, K, 1, 1), packed(w, 0), N, 1, bias=None if bias is None else bias.detach())
+        y = y.view(B, N)
+        if relu:
+            ops.relu_fwd(y, inplace=True)
+        ctx.relu = relu
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dy = dy.contiguous()
+        if ctx.relu:
+            dy = ops.relu_bwd(dy, y)
+        B, K = x.shape
+        N = w.shape[0]
+        dy4 = dy.view(B, N, 1, 1)
+        dw = ops.conv2d_wgrad(x.view(B, K, 1, 1), dy4, 1).view(N, K) if need[1] else None
+        db = ops.channel_sum(dy4) if (ctx.has_bias and need[2]) else None
+        dx = ops.conv2d_fwd(dy4, packed(w, 1), K, 1).view(B, K) if need[0] else None
+        return dx, dw, db, None
+
+
+# ---------------------------------------------------------------------------------------------------
+# sampler / losses
+# ---------------------------------------------------------------------------------------------------
+class ReparamFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        z = ops.reparam_fwd(mu, logvar, eps)
+        ctx.save_for_backward(logvar, eps)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        logvar, eps = ctx.saved_tensors
+        dmu, dlv = ops.reparam_bwd(dz.contiguous(), logvar, eps)
+        return dmu, dlv, None
+
+
+class KLFn(torch.autograd.Function):
+    """calc_kl: per-sample KL, optionally reduced ('sum' / 'mean') — train_soft_intro_vae.py:231-251"""
+
+    @staticmethod
+    def forward(ctx, logvar, mu, mu_o, logvar_o, reduce):
+        per = ops.kl_fwd(logvar, mu, mu_o, logvar_o)
+        ctx.save_for_backward(logvar, mu)
+        ctx.cfg = (mu_o, logvar_o, reduce, mu.shape[0])
+        if reduce == "sum":
+            return ops.vec_sum(per, 1.0)
+        if reduce == "mean":
+            return ops.vec_sum(per, 1.0 / mu.shape[0])
+        return per
+
+    @staticmethod
+    def backward(ctx, g):
+        logvar, mu = ctx.saved_tensors
+        mu_o, logvar_o, reduce, B = ctx.cfg
+        g = g.contiguous()
+        if reduce == "sum":
+            dlv, dmu = ops.kl_bwd(g, False, 1.0, logvar, mu, mu_o, logvar_o)
+        elif reduce == "mean":
+            dlv, dmu = ops.kl_bwd(g, False, 1.0 / B, logvar, mu, mu_o, logvar_o)
+        else:
+            dlv, dmu = ops.kl_bwd(g, True, 1.0, logvar, mu, mu_o, logvar_o)
+        return dlv, dmu, None, None, None
+
+
+class ReconFn(torch.autograd.Function):
+    """calc_reconstruction_loss — train_soft_intro_vae.py:268-294.
+    mode: 'rows' -> [B] per-sample sums, 'total' -> scalar (scale applied), 'elem' -> [B, D]"""
+
+    @staticmethod
+    def forward(ctx, x, recon, loss_type, mode, scale):
+        B = x.shape[0]
+        x2 = x.contiguous().view(B, -1)
+        r2 = recon.contiguous().view(B, -1)
+        ctx.save_for_backward(x2, r2)
+        ctx.cfg = (loss_type, mode, scale, x.shape, recon.shape)
+        if mode == "elem":
+            return ops.recon_elem_fwd(x2, r2, loss_type)
+        rows = ops.recon_rowsum_fwd(x2, r2, loss_type)
+        if mode == "rows":
+            return rows
+        return ops.vec_sum(rows, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, r2 = ctx.saved_tensors
+        loss_type, mode, scale, xshape, rshape = ctx.cfg
+        need = ctx.needs_input_grad
+        g = g.contiguous()
+        g_mode = {"rows": 0, "total": 1, "elem": 2}[mode]
+        d_r, d_x = ops.recon_bwd(x2, r2, loss_type, g, g_mode, scale if mode == "total" else 1.0,
+                                 want_drecon=need[1], want_dx=need[0])
+        return (d_x.view(xshape) if d_x is not None else None, d_r.view(rshape) if d_r is not None else None,
+                None, None, None)
+
+
+class ExpElboFn(torch.autograd.Function):
+    """mean_i exp(-2*scale*(beta_rec*L_i + beta_neg*KL_i)) — train_soft_intro_vae.py:580-581"""
+
+    @staticmethod
+    def forward(ctx, L, KL, scale, beta_rec, beta_neg):
+        out, e = ops.expelbo_fwd(L.contiguous(), KL.contiguous(), scale, beta_rec, beta_neg)
+        ctx.save_for_backward(e)
+        ctx.cfg = (scale, beta_rec, beta_neg)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (e,) = ctx.saved_tensors
+        scale, beta_rec, beta_neg = ctx.cfg
+        dL, dKL = ops.expelbo_bwd(g.contiguous(), e, scale, beta_rec, beta_neg)
+        return dL, dKL, None, None, None
+
+
+def residual_block(x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post=None):
+    return ResBlockFn.apply(x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post)
+
+
+def stem(x, w, g, b, st):
+    return StemFn.apply(x, w, g, b, st)
+
+
+def conv_bias(x, w, bias):
+    return ConvBiasFn.apply(x, w, bias)
+
+
+def linear(x, w, bias, relu=False):
+    return LinearFn.apply(x, w, bias, relu)
+
+
+def reparameterize(mu, logvar, eps):
+    return ReparamFn.apply(mu, logvar, eps)
+
+
+def kl(logvar, mu, mu_o=0.0, logvar_o=0.0, reduce="none"):
+    return KLFn.apply(logvar, mu, float(mu_o), float(logvar_o), reduce)
+
+
+def expelbo(L, KL, scale, beta_rec, beta_neg):
+    return ExpElboFn.apply(L, KL, float(scale), float(beta_rec), float(beta_neg))

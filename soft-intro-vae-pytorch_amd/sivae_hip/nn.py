@@ -1,0 +1,168 @@
+"""Module-level mirror of the reference networks, backed by the fused HIP blocks in `functional`.
+
+Class names, constructor signatures, attribute names and state_dict keys are the reference's
+(soft_intro_vae/train_soft_intro_vae.py:38-223, bootstrap variant
+soft_intro_vae_bootstrap/train_soft_intro_vae_bootstrap.py:44-246) so checkpoints are interchangeable and
+`main.py` / `metrics/fid_score.py` work unchanged.  The stock torch.nn layers below are used only as
+parameter/buffer containers (they give the reference's default initialisation and key names) — their
+forward() is never called; Encoder/Decoder/ResidualBlock.forward dispatch to the HIP blocks.
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as SF
+
+
+class ResidualBlock(nn.Module):
+    """reference: train_soft_intro_vae.py:38-75"""
+
+    def __init__(self, inc=64, outc=64, groups=1, scale=1.0):
+        super().__init__()
+        if groups != 1:
+            raise NotImplementedError("sivae_hip: grouped convolutions are not used by Soft-IntroVAE")
+        midc = int(outc * scale)
+        if inc != outc:
+            self.conv_expand = nn.Conv2d(inc, outc, kernel_size=1, stride=1, padding=0, groups=1, bias=False)
+        else:
+            self.conv_expand = None
+        self.conv1 = nn.Conv2d(inc, midc, kernel_size=3, stride=1, padding=1, groups=groups, bias=False)
+        self.bn1 = nn.BatchNorm2d(midc)
+        self.relu1 = nn.LeakyReLU(0.2, inplace=True)
+        self.conv2 = nn.Conv2d(midc, outc, kernel_size=3, stride=1, padding=1, groups=groups, bias=False)
+        self.bn2 = nn.BatchNorm2d(outc)
+        self.relu2 = nn.LeakyReLU(0.2, inplace=True)
+
+    def forward(self, x, post=None):
+        """post in {None, 'pool', 'up'} fuses the AvgPool2d / Upsample that follows the block in the nets."""
+        return SF.residual_block(x, None if self.conv_expand is None else self.conv_expand.weight,
+                                 self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight,
+                                 self.bn2.weight, self.bn2.bias, SF.BNState(self.bn1), SF.BNState(self.bn2), post)
+
+
+def _run_main(main, x):
+    """Walk a reference-shaped nn.Sequential, dispatching each group of layers to its fused HIP block."""
+    mods = list(main.children())
+    i, n = 0, len(mods)
+    while i < n:
+        m = mods[i]
+        nxt = mods[i + 1] if i + 1 < n else None
+        if isinstance(m, ResidualBlock):
+            if isinstance(nxt, nn.AvgPool2d):
+                x = m(x, post="pool")
+                i += 2
+            elif isinstance(nxt, nn.Upsample):
+                x = m(x, post="up")
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        elif isinstance(m, nn.Conv2d) and isinstance(nxt, nn.BatchNorm2d):
+            # encoder stem: conv5x5 -> BN -> LeakyReLU -> AvgPool2d
+            assert isinstance(mods[i + 2], nn.LeakyReLU) and isinstance(mods[i + 3], nn.AvgPool2d)
+            x = SF.stem(x, m.weight, nxt.weight, nxt.bias, SF.BNState(nxt))
+            i += 4
+        elif isinstance(m, nn.Conv2d):
+            x = SF.conv_bias(x, m.weight, m.bias)
+            i += 1
+        else:
+            raise RuntimeError("sivae_hip: unexpected layer %s in network" % type(m).__name__)
+    return x
+
+
+class Encoder(nn.Module):
+    """reference: train_soft_intro_vae.py:78-122"""
+
+    def __init__(self, cdim=3, zdim=512, channels=(64, 128, 256, 512, 512, 512), image_size=256, conditional=False,
+                 cond_dim=10):
+        super().__init__()
+        self.zdim = zdim
+        self.cdim = cdim
+        self.image_size = image_size
+        self.conditional = conditional
+        self.cond_dim = cond_dim
+        cc = channels[0]
+        self.main = nn.Sequential(
+            nn.Conv2d(cdim, cc, 5, 1, 2, bias=False),
+            nn.BatchNorm2d(cc),
+            nn.LeakyReLU(0.2),
+            nn.AvgPool2d(2),
+        )
+        sz = image_size // 2
+        for ch in channels[1:]:
+            self.main.add_module("res_in_{}".format(sz), ResidualBlock(cc, ch, scale=1.0))
+            self.main.add_module("down_to_{}".format(sz // 2), nn.AvgPool2d(2))
+            cc, sz = ch, sz // 2
+        self.main.add_module("res_in_{}".format(sz), ResidualBlock(cc, cc, scale=1.0))
+        self.conv_output_size = self.calc_conv_output_size()
+        num_fc_features = self.conv_output_size[0] * self.conv_output_size[1] * self.conv_output_size[2]
+        print("conv shape: ", self.conv_output_size)
+        print("num fc features: ", num_fc_features)
+        if self.conditional:
+            self.fc = nn.Linear(num_fc_features + self.cond_dim, 2 * zdim)
+        else:
+            self.fc = nn.Linear(num_fc_features, 2 * zdim)
+
+    def calc_conv_output_size(self):
+        """The reference discovers the feature size by pushing zeros through `main` IN TRAINING MODE
+        (train_soft_intro_vae.py:111-114), which also mutates every encoder BatchNorm buffer:
+        running_mean <- 0, running_var <- 0.9*1 + 0.1*0 = 0.9, num_batches_tracked <- 1.
+        Both effects are reproduced analytically here (no kernel launch at construction time)."""
+        s = self.image_size
+        n_pools = sum(1 for m in self.main.children() if isinstance(m, nn.AvgPool2d))
+        for _ in range(n_pools):
+            s = s // 2
+        last = [m for m in self.main.children() if isinstance(m, ResidualBlock)][-1]
+        with torch.no_grad():
+            for m in self.main.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.running_mean.zero_()
+                    m.running_var.fill_(0.9)
+                    m.num_batches_tracked.fill_(1)
+        return torch.Size([last.conv2.out_channels, s, s])
+
+    def forward(self, x, o_cond=None):
+        y = _run_main(self.main, x).reshape(x.size(0), -1)
+        if self.conditional and o_cond is not None:
+            y = torch.cat([y, o_cond], dim=1)
+        y = SF.linear(y, self.fc.weight, self.fc.bias)
+        mu, logvar = y.chunk(2, dim=1)
+        return mu, logvar
+
+
+class Decoder(nn.Module):
+    """reference: train_soft_intro_vae.py:125-169"""
+
+    def __init__(self, cdim=3, zdim=512, channels=(64, 128, 256, 512, 512, 512), image_size=256, conditional=False,
+                 conv_input_size=None, cond_dim=10):
+        super().__init__()
+        self.cdim = cdim
+        self.image_size = image_size
+        self.conditional = conditional
+        cc = channels[-1]
+        self.conv_input_size = conv_input_size
+        if conv_input_size is None:
+            num_fc_features = cc * 4 * 4
+        else:
+            num_fc_features = conv_input_size[0] * conv_input_size[1] * conv_input_size[2]
+        self.cond_dim = cond_dim
+        if self.conditional:
+            self.fc = nn.Sequential(nn.Linear(zdim + self.cond_dim, num_fc_features), nn.ReLU(True))
+        else:
+            self.fc = nn.Sequential(nn.Linear(zdim, num_fc_features), nn.ReLU(True))
+        sz = 4
+        self.main = nn.Sequential()
+        for ch in channels[::-1]:
+            self.main.add_module("res_in_{}".format(sz), ResidualBlock(cc, ch, scale=1.0))
+            self.main.add_module("up_to_{}".format(sz * 2), nn.Upsample(scale_factor=2, mode="nearest"))
+            cc, sz = ch, sz * 2
+        self.main.add_module("res_in_{}".format(sz), ResidualBlock(cc, cc, scale=1.0))
+        self.main.add_module("predict", nn.Conv2d(cc, cdim, 5, 1, 2))
+
+    def forward(self, z, y_cond=None):
+        z = z.reshape(z.size(0), -1)
+        if self.conditional and y_cond is not None:
+            y_cond = y_cond.reshape(y_cond.size(0), -1)
+            z = torch.cat([z, y_cond], dim=1)
+        y = SF.linear(z, self.fc[0].weight, self.fc[0].bias, relu=True)
+        y = y.view(z.size(0), *self.conv_input_size)
+        return _run_main(self.main, y)

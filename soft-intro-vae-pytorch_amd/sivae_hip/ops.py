@@ -141,9 +141,13 @@ def bn_apply_act(x, res, mean, invstd, gamma, beta, slope=LRELU_SLOPE, out=None)
     return y
 
 
-def bn_bwd(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_dz=False, want_param_grads=True):
-    """-> dx, dz (or None), dgamma, dbeta (or None, None)"""
-    _require(dy, y, x, mean, invstd, gamma)
+def bn_bwd(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_dz=False, want_param_grads=True, beta=None,
+           act_mode=None):
+    """-> dx, dz (or None), dgamma, dbeta (or None, None).
+    act_mode: 0 none, 1 LeakyReLU sign from the saved output y, 2 sign recomputed from x (needs beta)."""
+    if act_mode is None:
+        act_mode = 1 if y is not None else 0
+    _require(dy, y, x, mean, invstd, gamma, beta)
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
     L = _lib.load()
@@ -152,8 +156,8 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_dz=False, want
     dz = torch.empty_like(x) if want_dz else None
     dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
     dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
-    _lib.call("sivae_bn_bwd", _p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), float(slope), _p(dx), _p(dz),
-              _p(dgamma), _p(dbeta), B, C, HW, _p(ws), ws.numel(), _s())
+    _lib.call("sivae_bn_bwd", _p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), int(act_mode),
+              float(slope), _p(dx), _p(dz), _p(dgamma), _p(dbeta), B, C, HW, _p(ws), ws.numel(), _s())
     return dx, dz, dgamma, dbeta
 
 

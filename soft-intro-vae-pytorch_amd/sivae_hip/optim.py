@@ -1,0 +1,75 @@
+"""Flat-buffer Adam driven by one fused HIP kernel per network.
+
+The parameters of a network are re-pointed at views of ONE contiguous fp32 buffer (values preserved) and
+their .grad at views of one flat gradient buffer, so that
+  * the optimizer step is a single launch (sivae_adam_step) instead of ~6 elementwise launches per tensor,
+  * data-parallel gradient averaging is ONE RCCL all-reduce per network per iteration (see dp.py).
+Semantics follow torch.optim.Adam(lr, betas=(0.9, 0.999), eps=1e-8) as used at
+soft_intro_vae/train_soft_intro_vae.py:450-454; MultiStepLR is `set_lr`/`MultiStepLR` below.
+"""
+import torch
+
+from . import functional as SF
+from . import ops
+
+
+class FlatAdam:
+    def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("FlatAdam: empty parameter list")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatAdam needs ROCm-device parameters (no CPU fallback)")
+        self.lr, self.betas, self.eps = float(lr), betas, float(eps)
+        self.t = 0
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                self.flat[off:off + k].copy_(p.detach().reshape(-1))
+                p.data = self.flat[off:off + k].view(p.shape)
+                p.grad = self.flat_grad[off:off + k].view(p.shape)
+                off += k
+        self.param_groups = [{"lr": self.lr, "params": self.params}]  # torch-like surface for schedulers
+        SF.bump_generation(self.params)
+
+    def zero_grad(self, set_to_none=False):
+        # gradients must stay views of the flat buffer, so they are zeroed in place, never set to None
+        self.flat_grad.zero_()
+        for p, g in zip(self.params, self._grad_views()):
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+
+    def _grad_views(self):
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            yield self.flat_grad[off:off + k].view(p.shape)
+            off += k
+
+    def step(self, grad_scale=1.0):
+        self.t += 1
+        self.lr = float(self.param_groups[0]["lr"])
+        ops.adam_step(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.t, self.lr, self.betas[0],
+                      self.betas[1], self.eps, grad_scale)
+        SF.bump_generation(self.params)
+
+
+class MultiStepLR:
+    """torch.optim.lr_scheduler.MultiStepLR semantics for FlatAdam (milestones in scheduler steps)."""
+
+    def __init__(self, optimizer, milestones, gamma=0.1):
+        self.opt, self.milestones, self.gamma = optimizer, sorted(milestones), gamma
+        self.base_lr = optimizer.param_groups[0]["lr"]
+        self.last_epoch = 0
+
+    def step(self):
+        self.last_epoch += 1
+        k = sum(1 for m in self.milestones if m <= self.last_epoch)
+        self.opt.param_groups[0]["lr"] = self.base_lr * (self.gamma ** k)

@@ -199,6 +199,12 @@ def check_bn(shape, residual):
     res.append(("bn_dbeta%s" % tag, _err(dbeta, beta.grad), 2e-5))
     if residual:
         res.append(("bn_dres%s" % tag, _err(dz, r.grad), 1e-5))
+    else:
+        # sign of the activation recomputed from x instead of read from the saved output
+        dx2, _, dg2, db2 = ops.bn_bwd(_d(dy), None, xd, mean, invstd, _d(gamma.detach()), 0.2,
+                                      beta=_d(beta.detach()), act_mode=2)
+        res.append(("bn_dx_recompute%s" % tag, _err(dx2, x.grad), 2e-5))
+        res.append(("bn_dgamma_recompute%s" % tag, _err(dg2, gamma.grad), 2e-5))
     return res
 
 
