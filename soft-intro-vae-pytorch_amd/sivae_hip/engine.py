@@ -120,32 +120,42 @@ class SoftIntroEngine:
 
     # -- Soft-Intro iteration (reference :547-624) --------------------------------------------------------
     def soft_intro_step(self, real, noise=None, eps=None, keep=False):
-        """eps: optional list of the five Gaussian draws in the reference's order. Returns a dict of
+        """One full iteration: E-step + Adam(encoder) + D-step + Adam(decoder).
+        eps: optional list of the five Gaussian draws in the reference's order. Returns a dict of
         detached device tensors (no host sync); `keep=True` also returns the image-sized intermediates."""
-        m = self.model
-        B = real.size(0)
-        scale = 1.0 / (real.size(1) * real.size(2) * real.size(3))
-        br, bk, bn, gr, lt = self.beta_rec, self.beta_kl, self.beta_neg, self.gamma_r, self.loss_type
         if noise is None:
-            noise = rng.randn((B, m.zdim), real.device)
+            noise = rng.randn((real.size(0), self.model.zdim), real.device)
         e = eps if eps is not None else [None] * 5
-        dec2 = self._second_decoder()
         out = {}
+        es = self.e_step(real, noise, e[:3], keep)
+        ds = self.d_step(real, noise, es["z"], e[3:], keep)
+        if keep:
+            out["E"], out["D"] = es["kept"], ds["kept"]
+        # one small stats vector -> ONE device->host copy when the caller wants numbers
+        out["stats"] = torch.stack([es["lossE"], ds["lossD"], ds["loss_rec"], es["kl_real"], ds["kl_fake"],
+                                    ds["kl_rec"], es["expelbo_rec"], es["expelbo_fake"]])
+        out["fake"] = ds["fake"]
+        return out
 
-        # =========== Update E ================
+    def e_step(self, real, noise, eps=(None, None, None), keep=False):
+        """Encoder update (reference :551-589): forward passes, lossE, backward, [grad sync], Adam(encoder)."""
+        m = self.model
+        scale = 1.0 / (real.size(1) * real.size(2) * real.size(3))
+        br, bk, bn, lt = self.beta_rec, self.beta_kl, self.beta_neg, self.loss_type
+        dec2 = self._second_decoder()
         self._train_encoder_only()
         fake = m.sample(noise)
         real_mu, real_logvar = m.encode(real)
-        z = reparameterize(real_mu, real_logvar, e[0])
+        z = reparameterize(real_mu, real_logvar, eps[0])
         rec = m.decoder(z)
         loss_rec = calc_reconstruction_loss(real, rec, lt, "mean")
         kl_real = calc_kl(real_logvar, real_mu, reduce="mean")
 
         rec_mu, rec_logvar = m.encode(rec.detach())
-        z_rec = reparameterize(rec_mu, rec_logvar, e[1])
+        z_rec = reparameterize(rec_mu, rec_logvar, eps[1])
         rec_rec = dec2(z_rec)
         fake_mu, fake_logvar = m.encode(fake.detach())
-        z_fake = reparameterize(fake_mu, fake_logvar, e[2])
+        z_fake = reparameterize(fake_mu, fake_logvar, eps[2])
         rec_fake = dec2(z_fake)
 
         kl_rec = calc_kl(rec_logvar, rec_mu, reduce="none")
@@ -159,28 +169,34 @@ class SoftIntroEngine:
         lossE.backward()
         self._sync(self.opt_e)
         self.opt_e.step()
+        res = dict(z=z.detach(), lossE=lossE.detach(), kl_real=kl_real.detach(), expelbo_rec=expelbo_rec.detach(),
+                   expelbo_fake=expelbo_fake.detach())
         if keep:
-            out["E"] = dict(fake=fake.detach(), real_mu=real_mu.detach(), real_logvar=real_logvar.detach(),
-                            z=z.detach(), rec=rec.detach(), loss_rec=loss_rec.detach(), kl_real=kl_real.detach(),
-                            rec_mu=rec_mu.detach(), rec_logvar=rec_logvar.detach(), rec_rec=rec_rec.detach(),
-                            fake_mu=fake_mu.detach(), fake_logvar=fake_logvar.detach(), rec_fake=rec_fake.detach(),
-                            kl_rec=kl_rec.detach(), kl_fake=kl_fake.detach(), expelbo_rec=expelbo_rec.detach(),
-                            expelbo_fake=expelbo_fake.detach(), lossE=lossE.detach())
-        lossE_d, kl_real_d = lossE.detach(), kl_real.detach()
-        er_d, ef_d = expelbo_rec.detach(), expelbo_fake.detach()
-        z = z.detach()
-        self.last_z = z
-        del fake, rec, rec_rec, rec_fake, lossE, l_rec_rec, l_rec_fake, rec_mu, rec_logvar, fake_mu, fake_logvar
+            res["kept"] = dict(fake=fake.detach(), real_mu=real_mu.detach(), real_logvar=real_logvar.detach(),
+                               z=z.detach(), rec=rec.detach(), loss_rec=loss_rec.detach(),
+                               kl_real=kl_real.detach(), rec_mu=rec_mu.detach(), rec_logvar=rec_logvar.detach(),
+                               rec_rec=rec_rec.detach(), fake_mu=fake_mu.detach(),
+                               fake_logvar=fake_logvar.detach(), rec_fake=rec_fake.detach(),
+                               kl_rec=kl_rec.detach(), kl_fake=kl_fake.detach(),
+                               expelbo_rec=expelbo_rec.detach(), expelbo_fake=expelbo_fake.detach(),
+                               lossE=lossE.detach())
+        self.last_z = res["z"]
+        return res
 
-        # ========= Update D ==================
+    def d_step(self, real, noise, z, eps=(None, None), keep=False):
+        """Decoder update (reference :591-624; bootstrap :620-652). z = the E-step latent (detached)."""
+        m = self.model
+        scale = 1.0 / (real.size(1) * real.size(2) * real.size(3))
+        br, bk, gr, lt = self.beta_rec, self.beta_kl, self.gamma_r, self.loss_type
+        dec2 = self._second_decoder()
         self._train_decoder_only()
         fake = m.sample(noise)
-        rec = m.decoder(z)
+        rec = m.decoder(z.detach())
         loss_rec = calc_reconstruction_loss(real, rec, lt, "mean")
         rec_mu, rec_logvar = m.encode(rec)
-        z_rec = reparameterize(rec_mu, rec_logvar, e[3])
+        z_rec = reparameterize(rec_mu, rec_logvar, eps[0])
         fake_mu, fake_logvar = m.encode(fake)
-        z_fake = reparameterize(fake_mu, fake_logvar, e[4])
+        z_fake = reparameterize(fake_mu, fake_logvar, eps[1])
         if self.bootstrap:
             rec_rec = dec2(z_rec)
             rec_fake = dec2(z_fake)
@@ -198,14 +214,13 @@ class SoftIntroEngine:
         lossD.backward()
         self._sync(self.opt_d)
         self.opt_d.step()
+        res = dict(lossD=lossD.detach(), loss_rec=loss_rec.detach(), kl_rec=kl_rec.detach(),
+                   kl_fake=kl_fake.detach(), fake=fake.detach())
         if keep:
-            out["D"] = dict(fake=fake.detach(), rec=rec.detach(), loss_rec=loss_rec.detach(), rec_mu=rec_mu.detach(),
-                            rec_logvar=rec_logvar.detach(), fake_mu=fake_mu.detach(),
-                            fake_logvar=fake_logvar.detach(), rec_rec=rec_rec.detach(), rec_fake=rec_fake.detach(),
-                            loss_rec_rec=l_rr.detach(), loss_fake_rec=l_fr.detach(), kl_rec=kl_rec.detach(),
-                            kl_fake=kl_fake.detach(), lossD=lossD.detach())
-        # one small stats vector -> ONE device->host copy when the caller wants numbers
-        out["stats"] = torch.stack([lossE_d, lossD.detach(), loss_rec.detach(), kl_real_d, kl_fake.detach(),
-                                    kl_rec.detach(), er_d, ef_d])
-        out["fake"] = fake.detach()
-        return out
+            res["kept"] = dict(fake=fake.detach(), rec=rec.detach(), loss_rec=loss_rec.detach(),
+                               rec_mu=rec_mu.detach(), rec_logvar=rec_logvar.detach(), fake_mu=fake_mu.detach(),
+                               fake_logvar=fake_logvar.detach(), rec_rec=rec_rec.detach(),
+                               rec_fake=rec_fake.detach(), loss_rec_rec=l_rr.detach(),
+                               loss_fake_rec=l_fr.detach(), kl_rec=kl_rec.detach(), kl_fake=kl_fake.detach(),
+                               lossD=lossD.detach())
+        return res
