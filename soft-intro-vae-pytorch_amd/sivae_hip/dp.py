@@ -1,0 +1,79 @@
+"""One-process-per-GPU data parallelism for the Soft-IntroVAE iteration.
+
+The reference's hot path is single-device; its only DP precedent is the style variant (DDP over NCCL:
+style_soft_intro_vae/launcher.py:26-29, train_style_soft_intro_vae.py:154-161).  Here the batch shards
+per image, every rank keeps replicated weights + Adam state, and the ONLY exchange per backward is one
+all-reduce of a flat fp32 gradient buffer (encoder after lossE.backward(), decoder after
+lossD.backward()) — `torch.distributed` backend "nccl" is RCCL over xGMI on ROCm.  The 1/world scaling
+is folded into the fused Adam kernel (grad_scale), so the reduced buffer is touched exactly once.
+BatchNorm statistics stay per-rank ("local BN", what DDP does to this model; broadcast_buffers=False in
+the style precedent).  Works on any device the process group supports (gloo on CPU in the tests).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(
+        os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend=None):
+    """Initialise the default process group from the torchrun environment (no-op for world size 1)."""
+    world, rank, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return world, rank, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def allreduce_sum_(flat):
+    """in-place SUM all-reduce of a flat buffer (one collective per network per iteration)"""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
+def broadcast_(tensors, src=0):
+    """rank `src`'s values into every rank (initial weights / Adam state / buffers)"""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        for t in tensors:
+            dist.broadcast(t, src=src)
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def shard_batch(global_batch, world, rank):
+    """even per-image split of the global batch -> (start, count) of this rank"""
+    if global_batch % world != 0:
+        raise ValueError("global batch %d does not split evenly over %d ranks" % (global_batch, world))
+    per = global_batch // world
+    return rank * per, per
+
+
+class GradSync:
+    """callable handed to SoftIntroEngine: all-reduce(SUM) the flat gradient buffer; the mean's 1/world
+    factor is applied by FlatAdam.step(grad_scale)."""
+
+    def __init__(self):
+        self.world = world_size()
+        self.grad_scale = 1.0 / self.world
+        self.calls = 0
+        self.bytes = 0
+
+    def __call__(self, flat_grad):
+        self.calls += 1
+        self.bytes += flat_grad.numel() * 4
+        allreduce_sum_(flat_grad)

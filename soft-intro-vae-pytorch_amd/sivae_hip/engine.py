@@ -67,7 +67,8 @@ class SoftIntroEngine:
         self.beta_kl, self.beta_rec, self.beta_neg, self.gamma_r = beta_kl, beta_rec, beta_neg, gamma_r
         self.loss_type = recon_loss_type
         self.bootstrap = bootstrap
-        self.grad_sync = grad_sync  # callable(flat_grad) -> None (RCCL all-reduce mean) or None
+        self.grad_sync = grad_sync  # dp.GradSync (all-reduce SUM of the flat gradient) or None
+        self.grad_scale = getattr(grad_sync, "grad_scale", 1.0)  # 1/world, applied inside the fused Adam
         self.last_z = None
 
     # -- requires_grad toggles (reference :552-555, :592-595) -----------------------------------------
@@ -114,8 +115,8 @@ class SoftIntroEngine:
         loss.backward()
         self._sync(self.opt_e)
         self._sync(self.opt_d)
-        self.opt_e.step()
-        self.opt_d.step()
+        self.opt_e.step(self.grad_scale)
+        self.opt_d.step(self.grad_scale)
         return {"loss": loss.detach(), "loss_rec": loss_rec.detach(), "loss_kl": loss_kl.detach(), "rec": rec.detach()}
 
     # -- Soft-Intro iteration (reference :547-624) --------------------------------------------------------
@@ -168,7 +169,7 @@ class SoftIntroEngine:
         self.opt_e.zero_grad()
         lossE.backward()
         self._sync(self.opt_e)
-        self.opt_e.step()
+        self.opt_e.step(self.grad_scale)
         res = dict(z=z.detach(), lossE=lossE.detach(), kl_real=kl_real.detach(), expelbo_rec=expelbo_rec.detach(),
                    expelbo_fake=expelbo_fake.detach())
         if keep:
@@ -213,7 +214,7 @@ class SoftIntroEngine:
         self.opt_d.zero_grad()
         lossD.backward()
         self._sync(self.opt_d)
-        self.opt_d.step()
+        self.opt_d.step(self.grad_scale)
         res = dict(lossD=lossD.detach(), loss_rec=loss_rec.detach(), kl_rec=kl_rec.detach(),
                    kl_fake=kl_fake.detach(), fake=fake.detach())
         if keep:

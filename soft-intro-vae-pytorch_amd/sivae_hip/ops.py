@@ -16,6 +16,52 @@ LOSS_TYPES = {"mse": 0, "l1": 1, "bce": 2}
 _workspaces = {}
 
 
+class KernelTimer:
+    """Optional per-launch HIP-event timing of the MFMA conv kernels (used by bench.py for the roofline
+    object).  Events are recorded on torch's current stream — the stream the kernels are launched on —
+    and only read back after the timed region, so the instrumented run stays asynchronous."""
+
+    def __init__(self):
+        self.records = []  # (kernel_key, flops, start_event, end_event)
+
+    def begin(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def end(self, key, flops, start):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.records.append((key, flops, start, ev))
+
+    def summary(self):
+        """-> {kernel_key: dict(launches, total_ms, avg_ms, flops)} (call after torch.cuda.synchronize())"""
+        out = {}
+        for key, flops, s, e in self.records:
+            d = out.setdefault(key, dict(launches=0, total_ms=0.0, flops=0.0))
+            d["launches"] += 1
+            d["total_ms"] += s.elapsed_time(e)
+            d["flops"] += flops
+        for d in out.values():
+            d["avg_ms"] = d["total_ms"] / max(d["launches"], 1)
+        return out
+
+
+TIMER = None  # set to a KernelTimer() to instrument conv2d_fwd / conv2d_wgrad launches
+
+
+def conv_fwd_kernel_key(ks, Co, pro):
+    """name of the template instantiation sivae_conv2d_fwd dispatches to (mirrors conv_fwd.hip)"""
+    tile = {3: ("1,2,1,4,8,3", "2,2,1,4,8,3", "2,2,2,2,8,2"), 1: ("1,2,1,4,32,1", "2,2,1,4,32,1", "2,2,2,2,32,1"),
+            5: ("1,2,1,4,4,4", "2,2,1,4,4,4", "2,2,2,2,4,3")}[ks][0 if Co <= 32 else (1 if Co <= 64 else 2)]
+    return "conv_fwd_kernel<%d,%s,%s>" % (ks, tile, "true" if pro else "false")
+
+
+def conv_wgrad_kernel_key(ks, Co, pro):
+    tile = {3: "3,1,1,4,2,3", 1: "1,2,2,2,2,1", 5: ("1,1,1,1,2,2" if Co <= 32 else "1,1,1,2,1,2")}[ks]
+    return "conv_wgrad_kernel<%d,%s,%s>" % (ks, tile, "true" if pro else "false")
+
+
 def _require(*tensors):
     for t in tensors:
         if t is None:
@@ -83,8 +129,11 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
     if pro is not None:
         pm, pi, pg, pb, slope = pro
         _require(pm, pi, pg, pb)
+    t0 = TIMER.begin() if TIMER is not None else None
     _lib.call("sivae_conv2d_fwd", _p(x), _p(wp), _p(y), _p(bias), _p(pm), _p(pi), _p(pg), _p(pb), float(slope),
               _p(stats), B, Ci, Co, H, W, ks, int(bool(upsample)), int(bool(accumulate)), _s())
+    if t0 is not None:
+        TIMER.end(conv_fwd_kernel_key(ks, Co, pro is not None), 2.0 * B * H * W * Co * Ci * ks * ks, t0)
     return (y, stats) if want_stats else y
 
 
@@ -102,8 +151,11 @@ def conv2d_wgrad(x, dy, ks, pro=None, upsample=False):
     if pro is not None:
         pm, pi, pg, pb, slope = pro
         _require(pm, pi, pg, pb)
+    t0 = TIMER.begin() if TIMER is not None else None
     _lib.call("sivae_conv2d_wgrad", _p(x), _p(dy), _p(dw), _p(pm), _p(pi), _p(pg), _p(pb), float(slope), B, Ci, Co,
               H, W, ks, int(bool(upsample)), _p(ws), ws.numel(), _s())
+    if t0 is not None:  # (includes the tiny slice-reduce launch that follows the MFMA kernel)
+        TIMER.end(conv_wgrad_kernel_key(ks, Co, pro is not None), 2.0 * B * H * W * Co * Ci * ks * ks, t0)
     return dw
 
 
