@@ -1,0 +1,149 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol declared in
+include/sivae_hip.h, argument errors are reported through the documented codes (no GPU needed: validation
+happens before any launch), and the Python host mirror has the reference's surface."""
+import ctypes
+import inspect
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from sivae_hip import lib
+
+
+def test_library_exports_every_declared_symbol():
+    L = lib.load()
+    protos = lib.parse_header()
+    assert len(protos) >= 38
+    for name in protos:
+        assert hasattr(L, name), name
+    assert L.sivae_abi_version() == 1
+    assert L.sivae_arch() == b"gfx950"
+    assert L.sivae_device_count() >= 0
+    # and nothing sivae_* is exported that the header does not declare
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH]).decode()
+    exported = {l.split()[-1] for l in out.splitlines() if " T sivae_" in l}
+    assert exported == set(protos), exported ^ set(protos)
+
+
+def test_argument_errors_use_documented_codes():
+    L = lib.load()
+    null = None
+    one = ctypes.c_void_p(16)  # never dereferenced: validation fails first
+    assert L.sivae_conv2d_fwd(null, one, one, null, null, null, null, null, 0.2, null, 1, 1, 1, 4, 4, 3, 0, 0, null) == -1
+    assert L.sivae_conv2d_fwd(one, one, one, null, null, null, null, null, 0.2, null, 1, 1, 1, 4, 4, 2, 0, 0, null) == -3
+    assert L.sivae_conv2d_fwd(one, one, one, null, null, null, null, null, 0.2, null, 0, 1, 1, 4, 4, 3, 0, 0, null) == -2
+    assert L.sivae_conv2d_fwd(one, one, one, null, null, null, null, null, 0.2, null, 1, 1, 1, 5, 5, 3, 1, 0, null) == -2
+    assert L.sivae_conv2d_fwd(one, one, one, null, one, null, null, null, 0.2, null, 1, 1, 1, 4, 4, 3, 0, 0, null) == -1
+    assert L.sivae_conv2d_wgrad(one, one, one, null, null, null, null, 0.2, 1, 8, 8, 4, 4, 3, 0, null, 0, null) == -4
+    assert L.sivae_bn_bwd(one, null, one, one, one, one, null, 1, 0.2, one, null, null, null, 1, 1, 4, one, 1 << 20, null) == -1
+    assert L.sivae_bn_bwd(one, one, one, one, one, one, null, 7, 0.2, one, null, null, null, 1, 1, 4, one, 1 << 20, null) == -6
+    assert L.sivae_recon_rowsum_fwd(one, one, 9, one, 1, 4, one, 1 << 20, null) == -6
+    assert L.sivae_pack_conv_weight(one, one, 4, 4, 7, 0, null) == -3
+    assert L.sivae_pack_conv_weight(one, one, 4, 4, 3, 5, null) == -6
+
+
+def test_workspace_and_padding_queries():
+    L = lib.load()
+    assert L.sivae_conv_ck(3) == 8 and L.sivae_conv_ck(1) == 32 and L.sivae_conv_ck(5) == 4
+    assert L.sivae_conv_ci_pad(5, 3) == 4 and L.sivae_conv_co_pad(3) == 128 and L.sivae_conv_co_pad(129) == 256
+    assert L.sivae_pack_conv_weight_bytes(64, 3, 5, 0) == 25 * 4 * 128 * 4
+    assert L.sivae_pack_conv_weight_bytes(64, 3, 5, 1) == 25 * 64 * 128 * 4
+    assert L.sivae_conv2d_wgrad_workspace_bytes(128, 64, 64, 256, 256, 3) >= 64 * 64 * 9 * 4
+    assert L.sivae_conv2d_wgrad_workspace_bytes(0, 64, 64, 8, 8, 3) == 0
+    assert L.sivae_bn_workspace_bytes(128, 64, 65536) > 0
+    assert L.sivae_conv2d_fwd_num_px_tiles(128, 64, 256, 256) == 128 * 256  # 256-pixel tiles for Co <= 64
+    assert L.sivae_conv2d_fwd_num_px_tiles(128, 512, 4, 4) == 16            # 8 images per 128-pixel tile
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    import train_soft_intro_vae as T
+    from sivae_hip import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.bn_stats(torch.zeros(2, 4, 4, 4))
+    with pytest.raises(RuntimeError, match="no CPU"):
+        T.train_soft_intro_vae(dataset="synthetic-cifar10", device=torch.device("cpu"), num_epochs=1)
+    with pytest.raises(NotImplementedError):
+        T.train_soft_intro_vae(dataset="imagenet", device=torch.device("cpu"))
+    with pytest.raises(NotImplementedError):
+        T.calc_reconstruction_loss(torch.zeros(2, 3), torch.zeros(2, 3), loss_type="mse", reduction="avg")
+    with pytest.raises(NotImplementedError):
+        T.calc_reconstruction_loss(torch.zeros(2, 3), torch.zeros(2, 3), loss_type="huber", reduction="sum")
+
+
+def test_python_surface_matches_reference_signatures():
+    """names + parameter lists of the reference entry points (train_soft_intro_vae.py:337-341,
+    bootstrap :360-364, 2d :486-489, SoftIntroVAE/Encoder/Decoder ctor args)"""
+    import train_soft_intro_vae as T
+    import train_soft_intro_vae_2d as T2
+    import train_soft_intro_vae_bootstrap as TB
+    want = ["dataset", "z_dim", "lr_e", "lr_d", "batch_size", "num_workers", "start_epoch", "exit_on_negative_diff",
+            "num_epochs", "num_vae", "save_interval", "recon_loss_type", "beta_kl", "beta_rec", "beta_neg",
+            "test_iter", "seed", "pretrained", "device", "num_row", "gamma_r", "with_fid"]
+    assert list(inspect.signature(T.train_soft_intro_vae).parameters) == want
+    wb = want[:8] + ["copy_to_target_freq"] + want[8:]
+    assert list(inspect.signature(TB.train_soft_intro_vae).parameters) == wb
+    assert inspect.signature(TB.train_soft_intro_vae).parameters["gamma_r"].default == 1.0
+    assert list(inspect.signature(T2.train_soft_intro_vae_toy).parameters) == [
+        "z_dim", "lr_e", "lr_d", "batch_size", "n_iter", "num_vae", "save_interval", "recon_loss_type", "beta_kl",
+        "beta_rec", "beta_neg", "test_iter", "seed", "pretrained", "scale", "device", "dataset", "gamma_r"]
+    for mod in (T, TB):
+        for name in ("ResidualBlock", "Encoder", "Decoder", "SoftIntroVAE", "calc_kl", "reparameterize",
+                     "calc_reconstruction_loss", "load_model", "save_checkpoint", "str_to_list", "is_image_file"):
+            assert hasattr(mod, name), name
+    assert list(inspect.signature(T.SoftIntroVAE.__init__).parameters)[1:] == [
+        "cdim", "zdim", "channels", "image_size", "conditional", "cond_dim"]
+    assert hasattr(TB.SoftIntroVAE, "decode_target")
+
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name,seed,mod", [("step_cifar_narrow", 0, "train_soft_intro_vae"),
+                                           ("step_deep64_narrow", 1, "train_soft_intro_vae"),
+                                           ("step_mnist_narrow", 2, "train_soft_intro_vae"),
+                                           ("step_bootstrap_narrow", 3, "train_soft_intro_vae_bootstrap")])
+def test_constructor_reproduces_reference_state_dict(name, seed, mod):
+    """same seed -> bit-identical initial state_dict as the reference (same key order, same init draws, and the
+    encoder BatchNorm buffers mutated by the reference constructor's dummy forward)"""
+    import importlib
+    M = importlib.import_module(mod)
+    fx = np.load(os.path.join(GOLD, name + ".npz"))
+    torch.manual_seed(seed)
+    model = M.SoftIntroVAE(cdim=int(fx["meta_cdim"]), zdim=int(fx["meta_zdim"]),
+                           channels=[int(c) for c in fx["meta_channels"]], image_size=int(fx["meta_image_size"]))
+    sd = model.state_dict()
+    ref = {k[len("init/"):]: fx[k] for k in fx.files if k.startswith("init/")}
+    assert list(sd.keys()) == list(ref.keys())
+    for k, v in ref.items():
+        assert np.array_equal(sd[k].numpy(), v), k
+    assert model.zdim == int(fx["meta_zdim"]) and callable(model.sample)  # what metrics/fid_score.py:246-247 needs
+
+
+def test_2d_model_state_dict_keys():
+    import train_soft_intro_vae_2d as T2
+    fx = np.load(os.path.join(GOLD, "loop_2d.npz"))
+    m = T2.SoftIntroVAESimple(x_dim=2, zdim=2, n_layers=3, num_hidden=int(fx["meta_num_hidden"]))
+    ref = [k[len("init/"):] for k in fx.files if k.startswith("init/")]
+    assert list(m.state_dict().keys()) == ref
+    for k in ref:
+        assert tuple(m.state_dict()[k].shape) == fx["init/" + k].shape
+
+
+def test_philox_offsets_and_multistep_lr():
+    from sivae_hip.optim import MultiStepLR
+    from sivae_hip.rng import PhiloxStream
+
+    class Opt:
+        param_groups = [{"lr": 2e-4}]
+    o = Opt()
+    s = MultiStepLR(o, milestones=(2, 4), gamma=0.1)
+    lrs = []
+    for _ in range(5):
+        s.step()
+        lrs.append(o.param_groups[0]["lr"])
+    assert np.allclose(lrs, [2e-4, 2e-5, 2e-5, 2e-6, 2e-6])
+    a, b = PhiloxStream(5, 0), PhiloxStream(5, 1)
+    assert a.seed != b.seed and a.offset == 0
