@@ -103,8 +103,8 @@ def main():
     ap.add_argument("--global-batch", type=int, default=None, help="override the config's global batch")
     ap.add_argument("--bootstrap", action="store_true", help="soft_intro_vae_bootstrap variant (config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-iters", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()

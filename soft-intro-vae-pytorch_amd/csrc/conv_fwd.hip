@@ -27,6 +27,7 @@
 // Reference op being replaced: nn.Conv2d(k in {1,3,5}, stride 1, padding k//2) as used at
 // soft_intro_vae/train_soft_intro_vae.py:51-61,89,159 (and the F.linear calls at :109,:146 via KS=1).
 #include "common.h"
+#include <stdlib.h>
 
 struct ConvFwdArgs {
   const float* x;
@@ -48,8 +49,8 @@ struct ConvFwdArgs {
   int upsample;
 };
 
-template <int KS, int WM, int WN, int WVM, int WVN, int CK, int MAXPOS, bool PRO>
-__global__ void __launch_bounds__(WVM* WVN * 64, 2) conv_fwd_kernel(ConvFwdArgs a) {
+template <int KS, int WM, int WN, int WVM, int WVN, int CK, int MAXPOS, bool PRO, int MINW = 2>
+__global__ void __launch_bounds__(WVM* WVN * 64, MINW) conv_fwd_kernel(ConvFwdArgs a) {
   constexpr int P = KS / 2;
   constexpr int NT = WVM * WVN * 64;
   constexpr int TCO = WVM * WM * 32;
@@ -290,7 +291,7 @@ __global__ void __launch_bounds__(WVM* WVN * 64, 2) conv_fwd_kernel(ConvFwdArgs 
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-template <int KS, int WM, int WN, int WVM, int WVN, int CK, int MAXPOS>
+template <int KS, int WM, int WN, int WVM, int WVN, int CK, int MAXPOS, int MINW = 2>
 int launch_cfg(ConvFwdArgs& a, hipStream_t stream) {
   constexpr int TCO = WVM * WM * 32;
   constexpr int TPX = WVN * WN * 32;
@@ -311,8 +312,8 @@ int launch_cfg(ConvFwdArgs& a, hipStream_t stream) {
   if (lds < red) lds = red;
   const long long nblk = (long long)a.n_co_tiles * g.ntb * g.nth * g.ntw;
   if (nblk > 0x7fffffffLL) return SIVAE_ERR_RANGE;
-  auto kern = a.pro_mean ? conv_fwd_kernel<KS, WM, WN, WVM, WVN, CK, MAXPOS, true>
-                         : conv_fwd_kernel<KS, WM, WN, WVM, WVN, CK, MAXPOS, false>;
+  auto kern = a.pro_mean ? conv_fwd_kernel<KS, WM, WN, WVM, WVN, CK, MAXPOS, true, MINW>
+                         : conv_fwd_kernel<KS, WM, WN, WVM, WVN, CK, MAXPOS, false, MINW>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -333,9 +334,28 @@ extern "C" int sivae_conv_ci_pad(int ks, int ci) {
 extern "C" int sivae_conv_co_pad(int co) { return ((co + 127) / 128) * 128; }
 
 // Number of pixel tiles (= rows of the `stats` partial buffer) the forward kernel will use.
+// experiment switch (tools/bench_conv.py): SIVAE_FWD3_VARIANT selects the tile configuration of the
+// 3x3 kernels; the default (unset / 0) is the production choice.
+static int fwd3_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SIVAE_FWD3_VARIANT");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+static int fwd_tpx(int ks, int Co) {
+  if (ks == 3 && Co > 64) {
+    const int v = fwd3_variant();
+    if (v == 2 || v == 3) return 256;
+  }
+  if (ks == 3 && Co <= 64 && Co > 32 && fwd3_variant() == 4) return 512;
+  return (Co <= 64) ? 256 : 128;
+}
+
 extern "C" int sivae_conv2d_fwd_num_px_tiles(int B, int Co, int H, int W) {
   if (B <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
-  const int tpx = (Co <= 64) ? 256 : 128;
+  const int tpx = fwd_tpx(3, Co);
   TileGeom g = make_tile_geom(B, H, W, tpx);
   return g.ntb * g.nth * g.ntw;
 }
@@ -378,8 +398,16 @@ extern "C" int sivae_conv2d_fwd(const float* x, const float* wp, float* y, const
   // tile config by output-channel count:  Co<=32 -> 32x256, Co<=64 -> 64x256, else 128x128
   if (ks == 3) {
     if (Co <= 32) return launch_cfg<3, 1, 2, 1, 4, 8, 3>(a, stream);
-    if (Co <= 64) return launch_cfg<3, 2, 2, 1, 4, 8, 3>(a, stream);
-    return launch_cfg<3, 2, 2, 2, 2, 8, 2>(a, stream);
+    if (Co <= 64) {
+      if (fwd3_variant() == 4) return launch_cfg<3, 2, 4, 1, 4, 8, 5, 1>(a, stream);  // 64co x 512px
+      return launch_cfg<3, 2, 2, 1, 4, 8, 3>(a, stream);
+    }
+    switch (fwd3_variant()) {
+      case 1: return launch_cfg<3, 2, 2, 2, 2, 16, 2, 1>(a, stream);  // CK=16, one block per CU
+      case 2: return launch_cfg<3, 2, 4, 2, 2, 8, 3, 1>(a, stream);   // 128co x 256px, 4 waves (64x128 per wave)
+      case 3: return launch_cfg<3, 2, 2, 2, 4, 8, 2>(a, stream);      // 128co x 256px, 8 waves
+      default: return launch_cfg<3, 2, 2, 2, 2, 8, 2>(a, stream);
+    }
   } else if (ks == 1) {
     if (Co <= 32) return launch_cfg<1, 1, 2, 1, 4, 32, 1>(a, stream);
     if (Co <= 64) return launch_cfg<1, 2, 2, 1, 4, 32, 1>(a, stream);

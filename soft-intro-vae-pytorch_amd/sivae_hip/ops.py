@@ -58,7 +58,8 @@ def conv_fwd_kernel_key(ks, Co, pro):
 
 
 def conv_wgrad_kernel_key(ks, Co, pro):
-    tile = {3: "3,1,1,4,2,3", 1: "1,2,2,2,2,1", 5: ("1,1,1,1,2,2" if Co <= 32 else "1,1,1,2,1,2")}[ks]
+    tile = {3: ("3,1,1,2,2,3" if Co <= 64 else "3,1,1,4,2,3"), 1: "1,2,2,2,2,1",
+            5: ("1,1,1,1,2,2" if Co <= 32 else "1,1,1,2,1,2")}[ks]
     return "conv_wgrad_kernel<%d,%s,%s>" % (ks, tile, "true" if pro else "false")
 
 

@@ -1,0 +1,40 @@
+"""Micro-benchmark of the MFMA conv kernels on the headline layer shapes (GPU box).
+usage: python tools/bench_conv.py [B]   (env SIVAE_FWD3_VARIANT / SIVAE_WGRAD3_VARIANT select tile variants)"""
+import os, sys
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "soft-intro-vae-pytorch_amd"))
+from sivae_hip import ops
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+what = sys.argv[2] if len(sys.argv) > 2 else "fwd,wgrad"
+SHAPES = [  # (Ci, Co, H, ks)
+    (64, 128, 128, 3), (128, 128, 128, 3), (128, 256, 64, 3), (256, 256, 64, 3), (256, 512, 32, 3),
+    (512, 512, 32, 3), (512, 512, 16, 3), (512, 512, 8, 3), (64, 64, 256, 3), (128, 64, 128, 3),
+    (64, 128, 128, 1), (3, 64, 256, 5), (64, 3, 256, 5),
+]
+
+def timeit(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+print("variant fwd3=%s wgrad3=%s B=%d" % (os.environ.get("SIVAE_FWD3_VARIANT", "0"), os.environ.get("SIVAE_WGRAD3_VARIANT", "0"), B))
+for (Ci, Co, H, ks) in SHAPES:
+    x = torch.randn(B, Ci, H, H, device="cuda")
+    dy = torch.randn(B, Co, H, H, device="cuda")
+    w = torch.randn(Co, Ci, ks, ks, device="cuda") / (Ci * ks * ks) ** 0.5
+    wp = ops.pack_weight(w, 0)
+    fl = 2.0 * B * H * H * Ci * Co * ks * ks
+    out = "%4d->%-4d @%-3d k%d :" % (Ci, Co, H, ks)
+    if "fwd" in what:
+        t = timeit(lambda: ops.conv2d_fwd(x, wp, Co, ks, want_stats=True))
+        out += "  fwd %7.3f ms %6.1f TF" % (t, fl / t / 1e9)
+    if "wgrad" in what:
+        t = timeit(lambda: ops.conv2d_wgrad(x, dy, ks))
+        out += "  wgrad %7.3f ms %6.1f TF" % (t, fl / t / 1e9)
+    print(out)
+    del x, dy
