@@ -70,6 +70,20 @@ int sivae_conv2d_wgrad(const float* x, const float* dy, float* dw, const float* 
                        int B, int Ci, int Co, int H, int W, int ks, int upsample, void* workspace,
                        size_t workspace_bytes, sivae_stream_t stream);
 
+/* ---- 5x5 convolutions with <= 3 channels on one side (Decoder.predict :159, Encoder stem :89) -------------
+ * The small channel count is merged with the kernel column into one 16-wide MFMA dimension.
+ *   pack: n_small = the <=3 side, n_big = the other; mode 0 = forward operand of a [n_small][n_big][5][5]
+ *         weight (predict), mode 1 = data-gradient operand of a [n_big][n_small][5][5] weight (stem).
+ *   sivae_conv5_smallco_fwd: y[B][Co<=3][H][W] = conv5x5(x[B][Ci][H][W]) + bias.
+ *   sivae_conv5_edge_wgrad:  dw[Co][Ci][5][5] with min(Ci, Co) <= 3 (deterministic split over pixels). */
+size_t sivae_pack_conv5_smallco_bytes(int n_small, int n_big);
+int sivae_pack_conv5_smallco(const float* w, float* wq, int n_small, int n_big, int mode, sivae_stream_t stream);
+int sivae_conv5_smallco_fwd(const float* x, const float* wq, float* y, const float* bias, int B, int Ci, int Co,
+                            int H, int W, sivae_stream_t stream);
+size_t sivae_conv5_edge_wgrad_workspace_bytes(int B, int Ci, int Co, int H, int W);
+int sivae_conv5_edge_wgrad(const float* x, const float* dy, float* dw, int B, int Ci, int Co, int H, int W,
+                           void* workspace, size_t workspace_bytes, sivae_stream_t stream);
+
 /* ---- BatchNorm2d (training mode) + LeakyReLU + residual add ----------------------------------------
  * nn.BatchNorm2d(eps 1e-5, momentum 0.1) :58,:62,:90 ; nn.LeakyReLU(0.2) :59,:63,:91 ; torch.add :74.
  * running_var gets the unbiased variance, num_batches_tracked (int64, device) is incremented. */

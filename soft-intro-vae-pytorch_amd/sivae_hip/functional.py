@@ -49,6 +49,22 @@ def packed(w, mode):
     return wp
 
 
+def packed5(w, mode):
+    """pack for the small-channel 5x5 kernels (same invalidation rules as `packed`)"""
+    key = (id(w), 10 + mode)
+    tag = (w._version, getattr(w, "_sivae_gen", 0), w.data_ptr())
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    wq = ops.pack5_smallco(w.detach(), mode)
+    _pack_cache[key] = (tag, wq)
+    return wq
+
+
+def _is_edge5(w):
+    return w.dim() == 4 and w.shape[2] == 5 and w.shape[3] == 5 and min(w.shape[0], w.shape[1]) <= 3
+
+
 def clear_pack_cache():
     _pack_cache.clear()
 
@@ -187,8 +203,14 @@ class StemFn(torch.autograd.Function):
         da, _, dg, db = ops.bn_bwd(dyf, None, a, mean, invstd, g, SLOPE, want_dz=False,
                                    want_param_grads=need[2] or need[3], beta=b, act_mode=2)
         del dyf
-        dw = ops.conv2d_wgrad(x, da, 5) if need[1] else None
-        dx = ops.conv2d_fwd(da, packed(w, 1), x.shape[1], 5) if need[0] else None
+        edge = _is_edge5(w) and w.shape[1] <= 3
+        dw = None
+        if need[1]:
+            dw = ops.conv5_edge_wgrad(x, da) if edge else ops.conv2d_wgrad(x, da, 5)
+        dx = None
+        if need[0]:
+            dx = (ops.conv5_smallco_fwd(da, packed5(w, 1), x.shape[1]) if edge
+                  else ops.conv2d_fwd(da, packed(w, 1), x.shape[1], 5))
         return dx, dw, dg if need[2] else None, db if need[3] else None, None
 
 
@@ -199,7 +221,11 @@ class ConvBiasFn(torch.autograd.Function):
     def forward(ctx, x, w, bias):
         x = x.contiguous()
         ks = w.shape[2]
-        y = ops.conv2d_fwd(x, packed(w, 0), w.shape[0], ks, bias=None if bias is None else bias.detach())
+        b_ = None if bias is None else bias.detach()
+        if _is_edge5(w) and w.shape[0] <= 3:
+            y = ops.conv5_smallco_fwd(x, packed5(w, 0), w.shape[0], bias=b_)
+        else:
+            y = ops.conv2d_fwd(x, packed(w, 0), w.shape[0], ks, bias=b_)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         return y
@@ -210,7 +236,9 @@ class ConvBiasFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         dy = dy.contiguous()
         ks = w.shape[2]
-        dw = ops.conv2d_wgrad(x, dy, ks) if need[1] else None
+        dw = None
+        if need[1]:
+            dw = ops.conv5_edge_wgrad(x, dy) if _is_edge5(w) else ops.conv2d_wgrad(x, dy, ks)
         db = ops.channel_sum(dy) if (ctx.has_bias and need[2]) else None
         dx = ops.conv2d_fwd(dy, packed(w, 1), x.shape[1], ks) if need[0] else None
         return dx, dw, db

@@ -160,6 +160,43 @@ def conv2d_wgrad(x, dy, ks, pro=None, upsample=False):
     return dw
 
 
+# ------------------------------------------------------------------------------------------------ 5x5 edges
+def pack5_smallco(w, mode):
+    """mode 0: w [Cs<=3, Cb, 5, 5] (predict) ; mode 1: w [Cb, Cs<=3, 5, 5] (stem, data-gradient operand)"""
+    _require(w)
+    n_small, n_big = (w.shape[0], w.shape[1]) if mode == 0 else (w.shape[1], w.shape[0])
+    nbytes = _lib.load().sivae_pack_conv5_smallco_bytes(n_small, n_big)
+    if nbytes == 0:
+        raise _lib.SivaeError("sivae_pack_conv5_smallco_bytes", -2)
+    wq = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+    _lib.call("sivae_pack_conv5_smallco", _p(w), _p(wq), n_small, n_big, mode, _s())
+    return wq
+
+
+def conv5_smallco_fwd(x, wq, Co, bias=None):
+    _require(x, wq, bias)
+    B, Ci, H, W = x.shape
+    y = torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
+    t0 = TIMER.begin() if TIMER is not None else None
+    _lib.call("sivae_conv5_smallco_fwd", _p(x), _p(wq), _p(y), _p(bias), B, Ci, Co, H, W, _s())
+    if t0 is not None:
+        TIMER.end("conv5_smallco_fwd_kernel<9>", 2.0 * B * H * W * Co * Ci * 25, t0)
+    return y
+
+
+def conv5_edge_wgrad(x, dy):
+    _require(x, dy)
+    B, Ci, H, W = x.shape
+    Co = dy.shape[1]
+    ws = workspace(_lib.load().sivae_conv5_edge_wgrad_workspace_bytes(B, Ci, Co, H, W), x.device)
+    dw = torch.empty((Co, Ci, 5, 5), dtype=torch.float32, device=x.device)
+    t0 = TIMER.begin() if TIMER is not None else None
+    _lib.call("sivae_conv5_edge_wgrad", _p(x), _p(dy), _p(dw), B, Ci, Co, H, W, _p(ws), ws.numel(), _s())
+    if t0 is not None:
+        TIMER.end("conv5_edge_wgrad_kernel<%s>" % ("true" if Co <= 3 else "false"), 2.0 * B * H * W * Co * Ci * 25, t0)
+    return dw
+
+
 # ------------------------------------------------------------------------------------------------ BN
 def bn_stats(x, running_mean=None, running_var=None, num_batches_tracked=None, eps=1e-5, momentum=0.1):
     _require(x, running_mean, running_var, num_batches_tracked)

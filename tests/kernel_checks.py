@@ -138,6 +138,36 @@ def check_conv_fused(shape):
     return res
 
 
+def check_conv5_edge():
+    """the merged (channel, kw) 5x5 kernels: predict forward, stem data gradient, both weight gradients"""
+    from sivae_hip import ops
+    res = []
+    for (B, Cb, Cs, H, W) in [(2, 64, 3, 32, 32), (3, 64, 3, 64, 64), (2, 64, 1, 28, 28), (2, 40, 3, 12, 20),
+                              (1, 64, 3, 256, 256), (2, 16, 2, 130, 136)]:
+        tag = "(%d,%d,%d,%d,%d)" % (B, Cb, Cs, H, W)
+        # predict-like: Cb -> Cs
+        x = _rand(B, Cb, H, W, seed=1).requires_grad_()
+        w = _rand(Cs, Cb, 5, 5, seed=2, scale=1.0 / math.sqrt(Cb * 25)).requires_grad_()
+        b = _rand(Cs, seed=3)
+        dy = _rand(B, Cs, H, W, seed=4)
+        ref = F.conv2d(x, w, b, padding=2)
+        ref.backward(dy)
+        y = ops.conv5_smallco_fwd(_d(x.detach()), ops.pack5_smallco(_d(w.detach()), 0), Cs, bias=_d(b))
+        res.append(("conv5_smallco_fwd" + tag, _err(y, ref), 1e-5))
+        dw = ops.conv5_edge_wgrad(_d(x.detach()), _d(dy))
+        res.append(("conv5_smallco_wgrad" + tag, _err(dw, w.grad), 1e-5))
+        # stem-like: Cs -> Cb
+        x2 = _rand(B, Cs, H, W, seed=5).requires_grad_()
+        w2 = _rand(Cb, Cs, 5, 5, seed=6, scale=1.0 / math.sqrt(Cs * 25)).requires_grad_()
+        dy2 = _rand(B, Cb, H, W, seed=7)
+        F.conv2d(x2, w2, padding=2).backward(dy2)
+        dx2 = ops.conv5_smallco_fwd(_d(dy2), ops.pack5_smallco(_d(w2.detach()), 1), Cs)
+        res.append(("conv5_stem_dgrad" + tag, _err(dx2, x2.grad), 1e-5))
+        dw2 = ops.conv5_edge_wgrad(_d(x2.detach()), _d(dy2))
+        res.append(("conv5_smallci_wgrad" + tag, _err(dw2, w2.grad), 1e-5))
+    return res
+
+
 def check_linear():
     from sivae_hip import ops
     res = []
@@ -377,6 +407,7 @@ def all_checks():
                    + check_conv_fwd((3, 24, 40, 12, 12, 3), stats=True)))
     for s in [(2, 64, 128, 32, 32, 3), (2, 128, 64, 16, 16, 1), (3, 64, 64, 8, 8, 3), (2, 64, 3, 16, 16, 5)]:
         checks.append(("conv_fused%s" % (s,), lambda s=s: check_conv_fused(s)))
+    checks.append(("conv5_edge", check_conv5_edge))
     checks.append(("linear", check_linear))
     for s in BN_SHAPES:
         checks.append(("bn%s" % (s,), lambda s=s: check_bn(s, False)))

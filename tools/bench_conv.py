@@ -36,5 +36,16 @@ for (Ci, Co, H, ks) in SHAPES:
     if "wgrad" in what:
         t = timeit(lambda: ops.conv2d_wgrad(x, dy, ks))
         out += "  wgrad %7.3f ms %6.1f TF" % (t, fl / t / 1e9)
+    if ks == 5 and min(Ci, Co) <= 3:
+        if Co <= 3:
+            wq = ops.pack5_smallco(w, 0)
+            t = timeit(lambda: ops.conv5_smallco_fwd(x, wq, Co))
+            out += "  | edge fwd %7.3f ms %6.1f TF" % (t, fl / t / 1e9)
+        else:
+            wq = ops.pack5_smallco(w, 1)
+            t = timeit(lambda: ops.conv5_smallco_fwd(dy, wq, Ci))
+            out += "  | edge dgrad %7.3f ms %6.1f TF" % (t, fl / t / 1e9)
+        t = timeit(lambda: ops.conv5_edge_wgrad(x, dy))
+        out += "  edge wgrad %7.3f ms %6.1f TF" % (t, fl / t / 1e9)
     print(out)
     del x, dy
