@@ -8,8 +8,10 @@
 A "step" is one full Soft-IntroVAE iteration of soft_intro_vae/train_soft_intro_vae.py:547-624 (5 encoder +
 8 decoder forwards, both backwards, both Adam updates) on a synthetic U[0,1) NCHW batch already resident in
 HBM, fp32, random-init weights of the CelebA-HQ-256 network (channels [64,128,256,512,512,512], z 512).
-Global batch is fixed at 128 (128/N images per GPU -> "strong" scaling); gradients of the encoder and of the
-decoder are each all-reduced once per iteration over RCCL.
+Data parallel runs keep the per-GPU work fixed at the N = 1 workload (128 images per GPU, global batch 128*N:
+"weak" scaling, the per-image shard rule of this path); `--scaling strong` instead fixes the global batch at 128
+(128/N images per GPU).  Gradients of the encoder and of the decoder are each all-reduced once per iteration
+over RCCL (two flat fp32 buffers, 109.5 MB + 83.8 MB).
 
 Prints ONE JSON line (rank 0). Besides the contract keys it carries
   roofline      the dominant MFMA kernel timed with HIP events around every launch in the timed region
@@ -100,7 +102,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="celeb256", choices=sorted(CONFIGS))
-    ap.add_argument("--global-batch", type=int, default=None, help="override the config's global batch")
+    ap.add_argument("--global-batch", type=int, default=None, help="override the global batch")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: config batch PER GPU (global = batch*N); strong: config batch is the global batch")
     ap.add_argument("--bootstrap", action="store_true", help="soft_intro_vae_bootstrap variant (config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -128,6 +132,8 @@ def main():
     image_size, channels, zdim, gbatch, (bk, br, bn), gr = cfg
     if args.global_batch:
         gbatch = args.global_batch
+    elif args.scaling == "weak":
+        gbatch = gbatch * world
     if args.bootstrap:
         gr = 1.0
     _, per = dp.shard_batch(gbatch, world, rank)
@@ -197,7 +203,7 @@ def main():
         "metric": "training images/sec (whole node) at 256x256 bs128" if args.config == "celeb256"
         else "training images/sec (whole node)",
         "value": round(value, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "soft_intro_vae%s %s %dx%d zdim=%d channels=%s, full E-step + D-step iteration"
                                % ("_bootstrap" if args.bootstrap else "", args.config, image_size, image_size, zdim,

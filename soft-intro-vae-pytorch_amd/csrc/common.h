@@ -57,6 +57,17 @@ static inline TileGeom make_tile_geom(int B, int H, int W, int tpx /* pixels per
 }
 
 #ifdef __HIPCC__
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E) — the index is usable in
+// `constexpr` / `if constexpr`, which keeps register arrays statically indexed in unrolled pipelines
+#include <type_traits>
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
 // ---- wave64 reductions (butterfly over all 64 lanes; every lane ends with the total) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -198,6 +198,10 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) conv_fwd_kernel(ConvFwdAr
     __syncthreads();
     if (ch + 1 < nchunks) SIVAE_LOAD_CHUNK((ch + 1) * CK)
 
+    // MFMA loop over the (tap, channel-pair) k-steps of this chunk, fully unrolled; hipcc pipelines the
+    // ds_reads against the MFMAs with counted lgkmcnt waits.  (Hand-pipelining the operand reads one k-step
+    // ahead with sched_barrier pinning measured 0-3 % SLOWER at two waves per SIMD: the other wave already
+    // covers the LDS latency.  A static-priority stagger of co-resident waves also measured null.)
 #pragma unroll
     for (int kh = 0; kh < KS; ++kh) {
 #pragma unroll
@@ -406,7 +410,10 @@ extern "C" int sivae_conv2d_fwd(const float* x, const float* wp, float* y, const
       case 1: return launch_cfg<3, 2, 2, 2, 2, 16, 2, 1>(a, stream);  // CK=16, one block per CU
       case 2: return launch_cfg<3, 2, 4, 2, 2, 8, 3, 1>(a, stream);   // 128co x 256px, 4 waves (64x128 per wave)
       case 3: return launch_cfg<3, 2, 2, 2, 4, 8, 2>(a, stream);      // 128co x 256px, 8 waves
-      default: return launch_cfg<3, 2, 2, 2, 2, 8, 2>(a, stream);
+      case 5: return launch_cfg<3, 2, 2, 2, 2, 4, 2, 3>(a, stream);   // CK=4, three blocks per CU
+      case 6: return launch_cfg<3, 2, 2, 2, 2, 4, 2, 4>(a, stream);   // CK=4, four blocks per CU
+      case 7: return launch_cfg<3, 2, 2, 2, 2, 8, 2>(a, stream);      // CK=8, two blocks per CU (round-1 first version)
+      default: return launch_cfg<3, 2, 2, 2, 2, 4, 2, 3>(a, stream);  // production: CK=4, three blocks per CU (+2.4 % step)
     }
   } else if (ks == 1) {
     if (Co <= 32) return launch_cfg<1, 1, 2, 1, 4, 32, 1>(a, stream);
