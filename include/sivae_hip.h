@@ -94,6 +94,11 @@ int sivae_bn_stats(const float* x, int B, int C, int HW, float eps, float moment
 int sivae_bn_stats_from_conv(const float* partials, int n_tiles, int B, int C, int HW, float eps, float momentum,
                              float* running_mean, float* running_var, long long* num_batches_tracked,
                              float* mean_out, float* invstd_out, sivae_stream_t stream);
+/* one more running-stat update from saved batch statistics (a forward pass replayed from cached
+ * activations still counts as one BatchNorm call of the reference); count = B*H*W. */
+int sivae_bn_update_running(const float* mean, const float* invstd, int C, double count, float eps, float momentum,
+                            float* running_mean, float* running_var, long long* num_batches_tracked,
+                            sivae_stream_t stream);
 /* y = LeakyReLU((x-mean[c])*invstd[c]*gamma[c]+beta[c] (+ res), slope); slope = 1 -> identity act. */
 int sivae_bn_apply_act(const float* x, const float* res, const float* mean, const float* invstd,
                        const float* gamma, const float* beta, float slope, float* y, int B, int C, int HW,

@@ -169,6 +169,35 @@ extern "C" int sivae_bn_stats_from_conv(const float* partials, int n_tiles, int 
   return sivae_launch_status();
 }
 
+// Re-apply a running-statistics update from SAVED batch statistics (mean, invstd) without touching the
+// activations: used when a forward pass is replayed from cached activations (the decoder passes that the
+// reference recomputes with unchanged weights, train_soft_intro_vae.py:557 vs :597 and :561 vs :598) so that
+// running_mean / running_var / num_batches_tracked still receive exactly one update per reference pass.
+__global__ void __launch_bounds__(64) bn_update_running_kernel(const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, int C, double count,
+                                                               float eps, float momentum, float* running_mean,
+                                                               float* running_var, long long* num_batches_tracked) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  if (c >= C) return;
+  const double is = (double)invstd[c];
+  double var = 1.0 / (is * is) - (double)eps;
+  if (var < 0.0) var = 0.0;
+  const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+  running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * (double)mean[c]);
+  running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+}
+
+extern "C" int sivae_bn_update_running(const float* mean, const float* invstd, int C, double count, float eps,
+                                       float momentum, float* running_mean, float* running_var,
+                                       long long* num_batches_tracked, hipStream_t stream) {
+  if (!mean || !invstd || !running_mean || !running_var) return SIVAE_ERR_NULL;
+  if (C <= 0 || count <= 0.0) return SIVAE_ERR_SHAPE;
+  hipLaunchKernelGGL(bn_update_running_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, mean, invstd, C, count, eps,
+                     momentum, running_mean, running_var, num_batches_tracked);
+  return sivae_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------------
 // apply:  y = LeakyReLU( (x - mean[c]) * invstd[c]*gamma[c] + beta[c]  (+ res) )
 // slope == 1 -> no activation.

@@ -108,12 +108,31 @@ def _post_bwd(dy, post, shape):
 
 
 # ---------------------------------------------------------------------------------------------------
+def _replay_bn(st, mean, invstd, count):
+    if st.training:
+        ops.bn_update_running(mean, invstd, count, st.running_mean, st.running_var, st.num_batches_tracked, st.eps,
+                              st.momentum)
+
+
 class ResBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post):
+    def forward(ctx, x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache=None):
+        """cache: None, or a dict owned by the caller.  An empty dict is FILLED with this pass's activations;
+        a filled one is REPLAYED: no kernels run except the BatchNorm running-stat updates, the outputs and the
+        tensors saved for backward are the cached ones (valid only while x and all weights are unchanged)."""
         x = x.contiguous()
         B, Ci, H, W = x.shape
         Cm, Co = w1.shape[0], w2.shape[0]
+        if cache is not None and cache.get("y") is not None:
+            a, c, out, mean1, invstd1, mean2, invstd2, y = (cache[k] for k in ("a", "c", "out", "mean1", "invstd1",
+                                                                                 "mean2", "invstd2", "y"))
+            _replay_bn(st1, mean1, invstd1, B * H * W)
+            _replay_bn(st2, mean2, invstd2, B * H * W)
+            ctx.post = post
+            ctx.has_exp = w_exp is not None
+            ctx.training = st1.training and st2.training
+            ctx.save_for_backward(x, a, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2)
+            return y.view_as(y)
         idt = x
         if w_exp is not None:
             idt = ops.conv2d_fwd(x, packed(w_exp, 0), Co, 1)
@@ -130,6 +149,8 @@ class ResBlockFn(torch.autograd.Function):
         mean2, invstd2 = _stats(p2, B, Co, H * W, st2)
         out = ops.bn_apply_act(c, idt, mean2, invstd2, g2.detach(), b2.detach(), SLOPE)
         y = _post_fwd(out, post)
+        if cache is not None:
+            cache.update(a=a, c=c, out=out, mean1=mean1, invstd1=invstd1, mean2=mean2, invstd2=invstd2, y=y)
         ctx.post = post
         ctx.has_exp = w_exp is not None
         ctx.training = st1.training and st2.training
@@ -171,7 +192,7 @@ class ResBlockFn(torch.autograd.Function):
             dx = dz  # identity branch gradient; add the conv1 branch on top
             ops.conv2d_fwd(da, packed(w1, 1), x.shape[1], 3, out=dx, accumulate=True)
         return (dx, dwe, dw1, dg1 if need[3] else None, db1 if need[4] else None, dw2,
-                dg2 if need[6] else None, db2 if need[7] else None, None, None, None)
+                dg2 if need[6] else None, db2 if need[7] else None, None, None, None, None)
 
 
 class StemFn(torch.autograd.Function):
@@ -218,16 +239,20 @@ class ConvBiasFn(torch.autograd.Function):
     """plain conv + bias (Decoder.predict, train_soft_intro_vae.py:159)"""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
+    def forward(ctx, x, w, bias, cache=None):
         x = x.contiguous()
         ks = w.shape[2]
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        if cache is not None and cache.get("y") is not None:
+            return cache["y"].view_as(cache["y"])
         b_ = None if bias is None else bias.detach()
         if _is_edge5(w) and w.shape[0] <= 3:
             y = ops.conv5_smallco_fwd(x, packed5(w, 0), w.shape[0], bias=b_)
         else:
             y = ops.conv2d_fwd(x, packed(w, 0), w.shape[0], ks, bias=b_)
-        ctx.save_for_backward(x, w)
-        ctx.has_bias = bias is not None
+        if cache is not None:
+            cache["y"] = y
         return y
 
     @staticmethod
@@ -241,7 +266,7 @@ class ConvBiasFn(torch.autograd.Function):
             dw = ops.conv5_edge_wgrad(x, dy) if _is_edge5(w) else ops.conv2d_wgrad(x, dy, ks)
         db = ops.channel_sum(dy) if (ctx.has_bias and need[2]) else None
         dx = ops.conv2d_fwd(dy, packed(w, 1), x.shape[1], ks) if need[0] else None
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 class LinearFn(torch.autograd.Function):
@@ -371,16 +396,16 @@ class ExpElboFn(torch.autograd.Function):
         return dL, dKL, None, None, None
 
 
-def residual_block(x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post=None):
-    return ResBlockFn.apply(x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post)
+def residual_block(x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post=None, cache=None):
+    return ResBlockFn.apply(x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache)
 
 
 def stem(x, w, g, b, st):
     return StemFn.apply(x, w, g, b, st)
 
 
-def conv_bias(x, w, bias):
-    return ConvBiasFn.apply(x, w, bias)
+def conv_bias(x, w, bias, cache=None):
+    return ConvBiasFn.apply(x, w, bias, cache)
 
 
 def linear(x, w, bias, relu=False):

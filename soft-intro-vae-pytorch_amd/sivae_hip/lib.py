@@ -38,6 +38,7 @@ class SivaeError(RuntimeError):
 _CTYPE = {
     "int": ctypes.c_int,
     "float": ctypes.c_float,
+    "double": ctypes.c_double,
     "size_t": ctypes.c_size_t,
     "unsigned long long": ctypes.c_ulonglong,
     "sivae_stream_t": ctypes.c_void_p,

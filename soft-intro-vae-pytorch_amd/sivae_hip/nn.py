@@ -32,29 +32,32 @@ class ResidualBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(outc)
         self.relu2 = nn.LeakyReLU(0.2, inplace=True)
 
-    def forward(self, x, post=None):
-        """post in {None, 'pool', 'up'} fuses the AvgPool2d / Upsample that follows the block in the nets."""
+    def forward(self, x, post=None, cache=None):
+        """post in {None, 'pool', 'up'} fuses the AvgPool2d / Upsample that follows the block in the nets.
+        cache: see functional.ResBlockFn (activation cache for replaying an identical forward pass)."""
         return SF.residual_block(x, None if self.conv_expand is None else self.conv_expand.weight,
                                  self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight,
-                                 self.bn2.weight, self.bn2.bias, SF.BNState(self.bn1), SF.BNState(self.bn2), post)
+                                 self.bn2.weight, self.bn2.bias, SF.BNState(self.bn1), SF.BNState(self.bn2), post,
+                                 cache)
 
 
-def _run_main(main, x):
+def _run_main(main, x, cache=None):
     """Walk a reference-shaped nn.Sequential, dispatching each group of layers to its fused HIP block."""
     mods = list(main.children())
     i, n = 0, len(mods)
     while i < n:
         m = mods[i]
         nxt = mods[i + 1] if i + 1 < n else None
+        sub = None if cache is None else cache.setdefault(i, {})
         if isinstance(m, ResidualBlock):
             if isinstance(nxt, nn.AvgPool2d):
-                x = m(x, post="pool")
+                x = m(x, post="pool", cache=sub)
                 i += 2
             elif isinstance(nxt, nn.Upsample):
-                x = m(x, post="up")
+                x = m(x, post="up", cache=sub)
                 i += 2
             else:
-                x = m(x)
+                x = m(x, cache=sub)
                 i += 1
         elif isinstance(m, nn.Conv2d) and isinstance(nxt, nn.BatchNorm2d):
             # encoder stem: conv5x5 -> BN -> LeakyReLU -> AvgPool2d
@@ -62,7 +65,7 @@ def _run_main(main, x):
             x = SF.stem(x, m.weight, nxt.weight, nxt.bias, SF.BNState(nxt))
             i += 4
         elif isinstance(m, nn.Conv2d):
-            x = SF.conv_bias(x, m.weight, m.bias)
+            x = SF.conv_bias(x, m.weight, m.bias, sub)
             i += 1
         else:
             raise RuntimeError("sivae_hip: unexpected layer %s in network" % type(m).__name__)
@@ -158,11 +161,14 @@ class Decoder(nn.Module):
         self.main.add_module("res_in_{}".format(sz), ResidualBlock(cc, cc, scale=1.0))
         self.main.add_module("predict", nn.Conv2d(cc, cdim, 5, 1, 2))
 
-    def forward(self, z, y_cond=None):
+    def forward(self, z, y_cond=None, cache=None):
+        """cache (optional dict): filled by the first call, replayed by a second call with the SAME z and
+        unchanged decoder weights — see SoftIntroEngine (the reference recomputes `fake` and `rec` in the
+        D-step although the decoder has not changed since the E-step computed them)."""
         z = z.reshape(z.size(0), -1)
         if self.conditional and y_cond is not None:
             y_cond = y_cond.reshape(y_cond.size(0), -1)
             z = torch.cat([z, y_cond], dim=1)
         y = SF.linear(z, self.fc[0].weight, self.fc[0].bias, relu=True)
         y = y.view(z.size(0), *self.conv_input_size)
-        return _run_main(self.main, y)
+        return _run_main(self.main, y, cache)

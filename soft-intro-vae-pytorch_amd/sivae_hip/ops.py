@@ -221,6 +221,12 @@ def bn_stats_from_conv(partials, B, C, HW, running_mean=None, running_var=None, 
     return mean, invstd
 
 
+def bn_update_running(mean, invstd, count, running_mean, running_var, num_batches_tracked, eps=1e-5, momentum=0.1):
+    _require(mean, invstd, running_mean, running_var, num_batches_tracked)
+    _lib.call("sivae_bn_update_running", _p(mean), _p(invstd), mean.numel(), float(count), float(eps),
+              float(momentum), _p(running_mean), _p(running_var), _p(num_batches_tracked), _s())
+
+
 def bn_apply_act(x, res, mean, invstd, gamma, beta, slope=LRELU_SLOPE, out=None):
     _require(x, res, mean, invstd, gamma, beta, out)
     B, C = x.shape[0], x.shape[1]
