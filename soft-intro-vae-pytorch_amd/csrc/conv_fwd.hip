@@ -404,16 +404,23 @@ extern "C" int sivae_conv2d_fwd(const float* x, const float* wp, float* y, const
     if (Co <= 32) return launch_cfg<3, 1, 2, 1, 4, 8, 3>(a, stream);
     if (Co <= 64) {
       if (fwd3_variant() == 4) return launch_cfg<3, 2, 4, 1, 4, 8, 5, 1>(a, stream);  // 64co x 512px
-      return launch_cfg<3, 2, 2, 1, 4, 8, 3>(a, stream);
+      if (fwd3_variant() == 8) return launch_cfg<3, 2, 2, 1, 4, 4, 3, 3>(a, stream);  // CK=4, three blocks per CU
+      if (fwd3_variant() == 9 || fwd3_variant() == 12 || fwd3_variant() == 14)
+        return launch_cfg<3, 2, 2, 1, 4, 4, 3, 4>(a, stream);  // CK=4, four blocks per CU
+      if (fwd3_variant() == 7) return launch_cfg<3, 2, 2, 1, 4, 8, 3>(a, stream);     // CK=8, two blocks per CU (first version)
+      return launch_cfg<3, 2, 2, 1, 4, 2, 3, 4>(a, stream);  // production: CK=2, four blocks per CU
     }
     switch (fwd3_variant()) {
       case 1: return launch_cfg<3, 2, 2, 2, 2, 16, 2, 1>(a, stream);  // CK=16, one block per CU
       case 2: return launch_cfg<3, 2, 4, 2, 2, 8, 3, 1>(a, stream);   // 128co x 256px, 4 waves (64x128 per wave)
       case 3: return launch_cfg<3, 2, 2, 2, 4, 8, 2>(a, stream);      // 128co x 256px, 8 waves
+      case 6:
+      case 12: return launch_cfg<3, 2, 2, 2, 2, 4, 2, 4>(a, stream);  // CK=4, four blocks per CU
       case 5: return launch_cfg<3, 2, 2, 2, 2, 4, 2, 3>(a, stream);   // CK=4, three blocks per CU
-      case 6: return launch_cfg<3, 2, 2, 2, 2, 4, 2, 4>(a, stream);   // CK=4, four blocks per CU
       case 7: return launch_cfg<3, 2, 2, 2, 2, 8, 2>(a, stream);      // CK=8, two blocks per CU (round-1 first version)
-      default: return launch_cfg<3, 2, 2, 2, 2, 4, 2, 3>(a, stream);  // production: CK=4, three blocks per CU (+2.4 % step)
+      default: return launch_cfg<3, 2, 2, 2, 2, 2, 2, 4>(a, stream);  // production: CK=2, four blocks per CU
+                                                                       // (occupancy ladder at bs128: CK8/2 blocks 107.4,
+                                                                       //  CK4/3 blocks 110.0, CK2/4 blocks 122.6 img/s)
     }
   } else if (ks == 1) {
     if (Co <= 32) return launch_cfg<1, 1, 2, 1, 4, 32, 1>(a, stream);

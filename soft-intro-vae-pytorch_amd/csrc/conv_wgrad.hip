@@ -20,6 +20,7 @@
 // Reference op being replaced: the weight half of aten::convolution_backward for the Conv2d /
 // Linear layers of soft_intro_vae/train_soft_intro_vae.py:51-61,89,109,146,159.
 #include "common.h"
+#include <stdlib.h>
 
 struct ConvWgradArgs {
   const float* x;
@@ -254,9 +255,18 @@ struct WgradPlan {
 };
 
 // tile configuration table (must match the launch dispatch below)
+static int wgrad3_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SIVAE_WGRAD3_VARIANT");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 static int wgrad_plan(int B, int Ci, int Co, int H, int W, int ks, WgradPlan* p) {
   if (ks == 3) {
-    p->tco = Co <= 64 ? 64 : 128; p->tci = 64; p->khb = 3;
+    p->tco = (Co <= 64 || wgrad3_variant() != 3) ? 64 : 128; p->tci = 64; p->khb = wgrad3_variant() == 2 ? 1 : 3;
   } else if (ks == 1) {
     p->tco = 128; p->tci = 128; p->khb = 1;
   } else if (ks == 5) {
@@ -351,7 +361,8 @@ extern "C" int sivae_conv2d_wgrad(const float* x, const float* dy, float* dw, co
   a.upsample = upsample;
 
   // <KS, KHB, WM, WN, WVM, WVN, NPOS>: NPOS*64 >= largest halo plane of a 64-pixel tile
-  if (ks == 3 && Co <= 64) rc = launch_wgrad<3, 3, 1, 1, 2, 2, 3>(a, p, stream);  // co64 x ci64, 4 waves
+  if (ks == 3 && wgrad3_variant() == 2) rc = launch_wgrad<3, 1, 1, 1, 2, 2, 2>(a, p, stream);  // one kernel row per block
+  else if (ks == 3 && (Co <= 64 || wgrad3_variant() != 3)) rc = launch_wgrad<3, 3, 1, 1, 2, 2, 3>(a, p, stream);  // production: co64 x ci64, 4 waves
   else if (ks == 3) rc = launch_wgrad<3, 3, 1, 1, 4, 2, 3>(a, p, stream);   // co128 x ci64, 8 waves
   else if (ks == 1) rc = launch_wgrad<1, 1, 2, 2, 2, 2, 1>(a, p, stream);   // co128 x ci128, 4 waves
   else if (Co <= 32) rc = launch_wgrad<5, 1, 1, 1, 1, 2, 2>(a, p, stream);  // co32 x ci64, 2 waves
