@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="testing only: every rank uses cuda:0 (with --backend gloo) to exercise the DP path on one GPU")
     ap.add_argument("--no-reuse", action="store_true",
                     help="re-execute the two D-step decoder forwards whose inputs and weights are unchanged since the "
                          "E-step (the reference does); default: replay them from the E-step's activations")
@@ -124,11 +127,11 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the Soft-IntroVAE HIP engine has no CPU path)")
-    world, rank, local = dp.init()
+    world, rank, local = dp.init(backend=args.backend)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
-    dev = torch.device("cuda", local if world > 1 else 0)
+    dev = torch.device("cuda", local if (world > 1 and not args.same_device) else 0)
     torch.cuda.set_device(dev)
 
     cfg = CONFIGS[args.config]

@@ -52,13 +52,13 @@ TIMER = None  # set to a KernelTimer() to instrument conv2d_fwd / conv2d_wgrad l
 
 def conv_fwd_kernel_key(ks, Co, pro):
     """name of the template instantiation sivae_conv2d_fwd dispatches to (mirrors conv_fwd.hip)"""
-    tile = {3: ("1,2,1,4,8,3", "2,2,1,4,8,3", "2,2,2,2,4,2"), 1: ("1,2,1,4,32,1", "2,2,1,4,32,1", "2,2,2,2,32,1"),
+    tile = {3: ("1,2,1,4,8,3", "2,2,1,4,2,3", "2,2,2,2,2,2"), 1: ("1,2,1,4,32,1", "2,2,1,4,32,1", "2,2,2,2,32,1"),
             5: ("1,2,1,4,4,4", "2,2,1,4,4,4", "2,2,2,2,4,3")}[ks][0 if Co <= 32 else (1 if Co <= 64 else 2)]
     return "conv_fwd_kernel<%d,%s,%s>" % (ks, tile, "true" if pro else "false")
 
 
 def conv_wgrad_kernel_key(ks, Co, pro):
-    tile = {3: ("3,1,1,2,2,3" if Co <= 64 else "3,1,1,4,2,3"), 1: "1,2,2,2,2,1",
+    tile = {3: "3,1,1,2,2,3", 1: "1,2,2,2,2,1",
             5: ("1,1,1,1,2,2" if Co <= 32 else "1,1,1,2,1,2")}[ks]
     return "conv_wgrad_kernel<%d,%s,%s>" % (ks, tile, "true" if pro else "false")
 

@@ -1,0 +1,98 @@
+"""GPU: the drop-in entry points themselves (train_soft_intro_vae / _bootstrap / _toy) and the 2-D variant
+against the recorded run of the reference's own 2-D training function."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_train_soft_intro_vae_entry_point_runs(tmp_path, monkeypatch):
+    import train_soft_intro_vae as T
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("SIVAE_SYNTHETIC_IMAGES", "48")
+    model = T.train_soft_intro_vae(dataset="synthetic-cifar10", z_dim=32, batch_size=16, num_workers=0, num_epochs=2,
+                                   num_vae=1, beta_kl=1.0, beta_rec=1.0, beta_neg=256, seed=3, test_iter=2,
+                                   save_interval=1, device=torch.device("cuda:0"))
+    sd = model.state_dict()
+    assert all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
+    # constructor probe (1) + epoch 0: 3 vanilla-VAE iterations (1 encoder pass each) + epoch 1: 3 Soft-Intro
+    # iterations (5 encoder passes each) + the deterministic dump at cur_iter 4 (test_iter=2) + the final dump
+    assert int(sd["encoder.main.1.num_batches_tracked"]) == 1 + 3 + 15 + 1 + 1
+    ckpts = os.listdir(tmp_path / "saves")
+    assert any(c.endswith(".pth") for c in ckpts)
+    # checkpoint round trip in the reference's format {"epoch", "model"}
+    m2 = T.SoftIntroVAE(cdim=3, zdim=32, channels=[64, 128, 256], image_size=32).to("cuda:0")
+    T.load_model(m2, str(tmp_path / "saves" / sorted(ckpts)[-1]), torch.device("cuda:0"))
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+
+
+def test_bootstrap_entry_point_runs(tmp_path, monkeypatch):
+    import train_soft_intro_vae_bootstrap as TB
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("SIVAE_SYNTHETIC_IMAGES", "16")
+    model = TB.train_soft_intro_vae(dataset="synthetic-cifar10", z_dim=16, batch_size=8, num_workers=0, num_epochs=1,
+                                    beta_kl=1.0, beta_rec=1.0, beta_neg=256, seed=4, device=torch.device("cuda:0"))
+    sd = model.state_dict()
+    # after the epoch the target decoder is a copy of the decoder (bootstrap file :680-682)
+    for k, v in sd.items():
+        if k.startswith("decoder.") and "num_batches" not in k and "running" not in k:
+            assert torch.equal(v, sd["target_" + k]), k
+
+
+def test_nan_raises_system_error(tmp_path, monkeypatch):
+    import train_soft_intro_vae as T
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("SIVAE_SYNTHETIC_IMAGES", "8")
+    with pytest.raises(SystemError):
+        T.train_soft_intro_vae(dataset="synthetic-cifar10", z_dim=16, batch_size=8, num_workers=0, num_epochs=1,
+                               beta_kl=float("nan"), device=torch.device("cuda:0"))
+
+
+def test_2d_loop_matches_reference_recording():
+    """replays loop_2d.npz (the reference's unmodified train_soft_intro_vae_toy, recorded) on the HIP 2-D path"""
+    import train_soft_intro_vae_2d as T2
+    from sivae_hip.optim import FlatAdam
+    dev = torch.device("cuda:0")
+    fx = np.load(os.path.join(GOLD, "loop_2d.npz"))
+    model = T2.SoftIntroVAESimple(x_dim=2, zdim=2, n_layers=3, num_hidden=int(fx["meta_num_hidden"]))
+    model.load_state_dict({k[len("init/"):]: torch.from_numpy(np.array(fx[k])) for k in fx.files
+                           if k.startswith("init/")}, strict=True)
+    model = model.to(dev).train()
+    lr = float(fx["hp_lr_e"])
+    opt_e = FlatAdam(model.encoder.parameters(), lr=lr)
+    opt_d = FlatAdam([p for n, p in model.decoder.named_parameters() if n != "loggamma"], lr=lr)
+    hp = dict(beta_rec=float(fx["hp_beta_rec"]), beta_kl=float(fx["hp_beta_kl"]), beta_neg=float(fx["hp_beta_neg"]))
+    draws = [torch.from_numpy(fx["draw%d" % i]).to(dev) for i in range(int(fx["meta_n_draws"]))]
+    di = 0
+    for it in range(int(fx["meta_n_iter"])):
+        batch = torch.from_numpy(fx["batch%d" % it]).to(dev)
+        if it < int(fx["meta_num_vae"]):
+            T2.vae_iteration_2d(model, opt_e, opt_d, batch, hp, eps=draws[di])
+            di += 1
+        else:
+            res = T2.soft_intro_iteration_2d(model, opt_e, opt_d, batch, hp, noise=draws[di], eps=draws[di + 1:di + 6])
+            di += 6
+    torch.cuda.synchronize()
+    assert torch.isfinite(res["lossE"]) and torch.isfinite(res["lossD"])
+    sd = model.state_dict()
+    ds = []
+    for k in fx.files:
+        if k.startswith("final/"):
+            ds.append((sd[k[len("final/"):]].double().cpu().numpy() - fx[k].astype(np.float64)).ravel())
+    d = np.abs(np.concatenate(ds)) / lr
+    assert np.median(d) <= 0.05 and (d > 1.0).mean() <= 0.01, (float(d.max()), float(np.median(d)))
+
+
+def test_2d_toy_entry_point_runs(tmp_path, monkeypatch):
+    import train_soft_intro_vae_2d as T2
+    monkeypatch.chdir(tmp_path)
+    model = T2.train_soft_intro_vae_toy(z_dim=2, batch_size=64, n_iter=6, num_vae=2, save_interval=5000, beta_kl=0.3,
+                                        beta_rec=0.2, beta_neg=0.9, test_iter=3, seed=92, device=torch.device("cuda:0"),
+                                        dataset="8Gaussians")
+    assert all(torch.isfinite(v).all() for v in model.state_dict().values())
+    assert os.path.exists(tmp_path / "results_log_soft_intro_vae.txt")
