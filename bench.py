@@ -203,6 +203,17 @@ def main():
                     per_kernel={k: dict(launches=v["launches"], avg_ms=round(v["avg_ms"], 4),
                                         tflops=round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2))
                                 for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])})
+    if roof.get("kernel") and args.config == "celeb256" and per == 128 and not args.bootstrap:
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of THIS workload
+        # (tools/pmc_step.py + tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes, KiB units, read
+        # side x2.0 as calibrated on a 1 GiB copy in the same pass) — counters cannot be read from inside the bench
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
+        if os.path.exists(tpath):
+            tk = json.load(open(tpath))["kernels"]
+            hit = [v for k, v in tk.items() if k.startswith(roof["kernel"][:-1] + ",")]
+            if hit:
+                roof["traffic"] = hit[0]["hbm_bytes"]
+                roof["traffic_unit"] = "HBM bytes per launch (rocprofv3 PMC, profiles/r1_pmc_traffic.json)"
     executed_img = flops_img - (0.0 if args.no_reuse else 2 * fd)  # two decoder forwards replayed, not re-executed
     roof["step"] = dict(algorithmic_gflop_per_image=round(flops_img / 1e9, 1),
                         tflops_per_gpu=round(step_tflops, 2), frac=round(step_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
