@@ -62,6 +62,21 @@ int sivae_conv2d_fwd(const float* x, const float* wp, float* y, const float* bia
                      float* stats_partial, int B, int Ci, int Co, int H, int W, int ks, int upsample,
                      int accumulate, sivae_stream_t stream);
 
+/* Winograd F(2x2,3x3) version of sivae_conv2d_fwd for ks == 3 (same nn.Conv2d(k=3,s=1,p=1) of
+ * soft_intro_vae/train_soft_intro_vae.py:56-61; same fused prologue / upsample / epilogues): 2.25x fewer
+ * multiplies on the fp32 matrix pipe.  `up` is the transformed filter U = G g G^T from
+ * sivae_pack_wino_weight (mode 0 forward, mode 1 data gradient).  Handles even H >= 8 and even W >= 16
+ * (sivae_conv2d_wino_supported); stats_partial has sivae_conv2d_wino_num_px_tiles(B, H, W) rows. */
+size_t sivae_pack_wino_weight_bytes(int Co, int Ci, int mode);
+int sivae_pack_wino_weight(const float* w /*[Co][Ci][3][3]*/, float* up, int Co, int Ci, int mode,
+                           sivae_stream_t stream);
+int sivae_conv2d_wino_supported(int H, int W);
+int sivae_conv2d_wino_num_px_tiles(int B, int H, int W);
+int sivae_conv2d_wino_fwd(const float* x, const float* up, float* y, const float* bias, const float* pro_mean,
+                          const float* pro_invstd, const float* pro_gamma, const float* pro_beta, float pro_slope,
+                          float* stats_partial, int B, int Ci, int Co, int H, int W, int upsample, int accumulate,
+                          sivae_stream_t stream);
+
 /* dw[Co][Ci][ks][ks] = weight gradient (aten::convolution_backward, weight half); x is read with the
  * same optional prologue / upsample addressing as the forward. Deterministic split-K. */
 size_t sivae_conv2d_wgrad_workspace_bytes(int B, int Ci, int Co, int H, int W, int ks);

@@ -1,0 +1,401 @@
+// Winograd F(2x2, 3x3) stride-1 "same" convolution for gfx950 on the exact-fp32 matrix pipe
+// (v_mfma_f32_32x32x2_f32): 16 multiplies per 2x2 output tile instead of 36 -> 2.25x fewer MFMA
+// passes than the direct implicit GEMM of conv_fwd.hip for the same nn.Conv2d(k=3, s=1, p=1)
+// (reference: soft_intro_vae/train_soft_intro_vae.py:56-61).  Forward and — fed the flipped /
+// transposed weight transform — the data gradient.
+//
+//   V = B^T d B   (input 4x4 patch d of a tile, per input channel)
+//   U = G g G^T   (3x3 filter g, per (co, ci); done once per optimizer step by sivae_pack_wino_weight)
+//   M[i][j] = sum_ci U[i][j][co][ci] * V[i][j][ci][tile]      <- 16 independent GEMMs, K = Ci
+//   Y = A^T M A   (2x2 outputs of the tile)
+//
+// Work split: a block is 4 waves = 64 output channels x 32 tiles (128 pixels) x 16 frequencies.
+// Wave j owns frequency COLUMN j (i = 0..3): 4 freq x 2 co-subtiles of 32x32 accumulators = 128
+// registers.  Nothing the MFMA loop consumes is shared between waves except the raw input halo:
+//   * B operand: a lane (tile t = lane&31, channel k = lane>>5) reads the two raw columns its
+//     frequency column needs (8 ds_read_b32 of the zero-padded LDS halo tile), forms
+//     t = d[:,ca] +- d[:,cb] and V[0..3] = B^T t with 8 VALU ops — the transformed tile V is never
+//     stored anywhere.
+//   * A operand: U is packed [j][ci][co][i], so one 16-byte buffer load per (co-subtile, k-step)
+//     gives the lane its four frequencies; loaded straight to registers one chunk (8 channels)
+//     ahead (no LDS: no other wave wants it).
+// After the K loop the row transform A^T M is done in registers, the column transform exchanges
+// 2x32 KB through LDS (aliasing the halo buffers) and writes float2 pixel pairs, with the same
+// fused epilogues as the direct kernel (bias, accumulate, BatchNorm sum/sumsq partials).
+//
+// LDS halo tile layout: [ck][row][parity][col/2] with row stride RS = 2*PH chosen so that the 32
+// tiles of a half-wave hit 32 distinct banks (ds_read_b32 banks = dword address mod 32):
+// 4x8 tiles: RS = 20 (row pair = 40 = 8 mod 32), 2x16 tiles: RS = 40 (row pair = 80 = 16 mod 32).
+#include "common.h"
+
+struct WinoArgs {
+  const float* x;
+  const float* up;  // packed U [4(j)][Ci_pad][Co_pad][4(i)]
+  float* y;
+  const float* bias;
+  const float* pro_mean;
+  const float* pro_invstd;
+  const float* pro_gamma;
+  const float* pro_beta;
+  float pro_slope;
+  float* stats;  // [n_px_tiles][Co][2] or null
+  int B, Ci, Co, H, W;
+  int Ci_pad, Co_pad;
+  int nbh, nbw;
+  int n_co_tiles;
+  int accumulate;
+  int upsample;
+};
+
+#define WINO_CK 8
+#define WINO_TCO 64
+
+template <int TTH_L2, int TTW_L2, bool PRO>
+__global__ void __launch_bounds__(256, 2) conv_wino_kernel(WinoArgs a) {
+  constexpr int TTH = 1 << TTH_L2, TTW = 1 << TTW_L2;
+  static_assert(TTH * TTW == 32, "a block is 32 tiles");
+  constexpr int PXH = 2 * TTH, PXW = 2 * TTW;
+  constexpr int LH = PXH + 2, LWU = PXW + 2;
+  constexpr int PH = TTW + TTW / 4, RS = 2 * PH, PLANE = LH * RS;
+  constexpr int NPOS = LH * LWU;
+  static_assert(NPOS <= 256, "one halo position per thread");
+  constexpr int CK = WINO_CK;
+  constexpr int XBUF = CK * PLANE;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int H = a.H, W = a.W;
+  const int Hs = a.upsample ? (H >> 1) : H, Ws = a.upsample ? (W >> 1) : W;
+  const int HWs = Hs * Ws;
+
+  // block -> (co tile, tile block); co tile fastest: blockIdx % 8 is the XCD, so each XCD keeps
+  // re-using the U slabs of its co tiles in its private L2
+  const int bid = blockIdx.x;
+  const int co_tile = bid % a.n_co_tiles;
+  const int pt = bid / a.n_co_tiles;
+  const int tbx = pt % a.nbw;
+  const int t2 = pt / a.nbw;
+  const int tby = t2 % a.nbh;
+  const int b = t2 / a.nbh;
+  const int r0 = tby * PXH, c0 = tbx * PXW;
+  const int co0 = co_tile * WINO_TCO;
+
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      make_rsrc(a.x + (size_t)b * a.Ci * HWs, (unsigned long long)a.Ci * HWs * 4ull);
+  const __amdgpu_buffer_rsrc_t ursrc = make_rsrc(a.up, 16ull * a.Ci_pad * a.Co_pad * 4ull);
+
+  // ---- halo staging: thread tid owns position tid of the LH x LWU halo for all CK channels
+  unsigned xo = SIVAE_OOB;
+  int xl = 0;
+  {
+    const int rr = tid / LWU, cc = tid % LWU;
+    const int r = r0 + rr - 1, c = c0 + cc - 1;
+    if (tid < NPOS && r >= 0 && r < H && c >= 0 && c < W) {
+      const int rs = a.upsample ? (r >> 1) : r, cs = a.upsample ? (c >> 1) : c;
+      xo = (unsigned)(rs * Ws + cs) * 4u;
+    }
+    xl = rr * RS + (cc & 1) * PH + (cc >> 1);
+  }
+  const bool x_owner = tid < NPOS;
+
+  // ---- A operand (U) addressing: lane -> (ci = k-step*2 + hh, co = co0 + m*32 + l31), 16 B each
+  const unsigned va0 = (unsigned)(hh * a.Co_pad + l31) * 16u;
+  const unsigned va1 = va0 + 32u * 16u;
+  const unsigned ua_base = (unsigned)((wave * a.Ci_pad) * a.Co_pad + co0) * 16u;  // wave-uniform
+  const unsigned ua_step = (unsigned)a.Co_pad * 16u;                              // bytes per input channel
+
+  // ---- B operand: raw columns (ca, cb) and sign of frequency column j = wave
+  const int tx = l31 & (TTW - 1), ty = l31 >> TTW_L2;
+  const int ca = (wave == 0) ? 0 : ((wave == 2) ? 2 : 1);
+  const int cb = (wave == 0) ? 2 : ((wave == 1) ? 2 : ((wave == 2) ? 1 : 3));
+  const float sgn = (wave == 1) ? 1.f : -1.f;
+  const int bb = hh * PLANE + 2 * ty * RS + tx;
+  const int base_a = bb + (ca & 1) * PH + (ca >> 1);
+  const int base_b = bb + (cb & 1) * PH + (cb >> 1);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][m][r] = 0.f;
+
+  float xr[CK];
+  float4 A0[CK / 2][2], A1[CK / 2][2];
+
+#define WINO_LOAD_X(CH)                                                  \
+  {                                                                      \
+    _Pragma("unroll") for (int ck = 0; ck < CK; ++ck) {                  \
+      const int ci = (CH)*CK + ck;                                       \
+      const int cic = ci < a.Ci ? ci : a.Ci - 1;                         \
+      xr[ck] = buf_load_f32(xrsrc, xo, (unsigned)cic * (unsigned)HWs * 4u); \
+    }                                                                    \
+  }
+#define WINO_LOAD_A(CH, AR)                                              \
+  {                                                                      \
+    _Pragma("unroll") for (int kk = 0; kk < CK / 2; ++kk) {              \
+      const unsigned so = ua_base + (unsigned)((CH)*CK + 2 * kk) * ua_step; \
+      AR[kk][0] = buf_load_f32x4(ursrc, va0, so);                        \
+      AR[kk][1] = buf_load_f32x4(ursrc, va1, so);                        \
+    }                                                                    \
+  }
+#define WINO_STORE_X(CH, BUF)                                            \
+  {                                                                      \
+    _Pragma("unroll") for (int ck = 0; ck < CK; ++ck) {                  \
+      const int ci = (CH)*CK + ck;                                       \
+      const bool ci_ok = ci < a.Ci;                                      \
+      float v = xr[ck];                                                  \
+      if (PRO) {                                                         \
+        const int cic = ci_ok ? ci : a.Ci - 1;                           \
+        const float pm = a.pro_mean[cic], pg = a.pro_invstd[cic] * a.pro_gamma[cic], pb = a.pro_beta[cic]; \
+        v = (xo != SIVAE_OOB) ? lrelu((v - pm) * pg + pb, a.pro_slope) : 0.f; \
+      }                                                                  \
+      v = ci_ok ? v : 0.f;                                               \
+      if (x_owner) xs[(BUF)*XBUF + ck * PLANE + xl] = v;                 \
+    }                                                                    \
+  }
+#define WINO_MMA(AR, BUF)                                                \
+  {                                                                      \
+    _Pragma("unroll") for (int kk = 0; kk < CK / 2; ++kk) {              \
+      const float* pa = xs + (BUF)*XBUF + 2 * kk * PLANE + base_a;       \
+      const float* pb_ = xs + (BUF)*XBUF + 2 * kk * PLANE + base_b;      \
+      const float t0 = pa[0 * RS] + sgn * pb_[0 * RS];                   \
+      const float t1 = pa[1 * RS] + sgn * pb_[1 * RS];                   \
+      const float t2_ = pa[2 * RS] + sgn * pb_[2 * RS];                  \
+      const float t3 = pa[3 * RS] + sgn * pb_[3 * RS];                   \
+      const float v0 = t0 - t2_, v1 = t1 + t2_, v2 = t2_ - t1, v3 = t1 - t3; \
+      _Pragma("unroll") for (int m = 0; m < 2; ++m) {                    \
+        acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(AR[kk][m].x, v0, acc[0][m], 0, 0, 0); \
+        acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(AR[kk][m].y, v1, acc[1][m], 0, 0, 0); \
+        acc[2][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(AR[kk][m].z, v2, acc[2][m], 0, 0, 0); \
+        acc[3][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(AR[kk][m].w, v3, acc[3][m], 0, 0, 0); \
+      }                                                                  \
+    }                                                                    \
+  }
+
+  // One barrier per chunk: halo buffer (ch & 1) is written at the top of chunk ch, and its previous
+  // readers (chunk ch-2) are all past the barrier of chunk ch-1.
+  const int nchunks = a.Ci_pad / CK;
+  WINO_LOAD_X(0)
+  WINO_LOAD_A(0, A0)
+  int ch = 0;
+  for (; ch + 1 < nchunks; ch += 2) {
+    WINO_STORE_X(ch, 0)
+    __syncthreads();
+    WINO_LOAD_X(ch + 1)
+    WINO_LOAD_A(ch + 1, A1)
+    WINO_MMA(A0, 0)
+    WINO_STORE_X(ch + 1, 1)
+    __syncthreads();
+    if (ch + 2 < nchunks) {
+      WINO_LOAD_X(ch + 2)
+      WINO_LOAD_A(ch + 2, A0)
+    }
+    WINO_MMA(A1, 1)
+  }
+  if (ch < nchunks) {
+    WINO_STORE_X(ch, 0)
+    __syncthreads();
+    WINO_MMA(A0, 0)
+  }
+#undef WINO_LOAD_X
+#undef WINO_LOAD_A
+#undef WINO_STORE_X
+#undef WINO_MMA
+
+  // ---- output transform.  acc[i][m][r]: tile = l31, channel = m*32 + (r&3) + 8*(r>>2) + 4*hh
+  __syncthreads();
+  float* ex = smem;  // [4 j][2 m][16 r][64 lanes]
+  const int mm = wave & 1, rh = wave >> 1;
+  const int row_base = r0 + 2 * ty, col = c0 + 2 * tx;
+  const bool col_ok = col < W;  // W even: col + 1 < W too
+  float ssum[8], ssq[8];
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) ssum[rr] = ssq[rr] = 0.f;
+#pragma unroll
+  for (int ar = 0; ar < 2; ++ar) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float s = (ar == 0) ? (acc[0][m][r] + acc[1][m][r] + acc[2][m][r])
+                                  : (acc[1][m][r] - acc[2][m][r] - acc[3][m][r]);
+        ex[((wave * 2 + m) * 16 + r) * 64 + lane] = s;
+      }
+    __syncthreads();
+    const int row = row_base + ar;
+    const bool px_ok = col_ok && row < H;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = rh * 8 + rr;
+      const float e0 = ex[((0 * 2 + mm) * 16 + r) * 64 + lane];
+      const float e1 = ex[((1 * 2 + mm) * 16 + r) * 64 + lane];
+      const float e2 = ex[((2 * 2 + mm) * 16 + r) * 64 + lane];
+      const float e3 = ex[((3 * 2 + mm) * 16 + r) * 64 + lane];
+      const int chn = co0 + mm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (chn < a.Co && px_ok) {
+        const float bias = a.bias != nullptr ? a.bias[chn] : 0.f;
+        float y0 = e0 + e1 + e2 + bias;
+        float y1 = e1 - e2 - e3 + bias;
+        float2* dst = reinterpret_cast<float2*>(a.y + (((size_t)b * a.Co + chn) * H + row) * W + col);
+        if (a.accumulate) {
+          const float2 o = *dst;
+          y0 += o.x;
+          y1 += o.y;
+        }
+        *dst = make_float2(y0, y1);
+        ssum[rr] += y0 + y1;
+        ssq[rr] += y0 * y0 + y1 * y1;
+      }
+    }
+    __syncthreads();
+  }
+  if (a.stats != nullptr) {
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = rh * 8 + rr;
+      const int chn = co0 + mm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const float s = half_wave_sum(ssum[rr]);
+      const float q = half_wave_sum(ssq[rr]);
+      if (l31 == 0 && chn < a.Co) {
+        float* dst = a.stats + ((size_t)pt * a.Co + chn) * 2;
+        dst[0] = s;
+        dst[1] = q;
+      }
+    }
+  }
+}
+
+// ---- weight transform U = G g G^T, packed [j][ci_pad][co_pad][i]; padding entries are zero
+//   mode 0 (forward): g = w[n][k]            (n = output channel, k = input channel)
+//   mode 1 (dgrad):   g = flip180(w[k][n])   (k = w's output channel is the GEMM's input channel)
+__global__ void __launch_bounds__(256) pack_wino_kernel(const float* __restrict__ w, float* __restrict__ up, int Co,
+                                                        int Ci, int mode, int kdim, int ndim, int kpad, int npad) {
+  const size_t total = (size_t)kpad * npad;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int n = (int)(idx % npad), k = (int)(idx / npad);
+    float g[3][3];
+    const bool ok = k < kdim && n < ndim;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float v = 0.f;
+        if (ok) v = (mode == 0) ? w[((size_t)n * Ci + k) * 9 + r * 3 + c] : w[((size_t)k * Ci + n) * 9 + (2 - r) * 3 + (2 - c)];
+        g[r][c] = v;
+      }
+    float gg[4][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      gg[0][c] = g[0][c];
+      gg[1][c] = 0.5f * (g[0][c] + g[1][c] + g[2][c]);
+      gg[2][c] = 0.5f * (g[0][c] - g[1][c] + g[2][c]);
+      gg[3][c] = g[2][c];
+    }
+    float u[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u[i][0] = gg[i][0];
+      u[i][1] = 0.5f * (gg[i][0] + gg[i][1] + gg[i][2]);
+      u[i][2] = 0.5f * (gg[i][0] - gg[i][1] + gg[i][2]);
+      u[i][3] = gg[i][2];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4* dst = reinterpret_cast<float4*>(up + (((size_t)j * kpad + k) * npad + n) * 4);
+      *dst = make_float4(u[0][j], u[1][j], u[2][j], u[3][j]);
+    }
+  }
+}
+
+static inline int wino_kpad(int k) { return ((k + WINO_CK - 1) / WINO_CK) * WINO_CK; }
+static inline int wino_npad(int n) { return ((n + WINO_TCO - 1) / WINO_TCO) * WINO_TCO; }
+
+extern "C" size_t sivae_pack_wino_weight_bytes(int Co, int Ci, int mode) {
+  if (Co <= 0 || Ci <= 0 || (mode != 0 && mode != 1)) return 0;
+  const int kdim = mode == 0 ? Ci : Co, ndim = mode == 0 ? Co : Ci;
+  return (size_t)16 * wino_kpad(kdim) * wino_npad(ndim) * sizeof(float);
+}
+
+extern "C" int sivae_pack_wino_weight(const float* w, float* up, int Co, int Ci, int mode, hipStream_t stream) {
+  if (!w || !up) return SIVAE_ERR_NULL;
+  if (Co <= 0 || Ci <= 0) return SIVAE_ERR_SHAPE;
+  if (mode != 0 && mode != 1) return SIVAE_ERR_MODE;
+  const int kdim = mode == 0 ? Ci : Co, ndim = mode == 0 ? Co : Ci;
+  const int kpad = wino_kpad(kdim), npad = wino_npad(ndim);
+  int nb = cdiv((long long)kpad * npad, 256);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(pack_wino_kernel, dim3(nb), dim3(256), 0, stream, w, up, Co, Ci, mode, kdim, ndim, kpad, npad);
+  return sivae_launch_status();
+}
+
+// Winograd path handles even H >= 8 and even W >= 16 (tiles are whole 2x2 blocks; smaller maps are
+// <1 % of the FLOPs and stay on the direct kernel).
+extern "C" int sivae_conv2d_wino_supported(int H, int W) {
+  return (H >= 8 && W >= 16 && !(H & 1) && !(W & 1)) ? 1 : 0;
+}
+
+static inline bool wino_wide(int W) { return W >= 32; }  // 2x16 tiles (4x32 px) vs 4x8 tiles (8x16 px)
+
+extern "C" int sivae_conv2d_wino_num_px_tiles(int B, int H, int W) {
+  if (B <= 0 || !sivae_conv2d_wino_supported(H, W)) return SIVAE_ERR_SHAPE;
+  const int pxh = wino_wide(W) ? 4 : 8, pxw = wino_wide(W) ? 32 : 16;
+  return B * cdiv(H, pxh) * cdiv(W, pxw);
+}
+
+template <int TTH_L2, int TTW_L2>
+static int wino_launch(WinoArgs& a, hipStream_t stream) {
+  constexpr int PXH = 2 << TTH_L2, PXW = 2 << TTW_L2;
+  constexpr int PH = (1 << TTW_L2) + (1 << TTW_L2) / 4, PLANE = (PXH + 2) * 2 * PH;
+  a.nbh = cdiv(a.H, PXH);
+  a.nbw = cdiv(a.W, PXW);
+  a.n_co_tiles = cdiv(a.Co, WINO_TCO);
+  const long long nblk = (long long)a.B * a.nbh * a.nbw * a.n_co_tiles;
+  if (nblk > 0x7fffffffLL) return SIVAE_ERR_RANGE;
+  size_t lds = (size_t)2 * WINO_CK * PLANE * sizeof(float);
+  const size_t exch = (size_t)4 * 2 * 16 * 64 * sizeof(float);
+  if (lds < exch) lds = exch;
+  auto kern = a.pro_mean ? conv_wino_kernel<TTH_L2, TTW_L2, true> : conv_wino_kernel<TTH_L2, TTW_L2, false>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, stream, a);
+  return sivae_launch_status();
+}
+
+extern "C" int sivae_conv2d_wino_fwd(const float* x, const float* up, float* y, const float* bias,
+                                     const float* pro_mean, const float* pro_invstd, const float* pro_gamma,
+                                     const float* pro_beta, float pro_slope, float* stats_partial, int B, int Ci,
+                                     int Co, int H, int W, int upsample, int accumulate, hipStream_t stream) {
+  if (!x || !up || !y) return SIVAE_ERR_NULL;
+  if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
+  if (!sivae_conv2d_wino_supported(H, W)) return SIVAE_ERR_SHAPE;
+  if (pro_mean && (!pro_invstd || !pro_gamma || !pro_beta)) return SIVAE_ERR_NULL;
+  if (((uintptr_t)y & 7u) != 0) return SIVAE_ERR_SHAPE;  // float2 stores
+  const long long hw = (long long)H * W;
+  if ((long long)B * Co * hw >= 0xffffffffLL) return SIVAE_ERR_RANGE;
+  if ((long long)Ci * hw * 4 >= 0x7fffffffLL) return SIVAE_ERR_RANGE;
+  WinoArgs a;
+  a.x = x;
+  a.up = up;
+  a.y = y;
+  a.bias = bias;
+  a.pro_mean = pro_mean;
+  a.pro_invstd = pro_invstd;
+  a.pro_gamma = pro_gamma;
+  a.pro_beta = pro_beta;
+  a.pro_slope = pro_slope;
+  a.stats = stats_partial;
+  a.B = B;
+  a.Ci = Ci;
+  a.Co = Co;
+  a.H = H;
+  a.W = W;
+  a.Ci_pad = wino_kpad(Ci);
+  a.Co_pad = wino_npad(Co);
+  if (16ull * a.Ci_pad * a.Co_pad * 4ull >= 0xffffffffull) return SIVAE_ERR_RANGE;
+  a.accumulate = accumulate;
+  a.upsample = upsample;
+  return wino_wide(W) ? wino_launch<1, 4>(a, stream) : wino_launch<2, 3>(a, stream);
+}

@@ -44,7 +44,7 @@ def packed(w, mode):
     hit = _pack_cache.get(key)
     if hit is not None and hit[0] == tag:
         return hit[1]
-    wp = ops.pack_weight(w.detach(), mode)
+    wp = ops.PackedW(w.detach(), mode)
     _pack_cache[key] = (tag, wp)
     return wp
 

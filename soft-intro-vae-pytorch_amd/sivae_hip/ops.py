@@ -5,6 +5,7 @@ current HIP stream and returns immediately (stream-async). CPU tensors are rejec
 product path has no CPU fallback.
 """
 import ctypes
+import os
 
 import torch
 
@@ -29,19 +30,22 @@ class KernelTimer:
         ev.record()
         return ev
 
-    def end(self, key, flops, start):
+    def end(self, key, flops, start, executed=None):
+        """flops: algorithmic FLOPs of the reference op; executed: FLOPs the kernel actually issues to the matrix
+        pipe when that differs (Winograd)."""
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
-        self.records.append((key, flops, start, ev))
+        self.records.append((key, flops, start, ev, flops if executed is None else executed))
 
     def summary(self):
         """-> {kernel_key: dict(launches, total_ms, avg_ms, flops)} (call after torch.cuda.synchronize())"""
         out = {}
-        for key, flops, s, e in self.records:
-            d = out.setdefault(key, dict(launches=0, total_ms=0.0, flops=0.0))
+        for key, flops, s, e, ex in self.records:
+            d = out.setdefault(key, dict(launches=0, total_ms=0.0, flops=0.0, executed_flops=0.0))
             d["launches"] += 1
             d["total_ms"] += s.elapsed_time(e)
             d["flops"] += flops
+            d["executed_flops"] += ex
         for d in out.values():
             d["avg_ms"] = d["total_ms"] / max(d["launches"], 1)
         return out
@@ -111,19 +115,61 @@ def pack_weight(w, mode):
     return wp
 
 
+def pack_wino(w, mode):
+    """w [Co, Ci, 3, 3] -> Winograd F(2x2,3x3) filter transform U = G g G^T, packed [j][ci][co][i]."""
+    _require(w)
+    Co, Ci = w.shape[0], w.shape[1]
+    assert w.dim() == 4 and w.shape[2] == 3 and w.shape[3] == 3
+    nbytes = _lib.load().sivae_pack_wino_weight_bytes(Co, Ci, mode)
+    if nbytes == 0:
+        raise _lib.SivaeError("sivae_pack_wino_weight_bytes", -3)
+    up = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+    _lib.call("sivae_pack_wino_weight", _p(w), _p(up), Co, Ci, mode, _s())
+    return up
+
+
+# SIVAE_WINO=0 keeps every 3x3 conv on the direct implicit-GEMM kernel (A/B measurements, debugging)
+WINO = os.environ.get("SIVAE_WINO", "1") != "0"
+
+
+class PackedW:
+    """Both GEMM-operand forms of one weight tensor (direct pack; Winograd transform for 3x3), built lazily.
+    conv2d_fwd picks the kernel per call from the feature-map size."""
+
+    def __init__(self, w, mode):
+        self.w, self.mode = w, mode
+        self._direct = self._wino = None
+
+    def direct(self):
+        if self._direct is None:
+            self._direct = pack_weight(self.w, self.mode)
+        return self._direct
+
+    def wino(self):
+        if self._wino is None:
+            self._wino = pack_wino(self.w, self.mode)
+        return self._wino
+
+
 def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=False, out=None,
                accumulate=False):
     """x [B, Ci, H, W] (or [B, Ci, H/2, W/2] with upsample) -> y [B, Co, H, W] (+ stats partials).
 
+    wp: a direct pack (tensor from pack_weight) or a PackedW; with a PackedW, 3x3 convs on maps the Winograd
+    kernel supports (even H >= 8, even W >= 16) run sivae_conv2d_wino_fwd.
     pro = (mean, invstd, gamma, beta, slope): fused producer BatchNorm + LeakyReLU on load."""
-    _require(x, wp, bias, out)
     B, Ci, Hs, Ws = x.shape
     H, W = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
+    L = _lib.load()
+    wino = (WINO and ks == 3 and isinstance(wp, PackedW) and L.sivae_conv2d_wino_supported(H, W) == 1)
+    if isinstance(wp, PackedW):
+        wp = wp.wino() if wino else wp.direct()
+    _require(x, wp, bias, out)
     y = out if out is not None else torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
     assert y.shape == (B, Co, H, W)
     stats = None
     if want_stats:
-        nt = _lib.load().sivae_conv2d_fwd_num_px_tiles(B, Co, H, W)
+        nt = L.sivae_conv2d_wino_num_px_tiles(B, H, W) if wino else L.sivae_conv2d_fwd_num_px_tiles(B, Co, H, W)
         stats = torch.empty((nt, Co, 2), dtype=torch.float32, device=x.device)
     pm = pi = pg = pb = None
     slope = 1.0
@@ -131,10 +177,19 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
         pm, pi, pg, pb, slope = pro
         _require(pm, pi, pg, pb)
     t0 = TIMER.begin() if TIMER is not None else None
-    _lib.call("sivae_conv2d_fwd", _p(x), _p(wp), _p(y), _p(bias), _p(pm), _p(pi), _p(pg), _p(pb), float(slope),
-              _p(stats), B, Ci, Co, H, W, ks, int(bool(upsample)), int(bool(accumulate)), _s())
+    if wino:
+        _lib.call("sivae_conv2d_wino_fwd", _p(x), _p(wp), _p(y), _p(bias), _p(pm), _p(pi), _p(pg), _p(pb),
+                  float(slope), _p(stats), B, Ci, Co, H, W, int(bool(upsample)), int(bool(accumulate)), _s())
+    else:
+        _lib.call("sivae_conv2d_fwd", _p(x), _p(wp), _p(y), _p(bias), _p(pm), _p(pi), _p(pg), _p(pb), float(slope),
+                  _p(stats), B, Ci, Co, H, W, ks, int(bool(upsample)), int(bool(accumulate)), _s())
     if t0 is not None:
-        TIMER.end(conv_fwd_kernel_key(ks, Co, pro is not None), 2.0 * B * H * W * Co * Ci * ks * ks, t0)
+        flops = 2.0 * B * H * W * Co * Ci * ks * ks  # algorithmic (reference nn.Conv2d) FLOPs
+        if wino:
+            key = "conv_wino_kernel<%s,%s>" % ("1,4" if W >= 32 else "2,3", "true" if pro is not None else "false")
+            TIMER.end(key, flops, t0, executed=flops * 16.0 / 36.0)
+        else:
+            TIMER.end(conv_fwd_kernel_key(ks, Co, pro is not None), flops, t0)
     return (y, stats) if want_stats else y
 
 

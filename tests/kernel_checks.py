@@ -59,37 +59,59 @@ def _conv_ref(x, w, b=None):
     return F.conv2d(x, w, b, stride=1, padding=w.shape[-1] // 2)
 
 
-def check_conv_fwd(shape, bias=False, stats=False):
+WINO_SHAPES = [
+    # (B, Ci, Co, H, W, 3): maps the Winograd F(2x2,3x3) kernel accepts (even H >= 8, even W >= 16)
+    (2, 64, 128, 32, 32, 3),
+    (2, 128, 64, 16, 16, 3),
+    (3, 64, 64, 64, 64, 3),
+    (2, 64, 64, 28, 28, 3),    # partial tile blocks in both directions (8x16 px geometry)
+    (1, 20, 70, 8, 16, 3),     # smallest map, non-multiple channels
+    (2, 8, 8, 12, 20, 3),
+    (2, 72, 130, 16, 48, 3),   # 4x32 px geometry with a partial block
+    (1, 512, 512, 16, 16, 3),  # long K loop
+]
+
+
+def _pack(ops, w, mode, wino):
+    return ops.PackedW(w, mode) if wino else ops.pack_weight(w, mode)
+
+
+def check_conv_fwd(shape, bias=False, stats=False, wino=False):
     from sivae_hip import ops
     B, Ci, Co, H, W, ks = shape
     x = _rand(B, Ci, H, W, seed=1)
     w = _rand(Co, Ci, ks, ks, seed=2, scale=1.0 / math.sqrt(Ci * ks * ks))
     b = _rand(Co, seed=3) if bias else None
     ref = _conv_ref(x, w, b)
-    wp = ops.pack_weight(_d(w), 0)
+    wp = _pack(ops, _d(w), 0, wino)
     out = ops.conv2d_fwd(_d(x), wp, Co, ks, bias=_d(b) if bias else None, want_stats=stats)
     res = []
+    tag = "wino_" if wino else "conv_"
     if stats:
         y, part = out
         s = part.double().sum(0).cpu()
-        res.append(("conv_fwd_stats_sum%s" % (shape,), _err(s[:, 0], ref.sum((0, 2, 3))) , 2e-5))
-        res.append(("conv_fwd_stats_sq%s" % (shape,), _err(s[:, 1], (ref * ref).sum((0, 2, 3))), 2e-5))
+        res.append((tag + "fwd_stats_sum%s" % (shape,), _err(s[:, 0], ref.sum((0, 2, 3))) , 2e-5))
+        res.append((tag + "fwd_stats_sq%s" % (shape,), _err(s[:, 1], (ref * ref).sum((0, 2, 3))), 2e-5))
     else:
         y = out
-    res.append(("conv_fwd%s%s" % (shape, "+bias" if bias else ""), _err(y, ref), 1e-5))
+    # Winograd F(2x2,3x3) in fp32: the +-1 / 0.5 / 0.25 transforms cost about one extra bit pair of rounding
+    res.append((tag + "fwd%s%s" % (shape, "+bias" if bias else ""), _err(y, ref), WINO_TOL if wino else 1e-5))
     return res
 
 
-def check_conv_dgrad(shape):
+WINO_TOL = 2e-5
+
+
+def check_conv_dgrad(shape, wino=False):
     from sivae_hip import ops
     B, Ci, Co, H, W, ks = shape
     x = _rand(B, Ci, H, W, seed=1).requires_grad_()
     w = _rand(Co, Ci, ks, ks, seed=2, scale=1.0 / math.sqrt(Ci * ks * ks))
     dy = _rand(B, Co, H, W, seed=4)
     _conv_ref(x, w).backward(dy)
-    wpd = ops.pack_weight(_d(w), 1)
+    wpd = _pack(ops, _d(w), 1, wino)
     dx = ops.conv2d_fwd(_d(dy), wpd, Ci, ks)
-    return [("conv_dgrad%s" % (shape,), _err(dx, x.grad), 1e-5)]
+    return [(("wino_" if wino else "conv_") + "dgrad%s" % (shape,), _err(dx, x.grad), WINO_TOL if wino else 1e-5)]
 
 
 def check_conv_wgrad(shape):
@@ -103,9 +125,10 @@ def check_conv_wgrad(shape):
     return [("conv_wgrad%s" % (shape,), _err(dw, w.grad), 1e-5)]
 
 
-def check_conv_fused(shape):
+def check_conv_fused(shape, wino=False):
     """prologue BN+LeakyReLU, nearest-2x upsample addressing, accumulate — forward and wgrad"""
     from sivae_hip import ops
+    tag, tol = ("wino_", WINO_TOL) if wino else ("conv_", 1e-5)
     B, Ci, Co, H, W, ks = shape
     res = []
     xs = _rand(B, Ci, H // 2, W // 2, seed=5)
@@ -123,9 +146,9 @@ def check_conv_fused(shape):
     xin = F.interpolate(bnact(xs), scale_factor=2, mode="nearest")
     ref = _conv_ref(xin, w)
     ref.backward(dy)
-    wp = ops.pack_weight(_d(w.detach()), 0)
+    wp = _pack(ops, _d(w.detach()), 0, wino)
     y = ops.conv2d_fwd(_d(xs), wp, Co, ks, pro=pro, upsample=True)
-    res.append(("conv_fwd_pro_up%s" % (shape,), _err(y, ref), 1e-5))
+    res.append((tag + "fwd_pro_up%s" % (shape,), _err(y, ref), tol))
     dw = ops.conv2d_wgrad(_d(xs), _d(dy), ks, pro=pro, upsample=True)
     res.append(("conv_wgrad_pro_up%s" % (shape,), _err(dw, w.grad), 1e-5))
     # prologue only, full-res input, accumulate into an existing tensor
@@ -134,7 +157,7 @@ def check_conv_fused(shape):
     ref2 = _conv_ref(bnact(xf), w.detach()) + base
     out = _d(base).clone()
     ops.conv2d_fwd(_d(xf), wp, Co, ks, pro=pro, out=out, accumulate=True)
-    res.append(("conv_fwd_pro_acc%s" % (shape,), _err(out, ref2), 1e-5))
+    res.append((tag + "fwd_pro_acc%s" % (shape,), _err(out, ref2), tol))
     return res
 
 
@@ -407,6 +430,14 @@ def all_checks():
                    + check_conv_fwd((3, 24, 40, 12, 12, 3), stats=True)))
     for s in [(2, 64, 128, 32, 32, 3), (2, 128, 64, 16, 16, 1), (3, 64, 64, 8, 8, 3), (2, 64, 3, 16, 16, 5)]:
         checks.append(("conv_fused%s" % (s,), lambda s=s: check_conv_fused(s)))
+    for s in WINO_SHAPES:
+        checks.append(("wino_fwd%s" % (s,), lambda s=s: check_conv_fwd(s, wino=True)))
+        checks.append(("wino_dgrad%s" % (s,), lambda s=s: check_conv_dgrad(s, wino=True)))
+    checks.append(("wino_fwd_stats", lambda: check_conv_fwd((3, 64, 128, 32, 32, 3), stats=True, wino=True)
+                   + check_conv_fwd((3, 24, 40, 12, 20, 3), stats=True, wino=True)
+                   + check_conv_fwd((2, 64, 3, 16, 48, 3), bias=True, wino=True)))
+    for s in [(2, 64, 128, 32, 32, 3), (3, 40, 72, 16, 16, 3), (2, 16, 64, 24, 40, 3)]:
+        checks.append(("wino_fused%s" % (s,), lambda s=s: check_conv_fused(s, wino=True)))
     checks.append(("conv5_edge", check_conv5_edge))
     checks.append(("linear", check_linear))
     for s in BN_SHAPES:

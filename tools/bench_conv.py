@@ -33,6 +33,10 @@ for (Ci, Co, H, ks) in SHAPES:
     if "fwd" in what:
         t = timeit(lambda: ops.conv2d_fwd(x, wp, Co, ks, want_stats=True))
         out += "  fwd %7.3f ms %6.1f TF" % (t, fl / t / 1e9)
+        if ks == 3 and H >= 16:
+            wq = ops.PackedW(w, 0)
+            t = timeit(lambda: ops.conv2d_fwd(x, wq, Co, ks, want_stats=True))
+            out += "  wino %7.3f ms %6.1f TF(alg) %5.1f TF(exec)" % (t, fl / t / 1e9, fl * 16 / 36 / t / 1e9)
     if "wgrad" in what:
         t = timeit(lambda: ops.conv2d_wgrad(x, dy, ks))
         out += "  wgrad %7.3f ms %6.1f TF" % (t, fl / t / 1e9)
