@@ -27,6 +27,7 @@
 // tiles of a half-wave hit 32 distinct banks (ds_read_b32 banks = dword address mod 32):
 // 4x8 tiles: RS = 20 (row pair = 40 = 8 mod 32), 2x16 tiles: RS = 40 (row pair = 80 = 16 mod 32).
 #include "common.h"
+#include <stdlib.h>
 
 struct WinoArgs {
   const float* x;
@@ -47,26 +48,35 @@ struct WinoArgs {
   int upsample;
 };
 
-#define WINO_CK 8
+#define WINO_CK 16
 #define WINO_TCO 64
 
-template <int TTH_L2, int TTW_L2, bool PRO>
-__global__ void __launch_bounds__(256, 2) conv_wino_kernel(WinoArgs a) {
+// NG = output-channel groups per block (waves = 4*NG: group g, frequency column j), WM = 32-channel
+// subtiles per wave; NG*WM*32 = 64 output channels per block either way.
+//   <NG=1, WM=2>: 4 waves, 128 accumulator registers per wave, two blocks (8 waves) per CU
+//   <NG=2, WM=1>: 8 waves,  64 accumulator registers per wave, two blocks (16 waves) per CU
+template <int TTH_L2, int TTW_L2, bool PRO, int NG, int WM>
+__global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a) {
   constexpr int TTH = 1 << TTH_L2, TTW = 1 << TTW_L2;
   static_assert(TTH * TTW == 32, "a block is 32 tiles");
+  static_assert(NG * WM * 32 == WINO_TCO, "64 output channels per block");
+  constexpr int NT = NG * 256, NW = NG * 4;
   constexpr int PXH = 2 * TTH, PXW = 2 * TTW;
   constexpr int LH = PXH + 2, LWU = PXW + 2;
   constexpr int PH = TTW + TTW / 4, RS = 2 * PH, PLANE = LH * RS;
   constexpr int NPOS = LH * LWU;
-  static_assert(NPOS <= 256, "one halo position per thread");
+  static_assert(NPOS <= NT, "one halo position per thread");
   constexpr int CK = WINO_CK;
   constexpr int XBUF = CK * PLANE;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // wave index as an SGPR: the U loads use it in their scalar offset (a VGPR there costs a waterfall loop per load)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hh = lane >> 5;
+  const int wj = wave & 3, wg = wave >> 2;
   const int H = a.H, W = a.W;
   const int Hs = a.upsample ? (H >> 1) : H, Ws = a.upsample ? (W >> 1) : W;
   const int HWs = Hs * Ws;
@@ -101,31 +111,32 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(WinoArgs a) {
   }
   const bool x_owner = tid < NPOS;
 
-  // ---- A operand (U) addressing: lane -> (ci = k-step*2 + hh, co = co0 + m*32 + l31), 16 B each
-  const unsigned va0 = (unsigned)(hh * a.Co_pad + l31) * 16u;
-  const unsigned va1 = va0 + 32u * 16u;
-  const unsigned ua_base = (unsigned)((wave * a.Ci_pad) * a.Co_pad + co0) * 16u;  // wave-uniform
-  const unsigned ua_step = (unsigned)a.Co_pad * 16u;                              // bytes per input channel
+  // ---- A operand (U) addressing: lane -> (ci = k-step*2 + hh, co = co0 + (wg*WM + m)*32 + l31), 16 B each
+  const unsigned va0 = (unsigned)(hh * a.Co_pad + wg * WM * 32 + l31) * 16u;
+  const unsigned ua_base = (unsigned)((wj * a.Ci_pad) * a.Co_pad + co0) * 16u;  // wave-uniform
+  const unsigned ua_step = (unsigned)a.Co_pad * 16u;                            // bytes per input channel
 
-  // ---- B operand: raw columns (ca, cb) and sign of frequency column j = wave
+  // ---- B operand: raw columns (ca, cb) and sign of frequency column j
   const int tx = l31 & (TTW - 1), ty = l31 >> TTW_L2;
-  const int ca = (wave == 0) ? 0 : ((wave == 2) ? 2 : 1);
-  const int cb = (wave == 0) ? 2 : ((wave == 1) ? 2 : ((wave == 2) ? 1 : 3));
-  const float sgn = (wave == 1) ? 1.f : -1.f;
+  const int ca = (wj == 0) ? 0 : ((wj == 2) ? 2 : 1);
+  const int cb = (wj == 0) ? 2 : ((wj == 1) ? 2 : ((wj == 2) ? 1 : 3));
+  const float sgn = (wj == 1) ? 1.f : -1.f;
   const int bb = hh * PLANE + 2 * ty * RS + tx;
   const int base_a = bb + (ca & 1) * PH + (ca >> 1);
   const int base_b = bb + (cb & 1) * PH + (cb >> 1);
 
-  f32x16 acc[4][2];
+  f32x16 acc[4][WM];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < WM; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][m][r] = 0.f;
 
   float xr[CK];
-  float4 A0[CK / 2][2], A1[CK / 2][2];
+  float4 AR[4][WM];  // ring of U operands: slot (k-step & 3); a slot is refilled with k-step + 4 right after the
+                     // MFMAs that consumed it have been issued (prefetch distance = 4 k-steps, across chunks)
+  const int nksteps = a.Ci_pad / 2;
 
 #define WINO_LOAD_X(CH)                                                  \
   {                                                                      \
@@ -135,13 +146,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(WinoArgs a) {
       xr[ck] = buf_load_f32(xrsrc, xo, (unsigned)cic * (unsigned)HWs * 4u); \
     }                                                                    \
   }
-#define WINO_LOAD_A(CH, AR)                                              \
+#define WINO_LOAD_A(KS_ABS, SLOT)                                        \
   {                                                                      \
-    _Pragma("unroll") for (int kk = 0; kk < CK / 2; ++kk) {              \
-      const unsigned so = ua_base + (unsigned)((CH)*CK + 2 * kk) * ua_step; \
-      AR[kk][0] = buf_load_f32x4(ursrc, va0, so);                        \
-      AR[kk][1] = buf_load_f32x4(ursrc, va1, so);                        \
-    }                                                                    \
+    const unsigned so = ua_base + (unsigned)(2 * (KS_ABS)) * ua_step;    \
+    _Pragma("unroll") for (int m = 0; m < WM; ++m) AR[SLOT][m] = buf_load_f32x4(ursrc, va0 + m * 512u, so); \
   }
 #define WINO_STORE_X(CH, BUF)                                            \
   {                                                                      \
@@ -158,85 +166,115 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(WinoArgs a) {
       if (x_owner) xs[(BUF)*XBUF + ck * PLANE + xl] = v;                 \
     }                                                                    \
   }
-#define WINO_MMA(AR, BUF)                                                \
+  // raw halo reads of k-step KK (two columns x four rows) — issued one k-step ahead of their use so the LDS
+  // latency and the 8 transform VALU ops sit under the previous k-step's MFMAs
+#define WINO_READ(BUF, KK, DA, DB)                                       \
   {                                                                      \
-    _Pragma("unroll") for (int kk = 0; kk < CK / 2; ++kk) {              \
-      const float* pa = xs + (BUF)*XBUF + 2 * kk * PLANE + base_a;       \
-      const float* pb_ = xs + (BUF)*XBUF + 2 * kk * PLANE + base_b;      \
-      const float t0 = pa[0 * RS] + sgn * pb_[0 * RS];                   \
-      const float t1 = pa[1 * RS] + sgn * pb_[1 * RS];                   \
-      const float t2_ = pa[2 * RS] + sgn * pb_[2 * RS];                  \
-      const float t3 = pa[3 * RS] + sgn * pb_[3 * RS];                   \
-      const float v0 = t0 - t2_, v1 = t1 + t2_, v2 = t2_ - t1, v3 = t1 - t3; \
-      _Pragma("unroll") for (int m = 0; m < 2; ++m) {                    \
-        acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(AR[kk][m].x, v0, acc[0][m], 0, 0, 0); \
-        acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(AR[kk][m].y, v1, acc[1][m], 0, 0, 0); \
-        acc[2][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(AR[kk][m].z, v2, acc[2][m], 0, 0, 0); \
-        acc[3][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(AR[kk][m].w, v3, acc[3][m], 0, 0, 0); \
-      }                                                                  \
+    const float* pa = xs + (BUF)*XBUF + 2 * (KK)*PLANE + base_a;         \
+    const float* pb_ = xs + (BUF)*XBUF + 2 * (KK)*PLANE + base_b;        \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                      \
+      DA[r] = pa[r * RS];                                                \
+      DB[r] = pb_[r * RS];                                               \
     }                                                                    \
   }
+#define WINO_STEP(SLOT, DA, DB)                                          \
+  {                                                                      \
+    const float t0 = DA[0] + sgn * DB[0], t1 = DA[1] + sgn * DB[1];      \
+    const float t2_ = DA[2] + sgn * DB[2], t3 = DA[3] + sgn * DB[3];     \
+    const float v0 = t0 - t2_, v1 = t1 + t2_, v2 = t2_ - t1, v3 = t1 - t3; \
+    _Pragma("unroll") for (int m = 0; m < WM; ++m) {                     \
+      acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(AR[SLOT][m].x, v0, acc[0][m], 0, 0, 0); \
+      acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(AR[SLOT][m].y, v1, acc[1][m], 0, 0, 0); \
+      acc[2][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(AR[SLOT][m].z, v2, acc[2][m], 0, 0, 0); \
+      acc[3][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(AR[SLOT][m].w, v3, acc[3][m], 0, 0, 0); \
+    }                                                                    \
+  }
+  // one k-step: prefetch the raw reads of k-step KK+1 (into DAN/DBN), run k-step KK, refill its U slot
+#define WINO_KSTEP(CH, BUF, KK, DA, DB, DAN, DBN)                        \
+  {                                                                      \
+    if ((KK) + 1 < CK / 2) WINO_READ(BUF, (KK) + 1, DAN, DBN)            \
+    __builtin_amdgcn_sched_barrier(0);                                   \
+    WINO_STEP((KK)&3, DA, DB)                                            \
+    __builtin_amdgcn_sched_barrier(0);                                   \
+    if ((CH) * (CK / 2) + (KK) + 4 < nksteps) WINO_LOAD_A((CH) * (CK / 2) + (KK) + 4, (KK)&3) \
+  }
+  // MFMA phase of chunk CH on halo buffer BUF.  The staged registers of chunk CH+1 (loaded at the top) are
+  // written to the OTHER halo buffer late in the phase, so the only thing between two MFMA phases is the barrier.
+#define WINO_MMA(CH, BUF, NEXT)                                          \
+  {                                                                      \
+    float da0[4], db0[4], da1[4], db1[4];                                \
+    if (NEXT) WINO_LOAD_X((CH) + 1)                                      \
+    WINO_READ(BUF, 0, da0, db0)                                          \
+    WINO_KSTEP(CH, BUF, 0, da0, db0, da1, db1)                           \
+    WINO_KSTEP(CH, BUF, 1, da1, db1, da0, db0)                           \
+    WINO_KSTEP(CH, BUF, 2, da0, db0, da1, db1)                           \
+    WINO_KSTEP(CH, BUF, 3, da1, db1, da0, db0)                           \
+    WINO_KSTEP(CH, BUF, 4, da0, db0, da1, db1)                           \
+    WINO_KSTEP(CH, BUF, 5, da1, db1, da0, db0)                           \
+    WINO_KSTEP(CH, BUF, 6, da0, db0, da1, db1)                           \
+    if (NEXT) WINO_STORE_X((CH) + 1, (BUF) ^ 1)                          \
+    __builtin_amdgcn_sched_barrier(0);                                   \
+    WINO_KSTEP(CH, BUF, 7, da1, db1, da0, db0)                           \
+    __syncthreads();                                                     \
+  }
 
-  // One barrier per chunk: halo buffer (ch & 1) is written at the top of chunk ch, and its previous
-  // readers (chunk ch-2) are all past the barrier of chunk ch-1.
+  // One barrier per 16-channel chunk, at the end of its MFMA phase: it publishes the halo of chunk ch+1 (written
+  // during the phase into the other buffer) and retires the readers of buffer (ch & 1) before chunk ch+1's
+  // phase overwrites it with chunk ch+2.
   const int nchunks = a.Ci_pad / CK;
   WINO_LOAD_X(0)
-  WINO_LOAD_A(0, A0)
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) WINO_LOAD_A(kk, kk)
+  WINO_STORE_X(0, 0)
+  __syncthreads();
   int ch = 0;
   for (; ch + 1 < nchunks; ch += 2) {
-    WINO_STORE_X(ch, 0)
-    __syncthreads();
-    WINO_LOAD_X(ch + 1)
-    WINO_LOAD_A(ch + 1, A1)
-    WINO_MMA(A0, 0)
-    WINO_STORE_X(ch + 1, 1)
-    __syncthreads();
-    if (ch + 2 < nchunks) {
-      WINO_LOAD_X(ch + 2)
-      WINO_LOAD_A(ch + 2, A0)
-    }
-    WINO_MMA(A1, 1)
+    WINO_MMA(ch, 0, true)
+    const bool more = ch + 2 < nchunks;
+    WINO_MMA(ch + 1, 1, more)
   }
-  if (ch < nchunks) {
-    WINO_STORE_X(ch, 0)
-    __syncthreads();
-    WINO_MMA(A0, 0)
-  }
+  if (ch < nchunks) WINO_MMA(ch, 0, false)
 #undef WINO_LOAD_X
 #undef WINO_LOAD_A
 #undef WINO_STORE_X
 #undef WINO_MMA
+#undef WINO_KSTEP
+#undef WINO_READ
+#undef WINO_STEP
 
-  // ---- output transform.  acc[i][m][r]: tile = l31, channel = m*32 + (r&3) + 8*(r>>2) + 4*hh
-  __syncthreads();
-  float* ex = smem;  // [4 j][2 m][16 r][64 lanes]
-  const int mm = wave & 1, rh = wave >> 1;
+  // ---- output transform.  acc[i][m][r]: tile = l31, channel = (wg*WM + m)*32 + (r&3) + 8*(r>>2) + 4*hh.
+  // Row transform in registers, column transform across the four frequency-column waves through LDS:
+  // ex[j][cg][r][lane], cg = 32-channel group in the block (2 of them); NW waves share the 32 (cg, r) rows.
+  // (the K loop ended on a barrier, so the halo buffers are free to alias)
+  float* ex = smem;
+  constexpr int PPW = 32 / NW;  // (cg, r) rows per wave in the combine step
   const int row_base = r0 + 2 * ty, col = c0 + 2 * tx;
   const bool col_ok = col < W;  // W even: col + 1 < W too
-  float ssum[8], ssq[8];
+  float ssum[PPW], ssq[PPW];
 #pragma unroll
-  for (int rr = 0; rr < 8; ++rr) ssum[rr] = ssq[rr] = 0.f;
+  for (int rr = 0; rr < PPW; ++rr) ssum[rr] = ssq[rr] = 0.f;
 #pragma unroll
   for (int ar = 0; ar < 2; ++ar) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < WM; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float s = (ar == 0) ? (acc[0][m][r] + acc[1][m][r] + acc[2][m][r])
                                   : (acc[1][m][r] - acc[2][m][r] - acc[3][m][r]);
-        ex[((wave * 2 + m) * 16 + r) * 64 + lane] = s;
+        ex[((wj * 2 + wg * WM + m) * 16 + r) * 64 + lane] = s;
       }
     __syncthreads();
     const int row = row_base + ar;
     const bool px_ok = col_ok && row < H;
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const int r = rh * 8 + rr;
-      const float e0 = ex[((0 * 2 + mm) * 16 + r) * 64 + lane];
-      const float e1 = ex[((1 * 2 + mm) * 16 + r) * 64 + lane];
-      const float e2 = ex[((2 * 2 + mm) * 16 + r) * 64 + lane];
-      const float e3 = ex[((3 * 2 + mm) * 16 + r) * 64 + lane];
-      const int chn = co0 + mm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    for (int rr = 0; rr < PPW; ++rr) {
+      const int p = wave * PPW + rr;
+      const int cg = p >> 4, r = p & 15;
+      const float e0 = ex[((0 * 2 + cg) * 16 + r) * 64 + lane];
+      const float e1 = ex[((1 * 2 + cg) * 16 + r) * 64 + lane];
+      const float e2 = ex[((2 * 2 + cg) * 16 + r) * 64 + lane];
+      const float e3 = ex[((3 * 2 + cg) * 16 + r) * 64 + lane];
+      const int chn = co0 + cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
       if (chn < a.Co && px_ok) {
         const float bias = a.bias != nullptr ? a.bias[chn] : 0.f;
         float y0 = e0 + e1 + e2 + bias;
@@ -256,9 +294,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(WinoArgs a) {
   }
   if (a.stats != nullptr) {
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const int r = rh * 8 + rr;
-      const int chn = co0 + mm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    for (int rr = 0; rr < PPW; ++rr) {
+      const int p = wave * PPW + rr;
+      const int cg = p >> 4, r = p & 15;
+      const int chn = co0 + cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
       const float s = half_wave_sum(ssum[rr]);
       const float q = half_wave_sum(ssq[rr]);
       if (l31 == 0 && chn < a.Co) {
@@ -347,7 +386,16 @@ extern "C" int sivae_conv2d_wino_num_px_tiles(int B, int H, int W) {
   return B * cdiv(H, pxh) * cdiv(W, pxw);
 }
 
-template <int TTH_L2, int TTW_L2>
+static int wino_variant() {  // experiment switch (tools/bench_conv.py): SIVAE_WINO_VARIANT=2 -> 8-wave <NG=2,WM=1> blocks
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SIVAE_WINO_VARIANT");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
+template <int TTH_L2, int TTW_L2, int NG, int WM>
 static int wino_launch(WinoArgs& a, hipStream_t stream) {
   constexpr int PXH = 2 << TTH_L2, PXW = 2 << TTW_L2;
   constexpr int PH = (1 << TTW_L2) + (1 << TTW_L2) / 4, PLANE = (PXH + 2) * 2 * PH;
@@ -359,8 +407,8 @@ static int wino_launch(WinoArgs& a, hipStream_t stream) {
   size_t lds = (size_t)2 * WINO_CK * PLANE * sizeof(float);
   const size_t exch = (size_t)4 * 2 * 16 * 64 * sizeof(float);
   if (lds < exch) lds = exch;
-  auto kern = a.pro_mean ? conv_wino_kernel<TTH_L2, TTW_L2, true> : conv_wino_kernel<TTH_L2, TTW_L2, false>;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, stream, a);
+  auto kern = a.pro_mean ? conv_wino_kernel<TTH_L2, TTW_L2, true, NG, WM> : conv_wino_kernel<TTH_L2, TTW_L2, false, NG, WM>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NG * 256), lds, stream, a);
   return sivae_launch_status();
 }
 
@@ -397,5 +445,8 @@ extern "C" int sivae_conv2d_wino_fwd(const float* x, const float* up, float* y, 
   if (16ull * a.Ci_pad * a.Co_pad * 4ull >= 0xffffffffull) return SIVAE_ERR_RANGE;
   a.accumulate = accumulate;
   a.upsample = upsample;
-  return wino_wide(W) ? wino_launch<1, 4>(a, stream) : wino_launch<2, 3>(a, stream);
+  // production: 4-wave blocks, 64co x 32 tiles per block, 128 accumulator registers per wave (119 TF issued =
+  // 268 TF algorithmic on 512->512 @32x32; the 8-wave <NG=2,WM=1> split measured 106 TF)
+  if (wino_variant() == 2) return wino_wide(W) ? wino_launch<1, 4, 2, 1>(a, stream) : wino_launch<2, 3, 2, 1>(a, stream);
+  return wino_wide(W) ? wino_launch<1, 4, 1, 2>(a, stream) : wino_launch<2, 3, 1, 2>(a, stream);
 }

@@ -1,4 +1,4 @@
-"""Run ONE conv shape a few times (for rocprofv3 --pmc). usage: bench_one.py fwd|wgrad B Ci Co H ks [reps]"""
+"""Run ONE conv shape a few times (for rocprofv3 --pmc). usage: bench_one.py fwd|wino|wgrad B Ci Co H ks [reps]"""
 import os, sys
 import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,9 +9,9 @@ reps = int(sys.argv[7]) if len(sys.argv) > 7 else 3
 x = torch.randn(B, Ci, H, H, device="cuda")
 dy = torch.randn(B, Co, H, H, device="cuda")
 w = torch.randn(Co, Ci, ks, ks, device="cuda") / (Ci * ks * ks) ** 0.5
-wp = ops.pack_weight(w, 0)
+wp = ops.PackedW(w, 0) if kind == "wino" else ops.pack_weight(w, 0)
 for _ in range(reps):
-    if kind == "fwd":
+    if kind in ("fwd", "wino"):
         ops.conv2d_fwd(x, wp, Co, ks, want_stats=True)
     else:
         ops.conv2d_wgrad(x, dy, ks)
