@@ -77,6 +77,16 @@ int sivae_conv2d_wino_fwd(const float* x, const float* up, float* y, const float
                           float* stats_partial, int B, int Ci, int Co, int H, int W, int upsample, int accumulate,
                           sivae_stream_t stream);
 
+/* Winograd-domain weight gradient for ks == 3 (dU = sum_tiles (A dY A^T) . (B^T d B), dW = G^T dU G): the
+ * weight half of aten::convolution_backward for the nn.Conv2d(k=3) layers (:56-61) with 2.25x fewer multiplies;
+ * same prologue / upsample options and the same deterministic two-pass reduction as sivae_conv2d_wgrad.
+ * Maps: sivae_conv2d_wino_supported(H, W). */
+size_t sivae_conv2d_wino_wgrad_workspace_bytes(int B, int Ci, int Co, int H, int W);
+int sivae_conv2d_wino_wgrad(const float* x, const float* dy, float* dw, const float* pro_mean,
+                            const float* pro_invstd, const float* pro_gamma, const float* pro_beta, float pro_slope,
+                            int B, int Ci, int Co, int H, int W, int upsample, void* workspace,
+                            size_t workspace_bytes, sivae_stream_t stream);
+
 /* dw[Co][Ci][ks][ks] = weight gradient (aten::convolution_backward, weight half); x is read with the
  * same optional prologue / upsample addressing as the forward. Deterministic split-K. */
 size_t sivae_conv2d_wgrad_workspace_bytes(int B, int Ci, int Co, int H, int W, int ks);

@@ -130,6 +130,7 @@ def pack_wino(w, mode):
 
 # SIVAE_WINO=0 keeps every 3x3 conv on the direct implicit-GEMM kernel (A/B measurements, debugging)
 WINO = os.environ.get("SIVAE_WINO", "1") != "0"
+WINO_WGRAD = os.environ.get("SIVAE_WINO_WGRAD", os.environ.get("SIVAE_WINO", "1")) != "0"
 
 
 class PackedW:
@@ -199,7 +200,9 @@ def conv2d_wgrad(x, dy, ks, pro=None, upsample=False):
     B, Ci = x.shape[0], x.shape[1]
     _, Co, H, W = dy.shape
     L = _lib.load()
-    nbytes = L.sivae_conv2d_wgrad_workspace_bytes(B, Ci, Co, H, W, ks)
+    wino = WINO_WGRAD and ks == 3 and L.sivae_conv2d_wino_supported(H, W) == 1
+    nbytes = (L.sivae_conv2d_wino_wgrad_workspace_bytes(B, Ci, Co, H, W) if wino
+              else L.sivae_conv2d_wgrad_workspace_bytes(B, Ci, Co, H, W, ks))
     ws = workspace(nbytes, x.device)
     dw = torch.empty((Co, Ci, ks, ks), dtype=torch.float32, device=x.device)
     pm = pi = pg = pb = None
@@ -208,10 +211,19 @@ def conv2d_wgrad(x, dy, ks, pro=None, upsample=False):
         pm, pi, pg, pb, slope = pro
         _require(pm, pi, pg, pb)
     t0 = TIMER.begin() if TIMER is not None else None
-    _lib.call("sivae_conv2d_wgrad", _p(x), _p(dy), _p(dw), _p(pm), _p(pi), _p(pg), _p(pb), float(slope), B, Ci, Co,
-              H, W, ks, int(bool(upsample)), _p(ws), ws.numel(), _s())
+    if wino:
+        _lib.call("sivae_conv2d_wino_wgrad", _p(x), _p(dy), _p(dw), _p(pm), _p(pi), _p(pg), _p(pb), float(slope),
+                  B, Ci, Co, H, W, int(bool(upsample)), _p(ws), ws.numel(), _s())
+    else:
+        _lib.call("sivae_conv2d_wgrad", _p(x), _p(dy), _p(dw), _p(pm), _p(pi), _p(pg), _p(pb), float(slope), B, Ci,
+                  Co, H, W, ks, int(bool(upsample)), _p(ws), ws.numel(), _s())
     if t0 is not None:  # (includes the tiny slice-reduce launch that follows the MFMA kernel)
-        TIMER.end(conv_wgrad_kernel_key(ks, Co, pro is not None), 2.0 * B * H * W * Co * Ci * ks * ks, t0)
+        flops = 2.0 * B * H * W * Co * Ci * ks * ks
+        if wino:
+            TIMER.end("wino_wgrad_kernel<%s,1>" % ("true" if pro is not None else "false"), flops, t0,
+                      executed=flops * 16.0 / 36.0)
+        else:
+            TIMER.end(conv_wgrad_kernel_key(ks, Co, pro is not None), flops, t0)
     return dw
 
 

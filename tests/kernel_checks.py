@@ -114,15 +114,23 @@ def check_conv_dgrad(shape, wino=False):
     return [(("wino_" if wino else "conv_") + "dgrad%s" % (shape,), _err(dx, x.grad), WINO_TOL if wino else 1e-5)]
 
 
-def check_conv_wgrad(shape):
+def check_conv_wgrad(shape, wino=None):
+    """wino: None = whatever ops dispatches to (direct for maps the Winograd kernel does not take),
+    True / False force the Winograd-domain / direct kernel"""
     from sivae_hip import ops
     B, Ci, Co, H, W, ks = shape
     x = _rand(B, Ci, H, W, seed=1)
     w = _rand(Co, Ci, ks, ks, seed=2).requires_grad_()
     dy = _rand(B, Co, H, W, seed=4)
     _conv_ref(x, w).backward(dy)
-    dw = ops.conv2d_wgrad(_d(x), _d(dy), ks)
-    return [("conv_wgrad%s" % (shape,), _err(dw, w.grad), 1e-5)]
+    saved = ops.WINO_WGRAD
+    if wino is not None:
+        ops.WINO_WGRAD = wino
+    try:
+        dw = ops.conv2d_wgrad(_d(x), _d(dy), ks)
+    finally:
+        ops.WINO_WGRAD = saved
+    return [(("wino_" if wino else "conv_") + "wgrad%s" % (shape,), _err(dw, w.grad), WINO_TOL if wino else 1e-5)]
 
 
 def check_conv_fused(shape, wino=False):
@@ -149,8 +157,13 @@ def check_conv_fused(shape, wino=False):
     wp = _pack(ops, _d(w.detach()), 0, wino)
     y = ops.conv2d_fwd(_d(xs), wp, Co, ks, pro=pro, upsample=True)
     res.append((tag + "fwd_pro_up%s" % (shape,), _err(y, ref), tol))
-    dw = ops.conv2d_wgrad(_d(xs), _d(dy), ks, pro=pro, upsample=True)
-    res.append(("conv_wgrad_pro_up%s" % (shape,), _err(dw, w.grad), 1e-5))
+    saved = ops.WINO_WGRAD
+    ops.WINO_WGRAD = bool(wino)
+    try:
+        dw = ops.conv2d_wgrad(_d(xs), _d(dy), ks, pro=pro, upsample=True)
+    finally:
+        ops.WINO_WGRAD = saved
+    res.append((tag + "wgrad_pro_up%s" % (shape,), _err(dw, w.grad), tol))
     # prologue only, full-res input, accumulate into an existing tensor
     xf = _rand(B, Ci, H, W, seed=11)
     base = _rand(B, Co, H, W, seed=12)
@@ -423,7 +436,7 @@ def all_checks():
     for s in CONV_SHAPES:
         checks.append(("conv_fwd%s" % (s,), lambda s=s: check_conv_fwd(s)))
         checks.append(("conv_dgrad%s" % (s,), lambda s=s: check_conv_dgrad(s)))
-        checks.append(("conv_wgrad%s" % (s,), lambda s=s: check_conv_wgrad(s)))
+        checks.append(("conv_wgrad%s" % (s,), lambda s=s: check_conv_wgrad(s, wino=False)))
     checks.append(("conv_fwd_bias", lambda: check_conv_fwd((2, 64, 3, 32, 32, 5), bias=True)))
     checks.append(("conv_fwd_stats", lambda: check_conv_fwd((3, 64, 128, 32, 32, 3), stats=True)
                    + check_conv_fwd((3, 64, 64, 32, 32, 3), stats=True)
@@ -433,6 +446,7 @@ def all_checks():
     for s in WINO_SHAPES:
         checks.append(("wino_fwd%s" % (s,), lambda s=s: check_conv_fwd(s, wino=True)))
         checks.append(("wino_dgrad%s" % (s,), lambda s=s: check_conv_dgrad(s, wino=True)))
+        checks.append(("wino_wgrad%s" % (s,), lambda s=s: check_conv_wgrad(s, wino=True)))
     checks.append(("wino_fwd_stats", lambda: check_conv_fwd((3, 64, 128, 32, 32, 3), stats=True, wino=True)
                    + check_conv_fwd((3, 24, 40, 12, 20, 3), stats=True, wino=True)
                    + check_conv_fwd((2, 64, 3, 16, 48, 3), bias=True, wino=True)))

@@ -40,6 +40,11 @@ for (Ci, Co, H, ks) in SHAPES:
     if "wgrad" in what:
         t = timeit(lambda: ops.conv2d_wgrad(x, dy, ks))
         out += "  wgrad %7.3f ms %6.1f TF" % (t, fl / t / 1e9)
+        if ks == 3 and H >= 16 and ops.WINO_WGRAD:
+            ops.WINO_WGRAD = False
+            t = timeit(lambda: ops.conv2d_wgrad(x, dy, ks))
+            ops.WINO_WGRAD = True
+            out += "  (direct %7.3f ms %6.1f TF)" % (t, fl / t / 1e9)
     if ks == 5 and min(Ci, Co) <= 3:
         if Co <= 3:
             wq = ops.pack5_smallco(w, 0)
