@@ -125,6 +125,22 @@ __device__ __forceinline__ float4 buf_load_f32x4(__amdgpu_buffer_rsrc_t r, unsig
   return make_float4(f[0], f[1], f[2], f[3]);
 }
 
+// raw buffer stores / 8-byte loads with the same addressing rules (an out-of-range per-lane offset drops the
+// store / returns 0) — lets epilogues mask invalid lanes through the offset instead of exec-mask branches
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void buf_store_f32x2(__amdgpu_buffer_rsrc_t r, float a, float b, unsigned voff, unsigned soff) {
+  f32x2 v;
+  v[0] = a;
+  v[1] = b;
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ float2 buf_load_f32x2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const u32x2_t q = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+  const f32x2 f = __builtin_bit_cast(f32x2, q);
+  return make_float2(f[0], f[1]);
+}
+
 // exact floor(e / d) for e < 2^22, d < 2^10 with magic = floor(2^32 / d) + 1
 // magic == 0 encodes d == 1
 __device__ __forceinline__ unsigned fastdiv(unsigned e, unsigned magic) { return magic ? __umulhi(e, magic) : e; }

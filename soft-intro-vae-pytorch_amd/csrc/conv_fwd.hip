@@ -423,9 +423,11 @@ extern "C" int sivae_conv2d_fwd(const float* x, const float* wp, float* y, const
                                                                        //  CK4/3 blocks 110.0, CK2/4 blocks 122.6 img/s)
     }
   } else if (ks == 1) {
+    // 16-channel chunks at four blocks per CU: the 1x1 convs are short-K, HBM-leaning kernels (K = 64..512) that
+    // need occupancy more than chunk depth (64->128 @128x128 bs128: 0.99 ms with CK=32 / two blocks, 0.63 ms here)
     if (Co <= 32) return launch_cfg<1, 1, 2, 1, 4, 32, 1>(a, stream);
-    if (Co <= 64) return launch_cfg<1, 2, 2, 1, 4, 32, 1>(a, stream);
-    return launch_cfg<1, 2, 2, 2, 2, 32, 1>(a, stream);
+    if (Co <= 64) return launch_cfg<1, 2, 2, 1, 4, 16, 1, 4>(a, stream);
+    return launch_cfg<1, 2, 2, 2, 2, 16, 1, 4>(a, stream);
   } else {
     if (Co <= 32) return launch_cfg<5, 1, 2, 1, 4, 4, 4>(a, stream);
     if (Co <= 64) return launch_cfg<5, 2, 2, 1, 4, 4, 4>(a, stream);

@@ -46,9 +46,11 @@ struct WinoArgs {
   int n_co_tiles;
   int accumulate;
   int upsample;
+  int n_items;
 };
 
 #define WINO_CK 16
+#define WINO_EX_FLOATS (2 * 4 * 2 * 16 * 64)  // output-transform exchange area (64 KB), aliases the halo buffers
 #define WINO_TCO 64
 
 // NG = output-channel groups per block (waves = 4*NG: group g, frequency column j), WM = 32-channel
@@ -71,6 +73,10 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;
+  // fused-BatchNorm parameters {mean, invstd*gamma, beta, -} per input channel, staged once per block behind the
+  // 64 KB exchange area (reading them with scalar loads at halo-store time put 48 SMEM round trips and their
+  // lgkmcnt(0) waits into every chunk: 159 instead of 209 TF on 512->512)
+  float4* pro4 = reinterpret_cast<float4*>(smem + WINO_EX_FLOATS);
 
   const int tid = threadIdx.x, lane = tid & 63;
   // wave index as an SGPR: the U loads use it in their scalar offset (a VGPR there costs a waterfall loop per load)
@@ -81,39 +87,42 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
   const int Hs = a.upsample ? (H >> 1) : H, Ws = a.upsample ? (W >> 1) : W;
   const int HWs = Hs * Ws;
 
-  // block -> (co tile, tile block); co tile fastest: blockIdx % 8 is the XCD, so each XCD keeps
-  // re-using the U slabs of its co tiles in its private L2
-  const int bid = blockIdx.x;
-  const int co_tile = bid % a.n_co_tiles;
-  const int pt = bid / a.n_co_tiles;
-  const int tbx = pt % a.nbw;
-  const int t2 = pt / a.nbw;
-  const int tby = t2 % a.nbh;
-  const int b = t2 / a.nbh;
-  const int r0 = tby * PXH, c0 = tbx * PXW;
-  const int co0 = co_tile * WINO_TCO;
-
-  const __amdgpu_buffer_rsrc_t xrsrc =
-      make_rsrc(a.x + (size_t)b * a.Ci * HWs, (unsigned long long)a.Ci * HWs * 4ull);
+  // Work items (co tile, tile block), co tile fastest.  A block walks items bid, bid + gridDim, ... (the grid is
+  // two blocks per CU): the first halo chunk and U operands of the NEXT item are requested before the output
+  // transform of the current one, so launch latency, address set-up and the first HBM round trip are paid
+  // once per block instead of once per 128 output pixels.
+  const int n_items = a.n_items;
+  int item = blockIdx.x;
+  int pt, b, r0, c0, co0;
+  __amdgpu_buffer_rsrc_t xrsrc;
   const __amdgpu_buffer_rsrc_t ursrc = make_rsrc(a.up, 16ull * a.Ci_pad * a.Co_pad * 4ull);
-
-  // ---- halo staging: thread tid owns position tid of the LH x LWU halo for all CK channels
-  unsigned xo = SIVAE_OOB;
-  int xl = 0;
-  {
-    const int rr = tid / LWU, cc = tid % LWU;
-    const int r = r0 + rr - 1, c = c0 + cc - 1;
-    if (tid < NPOS && r >= 0 && r < H && c >= 0 && c < W) {
-      const int rs = a.upsample ? (r >> 1) : r, cs = a.upsample ? (c >> 1) : c;
-      xo = (unsigned)(rs * Ws + cs) * 4u;
-    }
-    xl = rr * RS + (cc & 1) * PH + (cc >> 1);
+  unsigned xo, ua_base;
+  const int xrr = tid / LWU, xcc = tid % LWU;
+  const int xl = xrr * RS + (xcc & 1) * PH + (xcc >> 1);
+#define WINO_SETUP(ITEM)                                                 \
+  {                                                                      \
+    const int co_tile = (ITEM) % a.n_co_tiles;                           \
+    pt = (ITEM) / a.n_co_tiles;                                          \
+    const int tbx = pt % a.nbw;                                          \
+    const int t2 = pt / a.nbw;                                           \
+    const int tby = t2 % a.nbh;                                          \
+    b = t2 / a.nbh;                                                      \
+    r0 = tby * PXH;                                                      \
+    c0 = tbx * PXW;                                                      \
+    co0 = co_tile * WINO_TCO;                                            \
+    xrsrc = make_rsrc(a.x + (size_t)b * a.Ci * HWs, (unsigned long long)a.Ci * HWs * 4ull); \
+    const int r = r0 + xrr - 1, c = c0 + xcc - 1;                        \
+    xo = SIVAE_OOB;                                                      \
+    if (tid < NPOS && r >= 0 && r < H && c >= 0 && c < W) {              \
+      const int rs = a.upsample ? (r >> 1) : r, cs = a.upsample ? (c >> 1) : c; \
+      xo = (unsigned)(rs * Ws + cs) * 4u;                                \
+    }                                                                    \
+    ua_base = (unsigned)((wj * a.Ci_pad) * a.Co_pad + co0) * 16u;        \
   }
   const bool x_owner = tid < NPOS;
 
   // ---- A operand (U) addressing: lane -> (ci = k-step*2 + hh, co = co0 + (wg*WM + m)*32 + l31), 16 B each
   const unsigned va0 = (unsigned)(hh * a.Co_pad + wg * WM * 32 + l31) * 16u;
-  const unsigned ua_base = (unsigned)((wj * a.Ci_pad) * a.Co_pad + co0) * 16u;  // wave-uniform
   const unsigned ua_step = (unsigned)a.Co_pad * 16u;                            // bytes per input channel
 
   // ---- B operand: raw columns (ca, cb) and sign of frequency column j
@@ -126,13 +135,6 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
   const int base_b = bb + (cb & 1) * PH + (cb >> 1);
 
   f32x16 acc[4][WM];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int m = 0; m < WM; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][m][r] = 0.f;
-
   float xr[CK];
   float4 AR[4][WM];  // ring of U operands: slot (k-step & 3); a slot is refilled with k-step + 4 right after the
                      // MFMAs that consumed it have been issued (prefetch distance = 4 k-steps, across chunks)
@@ -158,9 +160,8 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
       const bool ci_ok = ci < a.Ci;                                      \
       float v = xr[ck];                                                  \
       if (PRO) {                                                         \
-        const int cic = ci_ok ? ci : a.Ci - 1;                           \
-        const float pm = a.pro_mean[cic], pg = a.pro_invstd[cic] * a.pro_gamma[cic], pb = a.pro_beta[cic]; \
-        v = (xo != SIVAE_OOB) ? lrelu((v - pm) * pg + pb, a.pro_slope) : 0.f; \
+        const float4 pp = pro4[ci];                                      \
+        v = (xo != SIVAE_OOB) ? lrelu((v - pp.x) * pp.y + pp.z, a.pro_slope) : 0.f; \
       }                                                                  \
       v = ci_ok ? v : 0.f;                                               \
       if (x_owner) xs[(BUF)*XBUF + ck * PLANE + xl] = v;                 \
@@ -218,22 +219,121 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
     __syncthreads();                                                     \
   }
 
+  // ---- output transform of the item at (e_b, e_r0, e_c0, e_co0).  acc[i][m][r]: tile = l31, channel =
+  // (wg*WM + m)*32 + (r&3) + 8*(r>>2) + 4*hh.  Row transform in registers, column transform across the four
+  // frequency-column waves through LDS: ex[j][cg][r][lane], cg = 32-channel group in the block; NW waves share
+  // the 32 (cg, r) rows.  (The K loop ended on a barrier, so the halo buffers are free to alias; the last
+  // barrier of the epilogue frees them again for the next item's halo.)
+#define WINO_EPILOGUE                                                     \
+  {                                                                      \
+    float* ex = smem; /* [2 ar][4 j][2 cg][16 r][64 lanes] = 64 KB */    \
+    constexpr int PPW = 32 / NW;                                         \
+    const __amdgpu_buffer_rsrc_t yrsrc =                                 \
+        make_rsrc(a.y + (size_t)e_b * a.Co * H * W, (unsigned long long)a.Co * H * W * 4ull); \
+    const int row_base = e_r0 + 2 * ty, col = e_c0 + 2 * tx;             \
+    _Pragma("unroll") for (int m = 0; m < WM; ++m)                       \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                     \
+      ex[((wj * 2 + wg * WM + m) * 16 + r) * 64 + lane] = acc[0][m][r] + acc[1][m][r] + acc[2][m][r]; \
+      ex[(((4 + wj) * 2 + wg * WM + m) * 16 + r) * 64 + lane] = acc[1][m][r] - acc[2][m][r] - acc[3][m][r]; \
+    }                                                                    \
+    /* byte offset of (chn, row_base, col) per (cg, r) row of this wave; invalid channels / columns / rows get */ \
+    /* an out-of-range offset, so their stores are dropped (and accumulate-loads return 0) without branches */ \
+    unsigned yo[PPW];                                                    \
+    _Pragma("unroll") for (int rr = 0; rr < PPW; ++rr) {                 \
+      const int p = wave * PPW + rr;                                     \
+      const int chn = e_co0 + (p >> 4) * 32 + (p & 3) + 8 * ((p & 15) >> 2) + 4 * hh; \
+      yo[rr] = (chn < a.Co && col < W) ? (unsigned)((chn * H + row_base) * W + col) * 4u : SIVAE_OOB; \
+    }                                                                    \
+    __syncthreads();                                                     \
+    _Pragma("unroll") for (int rr = 0; rr < PPW; ++rr) {                 \
+      const int p = wave * PPW + rr;                                     \
+      float ssum = 0.f, ssq = 0.f;                                       \
+      _Pragma("unroll") for (int ar = 0; ar < 2; ++ar) {                 \
+        float e[4];                                                      \
+        _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) e[jj] = ex[(((ar * 4 + jj) * 2 + (p >> 4)) * 16 + (p & 15)) * 64 + lane]; \
+        const bool ok = yo[rr] != SIVAE_OOB && row_base + ar < H;        \
+        const unsigned off = ok ? yo[rr] + (unsigned)(ar * W) * 4u : SIVAE_OOB; \
+        float y0 = e[0] + e[1] + e[2];                                   \
+        float y1 = e[1] - e[2] - e[3];                                   \
+        if (a.accumulate) {                                              \
+          const float2 o = buf_load_f32x2(yrsrc, off, 0u);               \
+          y0 += o.x;                                                     \
+          y1 += o.y;                                                     \
+        }                                                                \
+        buf_store_f32x2(yrsrc, y0, y1, off, 0u);                         \
+        ssum += ok ? (y0 + y1) : 0.f;                                    \
+        ssq += ok ? (y0 * y0 + y1 * y1) : 0.f;                           \
+      }                                                                  \
+      if (a.stats != nullptr) {                                          \
+        const int chn = e_co0 + (p >> 4) * 32 + (p & 3) + 8 * ((p & 15) >> 2) + 4 * hh; \
+        const float s = half_wave_sum(ssum);                             \
+        const float q = half_wave_sum(ssq);                              \
+        if (l31 == 0 && chn < a.Co) {                                    \
+          float* dst = a.stats + ((size_t)e_pt * a.Co + chn) * 2;        \
+          dst[0] = s;                                                    \
+          dst[1] = q;                                                    \
+        }                                                                \
+      }                                                                  \
+    }                                                                    \
+    __syncthreads();                                                     \
+  }
+
   // One barrier per 16-channel chunk, at the end of its MFMA phase: it publishes the halo of chunk ch+1 (written
   // during the phase into the other buffer) and retires the readers of buffer (ch & 1) before chunk ch+1's
   // phase overwrites it with chunk ch+2.
   const int nchunks = a.Ci_pad / CK;
+  if (PRO) {
+    for (int c = tid; c < a.Ci_pad; c += NT) {
+      const int cc = c < a.Ci ? c : a.Ci - 1;
+      pro4[c] = make_float4(a.pro_mean[cc], a.pro_invstd[cc] * a.pro_gamma[cc], a.pro_beta[cc], 0.f);
+    }
+    __syncthreads();
+  }
+  WINO_SETUP(item)
   WINO_LOAD_X(0)
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) WINO_LOAD_A(kk, kk)
-  WINO_STORE_X(0, 0)
-  __syncthreads();
-  int ch = 0;
-  for (; ch + 1 < nchunks; ch += 2) {
-    WINO_MMA(ch, 0, true)
-    const bool more = ch + 2 < nchunks;
-    WINO_MMA(ch + 1, 1, more)
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][m][r] = 0.f;
+    WINO_STORE_X(0, 0)
+    __syncthreads();
+    int ch = 0;
+    for (; ch + 1 < nchunks; ch += 2) {
+      WINO_MMA(ch, 0, true)
+      const bool more = ch + 2 < nchunks;
+      WINO_MMA(ch + 1, 1, more)
+    }
+    if (ch < nchunks) WINO_MMA(ch, 0, false)
+
+    // coordinates of the item just accumulated; then put the next item's first loads in flight
+    const int e_pt = pt, e_b = b, e_r0 = r0, e_c0 = c0, e_co0 = co0;
+    const int next = item + (int)gridDim.x;
+    const bool has_next = next < n_items;
+    // (with accumulate the epilogue loads y; vmcnt completes in order, so the prefetch goes after it)
+    const bool early = has_next && !a.accumulate;
+    if (early) {
+      WINO_SETUP(next)
+      WINO_LOAD_X(0)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) WINO_LOAD_A(kk, kk)
+    }
+    WINO_EPILOGUE
+    if (has_next && !early) {
+      WINO_SETUP(next)
+      WINO_LOAD_X(0)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) WINO_LOAD_A(kk, kk)
+    }
+    if (!has_next) break;
+    item = next;
   }
-  if (ch < nchunks) WINO_MMA(ch, 0, false)
+#undef WINO_SETUP
+#undef WINO_EPILOGUE
 #undef WINO_LOAD_X
 #undef WINO_LOAD_A
 #undef WINO_STORE_X
@@ -242,71 +342,6 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
 #undef WINO_READ
 #undef WINO_STEP
 
-  // ---- output transform.  acc[i][m][r]: tile = l31, channel = (wg*WM + m)*32 + (r&3) + 8*(r>>2) + 4*hh.
-  // Row transform in registers, column transform across the four frequency-column waves through LDS:
-  // ex[j][cg][r][lane], cg = 32-channel group in the block (2 of them); NW waves share the 32 (cg, r) rows.
-  // (the K loop ended on a barrier, so the halo buffers are free to alias)
-  float* ex = smem;
-  constexpr int PPW = 32 / NW;  // (cg, r) rows per wave in the combine step
-  const int row_base = r0 + 2 * ty, col = c0 + 2 * tx;
-  const bool col_ok = col < W;  // W even: col + 1 < W too
-  float ssum[PPW], ssq[PPW];
-#pragma unroll
-  for (int rr = 0; rr < PPW; ++rr) ssum[rr] = ssq[rr] = 0.f;
-#pragma unroll
-  for (int ar = 0; ar < 2; ++ar) {
-#pragma unroll
-    for (int m = 0; m < WM; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float s = (ar == 0) ? (acc[0][m][r] + acc[1][m][r] + acc[2][m][r])
-                                  : (acc[1][m][r] - acc[2][m][r] - acc[3][m][r]);
-        ex[((wj * 2 + wg * WM + m) * 16 + r) * 64 + lane] = s;
-      }
-    __syncthreads();
-    const int row = row_base + ar;
-    const bool px_ok = col_ok && row < H;
-#pragma unroll
-    for (int rr = 0; rr < PPW; ++rr) {
-      const int p = wave * PPW + rr;
-      const int cg = p >> 4, r = p & 15;
-      const float e0 = ex[((0 * 2 + cg) * 16 + r) * 64 + lane];
-      const float e1 = ex[((1 * 2 + cg) * 16 + r) * 64 + lane];
-      const float e2 = ex[((2 * 2 + cg) * 16 + r) * 64 + lane];
-      const float e3 = ex[((3 * 2 + cg) * 16 + r) * 64 + lane];
-      const int chn = co0 + cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      if (chn < a.Co && px_ok) {
-        const float bias = a.bias != nullptr ? a.bias[chn] : 0.f;
-        float y0 = e0 + e1 + e2 + bias;
-        float y1 = e1 - e2 - e3 + bias;
-        float2* dst = reinterpret_cast<float2*>(a.y + (((size_t)b * a.Co + chn) * H + row) * W + col);
-        if (a.accumulate) {
-          const float2 o = *dst;
-          y0 += o.x;
-          y1 += o.y;
-        }
-        *dst = make_float2(y0, y1);
-        ssum[rr] += y0 + y1;
-        ssq[rr] += y0 * y0 + y1 * y1;
-      }
-    }
-    __syncthreads();
-  }
-  if (a.stats != nullptr) {
-#pragma unroll
-    for (int rr = 0; rr < PPW; ++rr) {
-      const int p = wave * PPW + rr;
-      const int cg = p >> 4, r = p & 15;
-      const int chn = co0 + cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      const float s = half_wave_sum(ssum[rr]);
-      const float q = half_wave_sum(ssq[rr]);
-      if (l31 == 0 && chn < a.Co) {
-        float* dst = a.stats + ((size_t)pt * a.Co + chn) * 2;
-        dst[0] = s;
-        dst[1] = q;
-      }
-    }
-  }
 }
 
 // ---- weight transform U = G g G^T, packed [j][ci_pad][co_pad][i]; padding entries are zero
@@ -395,6 +430,21 @@ static int wino_variant() {  // experiment switch (tools/bench_conv.py): SIVAE_W
   return v;
 }
 
+// persistent grid: two co-resident blocks per CU
+static int wino_grid_blocks() {
+  static int g = 0;
+  if (g == 0) {
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+    const char* e = getenv("SIVAE_WINO_GRID");
+    g = e ? atoi(e) : 2 * cus;
+    if (g <= 0) g = 2 * cus;
+  }
+  return g;
+}
+
 template <int TTH_L2, int TTW_L2, int NG, int WM>
 static int wino_launch(WinoArgs& a, hipStream_t stream) {
   constexpr int PXH = 2 << TTH_L2, PXW = 2 << TTW_L2;
@@ -405,10 +455,19 @@ static int wino_launch(WinoArgs& a, hipStream_t stream) {
   const long long nblk = (long long)a.B * a.nbh * a.nbw * a.n_co_tiles;
   if (nblk > 0x7fffffffLL) return SIVAE_ERR_RANGE;
   size_t lds = (size_t)2 * WINO_CK * PLANE * sizeof(float);
-  const size_t exch = (size_t)4 * 2 * 16 * 64 * sizeof(float);
-  if (lds < exch) lds = exch;
+  const size_t exch = (size_t)WINO_EX_FLOATS * sizeof(float);
+  if (lds > exch) return SIVAE_ERR_SHAPE;  // (halo buffers alias the exchange area)
+  lds = exch + (a.pro_mean ? (size_t)a.Ci_pad * 16 : 0);
+  if (lds > 80 * 1024) return SIVAE_ERR_SHAPE;
   auto kern = a.pro_mean ? conv_wino_kernel<TTH_L2, TTW_L2, true, NG, WM> : conv_wino_kernel<TTH_L2, TTW_L2, false, NG, WM>;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NG * 256), lds, stream, a);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  a.n_items = (int)nblk;
+  const int grid = nblk < wino_grid_blocks() ? (int)nblk : wino_grid_blocks();
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NG * 256), lds, stream, a);
   return sivae_launch_status();
 }
 
@@ -417,13 +476,14 @@ extern "C" int sivae_conv2d_wino_fwd(const float* x, const float* up, float* y, 
                                      const float* pro_beta, float pro_slope, float* stats_partial, int B, int Ci,
                                      int Co, int H, int W, int upsample, int accumulate, hipStream_t stream) {
   if (!x || !up || !y) return SIVAE_ERR_NULL;
+  if (bias) return SIVAE_ERR_MODE;  // none of the 3x3 convs has a bias (:56-61); sivae_conv2d_fwd handles that case
   if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
   if (!sivae_conv2d_wino_supported(H, W)) return SIVAE_ERR_SHAPE;
   if (pro_mean && (!pro_invstd || !pro_gamma || !pro_beta)) return SIVAE_ERR_NULL;
   if (((uintptr_t)y & 7u) != 0) return SIVAE_ERR_SHAPE;  // float2 stores
   const long long hw = (long long)H * W;
   if ((long long)B * Co * hw >= 0xffffffffLL) return SIVAE_ERR_RANGE;
-  if ((long long)Ci * hw * 4 >= 0x7fffffffLL) return SIVAE_ERR_RANGE;
+  if ((long long)Ci * hw * 4 >= 0x7fffffffLL || (long long)Co * hw * 4 >= 0x7fffffffLL) return SIVAE_ERR_RANGE;
   WinoArgs a;
   a.x = x;
   a.up = up;

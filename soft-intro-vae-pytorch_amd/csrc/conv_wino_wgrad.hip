@@ -57,6 +57,9 @@ __global__ void __launch_bounds__(NGI * 256, 2) wino_wgrad_kernel(WinoWgArgs a) 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;              // [2][CIT][XP]
   float* dys = smem + 2 * XBUF;  // [2][COT][YP]
+  // fused-BatchNorm parameters {mean, invstd*gamma, beta, -} of this block's CIT input channels (LDS instead of
+  // three scalar loads per channel and stage: those serialise on lgkmcnt(0) in the middle of the MFMA phase)
+  float4* pro4 = reinterpret_cast<float4*>(smem + 2 * XBUF + 2 * YBUF);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,10 +141,8 @@ __global__ void __launch_bounds__(NGI * 256, 2) wino_wgrad_kernel(WinoWgArgs a) 
     _Pragma("unroll") for (int q = 0; q < XQ; ++q) {                                                \
       float v = xr[q];                                                                              \
       if (PRO) {                                                                                    \
-        const int ci = ci0 + xsub + NSUB * q;                                                       \
-        const int cic = ci < a.Ci ? ci : a.Ci - 1;                                                  \
-        const float pm = a.pro_mean[cic], pg = a.pro_invstd[cic] * a.pro_gamma[cic], pb = a.pro_beta[cic]; \
-        v = (xoff != SIVAE_OOB) ? lrelu((v - pm) * pg + pb, a.pro_slope) : 0.f;                     \
+        const float4 pp = pro4[xsub + NSUB * q];                                                    \
+        v = (xoff != SIVAE_OOB) ? lrelu((v - pp.x) * pp.y + pp.z, a.pro_slope) : 0.f;               \
       }                                                                                             \
       if (x_owner) xs[(BUF)*XBUF + (xsub + NSUB * q) * XP + xpos] = v;                              \
     }                                                                                               \
@@ -206,6 +207,14 @@ __global__ void __launch_bounds__(NGI * 256, 2) wino_wgrad_kernel(WinoWgArgs a) 
     __syncthreads();                                                                                \
   }
 
+  if (PRO) {
+    if (tid < CIT) {
+      const int ci = ci0 + tid;
+      const int cc = ci < a.Ci ? ci : a.Ci - 1;
+      pro4[tid] = make_float4(a.pro_mean[cc], a.pro_invstd[cc] * a.pro_gamma[cc], a.pro_beta[cc], 0.f);
+    }
+    __syncthreads();
+  }
   if (s_begin < s_end) {
     WG_LOAD(s_begin)
     WG_STORE(0)
@@ -362,7 +371,7 @@ extern "C" int sivae_conv2d_wino_wgrad(const float* x, const float* dy, float* d
   const long long nblk = (long long)p.n_ci_tiles * p.n_co_tiles * p.n_slices;
   if (nblk > 0x7fffffffLL) return SIVAE_ERR_RANGE;
   constexpr int CIT = 32 * WG_NGI;
-  const size_t lds = (size_t)2 * (CIT * 109 + 64 * 65) * sizeof(float);
+  const size_t lds = (size_t)2 * (CIT * 109 + 64 * 65) * sizeof(float) + (pro_mean ? (size_t)CIT * 16 : 0);
   auto kern = pro_mean ? wino_wgrad_kernel<true, WG_NGI> : wino_wgrad_kernel<false, WG_NGI>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

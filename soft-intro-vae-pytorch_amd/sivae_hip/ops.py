@@ -56,7 +56,7 @@ TIMER = None  # set to a KernelTimer() to instrument conv2d_fwd / conv2d_wgrad l
 
 def conv_fwd_kernel_key(ks, Co, pro):
     """name of the template instantiation sivae_conv2d_fwd dispatches to (mirrors conv_fwd.hip)"""
-    tile = {3: ("1,2,1,4,8,3", "2,2,1,4,2,3", "2,2,2,2,2,2"), 1: ("1,2,1,4,32,1", "2,2,1,4,32,1", "2,2,2,2,32,1"),
+    tile = {3: ("1,2,1,4,8,3", "2,2,1,4,2,3", "2,2,2,2,2,2"), 1: ("1,2,1,4,32,1", "2,2,1,4,16,1", "2,2,2,2,16,1"),
             5: ("1,2,1,4,4,4", "2,2,1,4,4,4", "2,2,2,2,4,3")}[ks][0 if Co <= 32 else (1 if Co <= 64 else 2)]
     return "conv_fwd_kernel<%d,%s,%s>" % (ks, tile, "true" if pro else "false")
 
@@ -162,7 +162,8 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
     B, Ci, Hs, Ws = x.shape
     H, W = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
     L = _lib.load()
-    wino = (WINO and ks == 3 and isinstance(wp, PackedW) and L.sivae_conv2d_wino_supported(H, W) == 1)
+    wino = (WINO and ks == 3 and bias is None and isinstance(wp, PackedW)
+            and L.sivae_conv2d_wino_supported(H, W) == 1)
     if isinstance(wp, PackedW):
         wp = wp.wino() if wino else wp.direct()
     _require(x, wp, bias, out)

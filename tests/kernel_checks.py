@@ -449,7 +449,7 @@ def all_checks():
         checks.append(("wino_wgrad%s" % (s,), lambda s=s: check_conv_wgrad(s, wino=True)))
     checks.append(("wino_fwd_stats", lambda: check_conv_fwd((3, 64, 128, 32, 32, 3), stats=True, wino=True)
                    + check_conv_fwd((3, 24, 40, 12, 20, 3), stats=True, wino=True)
-                   + check_conv_fwd((2, 64, 3, 16, 48, 3), bias=True, wino=True)))
+                   + check_conv_fwd((2, 64, 3, 16, 48, 3), bias=True, wino=True)))  # bias -> direct kernel
     for s in [(2, 64, 128, 32, 32, 3), (3, 40, 72, 16, 16, 3), (2, 16, 64, 24, 40, 3)]:
         checks.append(("wino_fused%s" % (s,), lambda s=s: check_conv_fused(s, wino=True)))
     checks.append(("conv5_edge", check_conv5_edge))

@@ -11,7 +11,7 @@ what = sys.argv[2] if len(sys.argv) > 2 else "fwd,wgrad"
 SHAPES = [  # (Ci, Co, H, ks)
     (64, 128, 128, 3), (128, 128, 128, 3), (128, 256, 64, 3), (256, 256, 64, 3), (256, 512, 32, 3),
     (512, 512, 32, 3), (512, 512, 16, 3), (512, 512, 8, 3), (64, 64, 256, 3), (128, 64, 128, 3),
-    (64, 128, 128, 1), (3, 64, 256, 5), (64, 3, 256, 5),
+    (64, 128, 128, 1), (128, 64, 128, 1), (256, 128, 64, 1), (512, 256, 32, 1), (3, 64, 256, 5), (64, 3, 256, 5),
 ]
 
 def timeit(fn, reps=5):
@@ -35,7 +35,11 @@ for (Ci, Co, H, ks) in SHAPES:
         out += "  fwd %7.3f ms %6.1f TF" % (t, fl / t / 1e9)
         if ks == 3 and H >= 16:
             wq = ops.PackedW(w, 0)
-            t = timeit(lambda: ops.conv2d_fwd(x, wq, Co, ks, want_stats=True))
+            pro = None
+            if os.environ.get("BENCH_PRO"):
+                pro = (torch.zeros(Ci, device="cuda"), torch.ones(Ci, device="cuda"), torch.ones(Ci, device="cuda"),
+                       torch.zeros(Ci, device="cuda"), 0.2)
+            t = timeit(lambda: ops.conv2d_fwd(x, wq, Co, ks, want_stats=True, pro=pro))
             out += "  wino %7.3f ms %6.1f TF(alg) %5.1f TF(exec)" % (t, fl / t / 1e9, fl * 16 / 36 / t / 1e9)
     if "wgrad" in what:
         t = timeit(lambda: ops.conv2d_wgrad(x, dy, ks))
