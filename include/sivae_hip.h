@@ -129,6 +129,11 @@ int sivae_bn_update_running(const float* mean, const float* invstd, int C, doubl
 int sivae_bn_apply_act(const float* x, const float* res, const float* mean, const float* invstd,
                        const float* gamma, const float* beta, float slope, float* y, int B, int C, int HW,
                        sivae_stream_t stream);
+/* same, with the residual stored at half resolution [B][C][H/2][W/2] and read through nn.Upsample(2,'nearest')
+ * (:155) addressing — the upsampled tensor is never written; H even, W % 4 == 0. */
+int sivae_bn_apply_act_resup(const float* x, const float* res_half, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, float slope, float* y, int B, int C, int H, int W,
+                             sivae_stream_t stream);
 /* backward of the above: dz = dy*(s>0?1:slope); dx = BN backward of dz; dz_out (optional) = gradient
  * of the residual branch; dgamma/dbeta optional.  act_mode selects where the LeakyReLU sign s comes from:
  *   0 no activation, 1 the saved OUTPUT y (valid since slope > 0), 2 recomputed from x (needs beta; used
@@ -188,6 +193,13 @@ int sivae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
                     float step_size /* lr / (1 - beta1^t) */, float beta1, float beta2, float eps,
                     float bias_correction2_sqrt /* sqrt(1 - beta2^t) */, float grad_scale,
                     sivae_stream_t stream);
+
+/* ---- input side ------------------------------------------------------------------------------
+ * uint8 image batch [B][C][H][W] (nhwc == 0) or [B][H][W][C] (nhwc != 0) -> fp32 NCHW * scale, sample b mirrored
+ * horizontally when flip[b] != 0 (flip may be NULL): the reference's random mirror + transforms.ToTensor()
+ * (dataset.py:27-28,46,68-70; train_soft_intro_vae.py:379) done on the device, on the prefetch stream. */
+int sivae_u8_to_f32(const unsigned char* src, float* dst, const int* flip, int B, int C, int H, int W, int nhwc,
+                    float scale, sivae_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -261,6 +261,49 @@ extern "C" int sivae_bn_apply_act(const float* x, const float* res, const float*
   return sivae_launch_status();
 }
 
+// Same op with the residual stored at HALF resolution and read through nn.Upsample(2,'nearest') addressing
+// (res[b][c][h>>1][w>>1]): the decoder's upsampled block inputs (train_soft_intro_vae.py:155) are never
+// materialised — the convs read them the same way (upsample flag of the conv kernels).  W % 4 == 0.
+__global__ void __launch_bounds__(256) bn_apply_resup_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float slope,
+                                                             float* __restrict__ y, int C, int H, int W, size_t numel) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  const int W4 = W >> 2, Hs = H >> 1, Ws = W >> 1;
+  const size_t n4 = numel >> 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const int w4 = (int)(i % W4);
+    size_t t = i / W4;
+    const int h = (int)(t % H);
+    t /= H;  // b*C + c
+    const int c = (int)(t % C);
+    const float m = mean[c], g = invstd[c] * gamma[c], bt = beta[c];
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float2 r = *reinterpret_cast<const float2*>(res + (t * Hs + (h >> 1)) * Ws + 2 * w4);
+    v.x = lrelu((v.x - m) * g + bt + r.x, slope);
+    v.y = lrelu((v.y - m) * g + bt + r.x, slope);
+    v.z = lrelu((v.z - m) * g + bt + r.y, slope);
+    v.w = lrelu((v.w - m) * g + bt + r.y, slope);
+    reinterpret_cast<float4*>(y)[i] = v;
+  }
+}
+
+extern "C" int sivae_bn_apply_act_resup(const float* x, const float* res_half, const float* mean, const float* invstd,
+                                        const float* gamma, const float* beta, float slope, float* y, int B, int C,
+                                        int H, int W, hipStream_t stream) {
+  if (!x || !res_half || !mean || !invstd || !gamma || !beta || !y) return SIVAE_ERR_NULL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 3)) return SIVAE_ERR_SHAPE;
+  const size_t numel = (size_t)B * C * H * W;
+  int nb = cdiv((long long)(numel >> 2), 256 * 4);
+  if (nb > 8192) nb = 8192;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(bn_apply_resup_kernel, dim3(nb), dim3(256), 0, stream, x, res_half, mean, invstd, gamma, beta,
+                     slope, y, C, H, W, numel);
+  return sivae_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward of  y = LeakyReLU(BN(x) [+ res])
 //   dz = dy * (y > 0 ? 1 : slope)        (y is the saved OUTPUT; valid because slope > 0)

@@ -182,3 +182,38 @@ extern "C" int sivae_add_inplace(float* y, const float* x, size_t n, hipStream_t
   hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n >> 2 ? n >> 2 : n)), dim3(256), 0, stream, y, x, n);
   return sivae_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Input side of the path: uint8 image batch (as decoded: NCHW or NHWC) -> fp32 NCHW in [0, 1], with the
+// per-sample horizontal mirror of the reference's dataset (dataset.py:27-28,46,68-70: random mirror, then
+// transforms.ToTensor() = /255, train_soft_intro_vae.py:379).  Runs on the prefetch stream, so the step
+// itself never sees a host tensor.  flip[b] != 0 mirrors sample b; flip may be null.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) u8_to_f32_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst,
+                                                        const int* __restrict__ flip, int C, int H, int W, int nhwc,
+                                                        float scale, size_t numel) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < numel; o += stride) {
+    const int w = (int)(o % W);
+    size_t t = o / W;
+    const int h = (int)(t % H);
+    t /= H;
+    const int c = (int)(t % C);
+    const size_t b = t / C;
+    const int ws = (flip != nullptr && flip[b] != 0) ? (W - 1 - w) : w;
+    const size_t si = nhwc ? (((b * H + h) * W + ws) * C + c) : (((b * C + c) * H + h) * W + ws);
+    dst[o] = (float)src[si] * scale;
+  }
+}
+
+extern "C" int sivae_u8_to_f32(const unsigned char* src, float* dst, const int* flip, int B, int C, int H, int W,
+                               int nhwc, float scale, hipStream_t stream) {
+  if (!src || !dst) return SIVAE_ERR_NULL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
+  const size_t numel = (size_t)B * C * H * W;
+  int nb = cdiv((long long)numel, 256 * 4);
+  if (nb > 8192) nb = 8192;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(u8_to_f32_kernel, dim3(nb), dim3(256), 0, stream, src, dst, flip, C, H, W, nhwc, scale, numel);
+  return sivae_launch_status();
+}

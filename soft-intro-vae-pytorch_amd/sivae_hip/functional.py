@@ -116,12 +116,20 @@ def _replay_bn(st, mean, invstd, count):
 
 class ResBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache=None):
+    def forward(ctx, x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache=None, x_up=False):
         """cache: None, or a dict owned by the caller.  An empty dict is FILLED with this pass's activations;
         a filled one is REPLAYED: no kernels run except the BatchNorm running-stat updates, the outputs and the
-        tensors saved for backward are the cached ones (valid only while x and all weights are unchanged)."""
+        tensors saved for backward are the cached ones (valid only while x and all weights are unchanged).
+
+        x_up: x is stored at HALF resolution and stands for Upsample(2,'nearest')(x) (train_soft_intro_vae.py:155):
+        every consumer (conv1, conv_expand or the identity add, both weight gradients) reads it through upsample
+        addressing, so the 4x tensor is never written.  post == "up_deferred": the Upsample after this block is
+        left to the next block's x_up (the output is returned at this block's resolution)."""
         x = x.contiguous()
         B, Ci, H, W = x.shape
+        if x_up:
+            H, W = 2 * H, 2 * W
+        ctx.x_up = x_up
         Cm, Co = w1.shape[0], w2.shape[0]
         if cache is not None and cache.get("y") is not None:
             a, c, out, mean1, invstd1, mean2, invstd2, y = (cache[k] for k in ("a", "c", "out", "mean1", "invstd1",
@@ -135,11 +143,11 @@ class ResBlockFn(torch.autograd.Function):
             return y.view_as(y)
         idt = x
         if w_exp is not None:
-            idt = ops.conv2d_fwd(x, packed(w_exp, 0), Co, 1)
+            idt = ops.conv2d_fwd(x, packed(w_exp, 0), Co, 1, upsample=x_up)
         if st1.training:
-            a, p1 = ops.conv2d_fwd(x, packed(w1, 0), Cm, 3, want_stats=True)
+            a, p1 = ops.conv2d_fwd(x, packed(w1, 0), Cm, 3, want_stats=True, upsample=x_up)
         else:
-            a, p1 = ops.conv2d_fwd(x, packed(w1, 0), Cm, 3), None
+            a, p1 = ops.conv2d_fwd(x, packed(w1, 0), Cm, 3, upsample=x_up), None
         mean1, invstd1 = _stats(p1, B, Cm, H * W, st1)
         pro1 = (mean1, invstd1, g1.detach(), b1.detach(), SLOPE)
         if st2.training:
@@ -147,7 +155,8 @@ class ResBlockFn(torch.autograd.Function):
         else:
             c, p2 = ops.conv2d_fwd(a, packed(w2, 0), Co, 3, pro=pro1), None
         mean2, invstd2 = _stats(p2, B, Co, H * W, st2)
-        out = ops.bn_apply_act(c, idt, mean2, invstd2, g2.detach(), b2.detach(), SLOPE)
+        out = ops.bn_apply_act(c, idt, mean2, invstd2, g2.detach(), b2.detach(), SLOPE,
+                               res_up=x_up and w_exp is None)
         y = _post_fwd(out, post)
         if cache is not None:
             cache.update(a=a, c=c, out=out, mean1=mean1, invstd1=invstd1, mean2=mean2, invstd2=invstd2, y=y)
@@ -179,20 +188,23 @@ class ResBlockFn(torch.autograd.Function):
         da, _, dg1, db1 = ops.bn_bwd(dh, None, a, mean1, invstd1, g1, SLOPE, want_dz=False,
                                      want_param_grads=need_bn1, beta=b1, act_mode=2)
         del dh
-        dw1 = ops.conv2d_wgrad(x, da, 3) if need_w1 else None
+        x_up = ctx.x_up
+        dw1 = ops.conv2d_wgrad(x, da, 3, upsample=x_up) if need_w1 else None
         dwe = None
         dx = None
         if ctx.has_exp:
             if need_we:
-                dwe = ops.conv2d_wgrad(x, dz, 1)
+                dwe = ops.conv2d_wgrad(x, dz, 1, upsample=x_up)
             if need_x:
                 dx = ops.conv2d_fwd(da, packed(w1, 1), x.shape[1], 3)
                 ops.conv2d_fwd(dz, packed(w_exp, 1), x.shape[1], 1, out=dx, accumulate=True)
         elif need_x:
             dx = dz  # identity branch gradient; add the conv1 branch on top
             ops.conv2d_fwd(da, packed(w1, 1), x.shape[1], 3, out=dx, accumulate=True)
+        if x_up and dx is not None:
+            dx = ops.upsample2_bwd(dx)  # adjoint of the deferred Upsample: sum each 2x2 block
         return (dx, dwe, dw1, dg1 if need[3] else None, db1 if need[4] else None, dw2,
-                dg2 if need[6] else None, db2 if need[7] else None, None, None, None, None)
+                dg2 if need[6] else None, db2 if need[7] else None, None, None, None, None, None)
 
 
 class StemFn(torch.autograd.Function):
@@ -396,8 +408,8 @@ class ExpElboFn(torch.autograd.Function):
         return dL, dKL, None, None, None
 
 
-def residual_block(x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post=None, cache=None):
-    return ResBlockFn.apply(x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache)
+def residual_block(x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post=None, cache=None, x_up=False):
+    return ResBlockFn.apply(x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache, x_up)
 
 
 def stem(x, w, g, b, st):

@@ -7,10 +7,16 @@ soft_intro_vae_bootstrap/train_soft_intro_vae_bootstrap.py:44-246) so checkpoint
 parameter/buffer containers (they give the reference's default initialisation and key names) — their
 forward() is never called; Encoder/Decoder/ResidualBlock.forward dispatch to the HIP blocks.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from . import functional as SF
+
+
+# SIVAE_DEFER_UPSAMPLE=0 materialises every nn.Upsample output as the reference does (A/B measurements)
+DEFER_UPSAMPLE = os.environ.get("SIVAE_DEFER_UPSAMPLE", "1") != "0"
 
 
 class ResidualBlock(nn.Module):
@@ -32,32 +38,41 @@ class ResidualBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(outc)
         self.relu2 = nn.LeakyReLU(0.2, inplace=True)
 
-    def forward(self, x, post=None, cache=None):
-        """post in {None, 'pool', 'up'} fuses the AvgPool2d / Upsample that follows the block in the nets.
+    def forward(self, x, post=None, cache=None, x_up=False):
+        """post in {None, 'pool', 'up', 'up_deferred'} fuses the AvgPool2d / Upsample that follows the block in the
+        nets ('up_deferred': the next block reads this block's output through upsample addressing, x_up=True there).
         cache: see functional.ResBlockFn (activation cache for replaying an identical forward pass)."""
         return SF.residual_block(x, None if self.conv_expand is None else self.conv_expand.weight,
                                  self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight,
                                  self.bn2.weight, self.bn2.bias, SF.BNState(self.bn1), SF.BNState(self.bn2), post,
-                                 cache)
+                                 cache, x_up)
 
 
 def _run_main(main, x, cache=None):
     """Walk a reference-shaped nn.Sequential, dispatching each group of layers to its fused HIP block."""
     mods = list(main.children())
     i, n = 0, len(mods)
+    x_up = False  # x currently stands for Upsample(2,'nearest')(x): the consumers read it through upsample addressing
     while i < n:
         m = mods[i]
         nxt = mods[i + 1] if i + 1 < n else None
         sub = None if cache is None else cache.setdefault(i, {})
         if isinstance(m, ResidualBlock):
             if isinstance(nxt, nn.AvgPool2d):
-                x = m(x, post="pool", cache=sub)
+                x = m(x, post="pool", cache=sub, x_up=x_up)
+                x_up = False
                 i += 2
             elif isinstance(nxt, nn.Upsample):
-                x = m(x, post="up", cache=sub)
+                # leave the Upsample to the next block when that is a ResidualBlock (its kernels read through
+                # h>>1, w>>1; the residual add needs the upsampled width to be a multiple of 4)
+                w_here = x.shape[3] * (2 if x_up else 1)
+                defer = DEFER_UPSAMPLE and i + 2 < n and isinstance(mods[i + 2], ResidualBlock) and w_here % 2 == 0
+                x = m(x, post="up_deferred" if defer else "up", cache=sub, x_up=x_up)
+                x_up = defer
                 i += 2
             else:
-                x = m(x, cache=sub)
+                x = m(x, cache=sub, x_up=x_up)
+                x_up = False
                 i += 1
         elif isinstance(m, nn.Conv2d) and isinstance(nxt, nn.BatchNorm2d):
             # encoder stem: conv5x5 -> BN -> LeakyReLU -> AvgPool2d

@@ -67,6 +67,21 @@ def conv_wgrad_kernel_key(ks, Co, pro):
     return "conv_wgrad_kernel<%d,%s,%s>" % (ks, tile, "true" if pro else "false")
 
 
+def u8_to_f32(src, flip=None, nhwc=False, scale=1.0 / 255.0):
+    """uint8 image batch (NCHW, or NHWC with nhwc=True) -> fp32 NCHW * scale; flip: int32 [B], nonzero = mirror."""
+    if not src.is_cuda or src.dtype != torch.uint8 or not src.is_contiguous() or src.dim() != 4:
+        raise TypeError("sivae_hip.u8_to_f32: expected a contiguous 4-D uint8 ROCm tensor")
+    if nhwc:
+        B, H, W, C = src.shape
+    else:
+        B, C, H, W = src.shape
+    if flip is not None and (not flip.is_cuda or flip.dtype != torch.int32 or flip.numel() != B):
+        raise TypeError("sivae_hip.u8_to_f32: flip must be an int32 ROCm tensor with one entry per sample")
+    dst = torch.empty((B, C, H, W), dtype=torch.float32, device=src.device)
+    _lib.call("sivae_u8_to_f32", _p(src), _p(dst), _p(flip), B, C, H, W, int(bool(nhwc)), float(scale), _s())
+    return dst
+
+
 def _require(*tensors):
     for t in tensors:
         if t is None:
@@ -295,11 +310,18 @@ def bn_update_running(mean, invstd, count, running_mean, running_var, num_batche
               float(momentum), _p(running_mean), _p(running_var), _p(num_batches_tracked), _s())
 
 
-def bn_apply_act(x, res, mean, invstd, gamma, beta, slope=LRELU_SLOPE, out=None):
+def bn_apply_act(x, res, mean, invstd, gamma, beta, slope=LRELU_SLOPE, out=None, res_up=False):
+    """res_up: res is [B, C, H/2, W/2] and is added through nearest-2x upsample addressing"""
     _require(x, res, mean, invstd, gamma, beta, out)
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
     y = out if out is not None else torch.empty_like(x)
+    if res_up:
+        H, W = x.shape[2], x.shape[3]
+        assert res.shape == (B, C, H // 2, W // 2)
+        _lib.call("sivae_bn_apply_act_resup", _p(x), _p(res), _p(mean), _p(invstd), _p(gamma), _p(beta), float(slope),
+                  _p(y), B, C, H, W, _s())
+        return y
     _lib.call("sivae_bn_apply_act", _p(x), _p(res), _p(mean), _p(invstd), _p(gamma), _p(beta), float(slope), _p(y),
               B, C, HW, _s())
     return y

@@ -20,6 +20,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from sivae_hip import data as _data
 from sivae_hip import engine as _engine
 from sivae_hip import rng as _rng
 from sivae_hip.engine import calc_kl, calc_reconstruction_loss, reparameterize  # noqa: F401  (reference API)
@@ -113,9 +114,15 @@ _TUPLE_DATASETS = ("cifar10", "svhn", "fmnist", "mnist")
 
 
 class _SyntheticImages(torch.utils.data.Dataset):
+    """U[0,1) fp32 images (what ToTensor() yields); SIVAE_SYNTHETIC_U8=1: uint8 images as a decoder would hand them
+    over — the device-side input pipeline (sivae_hip/data.py) then does the mirror + /255."""
+
     def __init__(self, n, ch, size, seed=1234):
         g = torch.Generator().manual_seed(seed)
-        self.data = torch.rand(n, ch, size, size, generator=g)
+        if os.environ.get("SIVAE_SYNTHETIC_U8", "0") == "1":
+            self.data = torch.randint(0, 256, (n, ch, size, size), generator=g, dtype=torch.uint8)
+        else:
+            self.data = torch.rand(n, ch, size, size, generator=g)
 
     def __len__(self):
         return self.data.shape[0]
@@ -213,6 +220,9 @@ def _train(dataset, z_dim, lr_e, lr_d, batch_size, num_workers, start_epoch, exi
 
     loader = torch.utils.data.DataLoader(train_set, batch_size=batch_size, shuffle=True, num_workers=num_workers,
                                          pin_memory=True)
+    # torchvision datasets yield (img, label) (reference :510-511); 3-D batches are unsqueezed (:513-514)
+    batches = _data.DevicePrefetcher(loader, device, take_first=arch_key in _TUPLE_DATASETS,
+                                     hflip=dataset.startswith("synthetic-"), seed=max(seed, 0))
     start_time = time.time()
     cur_iter = 0
     hist = {k: [] for k in ("kl_real", "kl_fake", "kl_rec", "rec_err", "exp_elbo_f", "exp_elbo_r")}
@@ -258,12 +268,7 @@ def _train(dataset, z_dim, lr_e, lr_d, batch_size, num_workers, start_epoch, exi
                 ep["exp_elbo_f"].append(s["expelbo_fake"])
                 ep["exp_elbo_r"].append(s["expelbo_rec"])
 
-        for batch in loader:
-            if arch_key in _TUPLE_DATASETS and isinstance(batch, (list, tuple)):
-                batch = batch[0]
-            if batch.dim() == 3:
-                batch = batch.unsqueeze(0)
-            real_batch = batch.to(device, non_blocking=True)
+        for real_batch in batches:  # device-resident fp32 NCHW, one batch prefetched (sivae_hip/data.py)
             if epoch < num_vae:
                 res = eng.vae_step(real_batch)
                 if cur_iter % test_iter == 0:

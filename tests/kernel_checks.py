@@ -430,6 +430,38 @@ def check_adam():
             ("adam_3steps_update", _err(pd - p0.to(DEV), pr.detach() - p0), 2e-3)]
 
 
+def check_bn_apply_resup():
+    """BN-apply + residual read through nearest-2x upsample addressing + LeakyReLU"""
+    from sivae_hip import ops
+    res = []
+    for (B, C, H, W) in [(2, 8, 8, 8), (3, 5, 16, 32), (1, 64, 6, 12)]:
+        x, r = _rand(B, C, H, W, seed=1), _rand(B, C, H // 2, W // 2, seed=2)
+        mean, invstd = _rand(C, seed=6), _rand(C, seed=7).abs() + 0.5
+        gamma, beta = _rand(C, seed=8), _rand(C, seed=9)
+        v = (x - mean.view(1, -1, 1, 1)) * (invstd * gamma).view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+        ref = F.leaky_relu(v + F.interpolate(r, scale_factor=2, mode="nearest"), 0.2)
+        y = ops.bn_apply_act(_d(x), _d(r), _d(mean), _d(invstd), _d(gamma), _d(beta), 0.2, res_up=True)
+        res.append(("bn_apply_resup(%d,%d,%d,%d)" % (B, C, H, W), _err(y, ref), 1e-6))
+    return res
+
+
+def check_input_u8():
+    """uint8 -> fp32 (/255) with per-sample mirror, NCHW and NHWC sources (bit-exact: one multiply per element)"""
+    from sivae_hip import ops
+    g = torch.Generator().manual_seed(5)
+    res = []
+    for (B, C, H, W) in [(5, 3, 32, 32), (3, 1, 28, 28), (2, 3, 17, 23)]:
+        src = torch.randint(0, 256, (B, C, H, W), generator=g, dtype=torch.uint8)
+        flip = torch.tensor([i % 2 for i in range(B)], dtype=torch.int32)
+        ref = src.float() * (1.0 / 255.0)
+        ref_f = torch.where(flip.view(-1, 1, 1, 1) != 0, ref.flip(3), ref)
+        out = ops.u8_to_f32(src.to(DEV), flip.to(DEV))
+        res.append(("u8_to_f32_nchw_flip(%d,%d,%d,%d)" % (B, C, H, W), float((out.cpu() - ref_f).abs().max()), 0.0))
+        out = ops.u8_to_f32(src.permute(0, 2, 3, 1).contiguous().to(DEV), None, nhwc=True)
+        res.append(("u8_to_f32_nhwc(%d,%d,%d,%d)" % (B, C, H, W), float((out.cpu() - ref).abs().max()), 0.0))
+    return res
+
+
 def all_checks():
     """-> list of (label, thunk) ; every thunk returns a list of (name, err, tol)"""
     checks = []
@@ -459,6 +491,8 @@ def all_checks():
         checks.append(("bn+res%s" % (s,), lambda s=s: check_bn(s, True)))
     checks.append(("bn_from_conv", check_bn_from_conv))
     checks.append(("eltwise", check_eltwise))
+    checks.append(("input_u8", check_input_u8))
+    checks.append(("bn_apply_resup", check_bn_apply_resup))
     checks.append(("losses", check_losses))
     checks.append(("randn", check_randn))
     checks.append(("adam", check_adam))

@@ -31,6 +31,37 @@ def test_train_soft_intro_vae_entry_point_runs(tmp_path, monkeypatch):
         assert torch.equal(v, sd[k]), k
 
 
+def test_device_prefetcher_matches_host_pipeline():
+    """uint8 batches through sivae_hip.data.DevicePrefetcher == ToTensor()-style host conversion, same order;
+    float batches pass through unchanged"""
+    from sivae_hip.data import DevicePrefetcher
+    g = torch.Generator().manual_seed(0)
+    imgs = torch.randint(0, 256, (20, 3, 16, 16), generator=g, dtype=torch.uint8)
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(imgs), batch_size=8, shuffle=False)
+    got = [b.clone() for b in DevicePrefetcher(loader, "cuda:0", take_first=True)]
+    assert [b.shape[0] for b in got] == [8, 8, 4] and all(b.is_cuda and b.dtype == torch.float32 for b in got)
+    assert torch.equal(torch.cat(got).cpu(), imgs.float() * (1.0 / 255.0))
+    # mirror: every sample equals the source or its horizontal flip
+    got = torch.cat([b.clone() for b in DevicePrefetcher(loader, "cuda:0", take_first=True, hflip=True, seed=1)]).cpu()
+    ref = imgs.float() * (1.0 / 255.0)
+    same = (got == ref).flatten(1).all(1)
+    flipped = (got == ref.flip(3)).flatten(1).all(1)
+    assert bool((same | flipped).all()) and bool(flipped.any()) and bool(same.any())
+    fl = torch.rand(10, 3, 8, 8, generator=g)
+    got = torch.cat([b.clone() for b in DevicePrefetcher(torch.utils.data.DataLoader(fl, batch_size=4), "cuda:0")])
+    assert torch.equal(got.cpu(), fl)
+
+
+def test_train_entry_point_with_uint8_input_pipeline(tmp_path, monkeypatch):
+    import train_soft_intro_vae as T
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("SIVAE_SYNTHETIC_IMAGES", "16")
+    monkeypatch.setenv("SIVAE_SYNTHETIC_U8", "1")
+    model = T.train_soft_intro_vae(dataset="synthetic-cifar10", z_dim=16, batch_size=8, num_workers=0, num_epochs=1,
+                                   beta_kl=1.0, beta_rec=1.0, beta_neg=256, seed=5, device=torch.device("cuda:0"))
+    assert all(torch.isfinite(v).all() for v in model.state_dict().values() if v.is_floating_point())
+
+
 def test_bootstrap_entry_point_runs(tmp_path, monkeypatch):
     import train_soft_intro_vae_bootstrap as TB
     monkeypatch.chdir(tmp_path)
