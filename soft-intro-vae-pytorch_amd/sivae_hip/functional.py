@@ -17,11 +17,17 @@ Frozen networks (requires_grad=False) still run BatchNorm in training mode and u
 statistics, as in the reference; weight gradients are skipped per `needs_input_grad` — this is what makes
 the iteration cost 13 F_E + 19 F_D.
 """
+import os
+
 import torch
 
 from . import ops
 
 SLOPE = ops.LRELU_SLOPE
+# SIVAE_MATERIALIZE_H=1: store h = LeakyReLU(BN1(conv1)) once and keep it for backward instead of recomputing it in
+# the operand load of conv2 and of conv2's weight gradient.  Measured a wash at 256x256 bs128 (conv kernels -25 ms,
+# the extra BatchNorm-apply passes +25 ms per iteration), so the default keeps the smaller activation footprint.
+MATERIALIZE_H = os.environ.get("SIVAE_MATERIALIZE_H", "0") == "1"
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
@@ -132,14 +138,14 @@ class ResBlockFn(torch.autograd.Function):
         ctx.x_up = x_up
         Cm, Co = w1.shape[0], w2.shape[0]
         if cache is not None and cache.get("y") is not None:
-            a, c, out, mean1, invstd1, mean2, invstd2, y = (cache[k] for k in ("a", "c", "out", "mean1", "invstd1",
-                                                                                 "mean2", "invstd2", "y"))
+            a, h, c, out, mean1, invstd1, mean2, invstd2, y = (cache[k] for k in (
+                "a", "h", "c", "out", "mean1", "invstd1", "mean2", "invstd2", "y"))
             _replay_bn(st1, mean1, invstd1, B * H * W)
             _replay_bn(st2, mean2, invstd2, B * H * W)
             ctx.post = post
             ctx.has_exp = w_exp is not None
             ctx.training = st1.training and st2.training
-            ctx.save_for_backward(x, a, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2)
+            ctx.save_for_backward(x, a, h, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2)
             return y.view_as(y)
         idt = x
         if w_exp is not None:
@@ -149,28 +155,35 @@ class ResBlockFn(torch.autograd.Function):
         else:
             a, p1 = ops.conv2d_fwd(x, packed(w1, 0), Cm, 3, upsample=x_up), None
         mean1, invstd1 = _stats(p1, B, Cm, H * W, st1)
-        pro1 = (mean1, invstd1, g1.detach(), b1.detach(), SLOPE)
-        if st2.training:
-            c, p2 = ops.conv2d_fwd(a, packed(w2, 0), Co, 3, pro=pro1, want_stats=True)
+        if MATERIALIZE_H:
+            # h = LeakyReLU(BN1(a)) written once (2 HBM passes over a Cm-channel tensor) and kept for backward
+            h = ops.bn_apply_act(a, None, mean1, invstd1, g1.detach(), b1.detach(), SLOPE)
+            pro1 = None
         else:
-            c, p2 = ops.conv2d_fwd(a, packed(w2, 0), Co, 3, pro=pro1), None
+            h = a
+            pro1 = (mean1, invstd1, g1.detach(), b1.detach(), SLOPE)
+        if st2.training:
+            c, p2 = ops.conv2d_fwd(h, packed(w2, 0), Co, 3, pro=pro1, want_stats=True)
+        else:
+            c, p2 = ops.conv2d_fwd(h, packed(w2, 0), Co, 3, pro=pro1), None
         mean2, invstd2 = _stats(p2, B, Co, H * W, st2)
         out = ops.bn_apply_act(c, idt, mean2, invstd2, g2.detach(), b2.detach(), SLOPE,
                                res_up=x_up and w_exp is None)
         y = _post_fwd(out, post)
         if cache is not None:
-            cache.update(a=a, c=c, out=out, mean1=mean1, invstd1=invstd1, mean2=mean2, invstd2=invstd2, y=y)
+            cache.update(a=a, h=h, c=c, out=out, mean1=mean1, invstd1=invstd1, mean2=mean2, invstd2=invstd2, y=y)
         ctx.post = post
         ctx.has_exp = w_exp is not None
         ctx.training = st1.training and st2.training
-        ctx.save_for_backward(x, a, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2)
+        ctx.save_for_backward(x, a, h, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         if not ctx.training:
             raise RuntimeError("sivae_hip: backward through eval-mode BatchNorm is not supported")
-        x, a, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2 = ctx.saved_tensors
+        x, a, h, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2 = ctx.saved_tensors
+        h_saved = h.data_ptr() != a.data_ptr()
         need = ctx.needs_input_grad
         need_x, need_we, need_w1, need_bn1, need_w2, need_bn2 = need[0], need[1], need[2], need[3] or need[4], \
             need[5], need[6] or need[7]
@@ -180,13 +193,17 @@ class ResBlockFn(torch.autograd.Function):
         dc, dz, dg2, db2 = ops.bn_bwd(d_out, out, c, mean2, invstd2, g2, SLOPE, want_dz=True,
                                       want_param_grads=need_bn2, act_mode=1)
         del d_out
-        pro1 = (mean1, invstd1, g1, b1, SLOPE)
-        dw2 = ops.conv2d_wgrad(a, dc, 3, pro=pro1) if need_w2 else None
+        pro1 = None if h_saved else (mean1, invstd1, g1, b1, SLOPE)
+        dw2 = ops.conv2d_wgrad(h, dc, 3, pro=pro1) if need_w2 else None
         dh = ops.conv2d_fwd(dc, packed(w2, 1), Cm, 3)
         del dc
-        # BN1 + LeakyReLU (sign recomputed from a)
-        da, _, dg1, db1 = ops.bn_bwd(dh, None, a, mean1, invstd1, g1, SLOPE, want_dz=False,
-                                     want_param_grads=need_bn1, beta=b1, act_mode=2)
+        # BN1 + LeakyReLU (sign from the saved h, or recomputed from a when h was never stored)
+        if h_saved:
+            da, _, dg1, db1 = ops.bn_bwd(dh, h, a, mean1, invstd1, g1, SLOPE, want_dz=False,
+                                         want_param_grads=need_bn1, act_mode=1)
+        else:
+            da, _, dg1, db1 = ops.bn_bwd(dh, None, a, mean1, invstd1, g1, SLOPE, want_dz=False,
+                                         want_param_grads=need_bn1, beta=b1, act_mode=2)
         del dh
         x_up = ctx.x_up
         dw1 = ops.conv2d_wgrad(x, da, 3, upsample=x_up) if need_w1 else None
