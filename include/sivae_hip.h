@@ -65,7 +65,7 @@ int sivae_conv2d_fwd(const float* x, const float* wp, float* y, const float* bia
 /* Winograd F(2x2,3x3) version of sivae_conv2d_fwd for ks == 3 (same nn.Conv2d(k=3,s=1,p=1) of
  * soft_intro_vae/train_soft_intro_vae.py:56-61; same fused prologue / upsample / epilogues): 2.25x fewer
  * multiplies on the fp32 matrix pipe.  `up` is the transformed filter U = G g G^T from
- * sivae_pack_wino_weight (mode 0 forward, mode 1 data gradient).  Handles even H >= 8 and even W >= 16
+ * sivae_pack_wino_weight (mode 0 forward, mode 1 data gradient).  Handles even H >= 8 and even W >= 16, and 8x8 maps
  * (sivae_conv2d_wino_supported); stats_partial has sivae_conv2d_wino_num_px_tiles(B, H, W) rows.  bias must be
  * NULL (SIVAE_ERR_MODE otherwise): no 3x3 conv of the model has one. */
 size_t sivae_pack_wino_weight_bytes(int Co, int Ci, int mode);
@@ -81,7 +81,8 @@ int sivae_conv2d_wino_fwd(const float* x, const float* up, float* y, const float
 /* Winograd-domain weight gradient for ks == 3 (dU = sum_tiles (A dY A^T) . (B^T d B), dW = G^T dU G): the
  * weight half of aten::convolution_backward for the nn.Conv2d(k=3) layers (:56-61) with 2.25x fewer multiplies;
  * same prologue / upsample options and the same deterministic two-pass reduction as sivae_conv2d_wgrad.
- * Maps: sivae_conv2d_wino_supported(H, W). */
+ * Maps: sivae_conv2d_wino_wgrad_supported(H, W) (even H >= 8, even W >= 16). */
+int sivae_conv2d_wino_wgrad_supported(int H, int W);
 size_t sivae_conv2d_wino_wgrad_workspace_bytes(int B, int Ci, int Co, int H, int W);
 int sivae_conv2d_wino_wgrad(const float* x, const float* dy, float* dw, const float* pro_mean,
                             const float* pro_invstd, const float* pro_gamma, const float* pro_beta, float pro_slope,

@@ -59,14 +59,20 @@ struct WinoArgs {
 //   <NG=2, WM=1>: 8 waves,  64 accumulator registers per wave, two blocks (16 waves) per CU
 template <int TTH_L2, int TTW_L2, bool PRO, int NG, int WM>
 __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a) {
+  // tile block = TB images x TTH x TTW tiles; TB = 32 / (TTH*TTW) > 1 only for the 8x8 maps (one image = 16 tiles)
   constexpr int TTH = 1 << TTH_L2, TTW = 1 << TTW_L2;
-  static_assert(TTH * TTW == 32, "a block is 32 tiles");
+  constexpr int TB = 32 / (TTH * TTW), TB_L2 = 5 - TTH_L2 - TTW_L2;
+  static_assert(TB * TTH * TTW == 32 && (TB == 1 || TB == 2), "a block is 32 tiles");
   static_assert(NG * WM * 32 == WINO_TCO, "64 output channels per block");
   constexpr int NT = NG * 256, NW = NG * 4;
   constexpr int PXH = 2 * TTH, PXW = 2 * TTW;
   constexpr int LH = PXH + 2, LWU = PXW + 2;
-  constexpr int PH = TTW + TTW / 4, RS = 2 * PH, PLANE = LH * RS;
-  constexpr int NPOS = LH * LWU;
+  // bank-conflict-free strides: 4x8 tiles RS 20, 2x16 tiles RS 40; 2 images x 4x4 tiles: RS 18 (a tile-row pair =
+  // 36 = 4 mod 32) and an image stride of 208 (= 16 mod 32) -> bank = 16*tb + 4*ty + tx
+  constexpr int PH = (TTW == 4) ? 9 : TTW + TTW / 4, RS = 2 * PH;
+  constexpr int PLANE_IMG = (TB == 2) ? 208 : LH * RS, PLANE = TB * PLANE_IMG;
+  static_assert(PLANE_IMG >= LH * RS, "image plane holds the halo rows");
+  constexpr int NPOS = TB * LH * LWU;
   static_assert(NPOS <= NT, "one halo position per thread");
   constexpr int CK = WINO_CK;
   constexpr int XBUF = CK * PLANE;
@@ -97,8 +103,9 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
   __amdgpu_buffer_rsrc_t xrsrc;
   const __amdgpu_buffer_rsrc_t ursrc = make_rsrc(a.up, 16ull * a.Ci_pad * a.Co_pad * 4ull);
   unsigned xo, ua_base;
-  const int xrr = tid / LWU, xcc = tid % LWU;
-  const int xl = xrr * RS + (xcc & 1) * PH + (xcc >> 1);
+  const int xtb = tid / (LH * LWU), xrr = (tid / LWU) % LH, xcc = tid % LWU;
+  const int xl = xtb * PLANE_IMG + xrr * RS + (xcc & 1) * PH + (xcc >> 1);
+  int nb_here;  // images of this item that exist (TB == 2 and odd batch: the last item has one)
 #define WINO_SETUP(ITEM)                                                 \
   {                                                                      \
     const int co_tile = (ITEM) % a.n_co_tiles;                           \
@@ -106,16 +113,17 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
     const int tbx = pt % a.nbw;                                          \
     const int t2 = pt / a.nbw;                                           \
     const int tby = t2 % a.nbh;                                          \
-    b = t2 / a.nbh;                                                      \
+    b = (t2 / a.nbh) << TB_L2;                                           \
+    nb_here = a.B - b < TB ? a.B - b : TB;                               \
     r0 = tby * PXH;                                                      \
     c0 = tbx * PXW;                                                      \
     co0 = co_tile * WINO_TCO;                                            \
-    xrsrc = make_rsrc(a.x + (size_t)b * a.Ci * HWs, (unsigned long long)a.Ci * HWs * 4ull); \
+    xrsrc = make_rsrc(a.x + (size_t)b * a.Ci * HWs, (unsigned long long)nb_here * a.Ci * HWs * 4ull); \
     const int r = r0 + xrr - 1, c = c0 + xcc - 1;                        \
     xo = SIVAE_OOB;                                                      \
-    if (tid < NPOS && r >= 0 && r < H && c >= 0 && c < W) {              \
+    if (tid < NPOS && xtb < nb_here && r >= 0 && r < H && c >= 0 && c < W) { \
       const int rs = a.upsample ? (r >> 1) : r, cs = a.upsample ? (c >> 1) : c; \
-      xo = (unsigned)(rs * Ws + cs) * 4u;                                \
+      xo = (unsigned)((xtb * a.Ci * Hs + rs) * Ws + cs) * 4u;            \
     }                                                                    \
     ua_base = (unsigned)((wj * a.Ci_pad) * a.Co_pad + co0) * 16u;        \
   }
@@ -126,11 +134,11 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
   const unsigned ua_step = (unsigned)a.Co_pad * 16u;                            // bytes per input channel
 
   // ---- B operand: raw columns (ca, cb) and sign of frequency column j
-  const int tx = l31 & (TTW - 1), ty = l31 >> TTW_L2;
+  const int tx = l31 & (TTW - 1), ty = (l31 >> TTW_L2) & (TTH - 1), tb = l31 >> (TTW_L2 + TTH_L2);
   const int ca = (wj == 0) ? 0 : ((wj == 2) ? 2 : 1);
   const int cb = (wj == 0) ? 2 : ((wj == 1) ? 2 : ((wj == 2) ? 1 : 3));
   const float sgn = (wj == 1) ? 1.f : -1.f;
-  const int bb = hh * PLANE + 2 * ty * RS + tx;
+  const int bb = hh * PLANE + tb * PLANE_IMG + 2 * ty * RS + tx;
   const int base_a = bb + (ca & 1) * PH + (ca >> 1);
   const int base_b = bb + (cb & 1) * PH + (cb >> 1);
 
@@ -229,7 +237,7 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
     float* ex = smem; /* [2 ar][4 j][2 cg][16 r][64 lanes] = 64 KB */    \
     constexpr int PPW = 32 / NW;                                         \
     const __amdgpu_buffer_rsrc_t yrsrc =                                 \
-        make_rsrc(a.y + (size_t)e_b * a.Co * H * W, (unsigned long long)a.Co * H * W * 4ull); \
+        make_rsrc(a.y + (size_t)e_b * a.Co * H * W, (unsigned long long)e_nb * a.Co * H * W * 4ull); \
     const int row_base = e_r0 + 2 * ty, col = e_c0 + 2 * tx;             \
     _Pragma("unroll") for (int m = 0; m < WM; ++m)                       \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                     \
@@ -242,7 +250,7 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
     _Pragma("unroll") for (int rr = 0; rr < PPW; ++rr) {                 \
       const int p = wave * PPW + rr;                                     \
       const int chn = e_co0 + (p >> 4) * 32 + (p & 3) + 8 * ((p & 15) >> 2) + 4 * hh; \
-      yo[rr] = (chn < a.Co && col < W) ? (unsigned)((chn * H + row_base) * W + col) * 4u : SIVAE_OOB; \
+      yo[rr] = (chn < a.Co && col < W && tb < e_nb) ? (unsigned)(((tb * a.Co + chn) * H + row_base) * W + col) * 4u : SIVAE_OOB; \
     }                                                                    \
     __syncthreads();                                                     \
     _Pragma("unroll") for (int rr = 0; rr < PPW; ++rr) {                 \
@@ -311,7 +319,7 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
     if (ch < nchunks) WINO_MMA(ch, 0, false)
 
     // coordinates of the item just accumulated; then put the next item's first loads in flight
-    const int e_pt = pt, e_b = b, e_r0 = r0, e_c0 = c0, e_co0 = co0;
+    const int e_pt = pt, e_b = b, e_nb = nb_here, e_r0 = r0, e_c0 = c0, e_co0 = co0;
     const int next = item + (int)gridDim.x;
     const bool has_next = next < n_items;
     // (with accumulate the epilogue loads y; vmcnt completes in order, so the prefetch goes after it)
@@ -407,9 +415,10 @@ extern "C" int sivae_pack_wino_weight(const float* w, float* up, int Co, int Ci,
   return sivae_launch_status();
 }
 
-// Winograd path handles even H >= 8 and even W >= 16 (tiles are whole 2x2 blocks; smaller maps are
-// <1 % of the FLOPs and stay on the direct kernel).
+// Winograd path handles even H >= 8 and even W >= 16 (tiles are whole 2x2 blocks), plus the 8x8 maps with two
+// images per tile block; the 4x4 maps and odd sizes stay on the direct kernel.
 extern "C" int sivae_conv2d_wino_supported(int H, int W) {
+  if (H == 8 && W == 8) return 1;
   return (H >= 8 && W >= 16 && !(H & 1) && !(W & 1)) ? 1 : 0;
 }
 
@@ -417,6 +426,7 @@ static inline bool wino_wide(int W) { return W >= 32; }  // 2x16 tiles (4x32 px)
 
 extern "C" int sivae_conv2d_wino_num_px_tiles(int B, int H, int W) {
   if (B <= 0 || !sivae_conv2d_wino_supported(H, W)) return SIVAE_ERR_SHAPE;
+  if (W == 8) return cdiv(B, 2);
   const int pxh = wino_wide(W) ? 4 : 8, pxw = wino_wide(W) ? 32 : 16;
   return B * cdiv(H, pxh) * cdiv(W, pxw);
 }
@@ -447,12 +457,13 @@ static int wino_grid_blocks() {
 
 template <int TTH_L2, int TTW_L2, int NG, int WM>
 static int wino_launch(WinoArgs& a, hipStream_t stream) {
-  constexpr int PXH = 2 << TTH_L2, PXW = 2 << TTW_L2;
-  constexpr int PH = (1 << TTW_L2) + (1 << TTW_L2) / 4, PLANE = (PXH + 2) * 2 * PH;
+  constexpr int PXH = 2 << TTH_L2, PXW = 2 << TTW_L2, TB = 32 >> (TTH_L2 + TTW_L2);
+  constexpr int PH = (TTW_L2 == 2) ? 9 : (1 << TTW_L2) + (1 << TTW_L2) / 4;
+  constexpr int PLANE = (TB == 2) ? 2 * 208 : (PXH + 2) * 2 * PH;
   a.nbh = cdiv(a.H, PXH);
   a.nbw = cdiv(a.W, PXW);
   a.n_co_tiles = cdiv(a.Co, WINO_TCO);
-  const long long nblk = (long long)a.B * a.nbh * a.nbw * a.n_co_tiles;
+  const long long nblk = (long long)cdiv(a.B, TB) * a.nbh * a.nbw * a.n_co_tiles;
   if (nblk > 0x7fffffffLL) return SIVAE_ERR_RANGE;
   size_t lds = (size_t)2 * WINO_CK * PLANE * sizeof(float);
   const size_t exch = (size_t)WINO_EX_FLOATS * sizeof(float);
@@ -507,6 +518,7 @@ extern "C" int sivae_conv2d_wino_fwd(const float* x, const float* up, float* y, 
   a.upsample = upsample;
   // production: 4-wave blocks, 64co x 32 tiles per block, 128 accumulator registers per wave (119 TF issued =
   // 268 TF algorithmic on 512->512 @32x32; the 8-wave <NG=2,WM=1> split measured 106 TF)
+  if (W == 8) return wino_launch<2, 2, 1, 2>(a, stream);  // 8x8 maps: 2 images x 4x4 tiles per block
   if (wino_variant() == 2) return wino_wide(W) ? wino_launch<1, 4, 2, 1>(a, stream) : wino_launch<2, 3, 2, 1>(a, stream);
   return wino_wide(W) ? wino_launch<1, 4, 1, 2>(a, stream) : wino_launch<2, 3, 1, 2>(a, stream);
 }

@@ -321,11 +321,14 @@ int wino_wg_plan(int B, int Ci, int Co, int H, int W, WinoWgPlan* p) {
 }
 }  // namespace
 
-extern "C" int sivae_conv2d_wino_supported(int H, int W);
+// maps the Winograd-domain weight gradient takes (its stage is a 4 x 16 pixel region)
+extern "C" int sivae_conv2d_wino_wgrad_supported(int H, int W) {
+  return (H >= 8 && W >= 16 && !(H & 1) && !(W & 1)) ? 1 : 0;
+}
 
 extern "C" size_t sivae_conv2d_wino_wgrad_workspace_bytes(int B, int Ci, int Co, int H, int W) {
   WinoWgPlan p;
-  if (B <= 0 || Ci <= 0 || Co <= 0 || !sivae_conv2d_wino_supported(H, W)) return 0;
+  if (B <= 0 || Ci <= 0 || Co <= 0 || !sivae_conv2d_wino_wgrad_supported(H, W)) return 0;
   if (wino_wg_plan(B, Ci, Co, H, W, &p) != SIVAE_OK) return 0;
   return (size_t)p.n_slices * 16 * p.Co_pad * p.Ci_pad * sizeof(float);
 }
@@ -336,7 +339,7 @@ extern "C" int sivae_conv2d_wino_wgrad(const float* x, const float* dy, float* d
                                        void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!x || !dy || !dw || !workspace) return SIVAE_ERR_NULL;
   if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
-  if (!sivae_conv2d_wino_supported(H, W)) return SIVAE_ERR_SHAPE;
+  if (!sivae_conv2d_wino_wgrad_supported(H, W)) return SIVAE_ERR_SHAPE;
   if (pro_mean && (!pro_invstd || !pro_gamma || !pro_beta)) return SIVAE_ERR_NULL;
   const long long hw = (long long)H * W;
   if ((long long)Ci * hw * 4 >= 0x7fffffffLL || (long long)Co * hw * 4 >= 0x7fffffffLL) return SIVAE_ERR_RANGE;

@@ -203,7 +203,8 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
     if t0 is not None:
         flops = 2.0 * B * H * W * Co * Ci * ks * ks  # algorithmic (reference nn.Conv2d) FLOPs
         if wino:
-            key = "conv_wino_kernel<%s,%s>" % ("1,4" if W >= 32 else "2,3", "true" if pro is not None else "false")
+            key = "conv_wino_kernel<%s,%s>" % ("1,4" if W >= 32 else ("2,3" if W >= 16 else "2,2"),
+                                               "true" if pro is not None else "false")
             TIMER.end(key, flops, t0, executed=flops * 16.0 / 36.0)
         else:
             TIMER.end(conv_fwd_kernel_key(ks, Co, pro is not None), flops, t0)
@@ -216,7 +217,7 @@ def conv2d_wgrad(x, dy, ks, pro=None, upsample=False):
     B, Ci = x.shape[0], x.shape[1]
     _, Co, H, W = dy.shape
     L = _lib.load()
-    wino = WINO_WGRAD and ks == 3 and L.sivae_conv2d_wino_supported(H, W) == 1
+    wino = WINO_WGRAD and ks == 3 and L.sivae_conv2d_wino_wgrad_supported(H, W) == 1
     nbytes = (L.sivae_conv2d_wino_wgrad_workspace_bytes(B, Ci, Co, H, W) if wino
               else L.sivae_conv2d_wgrad_workspace_bytes(B, Ci, Co, H, W, ks))
     ws = workspace(nbytes, x.device)

@@ -69,6 +69,8 @@ WINO_SHAPES = [
     (2, 8, 8, 12, 20, 3),
     (2, 72, 130, 16, 48, 3),   # 4x32 px geometry with a partial block
     (1, 512, 512, 16, 16, 3),  # long K loop
+    (4, 64, 128, 8, 8, 3),     # 8x8 maps: two images per tile block
+    (3, 40, 70, 8, 8, 3),      # ... odd batch (last block has one image), non-multiple channels
 ]
 
 
@@ -478,12 +480,14 @@ def all_checks():
     for s in WINO_SHAPES:
         checks.append(("wino_fwd%s" % (s,), lambda s=s: check_conv_fwd(s, wino=True)))
         checks.append(("wino_dgrad%s" % (s,), lambda s=s: check_conv_dgrad(s, wino=True)))
-        checks.append(("wino_wgrad%s" % (s,), lambda s=s: check_conv_wgrad(s, wino=True)))
+        if s[4] >= 16:
+            checks.append(("wino_wgrad%s" % (s,), lambda s=s: check_conv_wgrad(s, wino=True)))
     checks.append(("wino_fwd_stats", lambda: check_conv_fwd((3, 64, 128, 32, 32, 3), stats=True, wino=True)
                    + check_conv_fwd((3, 24, 40, 12, 20, 3), stats=True, wino=True)
                    + check_conv_fwd((2, 64, 3, 16, 48, 3), bias=True, wino=True)))  # bias -> direct kernel
-    for s in [(2, 64, 128, 32, 32, 3), (3, 40, 72, 16, 16, 3), (2, 16, 64, 24, 40, 3)]:
+    for s in [(2, 64, 128, 32, 32, 3), (3, 40, 72, 16, 16, 3), (2, 16, 64, 24, 40, 3), (3, 64, 64, 8, 8, 3)]:
         checks.append(("wino_fused%s" % (s,), lambda s=s: check_conv_fused(s, wino=True)))
+    checks.append(("wino_fwd_stats8", lambda: check_conv_fwd((5, 32, 96, 8, 8, 3), stats=True, wino=True)))
     checks.append(("conv5_edge", check_conv5_edge))
     checks.append(("linear", check_linear))
     for s in BN_SHAPES:
