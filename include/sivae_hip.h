@@ -65,7 +65,7 @@ int sivae_conv2d_fwd(const float* x, const float* wp, float* y, const float* bia
 /* Winograd F(2x2,3x3) version of sivae_conv2d_fwd for ks == 3 (same nn.Conv2d(k=3,s=1,p=1) of
  * soft_intro_vae/train_soft_intro_vae.py:56-61; same fused prologue / upsample / epilogues): 2.25x fewer
  * multiplies on the fp32 matrix pipe.  `up` is the transformed filter U = G g G^T from
- * sivae_pack_wino_weight (mode 0 forward, mode 1 data gradient).  Handles even H >= 8 and even W >= 16, and 8x8 maps
+ * sivae_pack_wino_weight (mode 0 forward, mode 1 data gradient).  Handles even H >= 8 and even W >= 16, and the 8x8 / 4x4 maps
  * (sivae_conv2d_wino_supported); stats_partial has sivae_conv2d_wino_num_px_tiles(B, H, W) rows.  bias must be
  * NULL (SIVAE_ERR_MODE otherwise): no 3x3 conv of the model has one. */
 size_t sivae_pack_wino_weight_bytes(int Co, int Ci, int mode);

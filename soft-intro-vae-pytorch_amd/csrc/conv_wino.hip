@@ -59,18 +59,22 @@ struct WinoArgs {
 //   <NG=2, WM=1>: 8 waves,  64 accumulator registers per wave, two blocks (16 waves) per CU
 template <int TTH_L2, int TTW_L2, bool PRO, int NG, int WM>
 __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a) {
-  // tile block = TB images x TTH x TTW tiles; TB = 32 / (TTH*TTW) > 1 only for the 8x8 maps (one image = 16 tiles)
+  // tile block = TB images x TTH x TTW tiles.  The 32 tile columns of the MFMA hold 32/(TTH*TTW) images; that is
+  // 2 for the 8x8 maps (one image = 16 tiles) and 8 for the 4x4 maps, where only TB = 4 are staged and computed
+  // (their halos fill the 256 staging threads; the other 16 columns are discarded — it doubles the number of work
+  // items of these tiny, otherwise machine-starving layers: 512->512 @4x4 bs128 is 256 items instead of 128)
   constexpr int TTH = 1 << TTH_L2, TTW = 1 << TTW_L2;
-  constexpr int TB = 32 / (TTH * TTW), TB_L2 = 5 - TTH_L2 - TTW_L2;
-  static_assert(TB * TTH * TTW == 32 && (TB == 1 || TB == 2), "a block is 32 tiles");
+  constexpr int TBL = 32 / (TTH * TTW);
+  constexpr int TB = TBL > 4 ? 4 : TBL, TB_L2 = TB == 4 ? 2 : (TB == 2 ? 1 : 0);
+  static_assert(TBL * TTH * TTW == 32, "a block is 32 tile columns");
   static_assert(NG * WM * 32 == WINO_TCO, "64 output channels per block");
   constexpr int NT = NG * 256, NW = NG * 4;
   constexpr int PXH = 2 * TTH, PXW = 2 * TTW;
   constexpr int LH = PXH + 2, LWU = PXW + 2;
   // bank-conflict-free strides: 4x8 tiles RS 20, 2x16 tiles RS 40; 2 images x 4x4 tiles: RS 18 (a tile-row pair =
   // 36 = 4 mod 32) and an image stride of 208 (= 16 mod 32) -> bank = 16*tb + 4*ty + tx
-  constexpr int PH = (TTW == 4) ? 9 : TTW + TTW / 4, RS = 2 * PH;
-  constexpr int PLANE_IMG = (TB == 2) ? 208 : LH * RS, PLANE = TB * PLANE_IMG;
+  constexpr int PH = (TTW == 4) ? 9 : (TTW == 2 ? 3 : TTW + TTW / 4), RS = 2 * PH;
+  constexpr int PLANE_IMG = (TB == 2) ? 208 : (TB == 4 ? 40 : LH * RS), PLANE = TB * PLANE_IMG;
   static_assert(PLANE_IMG >= LH * RS, "image plane holds the halo rows");
   constexpr int NPOS = TB * LH * LWU;
   static_assert(NPOS <= NT, "one halo position per thread");
@@ -415,10 +419,10 @@ extern "C" int sivae_pack_wino_weight(const float* w, float* up, int Co, int Ci,
   return sivae_launch_status();
 }
 
-// Winograd path handles even H >= 8 and even W >= 16 (tiles are whole 2x2 blocks), plus the 8x8 maps with two
-// images per tile block; the 4x4 maps and odd sizes stay on the direct kernel.
+// Winograd path handles even H >= 8 and even W >= 16 (tiles are whole 2x2 blocks), plus the 8x8 and 4x4 maps with
+// two / four images per tile block; other sizes stay on the direct kernel.
 extern "C" int sivae_conv2d_wino_supported(int H, int W) {
-  if (H == 8 && W == 8) return 1;
+  if ((H == 8 && W == 8) || (H == 4 && W == 4)) return 1;
   return (H >= 8 && W >= 16 && !(H & 1) && !(W & 1)) ? 1 : 0;
 }
 
@@ -427,6 +431,7 @@ static inline bool wino_wide(int W) { return W >= 32; }  // 2x16 tiles (4x32 px)
 extern "C" int sivae_conv2d_wino_num_px_tiles(int B, int H, int W) {
   if (B <= 0 || !sivae_conv2d_wino_supported(H, W)) return SIVAE_ERR_SHAPE;
   if (W == 8) return cdiv(B, 2);
+  if (W == 4) return cdiv(B, 4);
   const int pxh = wino_wide(W) ? 4 : 8, pxw = wino_wide(W) ? 32 : 16;
   return B * cdiv(H, pxh) * cdiv(W, pxw);
 }
@@ -457,9 +462,10 @@ static int wino_grid_blocks() {
 
 template <int TTH_L2, int TTW_L2, int NG, int WM>
 static int wino_launch(WinoArgs& a, hipStream_t stream) {
-  constexpr int PXH = 2 << TTH_L2, PXW = 2 << TTW_L2, TB = 32 >> (TTH_L2 + TTW_L2);
-  constexpr int PH = (TTW_L2 == 2) ? 9 : (1 << TTW_L2) + (1 << TTW_L2) / 4;
-  constexpr int PLANE = (TB == 2) ? 2 * 208 : (PXH + 2) * 2 * PH;
+  constexpr int PXH = 2 << TTH_L2, PXW = 2 << TTW_L2;
+  constexpr int TBL = 32 >> (TTH_L2 + TTW_L2), TB = TBL > 4 ? 4 : TBL;
+  constexpr int PH = (TTW_L2 == 2) ? 9 : (TTW_L2 == 1 ? 3 : (1 << TTW_L2) + (1 << TTW_L2) / 4);
+  constexpr int PLANE = (TB == 2) ? 2 * 208 : (TB == 4 ? 4 * 40 : (PXH + 2) * 2 * PH);
   a.nbh = cdiv(a.H, PXH);
   a.nbw = cdiv(a.W, PXW);
   a.n_co_tiles = cdiv(a.Co, WINO_TCO);
@@ -519,6 +525,7 @@ extern "C" int sivae_conv2d_wino_fwd(const float* x, const float* up, float* y, 
   // production: 4-wave blocks, 64co x 32 tiles per block, 128 accumulator registers per wave (119 TF issued =
   // 268 TF algorithmic on 512->512 @32x32; the 8-wave <NG=2,WM=1> split measured 106 TF)
   if (W == 8) return wino_launch<2, 2, 1, 2>(a, stream);  // 8x8 maps: 2 images x 4x4 tiles per block
+  if (W == 4) return wino_launch<1, 1, 1, 2>(a, stream);  // 4x4 maps: 4 images x 2x2 tiles per block
   if (wino_variant() == 2) return wino_wide(W) ? wino_launch<1, 4, 2, 1>(a, stream) : wino_launch<2, 3, 2, 1>(a, stream);
   return wino_wide(W) ? wino_launch<1, 4, 1, 2>(a, stream) : wino_launch<2, 3, 1, 2>(a, stream);
 }

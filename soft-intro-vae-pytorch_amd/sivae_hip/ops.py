@@ -203,7 +203,7 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
     if t0 is not None:
         flops = 2.0 * B * H * W * Co * Ci * ks * ks  # algorithmic (reference nn.Conv2d) FLOPs
         if wino:
-            key = "conv_wino_kernel<%s,%s>" % ("1,4" if W >= 32 else ("2,3" if W >= 16 else "2,2"),
+            key = "conv_wino_kernel<%s,%s>" % ("1,4" if W >= 32 else ("2,3" if W >= 16 else ("2,2" if W == 8 else "1,1")),
                                                "true" if pro is not None else "false")
             TIMER.end(key, flops, t0, executed=flops * 16.0 / 36.0)
         else:

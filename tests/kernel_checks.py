@@ -71,6 +71,8 @@ WINO_SHAPES = [
     (1, 512, 512, 16, 16, 3),  # long K loop
     (4, 64, 128, 8, 8, 3),     # 8x8 maps: two images per tile block
     (3, 40, 70, 8, 8, 3),      # ... odd batch (last block has one image), non-multiple channels
+    (8, 64, 128, 4, 4, 3),     # 4x4 maps: four images per tile block
+    (6, 24, 40, 4, 4, 3),      # ... partial last block
 ]
 
 
@@ -485,9 +487,10 @@ def all_checks():
     checks.append(("wino_fwd_stats", lambda: check_conv_fwd((3, 64, 128, 32, 32, 3), stats=True, wino=True)
                    + check_conv_fwd((3, 24, 40, 12, 20, 3), stats=True, wino=True)
                    + check_conv_fwd((2, 64, 3, 16, 48, 3), bias=True, wino=True)))  # bias -> direct kernel
-    for s in [(2, 64, 128, 32, 32, 3), (3, 40, 72, 16, 16, 3), (2, 16, 64, 24, 40, 3), (3, 64, 64, 8, 8, 3)]:
+    for s in [(2, 64, 128, 32, 32, 3), (3, 40, 72, 16, 16, 3), (2, 16, 64, 24, 40, 3), (3, 64, 64, 8, 8, 3), (5, 32, 64, 4, 4, 3)]:
         checks.append(("wino_fused%s" % (s,), lambda s=s: check_conv_fused(s, wino=True)))
-    checks.append(("wino_fwd_stats8", lambda: check_conv_fwd((5, 32, 96, 8, 8, 3), stats=True, wino=True)))
+    checks.append(("wino_fwd_stats8", lambda: check_conv_fwd((5, 32, 96, 8, 8, 3), stats=True, wino=True)
+                   + check_conv_fwd((7, 32, 96, 4, 4, 3), stats=True, wino=True)))
     checks.append(("conv5_edge", check_conv5_edge))
     checks.append(("linear", check_linear))
     for s in BN_SHAPES:
