@@ -430,7 +430,9 @@ extern "C" int sivae_conv2d_fwd(const float* x, const float* wp, float* y, const
     return launch_cfg<1, 2, 2, 2, 2, 16, 1, 4>(a, stream);
   } else {
     if (Co <= 32) return launch_cfg<5, 1, 2, 1, 4, 4, 4>(a, stream);
-    if (Co <= 64) return launch_cfg<5, 2, 2, 1, 4, 4, 4>(a, stream);
+    // three blocks per CU: with Ci = 3 (stem forward, `predict` data gradient) the whole K loop is ONE chunk, so
+    // nothing inside a block overlaps its load latency — co-resident blocks have to (2.03 -> 1.64 ms at bs128)
+    if (Co <= 64) return launch_cfg<5, 2, 2, 1, 4, 4, 4, 3>(a, stream);
     return launch_cfg<5, 2, 2, 2, 2, 4, 3>(a, stream);
   }
 }
