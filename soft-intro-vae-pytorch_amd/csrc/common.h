@@ -102,6 +102,8 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 }
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+// same function for 0 <= slope <= 1 in two VALU ops (v_mul + v_max) instead of compare / multiply / select
+__device__ __forceinline__ float lrelu01(float v, float slope) { return fmaxf(v, v * slope); }
 
 // ---- raw buffer loads: wave-uniform 128-bit descriptor + 32-bit per-lane BYTE offset + uniform
 // SGPR offset.  A per-lane offset >= num_records returns 0 without touching memory, which is how

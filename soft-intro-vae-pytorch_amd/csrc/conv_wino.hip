@@ -171,11 +171,12 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
       const int ci = (CH)*CK + ck;                                       \
       const bool ci_ok = ci < a.Ci;                                      \
       float v = xr[ck];                                                  \
-      if (PRO) {                                                         \
+      if (PRO) { /* padded channels carry {0,0,0} parameters -> 0 */      \
         const float4 pp = pro4[ci];                                      \
-        v = (xo != SIVAE_OOB) ? lrelu((v - pp.x) * pp.y + pp.z, a.pro_slope) : 0.f; \
+        v = (xo != SIVAE_OOB) ? lrelu01((v - pp.x) * pp.y + pp.z, a.pro_slope) : 0.f; \
+      } else {                                                           \
+        v = ci_ok ? v : 0.f;                                             \
       }                                                                  \
-      v = ci_ok ? v : 0.f;                                               \
       if (x_owner) xs[(BUF)*XBUF + ck * PLANE + xl] = v;                 \
     }                                                                    \
   }
@@ -296,8 +297,8 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
   const int nchunks = a.Ci_pad / CK;
   if (PRO) {
     for (int c = tid; c < a.Ci_pad; c += NT) {
-      const int cc = c < a.Ci ? c : a.Ci - 1;
-      pro4[c] = make_float4(a.pro_mean[cc], a.pro_invstd[cc] * a.pro_gamma[cc], a.pro_beta[cc], 0.f);
+      pro4[c] = c < a.Ci ? make_float4(a.pro_mean[c], a.pro_invstd[c] * a.pro_gamma[c], a.pro_beta[c], 0.f)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
   }
@@ -497,6 +498,7 @@ extern "C" int sivae_conv2d_wino_fwd(const float* x, const float* up, float* y, 
   if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
   if (!sivae_conv2d_wino_supported(H, W)) return SIVAE_ERR_SHAPE;
   if (pro_mean && (!pro_invstd || !pro_gamma || !pro_beta)) return SIVAE_ERR_NULL;
+  if (pro_mean && !(pro_slope >= 0.f && pro_slope <= 1.f)) return SIVAE_ERR_MODE;  // prologue uses max(v, v*slope)
   if (((uintptr_t)y & 7u) != 0) return SIVAE_ERR_SHAPE;  // float2 stores
   const long long hw = (long long)H * W;
   if ((long long)B * Co * hw >= 0xffffffffLL) return SIVAE_ERR_RANGE;

@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(NGI * 256, 2) wino_wgrad_kernel(WinoWgArgs a) 
       float v = xr[q];                                                                              \
       if (PRO) {                                                                                    \
         const float4 pp = pro4[xsub + NSUB * q];                                                    \
-        v = (xoff != SIVAE_OOB) ? lrelu((v - pp.x) * pp.y + pp.z, a.pro_slope) : 0.f;               \
+        v = (xoff != SIVAE_OOB) ? lrelu01((v - pp.x) * pp.y + pp.z, a.pro_slope) : 0.f;             \
       }                                                                                             \
       if (x_owner) xs[(BUF)*XBUF + (xsub + NSUB * q) * XP + xpos] = v;                              \
     }                                                                                               \
@@ -341,6 +341,7 @@ extern "C" int sivae_conv2d_wino_wgrad(const float* x, const float* dy, float* d
   if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
   if (!sivae_conv2d_wino_wgrad_supported(H, W)) return SIVAE_ERR_SHAPE;
   if (pro_mean && (!pro_invstd || !pro_gamma || !pro_beta)) return SIVAE_ERR_NULL;
+  if (pro_mean && !(pro_slope >= 0.f && pro_slope <= 1.f)) return SIVAE_ERR_MODE;  // prologue uses max(v, v*slope)
   const long long hw = (long long)H * W;
   if ((long long)Ci * hw * 4 >= 0x7fffffffLL || (long long)Co * hw * 4 >= 0x7fffffffLL) return SIVAE_ERR_RANGE;
   WinoWgPlan p;
