@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
                     help="testing only: every rank uses cuda:0 (with --backend gloo) to exercise the DP path on one GPU")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="capture the whole iteration into a HIP graph and time replays (single GPU; pays off where the "
+                         "host launch rate is the limit: 32x32 nets, small batches)")
     ap.add_argument("--no-reuse", action="store_true",
                     help="re-execute the two D-step decoder forwards whose inputs and weights are unchanged since the "
                          "E-step (the reference does); default: replay them from the E-step's activations")
@@ -159,6 +162,14 @@ def main():
 
     for _ in range(args.warmup):
         eng.soft_intro_step(real)
+    if args.hip_graph:
+        if world > 1:
+            raise SystemExit("--hip-graph is single-GPU")
+        eng.capture(real, warmup=1)
+        step_fn = eng.replay
+        args.no_kernel_timing = True  # (HIP events cannot be recorded per launch inside a graph)
+    else:
+        step_fn = eng.soft_intro_step
     torch.cuda.synchronize()
     dp.barrier()
     if not args.no_kernel_timing:
@@ -167,7 +178,7 @@ def main():
     t0 = time.perf_counter()
     last = None
     for _ in range(args.steps):
-        last = eng.soft_intro_step(real)
+        last = step_fn(real)
     torch.cuda.synchronize()
     dp.barrier()
     torch.cuda.synchronize()
@@ -243,7 +254,7 @@ def main():
                                   channels),
                    "global_batch": gbatch, "per_gpu_batch": per, "parallelism": "dp%d" % world,
                    "betas": {"kl": bk, "rec": br, "neg": bn}, "gamma_r": gr, "lr": 2e-4,
-                   "decoder_forward_reuse": not args.no_reuse,
+                   "decoder_forward_reuse": not args.no_reuse, "hip_graph": bool(args.hip_graph),
                    "final_stats": stats},
         "roofline": roof,
     }

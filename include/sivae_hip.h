@@ -187,6 +187,10 @@ int sivae_expelbo_bwd(const float* gout, const float* e, float scale, float beta
                       float* dL, float* dKL, sivae_stream_t stream);
 /* Philox4x32-10 standard normals (replaces torch.randn / randn_like :264,:547 in fast mode). */
 int sivae_randn(float* out, size_t n, unsigned long long seed, unsigned long long offset, sivae_stream_t stream);
+/* same stream with its position kept in device memory (*offset_dev is read, then advanced by ceil(n/4)): nothing
+ * that a captured HIP graph bakes in changes between replays. */
+int sivae_randn_dev(float* out, size_t n, unsigned long long seed, unsigned long long* offset_dev,
+                    sivae_stream_t stream);
 
 /* ---- optimizer ------------------------------------------------------------------------------------------
  * torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) :450-451, one launch over a flat parameter buffer. */
@@ -194,6 +198,11 @@ int sivae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
                     float step_size /* lr / (1 - beta1^t) */, float beta1, float beta2, float eps,
                     float bias_correction2_sqrt /* sqrt(1 - beta2^t) */, float grad_scale,
                     sivae_stream_t stream);
+
+/* the same Adam step with its state on the device (for whole-iteration HIP graphs): state = double[4]
+ * {t, lr, lr/(1-beta1^t), sqrt(1-beta2^t)}; the call advances t and refreshes the two factors before the update. */
+int sivae_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double* state,
+                        double beta1, double beta2, float eps, float grad_scale, sivae_stream_t stream);
 
 /* ---- input side ------------------------------------------------------------------------------
  * uint8 image batch [B][C][H][W] (nhwc == 0) or [B][H][W][C] (nhwc != 0) -> fp32 NCHW * scale, sample b mirrored

@@ -148,4 +148,14 @@ __device__ __forceinline__ float2 buf_load_f32x2(__amdgpu_buffer_rsrc_t r, unsig
 __device__ __forceinline__ unsigned fastdiv(unsigned e, unsigned magic) { return magic ? __umulhi(e, magic) : e; }
 #endif
 
+// Raise a kernel's dynamic-LDS limit once per high-water mark instead of on every launch: keeps the attribute call
+// out of the launch path and, after an eager warm-up has seen the kernel, out of HIP-graph stream captures.
+static inline int sivae_ensure_lds(const void* kern, size_t lds, size_t* high_water) {
+  if (lds <= 64 * 1024 || lds <= *high_water) return SIVAE_OK;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  *high_water = lds;
+  return SIVAE_OK;
+}
+
 static inline unsigned make_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull / d) + 1ull); }

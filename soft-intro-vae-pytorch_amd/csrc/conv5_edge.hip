@@ -395,9 +395,9 @@ extern "C" int sivae_conv5_edge_wgrad(const float* x, const float* dy, float* dw
   if (small_co) {
     const size_t lds = (size_t)(64 * (8 * 32 + 1) + 4 * 4 * 40) * sizeof(float);
     auto kern = conv5_edge_wgrad_kernel<true>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) return (int)e;
+    static size_t lds_hwm = 0;
+    const int rc_lds = sivae_ensure_lds(reinterpret_cast<const void*>(kern), lds, &lds_hwm);
+    if (rc_lds != SIVAE_OK) return rc_lds;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
   } else {
     const size_t lds = (size_t)(64 * (4 * 32 + 1) + 4 * 8 * 40) * sizeof(float);

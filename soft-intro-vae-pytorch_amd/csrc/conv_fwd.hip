@@ -318,10 +318,10 @@ int launch_cfg(ConvFwdArgs& a, hipStream_t stream) {
   if (nblk > 0x7fffffffLL) return SIVAE_ERR_RANGE;
   auto kern = a.pro_mean ? conv_fwd_kernel<KS, WM, WN, WVM, WVN, CK, MAXPOS, true, MINW>
                          : conv_fwd_kernel<KS, WM, WN, WVM, WVN, CK, MAXPOS, false, MINW>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+  {
+    static size_t lds_hwm[2] = {0, 0};  // per template instantiation, per prologue variant
+    const int rc_lds = sivae_ensure_lds(reinterpret_cast<const void*>(kern), lds, &lds_hwm[a.pro_mean ? 1 : 0]);
+    if (rc_lds != SIVAE_OK) return rc_lds;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NT), lds, stream, a);
   return sivae_launch_status();

@@ -307,10 +307,10 @@ int launch_wgrad(ConvWgradArgs& a, const WgradPlan& p, hipStream_t stream) {
   const size_t lds = (size_t)(TCO * 65 + TCI * (plane | 1)) * sizeof(float);
   auto kern = a.pro_mean ? conv_wgrad_kernel<KS, KHB, WM, WN, WVM, WVN, NPOS, true>
                          : conv_wgrad_kernel<KS, KHB, WM, WN, WVM, WVN, NPOS, false>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+  {
+    static size_t lds_hwm[2] = {0, 0};  // per template instantiation, per prologue variant
+    const int rc_lds = sivae_ensure_lds(reinterpret_cast<const void*>(kern), lds, &lds_hwm[a.pro_mean ? 1 : 0]);
+    if (rc_lds != SIVAE_OK) return rc_lds;
   }
   dim3 grid(p.n_co_tiles * p.n_ci_tiles, p.n_slices, KS / KHB);
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, a);

@@ -478,10 +478,10 @@ static int wino_launch(WinoArgs& a, hipStream_t stream) {
   lds = exch + (a.pro_mean ? (size_t)a.Ci_pad * 16 : 0);
   if (lds > 80 * 1024) return SIVAE_ERR_SHAPE;
   auto kern = a.pro_mean ? conv_wino_kernel<TTH_L2, TTW_L2, true, NG, WM> : conv_wino_kernel<TTH_L2, TTW_L2, false, NG, WM>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+  {
+    static size_t lds_hwm[2] = {0, 0};  // per template instantiation, per prologue variant
+    const int rc_lds = sivae_ensure_lds(reinterpret_cast<const void*>(kern), lds, &lds_hwm[a.pro_mean ? 1 : 0]);
+    if (rc_lds != SIVAE_OK) return rc_lds;
   }
   a.n_items = (int)nblk;
   const int grid = nblk < wino_grid_blocks() ? (int)nblk : wino_grid_blocks();

@@ -377,10 +377,10 @@ extern "C" int sivae_conv2d_wino_wgrad(const float* x, const float* dy, float* d
   constexpr int CIT = 32 * WG_NGI;
   const size_t lds = (size_t)2 * (CIT * 109 + 64 * 65) * sizeof(float) + (pro_mean ? (size_t)CIT * 16 : 0);
   auto kern = pro_mean ? wino_wgrad_kernel<true, WG_NGI> : wino_wgrad_kernel<false, WG_NGI>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+  {
+    static size_t lds_hwm[2] = {0, 0};  // per template instantiation, per prologue variant
+    const int rc_lds = sivae_ensure_lds(reinterpret_cast<const void*>(kern), lds, &lds_hwm[pro_mean ? 1 : 0]);
+    if (rc_lds != SIVAE_OK) return rc_lds;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(WG_NGI * 256), lds, stream, a);
   rc = sivae_launch_status();

@@ -193,7 +193,9 @@ __device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigne
   c0 = n0; c1 = n1; c2 = n2; c3 = n3;
 }
 __global__ void __launch_bounds__(256) randn_kernel(float* __restrict__ out, size_t n, unsigned long long seed,
-                                                    unsigned long long offset) {
+                                                    unsigned long long offset,
+                                                    const unsigned long long* __restrict__ offset_dev) {
+  if (offset_dev != nullptr) offset += *offset_dev;  // stream position kept on the device (HIP-graph replay)
   const size_t n4 = (n + 3) >> 2;
   const size_t stride = (size_t)gridDim.x * 256;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
@@ -350,6 +352,21 @@ extern "C" int sivae_randn(float* out, size_t n, unsigned long long seed, unsign
                            hipStream_t stream) {
   if (!out) return SIVAE_ERR_NULL;
   if (n == 0) return SIVAE_ERR_SHAPE;
-  hipLaunchKernelGGL(randn_kernel, dim3(g1d((n + 3) >> 2)), dim3(256), 0, stream, out, n, seed, offset);
+  hipLaunchKernelGGL(randn_kernel, dim3(g1d((n + 3) >> 2)), dim3(256), 0, stream, out, n, seed, offset,
+                     (const unsigned long long*)nullptr);
+  return sivae_launch_status();
+}
+
+// Same stream with its position in DEVICE memory: draws from counter *offset_dev, then advances it by the number
+// of Philox counters used — nothing a captured HIP graph bakes in changes between replays.
+__global__ void counter_add_kernel(unsigned long long* c, unsigned long long inc) { *c += inc; }
+
+extern "C" int sivae_randn_dev(float* out, size_t n, unsigned long long seed, unsigned long long* offset_dev,
+                               hipStream_t stream) {
+  if (!out || !offset_dev) return SIVAE_ERR_NULL;
+  if (n == 0) return SIVAE_ERR_SHAPE;
+  hipLaunchKernelGGL(randn_kernel, dim3(g1d((n + 3) >> 2)), dim3(256), 0, stream, out, n, seed, 0ull,
+                     (const unsigned long long*)offset_dev);
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, stream, offset_dev, (unsigned long long)((n + 3) >> 2));
   return sivae_launch_status();
 }

@@ -78,6 +78,46 @@ class SoftIntroEngine:
         self.reuse_decoder_forward = reuse_decoder_forward
         self._cache_fake, self._cache_rec = None, None
 
+    # -- whole-iteration HIP graph -------------------------------------------------------
+    def capture(self, real_example, warmup=2):
+        """Capture one full Soft-Intro iteration (both steps, both Adam updates, ~2-3 thousand launches) into a
+        HIP graph.  Everything that changes between iterations lives in device memory — the Adam step counters
+        and learning rates (`FlatAdam.use_device_state`), the Philox stream position, the BatchNorm counters, the
+        input batch (a static buffer) — so a replay is one `hipGraphLaunch` instead of a python-driven launch
+        sequence.  At 256x256 / batch 128 the GPU is the bottleneck either way; at 32x32 or batch 16 the host is.
+        `warmup` eager iterations run first on the capture stream (they are REAL training iterations)."""
+        if self.grad_sync is not None:
+            raise RuntimeError("sivae_hip: HIP-graph capture of the data-parallel step is not supported")
+        dev = real_example.device
+        self.opt_e.use_device_state()
+        self.opt_d.use_device_state()
+        rng.default_stream().use_device_state(dev)
+        self._g_real = real_example.clone()
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.soft_intro_step(self._g_real)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        SF.clear_pack_cache()  # every weight re-pack of an iteration must be part of the captured sequence
+        torch.cuda.empty_cache()  # the graph gets its own pool: hand the warm-up's cached blocks back first
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            out = self.soft_intro_step(self._g_real)
+        self._g_out = {"stats": out["stats"], "fake": out["fake"]}
+        self.opt_e.t -= 1  # the capture pass launched nothing: undo its python-side counters
+        self.opt_d.t -= 1
+        return self
+
+    def replay(self, real):
+        """run the captured iteration on `real` (same shape as the example); returns the graph's static outputs"""
+        self._g_real.copy_(real, non_blocking=True)
+        self._graph.replay()
+        self.opt_e.replayed()
+        self.opt_d.replayed()
+        return self._g_out
+
     # -- requires_grad toggles (reference :552-555, :592-595) -----------------------------------------
     def _train_encoder_only(self):
         for p in self.model.encoder.parameters():

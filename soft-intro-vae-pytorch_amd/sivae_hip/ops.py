@@ -526,7 +526,23 @@ def randn(shape, seed, offset, device):
     return out
 
 
+def randn_dev(shape, seed, offset_dev, device):
+    """normals from the Philox stream whose position is the device scalar offset_dev (uint64 stored in an int64
+    tensor); the position is advanced on the device"""
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    _lib.call("sivae_randn_dev", _p(out), out.numel(), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(offset_dev), _s())
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ optimizer
+def adam_step_dev(param, grad, exp_avg, exp_avg_sq, state, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    """state: float64 device tensor [4] = {t, lr, step_size, sqrt(bias_correction2)} (t and the factors are advanced
+    on the device)"""
+    _require(param, grad, exp_avg, exp_avg_sq)
+    _lib.call("sivae_adam_step_dev", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), _p(state),
+              float(beta1), float(beta2), float(eps), float(grad_scale), _s())
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
     _require(param, grad, exp_avg, exp_avg_sq)
     bc1 = 1.0 - beta1 ** step

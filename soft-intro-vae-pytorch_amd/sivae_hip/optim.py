@@ -23,6 +23,7 @@ class FlatAdam:
             raise RuntimeError("FlatAdam needs ROCm-device parameters (no CPU fallback)")
         self.lr, self.betas, self.eps = float(lr), betas, float(eps)
         self.t = 0
+        self.dev_state = None
         n = sum(p.numel() for p in self.params)
         self.flat = torch.empty(n, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -56,8 +57,31 @@ class FlatAdam:
     def step(self, grad_scale=1.0):
         self.t += 1
         self.lr = float(self.param_groups[0]["lr"])
-        ops.adam_step(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.t, self.lr, self.betas[0],
-                      self.betas[1], self.eps, grad_scale)
+        if self.dev_state is not None:
+            # step count / learning rate / bias corrections live on the device (HIP-graph mode): the launch
+            # arguments are the same every iteration
+            ops.adam_step_dev(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.dev_state,
+                              self.betas[0], self.betas[1], self.eps, grad_scale)
+        else:
+            ops.adam_step(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.t, self.lr, self.betas[0],
+                          self.betas[1], self.eps, grad_scale)
+        SF.bump_generation(self.params)
+
+    def use_device_state(self):
+        """Move the step counter and learning rate into a device tensor {t, lr, ., .} (float64).  Needed before the
+        step is captured into a HIP graph; `sync_lr()` pushes a scheduler change to the device."""
+        if self.dev_state is None:
+            self.dev_state = torch.tensor([float(self.t), float(self.param_groups[0]["lr"]), 0.0, 0.0],
+                                          dtype=torch.float64, device=self.flat.device)
+        return self.dev_state
+
+    def sync_lr(self):
+        if self.dev_state is not None:
+            self.dev_state[1:2].fill_(float(self.param_groups[0]["lr"]))
+
+    def replayed(self, n=1):
+        """bookkeeping after n HIP-graph replays of a captured step (the kernels ran, this python did not)"""
+        self.t += n
         SF.bump_generation(self.params)
 
 
@@ -73,3 +97,5 @@ class MultiStepLR:
         self.last_epoch += 1
         k = sum(1 for m in self.milestones if m <= self.last_epoch)
         self.opt.param_groups[0]["lr"] = self.base_lr * (self.gamma ** k)
+        if hasattr(self.opt, "sync_lr"):
+            self.opt.sync_lr()
