@@ -149,7 +149,10 @@ class ResBlockFn(torch.autograd.Function):
             return y.view_as(y)
         idt = x
         if w_exp is not None:
-            idt = ops.conv2d_fwd(x, packed(w_exp, 0), Co, 1, upsample=x_up)
+            # a 1x1 conv commutes with nearest upsampling pixel for pixel (bit-exactly): with x_up it runs on the
+            # half-resolution tensor (1/4 of the FLOPs and output bytes) and the residual add reads it through
+            # upsample addressing like an identity skip
+            idt = ops.conv2d_fwd(x, packed(w_exp, 0), Co, 1)
         if st1.training:
             a, p1 = ops.conv2d_fwd(x, packed(w1, 0), Cm, 3, want_stats=True, upsample=x_up)
         else:
@@ -167,8 +170,7 @@ class ResBlockFn(torch.autograd.Function):
         else:
             c, p2 = ops.conv2d_fwd(h, packed(w2, 0), Co, 3, pro=pro1), None
         mean2, invstd2 = _stats(p2, B, Co, H * W, st2)
-        out = ops.bn_apply_act(c, idt, mean2, invstd2, g2.detach(), b2.detach(), SLOPE,
-                               res_up=x_up and w_exp is None)
+        out = ops.bn_apply_act(c, idt, mean2, invstd2, g2.detach(), b2.detach(), SLOPE, res_up=x_up)
         y = _post_fwd(out, post)
         if cache is not None:
             cache.update(a=a, h=h, c=c, out=out, mean1=mean1, invstd1=invstd1, mean2=mean2, invstd2=invstd2, y=y)
@@ -209,17 +211,26 @@ class ResBlockFn(torch.autograd.Function):
         dw1 = ops.conv2d_wgrad(x, da, 3, upsample=x_up) if need_w1 else None
         dwe = None
         dx = None
-        if ctx.has_exp:
+        if ctx.has_exp and x_up:
+            # the expand conv ran at half resolution: its gradients do too (dz summed over each 2x2 block first)
+            dzh = ops.upsample2_bwd(dz) if (need_we or need_x) else None
             if need_we:
-                dwe = ops.conv2d_wgrad(x, dz, 1, upsample=x_up)
+                dwe = ops.conv2d_wgrad(x, dzh, 1)
             if need_x:
-                dx = ops.conv2d_fwd(da, packed(w1, 1), x.shape[1], 3)
-                ops.conv2d_fwd(dz, packed(w_exp, 1), x.shape[1], 1, out=dx, accumulate=True)
-        elif need_x:
-            dx = dz  # identity branch gradient; add the conv1 branch on top
-            ops.conv2d_fwd(da, packed(w1, 1), x.shape[1], 3, out=dx, accumulate=True)
-        if x_up and dx is not None:
-            dx = ops.upsample2_bwd(dx)  # adjoint of the deferred Upsample: sum each 2x2 block
+                dx = ops.upsample2_bwd(ops.conv2d_fwd(da, packed(w1, 1), x.shape[1], 3))
+                ops.conv2d_fwd(dzh, packed(w_exp, 1), x.shape[1], 1, out=dx, accumulate=True)
+        else:
+            if ctx.has_exp:
+                if need_we:
+                    dwe = ops.conv2d_wgrad(x, dz, 1)
+                if need_x:
+                    dx = ops.conv2d_fwd(da, packed(w1, 1), x.shape[1], 3)
+                    ops.conv2d_fwd(dz, packed(w_exp, 1), x.shape[1], 1, out=dx, accumulate=True)
+            elif need_x:
+                dx = dz  # identity branch gradient; add the conv1 branch on top
+                ops.conv2d_fwd(da, packed(w1, 1), x.shape[1], 3, out=dx, accumulate=True)
+            if x_up and dx is not None:
+                dx = ops.upsample2_bwd(dx)  # adjoint of the deferred Upsample: sum each 2x2 block
         return (dx, dwe, dw1, dg1 if need[3] else None, db1 if need[4] else None, dw2,
                 dg2 if need[6] else None, db2 if need[7] else None, None, None, None, None, None)
 
