@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
                     help="testing only: every rank uses cuda:0 (with --backend gloo) to exercise the DP path on one GPU")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="synchronised BatchNorm across ranks (opt-in; default local BatchNorm as DDP would do)")
     ap.add_argument("--hip-graph", action="store_true",
                     help="capture the whole iteration into a HIP graph and time replays (single GPU; pays off where the "
                          "host launch rate is the limit: 32x32 nets, small batches)")
@@ -154,6 +156,7 @@ def main():
     opt_d = FlatAdam(model.decoder.parameters(), lr=2e-4)
     dp.broadcast_([opt_e.flat, opt_d.flat] + [b for b in model.buffers()])
     sync = dp.GradSync() if world > 1 else None
+    sync_bn = dp.enable_sync_bn(args.sync_bn)
     eng = SoftIntroEngine(model, opt_e, opt_d, beta_kl=bk, beta_rec=br, beta_neg=bn, gamma_r=gr,
                           bootstrap=args.bootstrap, grad_sync=sync, reuse_decoder_forward=not args.no_reuse)
     rng.manual_seed(0, rank)
@@ -255,6 +258,7 @@ def main():
                    "global_batch": gbatch, "per_gpu_batch": per, "parallelism": "dp%d" % world,
                    "betas": {"kl": bk, "rec": br, "neg": bn}, "gamma_r": gr, "lr": 2e-4,
                    "decoder_forward_reuse": not args.no_reuse, "hip_graph": bool(args.hip_graph),
+                   "batchnorm": "sync" if sync_bn else "local",
                    "final_stats": stats},
         "roofline": roof,
     }

@@ -121,6 +121,22 @@ int sivae_bn_stats(const float* x, int B, int C, int HW, float eps, float moment
 int sivae_bn_stats_from_conv(const float* partials, int n_tiles, int B, int C, int HW, float eps, float momentum,
                              float* running_mean, float* running_var, long long* num_batches_tracked,
                              float* mean_out, float* invstd_out, sivae_stream_t stream);
+/* ---- synchronised BatchNorm for data-parallel runs (opt-in): the shard's per-channel {sum, sumsq}
+ * (fp64 [C][2]) from the conv-epilogue partials — the caller all-reduces it — and the finalize from the (global) sums
+ * and the global element count.  Backward: `reduce` leaves the local {sum dz, sum dz*xhat} (fp64 [C][2]), `apply`
+ * takes the local sums (-> dgamma, dbeta) and the all-reduced sums + global count (-> dx, dz). */
+int sivae_bn_sums_from_conv(const float* partials, int n_tiles, int C, double* sums, sivae_stream_t stream);
+int sivae_bn_finalize_sums(const double* sums, int C, double count, float eps, float momentum, float* running_mean,
+                           float* running_var, long long* num_batches_tracked, float* mean_out, float* invstd_out,
+                           sivae_stream_t stream);
+int sivae_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                        const float* gamma, const float* beta, int act_mode, float slope, double* sums, int B, int C,
+                        int HW, void* workspace, size_t workspace_bytes, sivae_stream_t stream);
+int sivae_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                       const float* gamma, const float* beta, int act_mode, float slope, const double* sums_local,
+                       const double* sums_global, double count_global, float* dx, float* dz_out, float* dgamma,
+                       float* dbeta, int B, int C, int HW, void* workspace, size_t workspace_bytes,
+                       sivae_stream_t stream);
 /* one more running-stat update from saved batch statistics (a forward pass replayed from cached
  * activations still counts as one BatchNorm call of the reference); count = B*H*W. */
 int sivae_bn_update_running(const float* mean, const float* invstd, int C, double count, float eps, float momentum,

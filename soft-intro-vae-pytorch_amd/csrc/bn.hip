@@ -169,6 +169,64 @@ extern "C" int sivae_bn_stats_from_conv(const float* partials, int n_tiles, int 
   return sivae_launch_status();
 }
 
+// ---- synchronised BatchNorm (opt-in, data-parallel runs): the per-channel {sum, sumsq} of the local
+// shard in fp64, to be all-reduced by the caller, and the finalize from (global) sums.
+__global__ void __launch_bounds__(256) bn_sums_conv_kernel(const float* __restrict__ part, int S, int C,
+                                                           double* __restrict__ sums) {
+  __shared__ double red[4];
+  const int c = blockIdx.x;
+  double sum = 0.0, sq = 0.0;
+  for (int s = threadIdx.x; s < S; s += 256) {
+    const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)s * C + c) * 2);
+    sum += (double)v.x;
+    sq += (double)v.y;
+  }
+  sum = block_sum<256>(sum, red);
+  sq = block_sum<256>(sq, red);
+  if (threadIdx.x == 0) {
+    sums[c * 2 + 0] = sum;
+    sums[c * 2 + 1] = sq;
+  }
+}
+
+__global__ void __launch_bounds__(64) bn_finalize_sums_kernel(const double* __restrict__ sums, int C, double count,
+                                                              float eps, float momentum, float* running_mean,
+                                                              float* running_var, long long* num_batches_tracked,
+                                                              float* __restrict__ mean_out,
+                                                              float* __restrict__ invstd_out) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  const double mean = sums[c * 2] / count;
+  double var = sums[c * 2 + 1] / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  mean_out[c] = (float)mean;
+  invstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+  }
+}
+
+extern "C" int sivae_bn_sums_from_conv(const float* partials, int n_tiles, int C, double* sums, hipStream_t stream) {
+  if (!partials || !sums) return SIVAE_ERR_NULL;
+  if (C <= 0 || n_tiles <= 0) return SIVAE_ERR_SHAPE;
+  hipLaunchKernelGGL(bn_sums_conv_kernel, dim3(C), dim3(256), 0, stream, partials, n_tiles, C, sums);
+  return sivae_launch_status();
+}
+
+extern "C" int sivae_bn_finalize_sums(const double* sums, int C, double count, float eps, float momentum,
+                                      float* running_mean, float* running_var, long long* num_batches_tracked,
+                                      float* mean_out, float* invstd_out, hipStream_t stream) {
+  if (!sums || !mean_out || !invstd_out) return SIVAE_ERR_NULL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return SIVAE_ERR_NULL;
+  if (C <= 0 || !(count > 0.0)) return SIVAE_ERR_SHAPE;
+  hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, sums, C, count, eps, momentum,
+                     running_mean, running_var, num_batches_tracked, mean_out, invstd_out);
+  return sivae_launch_status();
+}
+
 // Re-apply a running-statistics update from SAVED batch statistics (mean, invstd) without touching the
 // activations: used when a forward pass is replayed from cached activations (the decoder passes that the
 // reference recomputes with unchanged weights, train_soft_intro_vae.py:557 vs :597 and :561 vs :598) so that
@@ -464,6 +522,90 @@ extern "C" int sivae_bn_bwd(const float* dy, const float* y, const float* x, con
 #undef LAUNCHP
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, (const double*)part, p.S, C,
                      (double)n, dgamma, dbeta, coef);
+  const size_t numel = (size_t)B * C * HW;
+  const bool vec = (HW & 3) == 0;
+  long long work = vec ? (long long)(numel >> 2) : (long long)numel;
+  int nb = cdiv(work, 256);
+  if (nb > 8192) nb = 8192;
+  if (nb < 1) nb = 1;
+#define LAUNCH(A, Z, V) \
+  hipLaunchKernelGGL((bn_bwd_dx_kernel<A, Z, V>), dim3(nb), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma, \
+                     beta, (const float*)coef, slope, dx, dz_out, C, HW, numel)
+#define LAUNCH_A(A) \
+  { if (hz) { if (vec) LAUNCH(A, true, true); else LAUNCH(A, true, false); } \
+    else { if (vec) LAUNCH(A, false, true); else LAUNCH(A, false, false); } }
+  const bool hz = dz_out != nullptr;
+  if (act_mode == 0) LAUNCH_A(0) else if (act_mode == 1) LAUNCH_A(1) else LAUNCH_A(2)
+#undef LAUNCH_A
+#undef LAUNCH
+  return sivae_launch_status();
+}
+
+// ---- the same backward in two calls for synchronised BatchNorm: `reduce` leaves the local per-channel
+// {sum dz, sum dz*xhat} in fp64 (the caller all-reduces a copy), `apply` takes the local sums (-> dgamma, dbeta, which
+// the data-parallel gradient all-reduce sums across ranks anyway) and the global sums + global count (-> dx).
+__global__ void __launch_bounds__(64) bn_bwd_sums_kernel(const double* __restrict__ part, int S, int C,
+                                                         double* __restrict__ sums) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = 0; s < S; ++s) {
+    s1 += part[((size_t)c * S + s) * 2 + 0];
+    s2 += part[((size_t)c * S + s) * 2 + 1];
+  }
+  sums[c * 2 + 0] = s1;
+  sums[c * 2 + 1] = s2;
+}
+
+__global__ void __launch_bounds__(64) bn_bwd_coef_kernel(const double* __restrict__ sums_local,
+                                                         const double* __restrict__ sums_global, int C, double count,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                         float* __restrict__ coef) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  if (dbeta) dbeta[c] = (float)sums_local[c * 2 + 0];
+  if (dgamma) dgamma[c] = (float)sums_local[c * 2 + 1];
+  coef[c * 2 + 0] = (float)(sums_global[c * 2 + 0] / count);
+  coef[c * 2 + 1] = (float)(sums_global[c * 2 + 1] / count);
+}
+
+extern "C" int sivae_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean,
+                                   const float* invstd, const float* gamma, const float* beta, int act_mode,
+                                   float slope, double* sums, int B, int C, int HW, void* workspace,
+                                   size_t workspace_bytes, hipStream_t stream) {
+  if (!dy || !x || !mean || !invstd || !gamma || !sums) return SIVAE_ERR_NULL;
+  if (act_mode < 0 || act_mode > 2) return SIVAE_ERR_MODE;
+  if (act_mode == 1 && !y) return SIVAE_ERR_NULL;
+  if (act_mode == 2 && !beta) return SIVAE_ERR_NULL;
+  if (B <= 0 || C <= 0 || HW <= 0) return SIVAE_ERR_SHAPE;
+  if (!workspace || workspace_bytes < sivae_bn_workspace_bytes(B, C, HW)) return SIVAE_ERR_WORKSPACE;
+  const long long n = (long long)B * HW;
+  SlicePlan p = plan_slices(n, C);
+  double* part = (double*)workspace;
+#define LAUNCHP(A) \
+  hipLaunchKernelGGL((bn_bwd_partial_kernel<A>), dim3(C, p.S), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma, \
+                     beta, slope, part, C, HW, n, p.len, p.S)
+  if (act_mode == 0) LAUNCHP(0); else if (act_mode == 1) LAUNCHP(1); else LAUNCHP(2);
+#undef LAUNCHP
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, (const double*)part, p.S, C, sums);
+  return sivae_launch_status();
+}
+
+extern "C" int sivae_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean,
+                                  const float* invstd, const float* gamma, const float* beta, int act_mode,
+                                  float slope, const double* sums_local, const double* sums_global,
+                                  double count_global, float* dx, float* dz_out, float* dgamma, float* dbeta, int B,
+                                  int C, int HW, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (!dy || !x || !mean || !invstd || !gamma || !dx || !sums_local || !sums_global) return SIVAE_ERR_NULL;
+  if (act_mode < 0 || act_mode > 2) return SIVAE_ERR_MODE;
+  if (act_mode == 1 && !y) return SIVAE_ERR_NULL;
+  if (act_mode == 2 && !beta) return SIVAE_ERR_NULL;
+  if (B <= 0 || C <= 0 || HW <= 0 || !(count_global > 0.0)) return SIVAE_ERR_SHAPE;
+  if (!workspace || workspace_bytes < sivae_bn_workspace_bytes(B, C, HW)) return SIVAE_ERR_WORKSPACE;
+  SlicePlan p = plan_slices((long long)B * HW, C);
+  float* coef = (float*)((double*)workspace + (size_t)C * p.S * 2);
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, sums_local, sums_global, C,
+                     count_global, dgamma, dbeta, coef);
   const size_t numel = (size_t)B * C * HW;
   const bool vec = (HW & 3) == 0;
   long long work = vec ? (long long)(numel >> 2) : (long long)numel;

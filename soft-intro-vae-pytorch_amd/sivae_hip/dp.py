@@ -77,3 +77,21 @@ class GradSync:
         self.calls += 1
         self.bytes += flat_grad.numel() * 4
         allreduce_sum_(flat_grad)
+
+
+def enable_sync_bn(enable=True):
+    """Opt-in synchronised BatchNorm: batch statistics and the two BatchNorm-backward means over the
+    GLOBAL batch — ~340 tiny fp64 all-reduces per iteration at 256x256, latency-bound — so that N shards of B/N
+    reproduce the single-process batch-B iteration.  Default is local BatchNorm."""
+    from . import ops
+    if not enable or not dist.is_initialized() or dist.get_world_size() == 1:
+        ops.SYNC_BN = None
+        return False
+
+    def sync(sums):
+        if sums is not None:
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        return dist.get_world_size()
+
+    ops.SYNC_BN = sync
+    return True

@@ -115,6 +115,8 @@ def _post_bwd(dy, post, shape):
 
 # ---------------------------------------------------------------------------------------------------
 def _replay_bn(st, mean, invstd, count):
+    if ops.SYNC_BN is not None:
+        count = count * ops.SYNC_BN(None)  # (None -> just the world size)
     if st.training:
         ops.bn_update_running(mean, invstd, count, st.running_mean, st.running_var, st.num_batches_tracked, st.eps,
                               st.momentum)

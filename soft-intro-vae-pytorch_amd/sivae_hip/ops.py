@@ -295,11 +295,25 @@ def bn_stats(x, running_mean=None, running_var=None, num_batches_tracked=None, e
     return mean, invstd
 
 
+# Synchronised BatchNorm (opt-in for data-parallel runs): SYNC_BN = None, or a callable
+# `sync(sums_fp64[C, 2]) -> world_size` that all-reduces (SUM) the per-channel sums in place.  With it, the batch
+# statistics (forward) and the two gradient means (backward) are those of the GLOBAL batch, so N shards of B/N
+# reproduce the single-process batch-B numbers; the default (None) is local BatchNorm, what DDP does to this model.
+SYNC_BN = None
+
+
 def bn_stats_from_conv(partials, B, C, HW, running_mean=None, running_var=None, num_batches_tracked=None,
                        eps=1e-5, momentum=0.1):
     _require(partials, running_mean, running_var, num_batches_tracked)
     mean = torch.empty(C, dtype=torch.float32, device=partials.device)
     invstd = torch.empty(C, dtype=torch.float32, device=partials.device)
+    if SYNC_BN is not None:
+        sums = torch.empty((C, 2), dtype=torch.float64, device=partials.device)
+        _lib.call("sivae_bn_sums_from_conv", _p(partials), partials.shape[0], C, _p(sums), _s())
+        world = SYNC_BN(sums)
+        _lib.call("sivae_bn_finalize_sums", _p(sums), C, float(B) * HW * world, float(eps), float(momentum),
+                  _p(running_mean), _p(running_var), _p(num_batches_tracked), _p(mean), _p(invstd), _s())
+        return mean, invstd
     _lib.call("sivae_bn_stats_from_conv", _p(partials), partials.shape[0], B, C, HW, float(eps), float(momentum),
               _p(running_mean), _p(running_var), _p(num_batches_tracked), _p(mean), _p(invstd), _s())
     return mean, invstd
@@ -343,6 +357,16 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_dz=False, want
     dz = torch.empty_like(x) if want_dz else None
     dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
     dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
+    if SYNC_BN is not None:
+        local = torch.empty((C, 2), dtype=torch.float64, device=x.device)
+        _lib.call("sivae_bn_bwd_reduce", _p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta),
+                  int(act_mode), float(slope), _p(local), B, C, HW, _p(ws), ws.numel(), _s())
+        glob = local.clone()
+        world = SYNC_BN(glob)
+        _lib.call("sivae_bn_bwd_apply", _p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta),
+                  int(act_mode), float(slope), _p(local), _p(glob), float(B) * HW * world, _p(dx), _p(dz),
+                  _p(dgamma), _p(dbeta), B, C, HW, _p(ws), ws.numel(), _s())
+        return dx, dz, dgamma, dbeta
     _lib.call("sivae_bn_bwd", _p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), int(act_mode),
               float(slope), _p(dx), _p(dz), _p(dgamma), _p(dbeta), B, C, HW, _p(ws), ws.numel(), _s())
     return dx, dz, dgamma, dbeta

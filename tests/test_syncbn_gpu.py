@@ -1,0 +1,82 @@
+"""GPU: opt-in synchronised BatchNorm — two data-parallel ranks (gloo, both on cuda:0) with 4 images each reproduce
+the single-process batch-8 iteration ('sync-BN reproduces the B=128 single-process numbers')."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    sys.path.insert(0, os.path.join(REPO, "soft-intro-vae-pytorch_amd"))
+    import torch.distributed as dist
+    import train_soft_intro_vae as T
+    from sivae_hip import dp
+    from sivae_hip.engine import SoftIntroEngine
+    from sivae_hip.optim import FlatAdam
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    B, z = 8, 16
+    g = torch.Generator().manual_seed(7)
+    real = torch.rand(B, 3, 32, 32, generator=g).to(dev)
+    noise = torch.randn(B, z, generator=g).to(dev)
+    eps = [torch.randn(B, z, generator=g).to(dev) for _ in range(5)]
+
+    def build(sync):
+        torch.manual_seed(11)
+        m = T.SoftIntroVAE(cdim=3, zdim=z, channels=[32, 64], image_size=32).to(dev).train()
+        oe, od = FlatAdam(m.encoder.parameters(), lr=2e-4), FlatAdam(m.decoder.parameters(), lr=2e-4)
+        return m, SoftIntroEngine(m, oe, od, beta_kl=1.0, beta_rec=1.0, beta_neg=256.0, grad_sync=sync)
+
+    assert dp.enable_sync_bn(True)
+    m_dp, e_dp = build(dp.GradSync())
+    lo, n = dp.shard_batch(B, world, rank)
+    out = e_dp.soft_intro_step(real[lo:lo + n], noise=noise[lo:lo + n], eps=[e[lo:lo + n] for e in eps])
+    stats = out["stats"].clone()
+    dist.all_reduce(stats)
+    stats /= world
+    torch.cuda.synchronize()
+    if rank == 0:
+        dp.enable_sync_bn(False)
+        m_ref, e_ref = build(None)
+        ref = e_ref.soft_intro_step(real, noise=noise, eps=eps)["stats"]
+        torch.cuda.synchronize()
+        lr, drift, worst_buf = 2e-4, [], 0.0
+        for (k, va), (_, vb) in zip(m_dp.state_dict().items(), m_ref.state_dict().items()):
+            if not va.is_floating_point():
+                assert torch.equal(va, vb), k
+            elif "running" in k:
+                worst_buf = max(worst_buf, float((va - vb).abs().max() / (vb.abs().max() + 1e-12)))
+            else:
+                drift.append(((va - vb).abs() / lr).flatten().cpu())
+        d = torch.cat(drift)
+        torch.save(dict(stats=stats.cpu(), ref=ref.cpu(), median=float(d.median()), frac=float((d > 1.0).float().mean()),
+                        worst_buf=worst_buf), out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_bn_two_ranks_match_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    out_path = str(tmp_path / "res.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    r = torch.load(out_path)
+    # losses / KLs / exp-ELBOs of the global batch: 1e-4 relative (north_star's forward/loss tolerance)
+    assert torch.allclose(r["stats"], r["ref"], rtol=1e-4, atol=1e-7), (r["stats"], r["ref"])
+    assert r["worst_buf"] <= 2e-4, r["worst_buf"]                      # BatchNorm running statistics
+    assert r["median"] <= 0.05 and r["frac"] <= 0.01, (r["median"], r["frac"])  # post-Adam weights, in units of lr
