@@ -78,6 +78,19 @@ int sivae_conv2d_wino_fwd(const float* x, const float* up, float* y, const float
                           float* stats_partial, int B, int Ci, int Co, int H, int W, int upsample, int accumulate,
                           sivae_stream_t stream);
 
+/* 3x3 conv of a nearest-2x-upsampled input (nn.Upsample :155 -> ResidualBlock.conv1 :56), computed on the low-resolution
+ * tensor: four output-parity phases, each a 2x2 conv run as Winograd F(2x2,2x2) — 36 multiplies per 4x4 output pixels
+ * instead of 64 (sivae_conv2d_wino_fwd with upsample) or 144 (direct).  x_half is [B][Ci][H/2][W/2], y is
+ * [B][Co][H][W]; same BatchNorm+LeakyReLU prologue and BatchNorm-partials epilogue (stats_partial has
+ * sivae_conv2d_wino_up_num_px_tiles(B, H, W) rows).  Forward only (the data gradient keeps the F(2x2,3x3) kernel). */
+size_t sivae_pack_wino_up_weight_bytes(int Co, int Ci);
+int sivae_pack_wino_up_weight(const float* w /*[Co][Ci][3][3]*/, float* up, int Co, int Ci, sivae_stream_t stream);
+int sivae_conv2d_wino_up_supported(int H, int W);
+int sivae_conv2d_wino_up_num_px_tiles(int B, int H, int W);
+int sivae_conv2d_wino_up_fwd(const float* x_half, const float* up, float* y, const float* pro_mean,
+                             const float* pro_invstd, const float* pro_gamma, const float* pro_beta, float pro_slope,
+                             float* stats_partial, int B, int Ci, int Co, int H, int W, sivae_stream_t stream);
+
 /* Winograd-domain weight gradient for ks == 3 (dU = sum_tiles (A dY A^T) . (B^T d B), dW = G^T dU G): the
  * weight half of aten::convolution_backward for the nn.Conv2d(k=3) layers (:56-61) with 2.25x fewer multiplies;
  * same prologue / upsample options and the same deterministic two-pass reduction as sivae_conv2d_wgrad.

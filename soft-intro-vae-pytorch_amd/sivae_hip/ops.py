@@ -145,6 +145,7 @@ def pack_wino(w, mode):
 
 # SIVAE_WINO=0 keeps every 3x3 conv on the direct implicit-GEMM kernel (A/B measurements, debugging)
 WINO = os.environ.get("SIVAE_WINO", "1") != "0"
+WINO_UP = os.environ.get("SIVAE_WINO_UP", "1") != "0"  # phase-decomposed F(2x2,2x2) kernel for conv-after-upsample
 WINO_WGRAD = os.environ.get("SIVAE_WINO_WGRAD", os.environ.get("SIVAE_WINO", "1")) != "0"
 
 
@@ -166,6 +167,18 @@ class PackedW:
             self._wino = pack_wino(self.w, self.mode)
         return self._wino
 
+    def wino_up(self):
+        """phase-decomposed F(2x2,2x2) transform for the conv-after-upsample forward kernel (mode 0 only)"""
+        if getattr(self, "_wino_up", None) is None:
+            assert self.mode == 0
+            w = self.w
+            Co, Ci = w.shape[0], w.shape[1]
+            nbytes = _lib.load().sivae_pack_wino_up_weight_bytes(Co, Ci)
+            up = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+            _lib.call("sivae_pack_wino_up_weight", _p(w), _p(up), Co, Ci, _s())
+            self._wino_up = up
+        return self._wino_up
+
 
 def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=False, out=None,
                accumulate=False):
@@ -179,14 +192,17 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
     L = _lib.load()
     wino = (WINO and ks == 3 and bias is None and isinstance(wp, PackedW)
             and L.sivae_conv2d_wino_supported(H, W) == 1)
+    wino_up = (wino and WINO_UP and upsample and not accumulate and wp.mode == 0
+               and L.sivae_conv2d_wino_up_supported(H, W) == 1)
     if isinstance(wp, PackedW):
-        wp = wp.wino() if wino else wp.direct()
+        wp = wp.wino_up() if wino_up else (wp.wino() if wino else wp.direct())
     _require(x, wp, bias, out)
     y = out if out is not None else torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
     assert y.shape == (B, Co, H, W)
     stats = None
     if want_stats:
-        nt = L.sivae_conv2d_wino_num_px_tiles(B, H, W) if wino else L.sivae_conv2d_fwd_num_px_tiles(B, Co, H, W)
+        nt = (L.sivae_conv2d_wino_up_num_px_tiles(B, H, W) if wino_up else
+              (L.sivae_conv2d_wino_num_px_tiles(B, H, W) if wino else L.sivae_conv2d_fwd_num_px_tiles(B, Co, H, W)))
         stats = torch.empty((nt, Co, 2), dtype=torch.float32, device=x.device)
     pm = pi = pg = pb = None
     slope = 1.0
@@ -194,7 +210,10 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
         pm, pi, pg, pb, slope = pro
         _require(pm, pi, pg, pb)
     t0 = TIMER.begin() if TIMER is not None else None
-    if wino:
+    if wino_up:
+        _lib.call("sivae_conv2d_wino_up_fwd", _p(x), _p(wp), _p(y), _p(pm), _p(pi), _p(pg), _p(pb), float(slope),
+                  _p(stats), B, Ci, Co, H, W, _s())
+    elif wino:
         _lib.call("sivae_conv2d_wino_fwd", _p(x), _p(wp), _p(y), _p(bias), _p(pm), _p(pi), _p(pg), _p(pb),
                   float(slope), _p(stats), B, Ci, Co, H, W, int(bool(upsample)), int(bool(accumulate)), _s())
     else:
@@ -202,7 +221,10 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
                   _p(stats), B, Ci, Co, H, W, ks, int(bool(upsample)), int(bool(accumulate)), _s())
     if t0 is not None:
         flops = 2.0 * B * H * W * Co * Ci * ks * ks  # algorithmic (reference nn.Conv2d) FLOPs
-        if wino:
+        if wino_up:
+            TIMER.end("conv_wino_up_kernel<%s,%s>" % ("1,4" if W >= 64 else "2,3", "true" if pro is not None else "false"),
+                      flops, t0, executed=flops * 9.0 / 36.0)
+        elif wino:
             key = "conv_wino_kernel<%s,%s>" % ("1,4" if W >= 32 else ("2,3" if W >= 16 else ("2,2" if W == 8 else "1,1")),
                                                "true" if pro is not None else "false")
             TIMER.end(key, flops, t0, executed=flops * 16.0 / 36.0)

@@ -449,6 +449,35 @@ def check_bn_apply_resup():
     return res
 
 
+def check_conv_up(shape, pro=False, stats=False):
+    """conv3x3(Upsample(2,'nearest')(x)) on the low-resolution tensor: phase-decomposed F(2x2,2x2) kernel"""
+    from sivae_hip import ops
+    B, Ci, Co, H, W, ks = shape  # H, W = output size
+    xs = _rand(B, Ci, H // 2, W // 2, seed=5)
+    w = _rand(Co, Ci, 3, 3, seed=2, scale=1.0 / math.sqrt(Ci * 9))
+    xin = xs
+    p = None
+    if pro:
+        mean, invstd = _rand(Ci, seed=6), _rand(Ci, seed=7).abs() + 0.5
+        gamma, beta = _rand(Ci, seed=8), _rand(Ci, seed=9)
+        p = (_d(mean), _d(invstd), _d(gamma), _d(beta), 0.2)
+        xin = F.leaky_relu((xs - mean.view(1, -1, 1, 1)) * (invstd * gamma).view(1, -1, 1, 1) + beta.view(1, -1, 1, 1), 0.2)
+    ref = _conv_ref(F.interpolate(xin, scale_factor=2, mode="nearest"), w)
+    assert ops.WINO_UP and ops._lib.load().sivae_conv2d_wino_up_supported(H, W) == 1
+    out = ops.conv2d_fwd(_d(xs), ops.PackedW(_d(w), 0), Co, 3, pro=p, upsample=True, want_stats=stats)
+    res = []
+    tag = "wino_up%s%s" % ("_pro" if pro else "", shape)
+    if stats:
+        y, part = out
+        sm = part.double().sum(0).cpu()
+        res.append((tag + "_stats_sum", _err(sm[:, 0], ref.sum((0, 2, 3))), 2e-5))
+        res.append((tag + "_stats_sq", _err(sm[:, 1], (ref * ref).sum((0, 2, 3))), 2e-5))
+    else:
+        y = out
+    res.append((tag, _err(y, ref), WINO_TOL))
+    return res
+
+
 def check_input_u8():
     """uint8 -> fp32 (/255) with per-sample mirror, NCHW and NHWC sources (bit-exact: one multiply per element)"""
     from sivae_hip import ops
@@ -491,6 +520,11 @@ def all_checks():
         checks.append(("wino_fused%s" % (s,), lambda s=s: check_conv_fused(s, wino=True)))
     checks.append(("wino_fwd_stats8", lambda: check_conv_fwd((5, 32, 96, 8, 8, 3), stats=True, wino=True)
                    + check_conv_fwd((7, 32, 96, 4, 4, 3), stats=True, wino=True)))
+    for s in [(2, 64, 64, 32, 32, 3), (2, 128, 64, 16, 64, 3), (3, 24, 40, 24, 40, 3), (1, 512, 256, 32, 32, 3),
+              (2, 16, 8, 20, 36, 3)]:
+        checks.append(("wino_up%s" % (s,), lambda s=s: check_conv_up(s) + check_conv_up(s, pro=True)))
+    checks.append(("wino_up_stats", lambda: check_conv_up((3, 32, 72, 32, 64, 3), stats=True)
+                   + check_conv_up((2, 20, 33, 16, 32, 3), pro=True, stats=True)))
     checks.append(("conv5_edge", check_conv5_edge))
     checks.append(("linear", check_linear))
     for s in BN_SHAPES:

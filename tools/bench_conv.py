@@ -41,6 +41,15 @@ for (Ci, Co, H, ks) in SHAPES:
                        torch.zeros(Ci, device="cuda"), 0.2)
             t = timeit(lambda: ops.conv2d_fwd(x, wq, Co, ks, want_stats=True, pro=pro))
             out += "  wino %7.3f ms %6.1f TF(alg) %5.1f TF(exec)" % (t, fl / t / 1e9, fl * 16 / 36 / t / 1e9)
+    if "up" in what and ks == 3 and H >= 32:
+        xs_ = torch.randn(B, Ci, H // 2, H // 2, device="cuda")
+        wq = ops.PackedW(w, 0)
+        t = timeit(lambda: ops.conv2d_fwd(xs_, wq, Co, ks, want_stats=True, upsample=True))
+        ops.WINO_UP = False
+        t2 = timeit(lambda: ops.conv2d_fwd(xs_, wq, Co, ks, want_stats=True, upsample=True))
+        ops.WINO_UP = True
+        out += "  up-F(2,2) %7.3f ms %6.1f TF(alg) %5.1f TF(exec) | F(2,3)+upsample %7.3f ms %6.1f TF(alg)" % (
+            t, fl / t / 1e9, fl * 9 / 36 / t / 1e9, t2, fl / t2 / 1e9)
     if "wgrad" in what:
         t = timeit(lambda: ops.conv2d_wgrad(x, dy, ks))
         out += "  wgrad %7.3f ms %6.1f TF" % (t, fl / t / 1e9)
