@@ -213,14 +213,23 @@ class ResBlockFn(torch.autograd.Function):
         dw1 = ops.conv2d_wgrad(x, da, 3, upsample=x_up) if need_w1 else None
         dwe = None
         dx = None
+        # conv1's data gradient straight to the low-resolution x.  The kernel's block is 128 output channels (4 waves
+        # x 32): with 64 (the last decoder block) half of it idles and the F(2x2,3x3) path + 2x2 sum stays faster.
+        up_dg = x_up and x.shape[1] >= 128 and ops.conv2d_up_dgrad_supported(x.shape[2], x.shape[3])
         if ctx.has_exp and x_up:
             # the expand conv ran at half resolution: its gradients do too (dz summed over each 2x2 block first)
             dzh = ops.upsample2_bwd(dz) if (need_we or need_x) else None
             if need_we:
                 dwe = ops.conv2d_wgrad(x, dzh, 1)
             if need_x:
-                dx = ops.upsample2_bwd(ops.conv2d_fwd(da, packed(w1, 1), x.shape[1], 3))
+                if up_dg:
+                    dx = ops.conv2d_up_dgrad(da, packed(w1, 0), x.shape[1])
+                else:
+                    dx = ops.upsample2_bwd(ops.conv2d_fwd(da, packed(w1, 1), x.shape[1], 3))
                 ops.conv2d_fwd(dzh, packed(w_exp, 1), x.shape[1], 1, out=dx, accumulate=True)
+        elif up_dg and need_x:
+            dx = ops.upsample2_bwd(dz)  # identity branch, already at low resolution
+            ops.conv2d_up_dgrad(da, packed(w1, 0), x.shape[1], out=dx, accumulate=True)
         else:
             if ctx.has_exp:
                 if need_we:

@@ -167,6 +167,17 @@ class PackedW:
             self._wino = pack_wino(self.w, self.mode)
         return self._wino
 
+    def wino_up_dgrad(self):
+        if getattr(self, "_wino_up_dgrad", None) is None:
+            assert self.mode == 0
+            w = self.w
+            Co, Ci = w.shape[0], w.shape[1]
+            nbytes = _lib.load().sivae_pack_wino_up_dgrad_weight_bytes(Co, Ci)
+            ud = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+            _lib.call("sivae_pack_wino_up_dgrad_weight", _p(w), _p(ud), Co, Ci, _s())
+            self._wino_up_dgrad = ud
+        return self._wino_up_dgrad
+
     def wino_up(self):
         """phase-decomposed F(2x2,2x2) transform for the conv-after-upsample forward kernel (mode 0 only)"""
         if getattr(self, "_wino_up", None) is None:
@@ -178,6 +189,29 @@ class PackedW:
             _lib.call("sivae_pack_wino_up_weight", _p(w), _p(up), Co, Ci, _s())
             self._wino_up = up
         return self._wino_up
+
+
+def conv2d_up_dgrad_supported(Hs, Ws):
+    return WINO_UP and _lib.load().sivae_conv2d_wino_up_dgrad_supported(Hs, Ws) == 1
+
+
+def conv2d_up_dgrad(dy, wp, N, out=None, accumulate=False):
+    """gradient of conv3x3(Upsample2(x)) with respect to the LOW-resolution x: dy [B, C, 2Hs, 2Ws] -> [B, N, Hs, Ws]
+    (wp: PackedW of the conv's weight [C, N, 3, 3], mode 0)."""
+    _require(dy, out)
+    B, C, H, W = dy.shape
+    Hs, Ws = H // 2, W // 2
+    dyp = torch.empty((B, 4 * C, Hs, Ws), dtype=torch.float32, device=dy.device)
+    _lib.call("sivae_space_to_depth2", _p(dy), _p(dyp), B, C, Hs, Ws, _s())
+    dx = out if out is not None else torch.empty((B, N, Hs, Ws), dtype=torch.float32, device=dy.device)
+    assert dx.shape == (B, N, Hs, Ws)
+    t0 = TIMER.begin() if TIMER is not None else None
+    _lib.call("sivae_conv2d_wino_up_dgrad", _p(dyp), _p(wp.wino_up_dgrad()), _p(dx), B, C, N, Hs, Ws,
+              int(bool(accumulate)), _s())
+    if t0 is not None:
+        flops = 2.0 * B * H * W * C * N * 9
+        TIMER.end("conv_wino_up_dgrad_kernel<%s>" % ("1,4" if Ws >= 32 else "2,3"), flops, t0, executed=flops * 9.0 / 36.0)
+    return dx
 
 
 def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=False, out=None,

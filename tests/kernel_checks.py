@@ -478,6 +478,23 @@ def check_conv_up(shape, pro=False, stats=False):
     return res
 
 
+def check_conv_up_dgrad(shape, accumulate=False):
+    """d/dx of conv3x3(Upsample(2,'nearest')(x)) with respect to the low-resolution x"""
+    from sivae_hip import ops
+    B, Ci, Co, H, W, ks = shape  # H, W = output (dy) size
+    xs = _rand(B, Ci, H // 2, W // 2, seed=5).requires_grad_()
+    w = _rand(Co, Ci, 3, 3, seed=2, scale=1.0 / math.sqrt(Ci * 9))
+    dy = _rand(B, Co, H, W, seed=4)
+    _conv_ref(F.interpolate(xs, scale_factor=2, mode="nearest"), w).backward(dy)
+    ref = xs.grad
+    base = _rand(B, Ci, H // 2, W // 2, seed=12)
+    out = _d(base).clone() if accumulate else None
+    dx = ops.conv2d_up_dgrad(_d(dy), ops.PackedW(_d(w), 0), Ci, out=out, accumulate=accumulate)
+    if accumulate:
+        ref = ref + base
+    return [("wino_up_dgrad%s%s" % ("_acc" if accumulate else "", shape), _err(dx, ref), WINO_TOL)]
+
+
 def check_input_u8():
     """uint8 -> fp32 (/255) with per-sample mirror, NCHW and NHWC sources (bit-exact: one multiply per element)"""
     from sivae_hip import ops
@@ -523,6 +540,9 @@ def all_checks():
     for s in [(2, 64, 64, 32, 32, 3), (2, 128, 64, 16, 64, 3), (3, 24, 40, 24, 40, 3), (1, 512, 256, 32, 32, 3),
               (2, 16, 8, 20, 36, 3)]:
         checks.append(("wino_up%s" % (s,), lambda s=s: check_conv_up(s) + check_conv_up(s, pro=True)))
+    for s in [(2, 64, 64, 32, 32, 3), (2, 64, 128, 16, 64, 3), (3, 40, 24, 24, 40, 3), (1, 256, 512, 32, 32, 3),
+              (2, 8, 16, 20, 36, 3), (2, 130, 20, 16, 32, 3)]:
+        checks.append(("wino_up_dgrad%s" % (s,), lambda s=s: check_conv_up_dgrad(s) + check_conv_up_dgrad(s, True)))
     checks.append(("wino_up_stats", lambda: check_conv_up((3, 32, 72, 32, 64, 3), stats=True)
                    + check_conv_up((2, 20, 33, 16, 32, 3), pro=True, stats=True)))
     checks.append(("conv5_edge", check_conv5_edge))

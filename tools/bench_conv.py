@@ -50,6 +50,13 @@ for (Ci, Co, H, ks) in SHAPES:
         ops.WINO_UP = True
         out += "  up-F(2,2) %7.3f ms %6.1f TF(alg) %5.1f TF(exec) | F(2,3)+upsample %7.3f ms %6.1f TF(alg)" % (
             t, fl / t / 1e9, fl * 9 / 36 / t / 1e9, t2, fl / t2 / 1e9)
+    if "updg" in what and ks == 3 and H >= 32:
+        wq = ops.PackedW(w, 0)
+        t = timeit(lambda: ops.conv2d_up_dgrad(dy, wq, Ci))
+        wd = ops.PackedW(w, 1)
+        t2 = timeit(lambda: ops.upsample2_bwd(ops.conv2d_fwd(dy, wd, Ci, 3)))
+        out += "  up-dgrad F(2,2) %7.3f ms %6.1f TF(alg) | F(2,3) + 2x2 sum %7.3f ms %6.1f TF(alg)" % (
+            t, fl / t / 1e9, t2, fl / t2 / 1e9)
     if "wgrad" in what:
         t = timeit(lambda: ops.conv2d_wgrad(x, dy, ks))
         out += "  wgrad %7.3f ms %6.1f TF" % (t, fl / t / 1e9)
