@@ -31,7 +31,11 @@ struct WinoUpDgArgs {
 #define WUD_CK 16
 #define WUD_TN 128
 
-template <int TTH_L2, int TTW_L2>
+// KS2 = false: 4 waves = 4 groups of 32 output channels (128 per block), each wave runs all 8 k-steps of a chunk.
+// KS2 = true (N <= 64): 2 groups of 32 output channels x 2 K-halves — waves 2,3 take k-steps 4..7 of every chunk —
+// so that all four waves work when the layer has only 64 input channels; the two partial outputs (the output
+// transform is linear, so already transformed: 64 floats per lane) are summed through LDS at the end.
+template <int TTH_L2, int TTW_L2, bool KS2>
 __global__ void __launch_bounds__(256, 2) conv_wino_up_dgrad_kernel(WinoUpDgArgs a) {
   constexpr int TTH = 1 << TTH_L2, TTW = 1 << TTW_L2;
   static_assert(TTH * TTW == 32, "a block is 32 tiles");
@@ -52,7 +56,11 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_dgrad_kernel(WinoUpDgArgs
   const int Hs = a.Hs, Ws = a.Ws, HWs = Hs * Ws;
   const int nch = a.Cpad / CK;  // chunks per phase
   const int nchunks = 4 * nch;
-  const int nksteps = nchunks * (CK / 2);
+  constexpr int KPC = KS2 ? CK / 4 : CK / 2;  // k-steps per chunk and wave
+  const int nksteps = nchunks * KPC;
+  const int ng = KS2 ? (wave & 1) : wave;     // output-channel group of this wave
+  const int kh = KS2 ? (wave >> 1) : 0;       // K half
+  const int koff = kh * (CK / 2);             // first channel of this wave inside a chunk
 
   const int n_items = a.n_items;
   int item = blockIdx.x;
@@ -73,19 +81,19 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_dgrad_kernel(WinoUpDgArgs
     b = t2 / a.nbh;                                                      \
     r0 = tby * PXH;                                                      \
     c0 = tbx * PXW;                                                      \
-    n0 = n_tile * WUD_TN;                                                \
+    n0 = n_tile * (KS2 ? WUD_TN / 2 : WUD_TN);                           \
     xrsrc = make_rsrc(a.dyp + (size_t)b * 4 * a.C * HWs, 4ull * a.C * HWs * 4ull); \
     const int r = r0 + xrr - 1, c = c0 + xcc - 1;                        \
     xo = SIVAE_OOB;                                                      \
     if (x_owner && r >= 0 && r < Hs && c >= 0 && c < Ws) xo = (unsigned)(r * Ws + c) * 4u; \
-    ua_base = (unsigned)(n0 + wave * 32) * 48u;                          \
+    ua_base = (unsigned)(n0 + ng * 32) * 48u + (unsigned)koff * ua_step; \
   }
 
   const unsigned va0 = (unsigned)(hh * a.Npad + l31) * 48u;
   const unsigned ua_step = (unsigned)a.Npad * 48u;  // bytes per K index
 
   const int tx = l31 & (TTW - 1), ty = l31 >> TTW_L2;
-  const int bb0 = hh * PLANE + 2 * ty * RS + tx;
+  const int bb0 = (hh + koff) * PLANE + 2 * ty * RS + tx;
   int bc0, bc1, bc2;  // per-chunk patch bases (phase shift folded in)
 
   f32x16 acc[9];
@@ -102,9 +110,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_dgrad_kernel(WinoUpDgArgs
       xr[ck] = buf_load_f32(xrsrc, xo, (unsigned)(ph_ * a.C + cclamp) * (unsigned)HWs * 4u); \
     }                                                                    \
   }
+  // this wave's k-step KS (counted over its own k-steps) -> K index (KS / KPC) * CK + koff + 2 * (KS % KPC)
 #define WUD_LOAD_A(KS_ABS, SLOT)                                         \
   {                                                                      \
-    const unsigned so = ua_base + (unsigned)(2 * (KS_ABS)) * ua_step;    \
+    const unsigned so = ua_base + (unsigned)(((KS_ABS) / KPC) * CK + 2 * ((KS_ABS) % KPC)) * ua_step; \
     AR[SLOT][0] = buf_load_f32x4(ursrc, va0, so);                        \
     AR[SLOT][1] = buf_load_f32x4(ursrc, va0 + 16u, so);                  \
     AR[SLOT][2] = buf_load_f32x4(ursrc, va0 + 32u, so);                  \
@@ -156,11 +165,11 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_dgrad_kernel(WinoUpDgArgs
   }
 #define WUD_KSTEP(Q, BUF, KK, D, DN)                                     \
   {                                                                      \
-    if ((KK) + 1 < CK / 2) WUD_READ(BUF, (KK) + 1, DN)                   \
+    if ((KK) + 1 < KPC) WUD_READ(BUF, (KK) + 1, DN)                      \
     __builtin_amdgcn_sched_barrier(0);                                   \
     WUD_STEP((KK)&3, D)                                                  \
     __builtin_amdgcn_sched_barrier(0);                                   \
-    if ((Q) * (CK / 2) + (KK) + 4 < nksteps) WUD_LOAD_A((Q) * (CK / 2) + (KK) + 4, (KK)&3) \
+    if ((Q) * KPC + (KK) + 4 < nksteps) WUD_LOAD_A((Q) * KPC + (KK) + 4, (KK)&3) \
   }
 #define WUD_MMA(Q, BUF, NEXT)                                            \
   {                                                                      \
@@ -171,13 +180,15 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_dgrad_kernel(WinoUpDgArgs
     WUD_KSTEP(Q, BUF, 0, d0, d1)                                         \
     WUD_KSTEP(Q, BUF, 1, d1, d0)                                         \
     WUD_KSTEP(Q, BUF, 2, d0, d1)                                         \
-    WUD_KSTEP(Q, BUF, 3, d1, d0)                                         \
-    WUD_KSTEP(Q, BUF, 4, d0, d1)                                         \
-    WUD_KSTEP(Q, BUF, 5, d1, d0)                                         \
-    WUD_KSTEP(Q, BUF, 6, d0, d1)                                         \
+    if (!KS2) {                                                          \
+      WUD_KSTEP(Q, BUF, 3, d1, d0)                                       \
+      WUD_KSTEP(Q, BUF, 4, d0, d1)                                       \
+      WUD_KSTEP(Q, BUF, 5, d1, d0)                                       \
+      WUD_KSTEP(Q, BUF, 6, d0, d1)                                       \
+    }                                                                    \
     if (NEXT) WUD_STORE_X((Q) + 1, (BUF) ^ 1)                            \
     __builtin_amdgcn_sched_barrier(0);                                   \
-    WUD_KSTEP(Q, BUF, 7, d1, d0)                                         \
+    if (KS2) WUD_KSTEP(Q, BUF, 3, d1, d0) else WUD_KSTEP(Q, BUF, 7, d1, d0) \
     __syncthreads();                                                     \
   }
 #define WUD_PREFETCH(ITEM)                                               \
@@ -214,26 +225,54 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_dgrad_kernel(WinoUpDgArgs
       const int li = e_r0 + 2 * ty, lj = e_c0 + 2 * tx;
       const bool okc = lj < Ws;  // Ws even: lj + 1 < Ws too
       const unsigned base = (unsigned)(li * Ws + lj) * 4u;
+      float* red = smem;  // KS2: [2 groups][64 values][64 lanes] partial outputs of the upper K half (32 KB)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int chn = e_n0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
         const float s00 = acc[0][r] + acc[3][r], s01 = acc[1][r] + acc[4][r], s02 = acc[2][r] + acc[5][r];
         const float s10 = acc[3][r] - acc[6][r], s11 = acc[4][r] - acc[7][r], s12 = acc[5][r] - acc[8][r];
-        float y00 = s00 + s01, y01 = s01 - s02, y10 = s10 + s11, y11 = s11 - s12;
-        const bool cok = chn < a.N && okc;
-        const unsigned cb = base + (unsigned)chn * (unsigned)HWs * 4u;
-        const unsigned o0 = (cok && li < Hs) ? cb : SIVAE_OOB;
-        const unsigned o1 = (cok && li + 1 < Hs) ? cb + (unsigned)Ws * 4u : SIVAE_OOB;
-        if (a.accumulate) {
-          const float2 p0 = buf_load_f32x2(yrsrc, o0, 0u), p1 = buf_load_f32x2(yrsrc, o1, 0u);
-          y00 += p0.x;
-          y01 += p0.y;
-          y10 += p1.x;
-          y11 += p1.y;
-        }
-        buf_store_f32x2(yrsrc, y00, y01, o0, 0u);
-        buf_store_f32x2(yrsrc, y10, y11, o1, 0u);
+        // (reuse the first four accumulators of row r as the transformed outputs)
+        acc[0][r] = s00 + s01;
+        acc[1][r] = s01 - s02;
+        acc[2][r] = s10 + s11;
+        acc[3][r] = s11 - s12;
       }
+      if (KS2) {
+        // the K loop ended on a barrier: the halo buffers are free
+        if (kh == 1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[((ng * 64) + r * 4 + k) * 64 + lane] = acc[k][r];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k][r] += red[((ng * 64) + r * 4 + k) * 64 + lane];
+        }
+      }
+      if (!KS2 || kh == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int chn = e_n0 + ng * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          float y00 = acc[0][r], y01 = acc[1][r], y10 = acc[2][r], y11 = acc[3][r];
+          const bool cok = chn < a.N && okc;
+          const unsigned cb = base + (unsigned)chn * (unsigned)HWs * 4u;
+          const unsigned o0 = (cok && li < Hs) ? cb : SIVAE_OOB;
+          const unsigned o1 = (cok && li + 1 < Hs) ? cb + (unsigned)Ws * 4u : SIVAE_OOB;
+          if (a.accumulate) {
+            const float2 p0 = buf_load_f32x2(yrsrc, o0, 0u), p1 = buf_load_f32x2(yrsrc, o1, 0u);
+            y00 += p0.x;
+            y01 += p0.y;
+            y10 += p1.x;
+            y11 += p1.y;
+          }
+          buf_store_f32x2(yrsrc, y00, y01, o0, 0u);
+          buf_store_f32x2(yrsrc, y10, y11, o1, 0u);
+        }
+      }
+      if (KS2) __syncthreads();  // the reduction area aliases the halo buffers of the next item
     }
     if (has_next && !early) WUD_PREFETCH(next)
     if (!has_next) break;
@@ -375,19 +414,21 @@ static int wud_grid_blocks() {
   return g;
 }
 
-template <int TTH_L2, int TTW_L2>
+template <int TTH_L2, int TTW_L2, bool KS2>
 static int wud_launch(WinoUpDgArgs& a, hipStream_t stream) {
   constexpr int PXH = 2 << TTH_L2, PXW = 2 << TTW_L2;
   constexpr int PH = (1 << TTW_L2) + (1 << TTW_L2) / 4, PLANE = (PXH + 2) * 2 * PH;
   a.nbh = cdiv(a.Hs, PXH);
   a.nbw = cdiv(a.Ws, PXW);
-  a.n_n_tiles = cdiv(a.N, WUD_TN);
+  a.n_n_tiles = cdiv(a.N, KS2 ? WUD_TN / 2 : WUD_TN);
   const long long nblk = (long long)a.B * a.nbh * a.nbw * a.n_n_tiles;
   if (nblk > 0x7fffffffLL) return SIVAE_ERR_RANGE;
-  const size_t lds = (size_t)2 * WUD_CK * PLANE * sizeof(float);
+  size_t lds = (size_t)2 * WUD_CK * PLANE * sizeof(float);
+  if (KS2 && lds < 2 * 64 * 64 * sizeof(float)) lds = 2 * 64 * 64 * sizeof(float);
   a.n_items = (int)nblk;
   const int grid = nblk < wud_grid_blocks() ? (int)nblk : wud_grid_blocks();
-  hipLaunchKernelGGL((conv_wino_up_dgrad_kernel<TTH_L2, TTW_L2>), dim3((unsigned)grid), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((conv_wino_up_dgrad_kernel<TTH_L2, TTW_L2, KS2>), dim3((unsigned)grid), dim3(256), lds, stream,
+                     a);
   return sivae_launch_status();
 }
 
@@ -412,5 +453,6 @@ extern "C" int sivae_conv2d_wino_up_dgrad(const float* dyp, const float* ud, flo
   a.Npad = wud_npad(N);
   a.accumulate = accumulate;
   if (4ull * a.Cpad * a.Npad * 48ull >= 0xffffffffull) return SIVAE_ERR_RANGE;
-  return (Ws >= 32) ? wud_launch<1, 4>(a, stream) : wud_launch<2, 3>(a, stream);
+  if (N <= 64) return (Ws >= 32) ? wud_launch<1, 4, true>(a, stream) : wud_launch<2, 3, true>(a, stream);
+  return (Ws >= 32) ? wud_launch<1, 4, false>(a, stream) : wud_launch<2, 3, false>(a, stream);
 }

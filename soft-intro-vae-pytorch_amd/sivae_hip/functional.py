@@ -213,9 +213,8 @@ class ResBlockFn(torch.autograd.Function):
         dw1 = ops.conv2d_wgrad(x, da, 3, upsample=x_up) if need_w1 else None
         dwe = None
         dx = None
-        # conv1's data gradient straight to the low-resolution x.  The kernel's block is 128 output channels (4 waves
-        # x 32): with 64 (the last decoder block) half of it idles and the F(2x2,3x3) path + 2x2 sum stays faster.
-        up_dg = x_up and x.shape[1] >= 128 and ops.conv2d_up_dgrad_supported(x.shape[2], x.shape[3])
+        # conv1's data gradient straight to the low-resolution x (phase-folded F(2x2,2x2) kernel)
+        up_dg = x_up and ops.conv2d_up_dgrad_supported(x.shape[2], x.shape[3])
         if ctx.has_exp and x_up:
             # the expand conv ran at half resolution: its gradients do too (dz summed over each 2x2 block first)
             dzh = ops.upsample2_bwd(dz) if (need_we or need_x) else None
