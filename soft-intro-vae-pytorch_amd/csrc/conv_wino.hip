@@ -107,7 +107,12 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
   __amdgpu_buffer_rsrc_t xrsrc;
   const __amdgpu_buffer_rsrc_t ursrc = make_rsrc(a.up, 16ull * a.Ci_pad * a.Co_pad * 4ull);
   unsigned xo, ua_base;
-  const int xtb = tid / (LH * LWU), xrr = (tid / LWU) % LH, xcc = tid % LWU;
+  // every thread stages a halo slot: threads beyond the NPOS slots duplicate the first ones (same address, same
+  // value), so the register -> LDS copy is straight-line code — with predicated stores and a select around the
+  // prologue the compiler emitted one exec-mask branch and one serialised ds_read + lgkmcnt(0) per element
+  const int teff = tid % NPOS;
+  const int xtb = teff / (LH * LWU), xrr = (teff / LWU) % LH, xcc = teff % LWU;
+  float xmask = 0.f;  // 1 inside the image, 0 on the zero padding (applied after the fused BatchNorm+LeakyReLU)
   const int xl = xtb * PLANE_IMG + xrr * RS + (xcc & 1) * PH + (xcc >> 1);
   int nb_here;  // images of this item that exist (TB == 2 and odd batch: the last item has one)
 #define WINO_SETUP(ITEM)                                                 \
@@ -125,13 +130,14 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
     xrsrc = make_rsrc(a.x + (size_t)b * a.Ci * HWs, (unsigned long long)nb_here * a.Ci * HWs * 4ull); \
     const int r = r0 + xrr - 1, c = c0 + xcc - 1;                        \
     xo = SIVAE_OOB;                                                      \
-    if (tid < NPOS && xtb < nb_here && r >= 0 && r < H && c >= 0 && c < W) { \
+    xmask = 0.f;                                                         \
+    if (xtb < nb_here && r >= 0 && r < H && c >= 0 && c < W) {           \
+      xmask = 1.f;                                                       \
       const int rs = a.upsample ? (r >> 1) : r, cs = a.upsample ? (c >> 1) : c; \
       xo = (unsigned)((xtb * a.Ci * Hs + rs) * Ws + cs) * 4u;            \
     }                                                                    \
     ua_base = (unsigned)((wj * a.Ci_pad) * a.Co_pad + co0) * 16u;        \
   }
-  const bool x_owner = tid < NPOS;
 
   // ---- A operand (U) addressing: lane -> (ci = k-step*2 + hh, co = co0 + (wg*WM + m)*32 + l31), 16 B each
   const unsigned va0 = (unsigned)(hh * a.Co_pad + wg * WM * 32 + l31) * 16u;
@@ -173,11 +179,11 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
       float v = xr[ck];                                                  \
       if (PRO) { /* padded channels carry {0,0,0} parameters -> 0 */      \
         const float4 pp = pro4[ci];                                      \
-        v = (xo != SIVAE_OOB) ? lrelu01((v - pp.x) * pp.y + pp.z, a.pro_slope) : 0.f; \
+        v = lrelu01((v - pp.x) * pp.y + pp.z, a.pro_slope) * xmask;      \
       } else {                                                           \
         v = ci_ok ? v : 0.f;                                             \
       }                                                                  \
-      if (x_owner) xs[(BUF)*XBUF + ck * PLANE + xl] = v;                 \
+      xs[(BUF)*XBUF + ck * PLANE + xl] = v;                              \
     }                                                                    \
   }
   // raw halo reads of k-step KK (two columns x four rows) — issued one k-step ahead of their use so the LDS

@@ -70,9 +70,11 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_kernel(WinoUpArgs a) {
   __amdgpu_buffer_rsrc_t xrsrc;
   const __amdgpu_buffer_rsrc_t ursrc = make_rsrc(a.up, 4ull * a.Ci_pad * a.Co_pad * 48ull);
   unsigned xo, ua_base;
-  const int xrr = tid / LWU, xcc = tid % LWU;
+  static_assert(2 * NPOS >= NT, "duplicate-owner mapping");
+  const int teff = tid < NPOS ? tid : tid - NPOS;  // (threads beyond the halo duplicate the first slots: no predication)
+  const int xrr = teff / LWU, xcc = teff % LWU;
   const int xl = xrr * RS + (xcc & 1) * PH + (xcc >> 1);
-  const bool x_owner = tid < NPOS;
+  float xmask = 0.f;
 #define WUP_SETUP(ITEM)                                                  \
   {                                                                      \
     const int co_tile = (ITEM) % a.n_co_tiles;                           \
@@ -87,7 +89,11 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_kernel(WinoUpArgs a) {
     xrsrc = make_rsrc(a.x + (size_t)b * a.Ci * HWs, (unsigned long long)a.Ci * HWs * 4ull); \
     const int r = r0 + xrr - 1, c = c0 + xcc - 1;                        \
     xo = SIVAE_OOB;                                                      \
-    if (x_owner && r >= 0 && r < Hs && c >= 0 && c < Ws) xo = (unsigned)(r * Ws + c) * 4u; \
+    xmask = 0.f;                                                         \
+    if (r >= 0 && r < Hs && c >= 0 && c < Ws) {                          \
+      xo = (unsigned)(r * Ws + c) * 4u;                                  \
+      xmask = 1.f;                                                       \
+    }                                                                    \
     ua_base = (unsigned)((wave * a.Ci_pad) * a.Co_pad + co0) * 48u;      \
   }
 
@@ -130,11 +136,11 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_kernel(WinoUpArgs a) {
       float v = xr[ck];                                                  \
       if (PRO) {                                                         \
         const float4 p4 = pro4[ci];                                      \
-        v = (xo != SIVAE_OOB) ? lrelu01((v - p4.x) * p4.y + p4.z, a.pro_slope) : 0.f; \
+        v = lrelu01((v - p4.x) * p4.y + p4.z, a.pro_slope) * xmask;      \
       } else {                                                           \
         v = ci < a.Ci ? v : 0.f;                                         \
       }                                                                  \
-      if (x_owner) xs[(BUF)*XBUF + ck * PLANE + xl] = v;                 \
+      xs[(BUF)*XBUF + ck * PLANE + xl] = v;                              \
     }                                                                    \
   }
 #define WUP_READ(BUF, KK, D)                                             \

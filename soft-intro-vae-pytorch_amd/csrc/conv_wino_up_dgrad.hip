@@ -68,9 +68,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_dgrad_kernel(WinoUpDgArgs
   __amdgpu_buffer_rsrc_t xrsrc;
   const __amdgpu_buffer_rsrc_t ursrc = make_rsrc(a.ud, 4ull * a.Cpad * a.Npad * 48ull);
   unsigned xo, ua_base;
-  const int xrr = tid / LWU, xcc = tid % LWU;
+  static_assert(2 * NPOS >= 256, "duplicate-owner mapping");
+  const int teff = tid < NPOS ? tid : tid - NPOS;  // (threads beyond the halo duplicate the first slots: no predication)
+  const int xrr = teff / LWU, xcc = teff % LWU;
   const int xl = xrr * RS + (xcc & 1) * PH + (xcc >> 1);
-  const bool x_owner = tid < NPOS;
 #define WUD_SETUP(ITEM)                                                  \
   {                                                                      \
     const int n_tile = (ITEM) % a.n_n_tiles;                             \
@@ -85,7 +86,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_dgrad_kernel(WinoUpDgArgs
     xrsrc = make_rsrc(a.dyp + (size_t)b * 4 * a.C * HWs, 4ull * a.C * HWs * 4ull); \
     const int r = r0 + xrr - 1, c = c0 + xcc - 1;                        \
     xo = SIVAE_OOB;                                                      \
-    if (x_owner && r >= 0 && r < Hs && c >= 0 && c < Ws) xo = (unsigned)(r * Ws + c) * 4u; \
+    if (r >= 0 && r < Hs && c >= 0 && c < Ws) xo = (unsigned)(r * Ws + c) * 4u; \
     ua_base = (unsigned)(n0 + ng * 32) * 48u + (unsigned)koff * ua_step; \
   }
 
@@ -123,7 +124,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_dgrad_kernel(WinoUpDgArgs
     const int ph_ = (Q) / nch, cc0_ = ((Q) - ph_ * nch) * CK;            \
     _Pragma("unroll") for (int ck = 0; ck < CK; ++ck) {                  \
       const float v = (cc0_ + ck) < a.C ? xr[ck] : 0.f;                  \
-      if (x_owner) xs[(BUF)*XBUF + ck * PLANE + xl] = v;                 \
+      xs[(BUF)*XBUF + ck * PLANE + xl] = v;                              \
     }                                                                    \
   }
   // plane (p, q) is read at rows (2*ty + (1-p) + r), columns (2*tx + (1-q) + c)

@@ -77,9 +77,11 @@ __global__ void __launch_bounds__(NGI * 256, 2) wino_wgrad_kernel(WinoWgArgs a) 
 
   // ---- staging maps
   const int xsub = __builtin_amdgcn_readfirstlane(tid >> 7);  // channel phase of this wave's x loads
-  const int xpos = tid & 127;                                 // halo slot (valid < 108)
+  // halo slot of this thread; slots 108..127 duplicate 0..19 (same address, same value) so that the
+  // register -> LDS copy needs no predication and the prologue no branch
+  const int xpos = (tid & 127) < NPOSX ? (tid & 127) : (tid & 127) - NPOSX;
   const int xrr = xpos / LWX, xcc = xpos % LWX;
-  const bool x_owner = xpos < NPOSX;
+  float xmask = 0.f;
   const int ypy = lane >> 4, ypx = lane & 15;
 
   // ---- operand bases.  k-step kk = tile pair (ty = kk >> 2, tx = 2*(kk & 3) + hh)
@@ -115,7 +117,9 @@ __global__ void __launch_bounds__(NGI * 256, 2) wino_wgrad_kernel(WinoWgArgs a) 
     {                                                                                               \
       const int r = r0_ + xrr - 1, c = c0_ + xcc - 1;                                               \
       xoff = SIVAE_OOB;                                                                             \
-      if (x_owner && r >= 0 && r < H && c >= 0 && c < W) {                                          \
+      xmask = 0.f;                                                                                  \
+      if (r >= 0 && r < H && c >= 0 && c < W) {                                                     \
+        xmask = 1.f;                                                                                \
         const int rs = a.upsample ? (r >> 1) : r, cs = a.upsample ? (c >> 1) : c;                   \
         xoff = (unsigned)(rs * Ws + cs) * 4u;                                                       \
       }                                                                                             \
@@ -142,9 +146,9 @@ __global__ void __launch_bounds__(NGI * 256, 2) wino_wgrad_kernel(WinoWgArgs a) 
       float v = xr[q];                                                                              \
       if (PRO) {                                                                                    \
         const float4 pp = pro4[xsub + NSUB * q];                                                    \
-        v = (xoff != SIVAE_OOB) ? lrelu01((v - pp.x) * pp.y + pp.z, a.pro_slope) : 0.f;             \
+        v = lrelu01((v - pp.x) * pp.y + pp.z, a.pro_slope) * xmask;                                 \
       }                                                                                             \
-      if (x_owner) xs[(BUF)*XBUF + (xsub + NSUB * q) * XP + xpos] = v;                              \
+      xs[(BUF)*XBUF + (xsub + NSUB * q) * XP + xpos] = v;                                           \
     }                                                                                               \
     _Pragma("unroll") for (int q = 0; q < YQ; ++q) dys[(BUF)*YBUF + (wave + NW * q) * YP + lane] = yr[q]; \
   }
