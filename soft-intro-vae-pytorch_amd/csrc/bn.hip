@@ -370,6 +370,16 @@ extern "C" int sivae_bn_apply_act_resup(const float* x, const float* res_half, c
 // pass 1: per-channel partial sums (fp64), pass 2: coefficients, pass 3: dx / dz.
 // If y == nullptr no activation mask is applied.
 // ------------------------------------------------------------------------------------------------
+// dy of 4 consecutive pixels of plane `pl` starting at hw (multiple of 4).  pool_w != 0: dy is the gradient of
+// AvgPool2d(2)(y) stored at half resolution [.][H/2][W/2] and is read through the pool's adjoint
+// (0.25 * dy_half[h>>1][w>>1]) — the full-resolution gradient of nn.AvgPool2d (:92,:98) is never written.
+__device__ __forceinline__ float4 bn_load_dy4(const float* __restrict__ dy, size_t pl, int hw, int HW, int pool_w) {
+  if (pool_w == 0) return *reinterpret_cast<const float4*>(dy + pl * HW + hw);
+  const int h = hw / pool_w, w = hw - h * pool_w;
+  const float2 d = *reinterpret_cast<const float2*>(dy + pl * (size_t)(HW >> 2) + (size_t)(h >> 1) * (pool_w >> 1) + (w >> 1));
+  return make_float4(0.25f * d.x, 0.25f * d.x, 0.25f * d.y, 0.25f * d.y);
+}
+
 template <int ACT>
 __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                              const float* __restrict__ x,
@@ -378,7 +388,8 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float slope,
                                                              double* __restrict__ part, int C, int HW,
-                                                             long long n_per_ch, long long slice_len, int S) {
+                                                             long long n_per_ch, long long slice_len, int S,
+                                                             int pool_w) {
   __shared__ double red[4];
   const int c = blockIdx.x, s = blockIdx.y;
   const long long n0 = (long long)s * slice_len;
@@ -391,7 +402,7 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float* __rest
     for (long long n = n0 + (long long)threadIdx.x * 4; n < n1; n += 1024) {
       const long long b = n / HW;
       const size_t o = ((size_t)b * C + c) * HW + (size_t)(n - b * HW);
-      const float4 g = *reinterpret_cast<const float4*>(dy + o);
+      const float4 g = bn_load_dy4(dy, (size_t)b * C + c, (int)(n - b * HW), HW, pool_w);
       const float4 xv = *reinterpret_cast<const float4*>(x + o);
       float gz[4] = {g.x, g.y, g.z, g.w};
       if (ACT == 1) {
@@ -456,7 +467,7 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const float* __restrict_
                                                         const float* __restrict__ beta,
                                                         const float* __restrict__ coef, float slope,
                                                         float* __restrict__ dx, float* __restrict__ dz_out, int C,
-                                                        int HW, size_t numel) {
+                                                        int HW, size_t numel, int pool_w) {
   const size_t stride = (size_t)gridDim.x * 256;
   if (VEC) {
     const size_t n4 = numel >> 2;
@@ -464,7 +475,7 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const float* __restrict_
       const size_t e = i << 2;
       const int c = (int)((e / HW) % C);
       const float m = mean[c], is = invstd[c], gs = gamma[c] * is, c1 = coef[c * 2], c2 = coef[c * 2 + 1];
-      const float4 g = reinterpret_cast<const float4*>(dy)[i];
+      const float4 g = bn_load_dy4(dy, e / HW, (int)(e % HW), HW, pool_w);
       const float4 xv = reinterpret_cast<const float4*>(x)[i];
       float gz[4] = {g.x, g.y, g.z, g.w};
       if (ACT == 1) {
@@ -501,10 +512,10 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const float* __restrict_
   }
 }
 
-extern "C" int sivae_bn_bwd(const float* dy, const float* y, const float* x, const float* mean,
-                            const float* invstd, const float* gamma, const float* beta, int act_mode,
-                            float slope, float* dx, float* dz_out, float* dgamma, float* dbeta, int B, int C,
-                            int HW, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+static int bn_bwd_impl(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                       const float* gamma, const float* beta, int act_mode, float slope, float* dx, float* dz_out,
+                       float* dgamma, float* dbeta, int B, int C, int HW, int pool_w, void* workspace,
+                       size_t workspace_bytes, hipStream_t stream) {
   if (!dy || !x || !mean || !invstd || !gamma || !dx) return SIVAE_ERR_NULL;
   if (act_mode < 0 || act_mode > 2) return SIVAE_ERR_MODE;
   if (act_mode == 1 && !y) return SIVAE_ERR_NULL;
@@ -517,7 +528,7 @@ extern "C" int sivae_bn_bwd(const float* dy, const float* y, const float* x, con
   float* coef = (float*)(part + (size_t)C * p.S * 2);
 #define LAUNCHP(A) \
   hipLaunchKernelGGL((bn_bwd_partial_kernel<A>), dim3(C, p.S), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma, \
-                     beta, slope, part, C, HW, n, p.len, p.S)
+                     beta, slope, part, C, HW, n, p.len, p.S, pool_w)
   if (act_mode == 0) LAUNCHP(0); else if (act_mode == 1) LAUNCHP(1); else LAUNCHP(2);
 #undef LAUNCHP
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, (const double*)part, p.S, C,
@@ -530,7 +541,7 @@ extern "C" int sivae_bn_bwd(const float* dy, const float* y, const float* x, con
   if (nb < 1) nb = 1;
 #define LAUNCH(A, Z, V) \
   hipLaunchKernelGGL((bn_bwd_dx_kernel<A, Z, V>), dim3(nb), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma, \
-                     beta, (const float*)coef, slope, dx, dz_out, C, HW, numel)
+                     beta, (const float*)coef, slope, dx, dz_out, C, HW, numel, pool_w)
 #define LAUNCH_A(A) \
   { if (hz) { if (vec) LAUNCH(A, true, true); else LAUNCH(A, true, false); } \
     else { if (vec) LAUNCH(A, false, true); else LAUNCH(A, false, false); } }
@@ -539,6 +550,26 @@ extern "C" int sivae_bn_bwd(const float* dy, const float* y, const float* x, con
 #undef LAUNCH_A
 #undef LAUNCH
   return sivae_launch_status();
+}
+
+extern "C" int sivae_bn_bwd(const float* dy, const float* y, const float* x, const float* mean,
+                            const float* invstd, const float* gamma, const float* beta, int act_mode,
+                            float slope, float* dx, float* dz_out, float* dgamma, float* dbeta, int B, int C,
+                            int HW, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  return bn_bwd_impl(dy, y, x, mean, invstd, gamma, beta, act_mode, slope, dx, dz_out, dgamma, dbeta, B, C, HW, 0,
+                     workspace, workspace_bytes, stream);
+}
+
+// Same with dy = the gradient of AvgPool2d(2)(y) at half resolution [B][C][H/2][W/2] (H even, W % 4 == 0): the
+// pool's adjoint is applied while reading, so the block backward of "ResidualBlock -> AvgPool2d" (:95-99) and of the
+// stem (:88-93) never materialises the full-resolution gradient.
+extern "C" int sivae_bn_bwd_pooled_dy(const float* dy_half, const float* y, const float* x, const float* mean,
+                                      const float* invstd, const float* gamma, const float* beta, int act_mode,
+                                      float slope, float* dx, float* dz_out, float* dgamma, float* dbeta, int B, int C,
+                                      int H, int W, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (H <= 0 || W <= 0 || (H & 1) || (W & 3)) return SIVAE_ERR_SHAPE;
+  return bn_bwd_impl(dy_half, y, x, mean, invstd, gamma, beta, act_mode, slope, dx, dz_out, dgamma, dbeta, B, C, H * W,
+                     W, workspace, workspace_bytes, stream);
 }
 
 // ---- the same backward in two calls for synchronised BatchNorm: `reduce` leaves the local per-channel
@@ -584,7 +615,7 @@ extern "C" int sivae_bn_bwd_reduce(const float* dy, const float* y, const float*
   double* part = (double*)workspace;
 #define LAUNCHP(A) \
   hipLaunchKernelGGL((bn_bwd_partial_kernel<A>), dim3(C, p.S), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma, \
-                     beta, slope, part, C, HW, n, p.len, p.S)
+                     beta, slope, part, C, HW, n, p.len, p.S, 0)
   if (act_mode == 0) LAUNCHP(0); else if (act_mode == 1) LAUNCHP(1); else LAUNCHP(2);
 #undef LAUNCHP
   hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, (const double*)part, p.S, C, sums);
@@ -614,7 +645,7 @@ extern "C" int sivae_bn_bwd_apply(const float* dy, const float* y, const float* 
   if (nb < 1) nb = 1;
 #define LAUNCH(A, Z, V) \
   hipLaunchKernelGGL((bn_bwd_dx_kernel<A, Z, V>), dim3(nb), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma, \
-                     beta, (const float*)coef, slope, dx, dz_out, C, HW, numel)
+                     beta, (const float*)coef, slope, dx, dz_out, C, HW, numel, 0)
 #define LAUNCH_A(A) \
   { if (hz) { if (vec) LAUNCH(A, true, true); else LAUNCH(A, true, false); } \
     else { if (vec) LAUNCH(A, false, true); else LAUNCH(A, false, false); } }

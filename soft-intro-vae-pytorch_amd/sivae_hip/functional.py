@@ -192,11 +192,15 @@ class ResBlockFn(torch.autograd.Function):
         need_x, need_we, need_w1, need_bn1, need_w2, need_bn2 = need[0], need[1], need[2], need[3] or need[4], \
             need[5], need[6] or need[7]
         Cm = w1.shape[0]
-        d_out = _post_bwd(dy.contiguous(), ctx.post, out.shape)
-        # BN2 + residual + LeakyReLU
-        dc, dz, dg2, db2 = ops.bn_bwd(d_out, out, c, mean2, invstd2, g2, SLOPE, want_dz=True,
-                                      want_param_grads=need_bn2, act_mode=1)
-        del d_out
+        # BN2 + residual + LeakyReLU; the AvgPool2d that follows an encoder block is undone while reading dy
+        if ctx.post == "pool":
+            dc, dz, dg2, db2 = ops.bn_bwd(dy.contiguous(), out, c, mean2, invstd2, g2, SLOPE, want_dz=True,
+                                          want_param_grads=need_bn2, act_mode=1, dy_pooled=True)
+        else:
+            d_out = _post_bwd(dy.contiguous(), ctx.post, out.shape)
+            dc, dz, dg2, db2 = ops.bn_bwd(d_out, out, c, mean2, invstd2, g2, SLOPE, want_dz=True,
+                                          want_param_grads=need_bn2, act_mode=1)
+            del d_out
         pro1 = None if h_saved else (mean1, invstd1, g1, b1, SLOPE)
         dw2 = ops.conv2d_wgrad(h, dc, 3, pro=pro1) if need_w2 else None
         dh = ops.conv2d_fwd(dc, packed(w2, 1), Cm, 3)
@@ -270,10 +274,8 @@ class StemFn(torch.autograd.Function):
             raise RuntimeError("sivae_hip: backward through eval-mode BatchNorm is not supported")
         x, a, mean, invstd, w, g, b = ctx.saved_tensors
         need = ctx.needs_input_grad
-        dyf = ops.avgpool2_bwd(dy.contiguous(), a.shape[2], a.shape[3])
-        da, _, dg, db = ops.bn_bwd(dyf, None, a, mean, invstd, g, SLOPE, want_dz=False,
-                                   want_param_grads=need[2] or need[3], beta=b, act_mode=2)
-        del dyf
+        da, _, dg, db = ops.bn_bwd(dy.contiguous(), None, a, mean, invstd, g, SLOPE, want_dz=False,
+                                   want_param_grads=need[2] or need[3], beta=b, act_mode=2, dy_pooled=True)
         edge = _is_edge5(w) and w.shape[1] <= 3
         dw = None
         if need[1]:

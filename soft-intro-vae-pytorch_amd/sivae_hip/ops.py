@@ -399,11 +399,15 @@ def bn_apply_act(x, res, mean, invstd, gamma, beta, slope=LRELU_SLOPE, out=None,
 
 
 def bn_bwd(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_dz=False, want_param_grads=True, beta=None,
-           act_mode=None):
+           act_mode=None, dy_pooled=False):
     """-> dx, dz (or None), dgamma, dbeta (or None, None).
-    act_mode: 0 none, 1 LeakyReLU sign from the saved output y, 2 sign recomputed from x (needs beta)."""
+    act_mode: 0 none, 1 LeakyReLU sign from the saved output y, 2 sign recomputed from x (needs beta).
+    dy_pooled: dy is the gradient of AvgPool2d(2)(output) at half resolution; the pool's adjoint is applied on load."""
     if act_mode is None:
         act_mode = 1 if y is not None else 0
+    if dy_pooled and (SYNC_BN is not None or (x.shape[2] & 1) or (x.shape[3] & 3)):
+        dy = avgpool2_bwd(dy, x.shape[2], x.shape[3])  # (shapes / modes the fused read does not cover)
+        dy_pooled = False
     _require(dy, y, x, mean, invstd, gamma, beta)
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
@@ -422,6 +426,11 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_dz=False, want
         _lib.call("sivae_bn_bwd_apply", _p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta),
                   int(act_mode), float(slope), _p(local), _p(glob), float(B) * HW * world, _p(dx), _p(dz),
                   _p(dgamma), _p(dbeta), B, C, HW, _p(ws), ws.numel(), _s())
+        return dx, dz, dgamma, dbeta
+    if dy_pooled:
+        _lib.call("sivae_bn_bwd_pooled_dy", _p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta),
+                  int(act_mode), float(slope), _p(dx), _p(dz), _p(dgamma), _p(dbeta), B, C, x.shape[2], x.shape[3],
+                  _p(ws), ws.numel(), _s())
         return dx, dz, dgamma, dbeta
     _lib.call("sivae_bn_bwd", _p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), int(act_mode),
               float(slope), _p(dx), _p(dz), _p(dgamma), _p(dbeta), B, C, HW, _p(ws), ws.numel(), _s())

@@ -495,6 +495,36 @@ def check_conv_up_dgrad(shape, accumulate=False):
     return [("wino_up_dgrad%s%s" % ("_acc" if accumulate else "", shape), _err(dx, ref), WINO_TOL)]
 
 
+def check_bn_bwd_pooled():
+    """BN(+LeakyReLU) backward with dy given as the gradient of AvgPool2d(2)(y) at half resolution"""
+    from sivae_hip import ops
+    res = []
+    for (B, C, H, W), mode in [((3, 8, 8, 16), 1), ((2, 5, 12, 8), 2), ((2, 16, 32, 32), 1)]:
+        x = _rand(B, C, H, W, seed=1)
+        r = _rand(B, C, H, W, seed=2)
+        gamma, beta = _rand(C, seed=8).abs() + 0.5, _rand(C, seed=9)
+        dyh = _rand(B, C, H // 2, W // 2, seed=4)
+        xt = x.clone().requires_grad_()
+        gt, bt = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+        rt = r.clone().requires_grad_()
+        z = F.batch_norm(xt, None, None, gt, bt, True, 0.1, 1e-5)
+        y = F.leaky_relu(z + rt if mode == 1 else z, 0.2)
+        F.avg_pool2d(y, 2).backward(dyh)
+        mean = x.mean((0, 2, 3))
+        invstd = 1.0 / torch.sqrt(x.var((0, 2, 3), unbiased=False) + 1e-5)
+        if mode == 1:
+            dx, dz, dg, db = ops.bn_bwd(_d(dyh), _d(y.detach()), _d(x), _d(mean), _d(invstd), _d(gamma), 0.2,
+                                        want_dz=True, act_mode=1, dy_pooled=True)
+            res.append(("bn_bwd_pooled_dz(%d,%d,%d,%d)" % (B, C, H, W), _err(dz, rt.grad), 1e-5))
+        else:
+            dx, _, dg, db = ops.bn_bwd(_d(dyh), None, _d(x), _d(mean), _d(invstd), _d(gamma), 0.2, want_dz=False,
+                                       beta=_d(beta), act_mode=2, dy_pooled=True)
+        res.append(("bn_bwd_pooled_dx(%d,%d,%d,%d)" % (B, C, H, W), _err(dx, xt.grad), 2e-5))
+        res.append(("bn_bwd_pooled_dgamma(%d,%d,%d,%d)" % (B, C, H, W), _err(dg, gt.grad), 2e-5))
+        res.append(("bn_bwd_pooled_dbeta(%d,%d,%d,%d)" % (B, C, H, W), _err(db, bt.grad), 2e-5))
+    return res
+
+
 def check_input_u8():
     """uint8 -> fp32 (/255) with per-sample mirror, NCHW and NHWC sources (bit-exact: one multiply per element)"""
     from sivae_hip import ops
@@ -553,6 +583,7 @@ def all_checks():
     checks.append(("bn_from_conv", check_bn_from_conv))
     checks.append(("eltwise", check_eltwise))
     checks.append(("input_u8", check_input_u8))
+    checks.append(("bn_bwd_pooled", check_bn_bwd_pooled))
     checks.append(("bn_apply_resup", check_bn_apply_resup))
     checks.append(("losses", check_losses))
     checks.append(("randn", check_randn))
