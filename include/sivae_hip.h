@@ -172,6 +172,12 @@ int sivae_bn_update_running(const float* mean, const float* invstd, int C, doubl
 int sivae_bn_apply_act(const float* x, const float* res, const float* mean, const float* invstd,
                        const float* gamma, const float* beta, float slope, float* y, int B, int C, int HW,
                        sivae_stream_t stream);
+/* same op, also writing AvgPool2d(2) (:92,:98) of the result in the same pass: y [B][C][H][W] (kept for backward)
+ * and y_pooled [B][C][H/2][W/2]; res may be NULL; y may be NULL (pooled output only: the stem, whose backward
+ * recomputes the activation from the conv output); H even, W % 4 == 0. */
+int sivae_bn_apply_act_pool(const float* x, const float* res, const float* mean, const float* invstd,
+                            const float* gamma, const float* beta, float slope, float* y, float* y_pooled, int B, int C,
+                            int H, int W, sivae_stream_t stream);
 /* same, with the residual stored at half resolution [B][C][H/2][W/2] and read through nn.Upsample(2,'nearest')
  * (:155) addressing — the upsampled tensor is never written; H even, W % 4 == 0. */
 int sivae_bn_apply_act_resup(const float* x, const float* res_half, const float* mean, const float* invstd,

@@ -362,6 +362,65 @@ extern "C" int sivae_bn_apply_act_resup(const float* x, const float* res_half, c
   return sivae_launch_status();
 }
 
+// Same op, also writing AvgPool2d(2) of the result (the pool that follows every encoder block and the stem,
+// :92,:98): one pass produces `y` (kept for backward) and the pooled tensor the next layer reads.
+// One thread = 2 rows x 4 columns.  H even, W % 4 == 0.
+template <bool HAS_RES>
+__global__ void __launch_bounds__(256) bn_apply_pool_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float slope,
+                                                            float* __restrict__ y, float* __restrict__ yp, int C, int H,
+                                                            int W, size_t n_quads) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  const int W4 = W >> 2, H2 = H >> 1;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_quads; i += stride) {
+    const int w4 = (int)(i % W4);
+    size_t t = i / W4;
+    const int h2 = (int)(t % H2);
+    t /= H2;  // b*C + c
+    const int c = (int)(t % C);
+    const float m = mean[c], g = invstd[c] * gamma[c], bt = beta[c];
+    const size_t o0 = (t * H + 2 * h2) * (size_t)W + 4 * w4, o1 = o0 + W;
+    float4 a = *reinterpret_cast<const float4*>(x + o0), b = *reinterpret_cast<const float4*>(x + o1);
+    a.x = (a.x - m) * g + bt; a.y = (a.y - m) * g + bt; a.z = (a.z - m) * g + bt; a.w = (a.w - m) * g + bt;
+    b.x = (b.x - m) * g + bt; b.y = (b.y - m) * g + bt; b.z = (b.z - m) * g + bt; b.w = (b.w - m) * g + bt;
+    if (HAS_RES) {
+      const float4 ra = *reinterpret_cast<const float4*>(res + o0), rb = *reinterpret_cast<const float4*>(res + o1);
+      a.x += ra.x; a.y += ra.y; a.z += ra.z; a.w += ra.w;
+      b.x += rb.x; b.y += rb.y; b.z += rb.z; b.w += rb.w;
+    }
+    a.x = lrelu(a.x, slope); a.y = lrelu(a.y, slope); a.z = lrelu(a.z, slope); a.w = lrelu(a.w, slope);
+    b.x = lrelu(b.x, slope); b.y = lrelu(b.y, slope); b.z = lrelu(b.z, slope); b.w = lrelu(b.w, slope);
+    if (y != nullptr) {
+      *reinterpret_cast<float4*>(y + o0) = a;
+      *reinterpret_cast<float4*>(y + o1) = b;
+    }
+    // same summation order as avgpool2_fwd_kernel: ((row0.l + row0.r) + (row1.l + row1.r)) * 0.25
+    *reinterpret_cast<float2*>(yp + (t * H2 + h2) * (size_t)(W >> 1) + 2 * w4) =
+        make_float2(((a.x + a.y) + (b.x + b.y)) * 0.25f, ((a.z + a.w) + (b.z + b.w)) * 0.25f);
+  }
+}
+
+extern "C" int sivae_bn_apply_act_pool(const float* x, const float* res, const float* mean, const float* invstd,
+                                       const float* gamma, const float* beta, float slope, float* y, float* y_pooled,
+                                       int B, int C, int H, int W, hipStream_t stream) {
+  if (!x || !mean || !invstd || !gamma || !beta || !y_pooled) return SIVAE_ERR_NULL;  // y may be NULL: pooled only
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 3)) return SIVAE_ERR_SHAPE;
+  const size_t n_quads = (size_t)B * C * (H >> 1) * (W >> 2);
+  int nb = cdiv((long long)n_quads, 256 * 2);
+  if (nb > 8192) nb = 8192;
+  if (nb < 1) nb = 1;
+  if (res)
+    hipLaunchKernelGGL(bn_apply_pool_kernel<true>, dim3(nb), dim3(256), 0, stream, x, res, mean, invstd, gamma, beta,
+                       slope, y, y_pooled, C, H, W, n_quads);
+  else
+    hipLaunchKernelGGL(bn_apply_pool_kernel<false>, dim3(nb), dim3(256), 0, stream, x, res, mean, invstd, gamma, beta,
+                       slope, y, y_pooled, C, H, W, n_quads);
+  return sivae_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward of  y = LeakyReLU(BN(x) [+ res])
 //   dz = dy * (y > 0 ? 1 : slope)        (y is the saved OUTPUT; valid because slope > 0)

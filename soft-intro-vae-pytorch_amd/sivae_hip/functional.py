@@ -172,8 +172,14 @@ class ResBlockFn(torch.autograd.Function):
         else:
             c, p2 = ops.conv2d_fwd(h, packed(w2, 0), Co, 3, pro=pro1), None
         mean2, invstd2 = _stats(p2, B, Co, H * W, st2)
-        out = ops.bn_apply_act(c, idt, mean2, invstd2, g2.detach(), b2.detach(), SLOPE, res_up=x_up)
-        y = _post_fwd(out, post)
+        fused = None
+        if post == "pool" and not (x_up and w_exp is None):
+            fused = ops.bn_apply_act_pool(c, idt, mean2, invstd2, g2.detach(), b2.detach(), SLOPE)
+        if fused is not None:
+            out, y = fused  # BatchNorm + residual + LeakyReLU and the AvgPool2d that follows, one pass
+        else:
+            out = ops.bn_apply_act(c, idt, mean2, invstd2, g2.detach(), b2.detach(), SLOPE, res_up=x_up)
+            y = _post_fwd(out, post)
         if cache is not None:
             cache.update(a=a, h=h, c=c, out=out, mean1=mean1, invstd1=invstd1, mean2=mean2, invstd2=invstd2, y=y)
         ctx.post = post
@@ -262,8 +268,11 @@ class StemFn(torch.autograd.Function):
         else:
             a, p = ops.conv2d_fwd(x, packed(w, 0), Co, 5), None
         mean, invstd = _stats(p, B, Co, H * W, st)
-        y = ops.bn_apply_act(a, None, mean, invstd, g.detach(), b.detach(), SLOPE)
-        out = ops.avgpool2_fwd(y)
+        fused = ops.bn_apply_act_pool(a, None, mean, invstd, g.detach(), b.detach(), SLOPE, want_full=False)
+        if fused is not None:
+            out = fused[1]  # (the full-resolution activation is never written: backward recomputes it from `a`)
+        else:
+            out = ops.avgpool2_fwd(ops.bn_apply_act(a, None, mean, invstd, g.detach(), b.detach(), SLOPE))
         ctx.training = st.training
         ctx.save_for_backward(x, a, mean, invstd, w, g, b)
         return out

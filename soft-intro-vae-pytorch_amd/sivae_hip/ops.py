@@ -398,6 +398,20 @@ def bn_apply_act(x, res, mean, invstd, gamma, beta, slope=LRELU_SLOPE, out=None,
     return y
 
 
+def bn_apply_act_pool(x, res, mean, invstd, gamma, beta, slope=LRELU_SLOPE, want_full=True):
+    """-> (y, AvgPool2d(2)(y)) in one pass (y is None with want_full=False); None when the shape is not covered
+    (odd H or W % 4 != 0)"""
+    B, C, H, W = x.shape
+    if (H & 1) or (W & 3):
+        return None
+    _require(x, res, mean, invstd, gamma, beta)
+    y = torch.empty_like(x) if want_full else None
+    yp = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    _lib.call("sivae_bn_apply_act_pool", _p(x), _p(res), _p(mean), _p(invstd), _p(gamma), _p(beta), float(slope),
+              _p(y), _p(yp), B, C, H, W, _s())
+    return y, yp
+
+
 def bn_bwd(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_dz=False, want_param_grads=True, beta=None,
            act_mode=None, dy_pooled=False):
     """-> dx, dz (or None), dgamma, dbeta (or None, None).

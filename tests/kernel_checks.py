@@ -495,6 +495,24 @@ def check_conv_up_dgrad(shape, accumulate=False):
     return [("wino_up_dgrad%s%s" % ("_acc" if accumulate else "", shape), _err(dx, ref), WINO_TOL)]
 
 
+def check_bn_apply_pool():
+    """BN-apply (+ residual) + LeakyReLU + AvgPool2d(2) in one pass"""
+    from sivae_hip import ops
+    res = []
+    for (B, C, H, W), has_res in [((2, 8, 8, 8), True), ((3, 5, 12, 16), False), ((1, 64, 6, 12), True)]:
+        x, r = _rand(B, C, H, W, seed=1), _rand(B, C, H, W, seed=2)
+        mean, invstd = _rand(C, seed=6), _rand(C, seed=7).abs() + 0.5
+        gamma, beta = _rand(C, seed=8), _rand(C, seed=9)
+        v = (x - mean.view(1, -1, 1, 1)) * (invstd * gamma).view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+        ref = F.leaky_relu(v + r if has_res else v, 0.2)
+        y, yp = ops.bn_apply_act_pool(_d(x), _d(r) if has_res else None, _d(mean), _d(invstd), _d(gamma), _d(beta), 0.2)
+        res.append(("bn_apply_pool_full(%d,%d,%d,%d)" % (B, C, H, W), _err(y, ref), 1e-6))
+        res.append(("bn_apply_pool_pooled(%d,%d,%d,%d)" % (B, C, H, W), _err(yp, F.avg_pool2d(ref, 2)), 1e-6))
+        _, yp2 = ops.bn_apply_act_pool(_d(x), None, _d(mean), _d(invstd), _d(gamma), _d(beta), 0.2, want_full=False)
+        res.append(("bn_apply_pool_only(%d,%d,%d,%d)" % (B, C, H, W), _err(yp2, F.avg_pool2d(F.leaky_relu(v, 0.2), 2)), 1e-6))
+    return res
+
+
 def check_bn_bwd_pooled():
     """BN(+LeakyReLU) backward with dy given as the gradient of AvgPool2d(2)(y) at half resolution"""
     from sivae_hip import ops
@@ -584,6 +602,7 @@ def all_checks():
     checks.append(("eltwise", check_eltwise))
     checks.append(("input_u8", check_input_u8))
     checks.append(("bn_bwd_pooled", check_bn_bwd_pooled))
+    checks.append(("bn_apply_pool", check_bn_apply_pool))
     checks.append(("bn_apply_resup", check_bn_apply_resup))
     checks.append(("losses", check_losses))
     checks.append(("randn", check_randn))
