@@ -92,16 +92,17 @@ int sivae_conv2d_wino_up_fwd(const float* x_half, const float* up, float* y, con
                              float* stats_partial, int B, int Ci, int Co, int H, int W, sivae_stream_t stream);
 
 /* Data gradient of the same op with respect to the low-resolution input (replaces the full-resolution F(2x2,3x3) data
- * gradient followed by nn.Upsample's 2x2 block sum): one 2x2 conv over the 4*C parity planes of dy
- * (sivae_space_to_depth2: dyp[b][2p+q][c][i][j] = dy[b][c][2i+p][2j+q]) as Winograd F(2x2,2x2) with the phases folded
- * into K.  dx is [B][N][Hs][Ws] (N = the conv's input channels); accumulate != 0: dx += result. */
+ * gradient followed by nn.Upsample's 2x2 block sum): one 2x2 conv over the 4*C parity planes dy[2i+p][2j+q] of
+ * dy [B][C][2Hs][2Ws] (read in place with stride-2 addressing) as Winograd F(2x2,2x2) with the phases folded into K.
+ * dx is [B][N][Hs][Ws] (N = the conv's input channels); accumulate != 0: dx += result.
+ * sivae_space_to_depth2 materialises the parity planes ([B][4][C][Hs][Ws]); the kernels do not need it. */
 int sivae_space_to_depth2(const float* in /*[B][C][2Hs][2Ws]*/, float* out /*[B][4][C][Hs][Ws]*/, int B, int C, int Hs,
                           int Ws, sivae_stream_t stream);
 size_t sivae_pack_wino_up_dgrad_weight_bytes(int Co, int Ci);
 int sivae_pack_wino_up_dgrad_weight(const float* w /*[Co][Ci][3][3]*/, float* ud, int Co, int Ci,
                                     sivae_stream_t stream);
 int sivae_conv2d_wino_up_dgrad_supported(int Hs, int Ws);
-int sivae_conv2d_wino_up_dgrad(const float* dyp, const float* ud, float* dx, int B, int C, int N, int Hs, int Ws,
+int sivae_conv2d_wino_up_dgrad(const float* dy, const float* ud, float* dx, int B, int C, int N, int Hs, int Ws,
                                int accumulate, sivae_stream_t stream);
 
 /* Winograd-domain weight gradient for ks == 3 (dU = sum_tiles (A dY A^T) . (B^T d B), dW = G^T dU G): the

@@ -5,8 +5,8 @@
 //     dx[u][v] = sum_{p,q} sum_{a',b'} gf_pq[a'][b'] * dy_pq[u - p + a'][v - q + b'],   gf_pq[a'][b'] = g_pq[1-a'][1-b'],
 //
 // i.e. ONE 2x2 convolution over 4*C input planes — the four parity planes dy_pq[i][j] = dy[2i+p][2j+q] of every
-// dy channel (made by sivae_space_to_depth2, one streaming pass) — where plane (p, q) is read with a shift of
-// (1-p, 1-q).  It runs as Winograd F(2x2,2x2) with the phases folded into the K dimension: 9 multiplies per
+// dy channel, read in place with stride-2 addressing (the parity goes into the scalar offset of the buffer loads) —
+// where plane (p, q) is read with a shift of (1-p, 1-q).  It runs as Winograd F(2x2,2x2) with the phases folded into the K dimension: 9 multiplies per
 // (2x2 low-res outputs, channel pair, phase) = 36 per 4x4 block of dy pixels instead of 64.
 //
 // Work split: all 9 frequencies of an output in one wave (144 accumulator registers, output transform in
@@ -17,7 +17,7 @@
 #include <stdlib.h>
 
 struct WinoUpDgArgs {
-  const float* dyp;  // [B][4][C][Hs][Ws]
+  const float* dyp;  // dy [B][C][2Hs][2Ws], read as its four parity planes dy[2i+p][2j+q]
   const float* ud;   // packed [4*Cpad][Npad][12]
   float* dx;         // [B][N][Hs][Ws]
   int B, C, N, Hs, Ws;
@@ -86,7 +86,8 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_dgrad_kernel(WinoUpDgArgs
     xrsrc = make_rsrc(a.dyp + (size_t)b * 4 * a.C * HWs, 4ull * a.C * HWs * 4ull); \
     const int r = r0 + xrr - 1, c = c0 + xcc - 1;                        \
     xo = SIVAE_OOB;                                                      \
-    if (r >= 0 && r < Hs && c >= 0 && c < Ws) xo = (unsigned)(r * Ws + c) * 4u; \
+    /* parity plane (p, q), position (r, c) = dy[2r + p][2c + q]: the (p, q) part goes into the scalar offset */ \
+    if (r >= 0 && r < Hs && c >= 0 && c < Ws) xo = (unsigned)(2 * r * (2 * Ws) + 2 * c) * 4u; \
     ua_base = (unsigned)(n0 + ng * 32) * 48u + (unsigned)koff * ua_step; \
   }
 
@@ -108,7 +109,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_dgrad_kernel(WinoUpDgArgs
     _Pragma("unroll") for (int ck = 0; ck < CK; ++ck) {                  \
       const int c = cc0_ + ck;                                           \
       const int cclamp = c < a.C ? c : a.C - 1;                          \
-      xr[ck] = buf_load_f32(xrsrc, xo, (unsigned)(ph_ * a.C + cclamp) * (unsigned)HWs * 4u); \
+      xr[ck] = buf_load_f32(xrsrc, xo, (unsigned)cclamp * (unsigned)HWs * 16u + (unsigned)((ph_ >> 1) * 2 * Ws + (ph_ & 1)) * 4u); \
     }                                                                    \
   }
   // this wave's k-step KS (counted over its own k-steps) -> K index (KS / KPC) * CK + koff + 2 * (KS % KPC)
@@ -433,8 +434,9 @@ static int wud_launch(WinoUpDgArgs& a, hipStream_t stream) {
   return sivae_launch_status();
 }
 
-extern "C" int sivae_conv2d_wino_up_dgrad(const float* dyp, const float* ud, float* dx, int B, int C, int N, int Hs,
+extern "C" int sivae_conv2d_wino_up_dgrad(const float* dy, const float* ud, float* dx, int B, int C, int N, int Hs,
                                           int Ws, int accumulate, hipStream_t stream) {
+  const float* dyp = dy;  // [B][C][2Hs][2Ws]
   if (!dyp || !ud || !dx) return SIVAE_ERR_NULL;
   if (B <= 0 || C <= 0 || N <= 0 || Hs <= 0 || Ws <= 0) return SIVAE_ERR_SHAPE;
   if (!sivae_conv2d_wino_up_dgrad_supported(Hs, Ws)) return SIVAE_ERR_SHAPE;

@@ -191,6 +191,15 @@ class PackedW:
         return self._wino_up
 
 
+def space_to_depth2(x):
+    """[B, C, 2Hs, 2Ws] -> parity planes [B, 4, C, Hs, Ws] (plane 2p+q = x[..., p::2, q::2])"""
+    _require(x)
+    B, C, H, W = x.shape
+    out = torch.empty((B, 4, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    _lib.call("sivae_space_to_depth2", _p(x), _p(out), B, C, H // 2, W // 2, _s())
+    return out
+
+
 def conv2d_up_dgrad_supported(Hs, Ws):
     return WINO_UP and _lib.load().sivae_conv2d_wino_up_dgrad_supported(Hs, Ws) == 1
 
@@ -201,12 +210,10 @@ def conv2d_up_dgrad(dy, wp, N, out=None, accumulate=False):
     _require(dy, out)
     B, C, H, W = dy.shape
     Hs, Ws = H // 2, W // 2
-    dyp = torch.empty((B, 4 * C, Hs, Ws), dtype=torch.float32, device=dy.device)
-    _lib.call("sivae_space_to_depth2", _p(dy), _p(dyp), B, C, Hs, Ws, _s())
     dx = out if out is not None else torch.empty((B, N, Hs, Ws), dtype=torch.float32, device=dy.device)
     assert dx.shape == (B, N, Hs, Ws)
     t0 = TIMER.begin() if TIMER is not None else None
-    _lib.call("sivae_conv2d_wino_up_dgrad", _p(dyp), _p(wp.wino_up_dgrad()), _p(dx), B, C, N, Hs, Ws,
+    _lib.call("sivae_conv2d_wino_up_dgrad", _p(dy), _p(wp.wino_up_dgrad()), _p(dx), B, C, N, Hs, Ws,
               int(bool(accumulate)), _s())
     if t0 is not None:
         flops = 2.0 * B * H * W * C * N * 9

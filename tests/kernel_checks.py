@@ -495,6 +495,14 @@ def check_conv_up_dgrad(shape, accumulate=False):
     return [("wino_up_dgrad%s%s" % ("_acc" if accumulate else "", shape), _err(dx, ref), WINO_TOL)]
 
 
+def check_space_to_depth():
+    from sivae_hip import ops
+    x = _rand(3, 5, 12, 20, seed=1)
+    out = ops.space_to_depth2(_d(x)).cpu()
+    ref = torch.stack([x[:, :, p::2, q::2] for p in (0, 1) for q in (0, 1)], dim=1).float()
+    return [("space_to_depth2", float((out - ref).abs().max()), 0.0)]
+
+
 def check_bn_apply_pool():
     """BN-apply (+ residual) + LeakyReLU + AvgPool2d(2) in one pass"""
     from sivae_hip import ops
@@ -603,6 +611,7 @@ def all_checks():
     checks.append(("input_u8", check_input_u8))
     checks.append(("bn_bwd_pooled", check_bn_bwd_pooled))
     checks.append(("bn_apply_pool", check_bn_apply_pool))
+    checks.append(("space_to_depth", check_space_to_depth))
     checks.append(("bn_apply_resup", check_bn_apply_resup))
     checks.append(("losses", check_losses))
     checks.append(("randn", check_randn))
