@@ -105,6 +105,14 @@ int sivae_conv2d_wino_up_dgrad_supported(int Hs, int Ws);
 int sivae_conv2d_wino_up_dgrad(const float* dy, const float* ud, float* dx, int B, int C, int N, int Hs, int Ws,
                                int accumulate, sivae_stream_t stream);
 
+/* Weight gradient of the same op in the phase form (dU_pq = sum_tiles (A dY_pq A^T).(B^T d_pq B), F(2x2,2x2);
+ * dW folded back from the four 2x2 phase filters): 36 multiplies per 4x4 dy pixels instead of 64.  x_half is
+ * [B][Ci][Hs][Ws], dy [B][Co][2Hs][2Ws], dw [Co][Ci][3][3]; deterministic two-pass reduction. */
+int sivae_conv2d_wino_up_wgrad_supported(int Hs, int Ws);
+size_t sivae_conv2d_wino_up_wgrad_workspace_bytes(int B, int Ci, int Co, int Hs, int Ws);
+int sivae_conv2d_wino_up_wgrad(const float* x_half, const float* dy, float* dw, int B, int Ci, int Co, int Hs, int Ws,
+                               void* workspace, size_t workspace_bytes, sivae_stream_t stream);
+
 /* Winograd-domain weight gradient for ks == 3 (dU = sum_tiles (A dY A^T) . (B^T d B), dW = G^T dU G): the
  * weight half of aten::convolution_backward for the nn.Conv2d(k=3) layers (:56-61) with 2.25x fewer multiplies;
  * same prologue / upsample options and the same deterministic two-pass reduction as sivae_conv2d_wgrad.

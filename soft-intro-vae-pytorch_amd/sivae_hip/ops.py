@@ -280,6 +280,18 @@ def conv2d_wgrad(x, dy, ks, pro=None, upsample=False):
     B, Ci = x.shape[0], x.shape[1]
     _, Co, H, W = dy.shape
     L = _lib.load()
+    if (WINO_WGRAD and WINO_UP and upsample and ks == 3 and pro is None
+            and L.sivae_conv2d_wino_up_wgrad_supported(H // 2, W // 2) == 1):
+        # conv after nearest-2x upsample: phase-form F(2x2,2x2) weight gradient on the low-resolution x
+        ws = workspace(L.sivae_conv2d_wino_up_wgrad_workspace_bytes(B, Ci, Co, H // 2, W // 2), x.device)
+        dw = torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=x.device)
+        t0 = TIMER.begin() if TIMER is not None else None
+        _lib.call("sivae_conv2d_wino_up_wgrad", _p(x), _p(dy), _p(dw), B, Ci, Co, H // 2, W // 2, _p(ws), ws.numel(),
+                  _s())
+        if t0 is not None:
+            flops = 2.0 * B * H * W * Co * Ci * 9
+            TIMER.end("wino_up_wgrad_kernel", flops, t0, executed=flops * 9.0 / 36.0)
+        return dw
     wino = WINO_WGRAD and ks == 3 and L.sivae_conv2d_wino_wgrad_supported(H, W) == 1
     nbytes = (L.sivae_conv2d_wino_wgrad_workspace_bytes(B, Ci, Co, H, W) if wino
               else L.sivae_conv2d_wgrad_workspace_bytes(B, Ci, Co, H, W, ks))

@@ -551,6 +551,19 @@ def check_bn_bwd_pooled():
     return res
 
 
+def check_conv_up_wgrad(shape):
+    """d/dw of conv3x3(Upsample(2,'nearest')(x)) — phase-form F(2x2,2x2) weight gradient"""
+    from sivae_hip import ops
+    B, Ci, Co, H, W, ks = shape  # H, W = dy size
+    xs = _rand(B, Ci, H // 2, W // 2, seed=5)
+    w = _rand(Co, Ci, 3, 3, seed=2).requires_grad_()
+    dy = _rand(B, Co, H, W, seed=4)
+    _conv_ref(F.interpolate(xs, scale_factor=2, mode="nearest"), w).backward(dy)
+    assert ops._lib.load().sivae_conv2d_wino_up_wgrad_supported(H // 2, W // 2) == 1
+    dw = ops.conv2d_wgrad(_d(xs), _d(dy), 3, upsample=True)
+    return [("wino_up_wgrad%s" % (shape,), _err(dw, w.grad), WINO_TOL)]
+
+
 def check_input_u8():
     """uint8 -> fp32 (/255) with per-sample mirror, NCHW and NHWC sources (bit-exact: one multiply per element)"""
     from sivae_hip import ops
@@ -599,6 +612,9 @@ def all_checks():
     for s in [(2, 64, 64, 32, 32, 3), (2, 64, 128, 16, 64, 3), (3, 40, 24, 24, 40, 3), (1, 256, 512, 32, 32, 3),
               (2, 8, 16, 20, 36, 3), (2, 130, 20, 16, 32, 3)]:
         checks.append(("wino_up_dgrad%s" % (s,), lambda s=s: check_conv_up_dgrad(s) + check_conv_up_dgrad(s, True)))
+    for s in [(2, 64, 64, 32, 32, 3), (2, 64, 128, 16, 64, 3), (3, 40, 24, 24, 40, 3), (1, 256, 512, 32, 32, 3),
+              (2, 8, 16, 20, 36, 3), (5, 130, 20, 8, 32, 3), (4, 64, 64, 64, 64, 3)]:
+        checks.append(("wino_up_wgrad%s" % (s,), lambda s=s: check_conv_up_wgrad(s)))
     checks.append(("wino_up_stats", lambda: check_conv_up((3, 32, 72, 32, 64, 3), stats=True)
                    + check_conv_up((2, 20, 33, 16, 32, 3), pro=True, stats=True)))
     checks.append(("conv5_edge", check_conv5_edge))

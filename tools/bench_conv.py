@@ -57,6 +57,14 @@ for (Ci, Co, H, ks) in SHAPES:
         t2 = timeit(lambda: ops.upsample2_bwd(ops.conv2d_fwd(dy, wd, Ci, 3)))
         out += "  up-dgrad F(2,2) %7.3f ms %6.1f TF(alg) | F(2,3) + 2x2 sum %7.3f ms %6.1f TF(alg)" % (
             t, fl / t / 1e9, t2, fl / t2 / 1e9)
+    if "upwg" in what and ks == 3 and H >= 32:
+        xs_ = torch.randn(B, Ci, H // 2, H // 2, device="cuda")
+        t = timeit(lambda: ops.conv2d_wgrad(xs_, dy, 3, upsample=True))
+        ops.WINO_UP = False
+        t2 = timeit(lambda: ops.conv2d_wgrad(xs_, dy, 3, upsample=True))
+        ops.WINO_UP = True
+        out += "  up-wgrad F(2,2) %7.3f ms %6.1f TF(alg) | F(2,3)+upsample %7.3f ms %6.1f TF(alg)" % (
+            t, fl / t / 1e9, t2, fl / t2 / 1e9)
     if "wgrad" in what:
         t = timeit(lambda: ops.conv2d_wgrad(x, dy, ks))
         out += "  wgrad %7.3f ms %6.1f TF" % (t, fl / t / 1e9)
