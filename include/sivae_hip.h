@@ -113,6 +113,18 @@ size_t sivae_conv2d_wino_up_wgrad_workspace_bytes(int B, int Ci, int Co, int Hs,
 int sivae_conv2d_wino_up_wgrad(const float* x_half, const float* dy, float* dw, int B, int Ci, int Co, int Hs, int Ws,
                                void* workspace, size_t workspace_bytes, sivae_stream_t stream);
 
+/* sivae_conv2d_wino_fwd used as a DATA GRADIENT whose output y = dL/dh feeds the backward of
+ * h = LeakyReLU(BatchNorm(bn_x)) (:58-59): the epilogue also reads bn_x (same shape as y) and leaves per pixel tile
+ * {sum g, sum g*xhat}, g = y * LeakyReLU'(z), in bnbwd_partial [sivae_conv2d_wino_num_px_tiles(B,H,W)][Co][2] —
+ * the first reduction pass of the BatchNorm backward; sivae_bn_bwd_from_partials finishes it. */
+int sivae_conv2d_wino_dgrad_bnbwd(const float* dy, const float* up, float* y, const float* bn_x, const float* bn_mean,
+                                  const float* bn_invstd, const float* bn_gamma, const float* bn_beta, float slope,
+                                  float* bnbwd_partial, int B, int Ci, int Co, int H, int W, sivae_stream_t stream);
+int sivae_bn_bwd_from_partials(const float* dy, const float* x, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, float slope, const float* partials, int n_tiles,
+                               float* dx, float* dgamma, float* dbeta, int B, int C, int HW, void* workspace,
+                               size_t workspace_bytes, sivae_stream_t stream);
+
 /* Winograd-domain weight gradient for ks == 3 (dU = sum_tiles (A dY A^T) . (B^T d B), dW = G^T dU G): the
  * weight half of aten::convolution_backward for the nn.Conv2d(k=3) layers (:56-61) with 2.25x fewer multiplies;
  * same prologue / upsample options and the same deterministic two-pass reduction as sivae_conv2d_wgrad.

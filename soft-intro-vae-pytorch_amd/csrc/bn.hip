@@ -631,6 +631,56 @@ extern "C" int sivae_bn_bwd_pooled_dy(const float* dy_half, const float* y, cons
                      W, workspace, workspace_bytes, stream);
 }
 
+// ---- backward whose first reduction was done by the producer of dy (sivae_conv2d_wino_dgrad_bnbwd): per-tile
+// {sum g, sum g*xhat} float partials [n_tiles][C][2] -> coefficients (+ dgamma, dbeta), then the dx pass.
+__global__ void __launch_bounds__(256) bn_bwd_coef_partials_kernel(const float* __restrict__ part, int S, int C,
+                                                                   double count, float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta, float* __restrict__ coef) {
+  __shared__ double red[4];
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = threadIdx.x; s < S; s += 256) {
+    const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)s * C + c) * 2);
+    s1 += (double)v.x;
+    s2 += (double)v.y;
+  }
+  s1 = block_sum<256>(s1, red);
+  s2 = block_sum<256>(s2, red);
+  if (threadIdx.x != 0) return;
+  if (dbeta) dbeta[c] = (float)s1;
+  if (dgamma) dgamma[c] = (float)s2;
+  coef[c * 2 + 0] = (float)(s1 / count);
+  coef[c * 2 + 1] = (float)(s2 / count);
+}
+
+extern "C" int sivae_bn_bwd_from_partials(const float* dy, const float* x, const float* mean, const float* invstd,
+                                          const float* gamma, const float* beta, float slope, const float* partials,
+                                          int n_tiles, float* dx, float* dgamma, float* dbeta, int B, int C, int HW,
+                                          void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (!dy || !x || !mean || !invstd || !gamma || !beta || !partials || !dx) return SIVAE_ERR_NULL;
+  if (B <= 0 || C <= 0 || HW <= 0 || n_tiles <= 0) return SIVAE_ERR_SHAPE;
+  if (!workspace || workspace_bytes < sivae_bn_workspace_bytes(B, C, HW)) return SIVAE_ERR_WORKSPACE;
+  SlicePlan p = plan_slices((long long)B * HW, C);
+  float* coef = (float*)((double*)workspace + (size_t)C * p.S * 2);
+  hipLaunchKernelGGL(bn_bwd_coef_partials_kernel, dim3(C), dim3(256), 0, stream, partials, n_tiles, C,
+                     (double)B * HW, dgamma, dbeta, coef);
+  const size_t numel = (size_t)B * C * HW;
+  const bool vec = (HW & 3) == 0;
+  long long work = vec ? (long long)(numel >> 2) : (long long)numel;
+  int nb = cdiv(work, 256);
+  if (nb > 8192) nb = 8192;
+  if (nb < 1) nb = 1;
+  const float* y = nullptr;
+  float* dz_out = nullptr;
+  if (vec)
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<2, false, true>), dim3(nb), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma,
+                       beta, (const float*)coef, slope, dx, dz_out, C, HW, numel, 0);
+  else
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<2, false, false>), dim3(nb), dim3(256), 0, stream, dy, y, x, mean, invstd,
+                       gamma, beta, (const float*)coef, slope, dx, dz_out, C, HW, numel, 0);
+  return sivae_launch_status();
+}
+
 // ---- the same backward in two calls for synchronised BatchNorm: `reduce` leaves the local per-channel
 // {sum dz, sum dz*xhat} in fp64 (the caller all-reduces a copy), `apply` takes the local sums (-> dgamma, dbeta, which
 // the data-parallel gradient all-reduce sums across ranks anyway) and the global sums + global count (-> dx).

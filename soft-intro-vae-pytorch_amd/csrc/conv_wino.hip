@@ -47,6 +47,15 @@ struct WinoArgs {
   int accumulate;
   int upsample;
   int n_items;
+  // optional: the output y is the gradient flowing into LeakyReLU(BatchNorm(bnb_x)) (the data gradient of conv2 feeding
+  // BatchNorm-1's backward): the `stats` partials then hold {sum g, sum g * xhat}, g = y * LeakyReLU'(z), instead of
+  // {sum y, sum y^2} — the first reduction pass of the BatchNorm backward disappears
+  const float* bnb_x;
+  const float* bnb_mean;
+  const float* bnb_invstd;
+  const float* bnb_gamma;
+  const float* bnb_beta;
+  float bnb_slope;
 };
 
 #define WINO_CK 16
@@ -263,10 +272,22 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
       const int chn = e_co0 + (p >> 4) * 32 + (p & 3) + 8 * ((p & 15) >> 2) + 4 * hh; \
       yo[rr] = (chn < a.Co && col < W && tb < e_nb) ? (unsigned)(((tb * a.Co + chn) * H + row_base) * W + col) * 4u : SIVAE_OOB; \
     }                                                                    \
+    const bool bnb = a.bnb_x != nullptr;                                 \
+    const __amdgpu_buffer_rsrc_t brsrc =                                 \
+        make_rsrc((bnb ? a.bnb_x : a.y) + (size_t)e_b * a.Co * H * W, (unsigned long long)e_nb * a.Co * H * W * 4ull); \
     __syncthreads();                                                     \
     _Pragma("unroll") for (int rr = 0; rr < PPW; ++rr) {                 \
       const int p = wave * PPW + rr;                                     \
       float ssum = 0.f, ssq = 0.f;                                       \
+      float bm = 0.f, bis = 0.f, bgs = 0.f, bbt = 0.f;                   \
+      if (bnb) {                                                         \
+        const int chn_ = e_co0 + (p >> 4) * 32 + (p & 3) + 8 * ((p & 15) >> 2) + 4 * hh; \
+        const int cc_ = chn_ < a.Co ? chn_ : a.Co - 1;                   \
+        bm = a.bnb_mean[cc_];                                            \
+        bis = a.bnb_invstd[cc_];                                         \
+        bgs = bis * a.bnb_gamma[cc_];                                    \
+        bbt = a.bnb_beta[cc_];                                           \
+      }                                                                  \
       _Pragma("unroll") for (int ar = 0; ar < 2; ++ar) {                 \
         float e[4];                                                      \
         _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) e[jj] = ex[(((ar * 4 + jj) * 2 + (p >> 4)) * 16 + (p & 15)) * 64 + lane]; \
@@ -280,8 +301,16 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
           y1 += o.y;                                                     \
         }                                                                \
         buf_store_f32x2(yrsrc, y0, y1, off, 0u);                         \
-        ssum += ok ? (y0 + y1) : 0.f;                                    \
-        ssq += ok ? (y0 * y0 + y1 * y1) : 0.f;                           \
+        if (bnb) {                                                       \
+          const float2 xv = buf_load_f32x2(brsrc, off, 0u);              \
+          const float g0 = ((xv.x - bm) * bgs + bbt) > 0.f ? y0 : y0 * a.bnb_slope; \
+          const float g1 = ((xv.y - bm) * bgs + bbt) > 0.f ? y1 : y1 * a.bnb_slope; \
+          ssum += ok ? (g0 + g1) : 0.f;                                  \
+          ssq += ok ? (g0 * ((xv.x - bm) * bis) + g1 * ((xv.y - bm) * bis)) : 0.f; \
+        } else {                                                         \
+          ssum += ok ? (y0 + y1) : 0.f;                                  \
+          ssq += ok ? (y0 * y0 + y1 * y1) : 0.f;                         \
+        }                                                                \
       }                                                                  \
       if (a.stats != nullptr) {                                          \
         const int chn = e_co0 + (p >> 4) * 32 + (p & 3) + 8 * ((p & 15) >> 2) + 4 * hh; \
@@ -334,7 +363,7 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
     const int next = item + (int)gridDim.x;
     const bool has_next = next < n_items;
     // (with accumulate the epilogue loads y; vmcnt completes in order, so the prefetch goes after it)
-    const bool early = has_next && !a.accumulate;
+    const bool early = has_next && !a.accumulate && a.bnb_x == nullptr;
     if (early) {
       WINO_SETUP(next)
       WINO_LOAD_X(0)
@@ -495,10 +524,11 @@ static int wino_launch(WinoArgs& a, hipStream_t stream) {
   return sivae_launch_status();
 }
 
-extern "C" int sivae_conv2d_wino_fwd(const float* x, const float* up, float* y, const float* bias,
-                                     const float* pro_mean, const float* pro_invstd, const float* pro_gamma,
-                                     const float* pro_beta, float pro_slope, float* stats_partial, int B, int Ci,
-                                     int Co, int H, int W, int upsample, int accumulate, hipStream_t stream) {
+static int wino_fwd_impl(const float* x, const float* up, float* y, const float* bias, const float* pro_mean,
+                         const float* pro_invstd, const float* pro_gamma, const float* pro_beta, float pro_slope,
+                         float* stats_partial, const float* bnb_x, const float* bnb_mean, const float* bnb_invstd,
+                         const float* bnb_gamma, const float* bnb_beta, float bnb_slope, int B, int Ci, int Co, int H,
+                         int W, int upsample, int accumulate, hipStream_t stream) {
   if (!x || !up || !y) return SIVAE_ERR_NULL;
   if (bias) return SIVAE_ERR_MODE;  // none of the 3x3 convs has a bias (:56-61); sivae_conv2d_fwd handles that case
   if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
@@ -530,10 +560,37 @@ extern "C" int sivae_conv2d_wino_fwd(const float* x, const float* up, float* y, 
   if (16ull * a.Ci_pad * a.Co_pad * 4ull >= 0xffffffffull) return SIVAE_ERR_RANGE;
   a.accumulate = accumulate;
   a.upsample = upsample;
+  if (bnb_x && (!bnb_mean || !bnb_invstd || !bnb_gamma || !bnb_beta || !stats_partial)) return SIVAE_ERR_NULL;
+  a.bnb_x = bnb_x;
+  a.bnb_mean = bnb_mean;
+  a.bnb_invstd = bnb_invstd;
+  a.bnb_gamma = bnb_gamma;
+  a.bnb_beta = bnb_beta;
+  a.bnb_slope = bnb_slope;
   // production: 4-wave blocks, 64co x 32 tiles per block, 128 accumulator registers per wave (119 TF issued =
   // 268 TF algorithmic on 512->512 @32x32; the 8-wave <NG=2,WM=1> split measured 106 TF)
   if (W == 8) return wino_launch<2, 2, 1, 2>(a, stream);  // 8x8 maps: 2 images x 4x4 tiles per block
   if (W == 4) return wino_launch<1, 1, 1, 2>(a, stream);  // 4x4 maps: 4 images x 2x2 tiles per block
   if (wino_variant() == 2) return wino_wide(W) ? wino_launch<1, 4, 2, 1>(a, stream) : wino_launch<2, 3, 2, 1>(a, stream);
   return wino_wide(W) ? wino_launch<1, 4, 1, 2>(a, stream) : wino_launch<2, 3, 1, 2>(a, stream);
+}
+
+extern "C" int sivae_conv2d_wino_fwd(const float* x, const float* up, float* y, const float* bias,
+                                     const float* pro_mean, const float* pro_invstd, const float* pro_gamma,
+                                     const float* pro_beta, float pro_slope, float* stats_partial, int B, int Ci,
+                                     int Co, int H, int W, int upsample, int accumulate, hipStream_t stream) {
+  return wino_fwd_impl(x, up, y, bias, pro_mean, pro_invstd, pro_gamma, pro_beta, pro_slope, stats_partial, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, 1.f, B, Ci, Co, H, W, upsample, accumulate, stream);
+}
+
+// Data-gradient use feeding a BatchNorm backward: y = dL/dh with h = LeakyReLU(BatchNorm(bn_x)) (bn_x has y's shape);
+// bnbwd_partial [sivae_conv2d_wino_num_px_tiles][Co][2] receives per tile {sum g, sum g * xhat}, g = y * LeakyReLU'(z)
+// — the first reduction of sivae_bn_bwd (see sivae_bn_bwd_from_partials).
+extern "C" int sivae_conv2d_wino_dgrad_bnbwd(const float* dy, const float* up, float* y, const float* bn_x,
+                                             const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                                             const float* bn_beta, float slope, float* bnbwd_partial, int B, int Ci,
+                                             int Co, int H, int W, hipStream_t stream) {
+  if (!bn_x) return SIVAE_ERR_NULL;
+  return wino_fwd_impl(dy, up, y, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, bnbwd_partial, bn_x, bn_mean,
+                       bn_invstd, bn_gamma, bn_beta, slope, B, Ci, Co, H, W, 0, 0, stream);
 }

@@ -209,10 +209,18 @@ class ResBlockFn(torch.autograd.Function):
             del d_out
         pro1 = None if h_saved else (mean1, invstd1, g1, b1, SLOPE)
         dw2 = ops.conv2d_wgrad(h, dc, 3, pro=pro1) if need_w2 else None
-        dh = ops.conv2d_fwd(dc, packed(w2, 1), Cm, 3)
+        fuse_bn1 = (not h_saved) and ops.conv2d_dgrad_bnbwd_supported(dc.shape[2], dc.shape[3])
+        if fuse_bn1:
+            # conv2's data gradient also reduces BatchNorm-1's backward sums in its epilogue (one pass fewer over dh, a)
+            dh, part1 = ops.conv2d_dgrad_bnbwd(dc, packed(w2, 1), Cm, a, mean1, invstd1, g1, b1, SLOPE)
+        else:
+            dh = ops.conv2d_fwd(dc, packed(w2, 1), Cm, 3)
         del dc
         # BN1 + LeakyReLU (sign from the saved h, or recomputed from a when h was never stored)
-        if h_saved:
+        if fuse_bn1:
+            da, dg1, db1 = ops.bn_bwd_from_partials(dh, a, mean1, invstd1, g1, b1, part1, SLOPE,
+                                                    want_param_grads=need_bn1)
+        elif h_saved:
             da, _, dg1, db1 = ops.bn_bwd(dh, h, a, mean1, invstd1, g1, SLOPE, want_dz=False,
                                          want_param_grads=need_bn1, act_mode=1)
         else:

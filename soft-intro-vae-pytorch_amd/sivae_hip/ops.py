@@ -146,6 +146,10 @@ def pack_wino(w, mode):
 # SIVAE_WINO=0 keeps every 3x3 conv on the direct implicit-GEMM kernel (A/B measurements, debugging)
 WINO = os.environ.get("SIVAE_WINO", "1") != "0"
 WINO_UP = os.environ.get("SIVAE_WINO_UP", "1") != "0"  # phase-decomposed F(2x2,2x2) kernel for conv-after-upsample
+# SIVAE_FUSE_BN_BWD=1: reduce BatchNorm-1's backward sums in the epilogue of conv2's data gradient.  Measured a LOSS at
+# 256x256 bs128 (593 vs 585 ms per iteration: the extra tensor read sits on the kernel's critical path and disables its
+# next-item prefetch, which costs more than the 14 ms reduction pass it removes) -> off by default.
+FUSE_BN_BWD = os.environ.get("SIVAE_FUSE_BN_BWD", "0") == "1"
 WINO_WGRAD = os.environ.get("SIVAE_WINO_WGRAD", os.environ.get("SIVAE_WINO", "1")) != "0"
 
 
@@ -198,6 +202,42 @@ def space_to_depth2(x):
     out = torch.empty((B, 4, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
     _lib.call("sivae_space_to_depth2", _p(x), _p(out), B, C, H // 2, W // 2, _s())
     return out
+
+
+def conv2d_dgrad_bnbwd_supported(H, W):
+    return WINO and FUSE_BN_BWD and SYNC_BN is None and _lib.load().sivae_conv2d_wino_supported(H, W) == 1
+
+
+def conv2d_dgrad_bnbwd(dy, wp, Cm, bn_x, mean, invstd, gamma, beta, slope=LRELU_SLOPE):
+    """3x3 data gradient dh = dgrad(dy) whose epilogue also reduces the BatchNorm-backward sums of
+    h = LeakyReLU(BN(bn_x)): -> (dh, partials [n_tiles, Cm, 2])"""
+    _require(dy, bn_x, mean, invstd, gamma, beta)
+    B, Ci, H, W = dy.shape
+    L = _lib.load()
+    dh = torch.empty((B, Cm, H, W), dtype=torch.float32, device=dy.device)
+    part = torch.empty((L.sivae_conv2d_wino_num_px_tiles(B, H, W), Cm, 2), dtype=torch.float32, device=dy.device)
+    t0 = TIMER.begin() if TIMER is not None else None
+    _lib.call("sivae_conv2d_wino_dgrad_bnbwd", _p(dy), _p(wp.wino()), _p(dh), _p(bn_x), _p(mean), _p(invstd), _p(gamma),
+              _p(beta), float(slope), _p(part), B, Ci, Cm, H, W, _s())
+    if t0 is not None:
+        flops = 2.0 * B * H * W * Cm * Ci * 9
+        TIMER.end("conv_wino_kernel<%s,false>" % ("1,4" if W >= 32 else ("2,3" if W >= 16 else ("2,2" if W == 8 else "1,1"))),
+                  flops, t0, executed=flops * 16.0 / 36.0)
+    return dh, part
+
+
+def bn_bwd_from_partials(dy, x, mean, invstd, gamma, beta, partials, slope=LRELU_SLOPE, want_param_grads=True):
+    """BatchNorm(+LeakyReLU, sign recomputed from x) backward whose reduction pass was done by the producer of dy"""
+    _require(dy, x, mean, invstd, gamma, beta, partials)
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    ws = workspace(_lib.load().sivae_bn_workspace_bytes(B, C, HW), x.device)
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
+    _lib.call("sivae_bn_bwd_from_partials", _p(dy), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), float(slope),
+              _p(partials), partials.shape[0], _p(dx), _p(dgamma), _p(dbeta), B, C, HW, _p(ws), ws.numel(), _s())
+    return dx, dgamma, dbeta
 
 
 def conv2d_up_dgrad_supported(Hs, Ws):

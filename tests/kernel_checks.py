@@ -564,6 +564,28 @@ def check_conv_up_wgrad(shape):
     return [("wino_up_wgrad%s" % (shape,), _err(dw, w.grad), WINO_TOL)]
 
 
+def check_dgrad_bnbwd(shape):
+    """conv2 data gradient with the BatchNorm-1 backward sums reduced in its epilogue + the finishing dx pass"""
+    from sivae_hip import ops
+    B, Cm, Co, H, W, ks = shape
+    a = _rand(B, Cm, H, W, seed=1).requires_grad_()
+    gamma, beta = (_rand(Cm, seed=8).abs() + 0.5).requires_grad_(), _rand(Cm, seed=9).requires_grad_()
+    w2 = _rand(Co, Cm, 3, 3, seed=2, scale=1.0 / math.sqrt(Cm * 9))
+    dc = _rand(B, Co, H, W, seed=4)
+    h = F.leaky_relu(F.batch_norm(a, None, None, gamma, beta, True, 0.1, 1e-5), 0.2)
+    _conv_ref(h, w2).backward(dc)
+    ad = a.detach()
+    mean = ad.mean((0, 2, 3))
+    invstd = 1.0 / torch.sqrt(ad.var((0, 2, 3), unbiased=False) + 1e-5)
+    assert ops._lib.load().sivae_conv2d_wino_supported(H, W) == 1
+    dh, part = ops.conv2d_dgrad_bnbwd(_d(dc), ops.PackedW(_d(w2), 1), Cm, _d(ad), _d(mean), _d(invstd),
+                                      _d(gamma.detach()), _d(beta.detach()), 0.2)
+    da, dg, db = ops.bn_bwd_from_partials(dh, _d(ad), _d(mean), _d(invstd), _d(gamma.detach()), _d(beta.detach()), part, 0.2)
+    return [("dgrad_bnbwd_da%s" % (shape,), _err(da, a.grad), 5e-5),
+            ("dgrad_bnbwd_dgamma%s" % (shape,), _err(dg, gamma.grad), 5e-5),
+            ("dgrad_bnbwd_dbeta%s" % (shape,), _err(db, beta.grad), 5e-5)]
+
+
 def check_input_u8():
     """uint8 -> fp32 (/255) with per-sample mirror, NCHW and NHWC sources (bit-exact: one multiply per element)"""
     from sivae_hip import ops
@@ -615,6 +637,8 @@ def all_checks():
     for s in [(2, 64, 64, 32, 32, 3), (2, 64, 128, 16, 64, 3), (3, 40, 24, 24, 40, 3), (1, 256, 512, 32, 32, 3),
               (2, 8, 16, 20, 36, 3), (5, 130, 20, 8, 32, 3), (4, 64, 64, 64, 64, 3)]:
         checks.append(("wino_up_wgrad%s" % (s,), lambda s=s: check_conv_up_wgrad(s)))
+    for s in [(2, 64, 64, 32, 32, 3), (3, 40, 72, 16, 16, 3), (4, 64, 32, 8, 8, 3), (6, 32, 64, 4, 4, 3), (2, 24, 16, 12, 20, 3)]:
+        checks.append(("dgrad_bnbwd%s" % (s,), lambda s=s: check_dgrad_bnbwd(s)))
     checks.append(("wino_up_stats", lambda: check_conv_up((3, 32, 72, 32, 64, 3), stats=True)
                    + check_conv_up((2, 20, 33, 16, 32, 3), pro=True, stats=True)))
     checks.append(("conv5_edge", check_conv5_edge))
