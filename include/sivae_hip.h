@@ -212,6 +212,12 @@ int sivae_bn_bwd(const float* dy, const float* y, const float* x, const float* m
                  const float* gamma, const float* beta, int act_mode, float slope, float* dx, float* dz_out,
                  float* dgamma, float* dbeta, int B, int C, int HW, void* workspace, size_t workspace_bytes,
                  sivae_stream_t stream);
+/* act_mode-1 backward (LeakyReLU sign from the saved output y) that returns the residual-branch gradient as its 2x2
+ * block sum dz_half [B][C][H/2][W/2] — the adjoint of the nn.Upsample (:155) in front of a decoder block — instead of
+ * the full-resolution dz; H even, W % 4 == 0. */
+int sivae_bn_bwd_dzsum(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                       const float* gamma, float slope, float* dx, float* dz_half, float* dgamma, float* dbeta, int B,
+                       int C, int H, int W, void* workspace, size_t workspace_bytes, sivae_stream_t stream);
 /* same with dy given as the gradient of AvgPool2d(2)(y) at half resolution [B][C][H/2][W/2] (:92,:98): the pool's
  * adjoint (0.25 * dy_half[h>>1][w>>1]) is applied on load; H even, W % 4 == 0. */
 int sivae_bn_bwd_pooled_dy(const float* dy_half, const float* y, const float* x, const float* mean,

@@ -571,10 +571,61 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const float* __restrict_
   }
 }
 
+// dx pass of the ACT == 1 backward (sign from the saved output y) that leaves the residual-branch gradient dz as its
+// 2x2 BLOCK SUM at half resolution — the adjoint of the nn.Upsample (:155) the block's input went through — instead of
+// the full-resolution tensor: in the decoder dz is only ever consumed through that sum (identity skip, or the 1x1
+// expand conv that runs at half resolution).  One thread = 2 rows x 4 columns; H even, W % 4 == 0.
+__global__ void __launch_bounds__(256) bn_bwd_dx_dzsum_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                              const float* __restrict__ x,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ coef, float slope,
+                                                              float* __restrict__ dx, float* __restrict__ dz_half, int C,
+                                                              int H, int W, size_t n_quads) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  const int W4 = W >> 2, H2 = H >> 1;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_quads; i += stride) {
+    const int w4 = (int)(i % W4);
+    size_t t = i / W4;
+    const int h2 = (int)(t % H2);
+    t /= H2;  // b*C + c
+    const int c = (int)(t % C);
+    const float m = mean[c], is = invstd[c], gs = gamma[c] * is, c1 = coef[c * 2], c2 = coef[c * 2 + 1];
+    const size_t o0 = (t * H + 2 * h2) * (size_t)W + 4 * w4;
+    float gsum[2] = {0.f, 0.f};
+    float row0[2] = {0.f, 0.f};
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const size_t o = o0 + (size_t)rr * W;
+      const float4 g = *reinterpret_cast<const float4*>(dy + o);
+      const float4 yv = *reinterpret_cast<const float4*>(y + o);
+      const float4 xv = *reinterpret_cast<const float4*>(x + o);
+      const float gz0 = yv.x > 0.f ? g.x : g.x * slope, gz1 = yv.y > 0.f ? g.y : g.y * slope;
+      const float gz2 = yv.z > 0.f ? g.z : g.z * slope, gz3 = yv.w > 0.f ? g.w : g.w * slope;
+      float4 d;
+      d.x = gs * (gz0 - c1 - (xv.x - m) * is * c2);
+      d.y = gs * (gz1 - c1 - (xv.y - m) * is * c2);
+      d.z = gs * (gz2 - c1 - (xv.z - m) * is * c2);
+      d.w = gs * (gz3 - c1 - (xv.w - m) * is * c2);
+      *reinterpret_cast<float4*>(dx + o) = d;
+      // same order as upsample2_bwd_kernel: (row0.l + row0.r) + (row1.l + row1.r)
+      if (rr == 0) {
+        row0[0] = gz0 + gz1;
+        row0[1] = gz2 + gz3;
+      } else {
+        gsum[0] = row0[0] + (gz0 + gz1);
+        gsum[1] = row0[1] + (gz2 + gz3);
+      }
+    }
+    *reinterpret_cast<float2*>(dz_half + (t * H2 + h2) * (size_t)(W >> 1) + 2 * w4) = make_float2(gsum[0], gsum[1]);
+  }
+}
+
 static int bn_bwd_impl(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
                        const float* gamma, const float* beta, int act_mode, float slope, float* dx, float* dz_out,
                        float* dgamma, float* dbeta, int B, int C, int HW, int pool_w, void* workspace,
-                       size_t workspace_bytes, hipStream_t stream) {
+                       size_t workspace_bytes, hipStream_t stream, int dzsum_w = 0) {
   if (!dy || !x || !mean || !invstd || !gamma || !dx) return SIVAE_ERR_NULL;
   if (act_mode < 0 || act_mode > 2) return SIVAE_ERR_MODE;
   if (act_mode == 1 && !y) return SIVAE_ERR_NULL;
@@ -593,6 +644,16 @@ static int bn_bwd_impl(const float* dy, const float* y, const float* x, const fl
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, (const double*)part, p.S, C,
                      (double)n, dgamma, dbeta, coef);
   const size_t numel = (size_t)B * C * HW;
+  if (dzsum_w > 0) {  // dz_out is [B][C][H/2][W/2] block sums (act_mode 1 only, checked by the caller)
+    const int W_ = dzsum_w, H_ = HW / dzsum_w;
+    const size_t n_quads = (size_t)B * C * (H_ >> 1) * (W_ >> 2);
+    int nq = cdiv((long long)n_quads, 256 * 2);
+    if (nq > 8192) nq = 8192;
+    if (nq < 1) nq = 1;
+    hipLaunchKernelGGL(bn_bwd_dx_dzsum_kernel, dim3(nq), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma,
+                       (const float*)coef, slope, dx, dz_out, C, H_, W_, n_quads);
+    return sivae_launch_status();
+  }
   const bool vec = (HW & 3) == 0;
   long long work = vec ? (long long)(numel >> 2) : (long long)numel;
   int nb = cdiv(work, 256);
@@ -617,6 +678,18 @@ extern "C" int sivae_bn_bwd(const float* dy, const float* y, const float* x, con
                             int HW, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   return bn_bwd_impl(dy, y, x, mean, invstd, gamma, beta, act_mode, slope, dx, dz_out, dgamma, dbeta, B, C, HW, 0,
                      workspace, workspace_bytes, stream);
+}
+
+// act_mode-1 backward whose residual-branch gradient comes out as its 2x2 block sum dz_half [B][C][H/2][W/2]
+// (the adjoint of the nn.Upsample in front of the block) instead of the full-resolution dz; H even, W % 4 == 0.
+extern "C" int sivae_bn_bwd_dzsum(const float* dy, const float* y, const float* x, const float* mean,
+                                  const float* invstd, const float* gamma, float slope, float* dx, float* dz_half,
+                                  float* dgamma, float* dbeta, int B, int C, int H, int W, void* workspace,
+                                  size_t workspace_bytes, hipStream_t stream) {
+  if (!y || !dz_half) return SIVAE_ERR_NULL;
+  if (H <= 0 || W <= 0 || (H & 1) || (W & 3)) return SIVAE_ERR_SHAPE;
+  return bn_bwd_impl(dy, y, x, mean, invstd, gamma, nullptr, 1, slope, dx, dz_half, dgamma, dbeta, B, C, H * W, 0,
+                     workspace, workspace_bytes, stream, W);
 }
 
 // Same with dy = the gradient of AvgPool2d(2)(y) at half resolution [B][C][H/2][W/2] (H even, W % 4 == 0): the

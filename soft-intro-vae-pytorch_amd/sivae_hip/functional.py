@@ -199,7 +199,14 @@ class ResBlockFn(torch.autograd.Function):
             need[5], need[6] or need[7]
         Cm = w1.shape[0]
         # BN2 + residual + LeakyReLU; the AvgPool2d that follows an encoder block is undone while reading dy
-        if ctx.post == "pool":
+        x_up = ctx.x_up
+        dzh = None  # 2x2 block sums of dz: all a block behind an Upsample ever needs of it
+        if x_up and ctx.post != "pool" and ops.bn_bwd_dzsum_supported(c):
+            d_out = _post_bwd(dy.contiguous(), ctx.post, out.shape)
+            dc, dzh, dg2, db2 = ops.bn_bwd_dzsum(d_out, out, c, mean2, invstd2, g2, SLOPE, want_param_grads=need_bn2)
+            dz = None
+            del d_out
+        elif ctx.post == "pool":
             dc, dz, dg2, db2 = ops.bn_bwd(dy.contiguous(), out, c, mean2, invstd2, g2, SLOPE, want_dz=True,
                                           want_param_grads=need_bn2, act_mode=1, dy_pooled=True)
         else:
@@ -227,7 +234,6 @@ class ResBlockFn(torch.autograd.Function):
             da, _, dg1, db1 = ops.bn_bwd(dh, None, a, mean1, invstd1, g1, SLOPE, want_dz=False,
                                          want_param_grads=need_bn1, beta=b1, act_mode=2)
         del dh
-        x_up = ctx.x_up
         dw1 = ops.conv2d_wgrad(x, da, 3, upsample=x_up) if need_w1 else None
         dwe = None
         dx = None
@@ -235,7 +241,8 @@ class ResBlockFn(torch.autograd.Function):
         up_dg = x_up and ops.conv2d_up_dgrad_supported(x.shape[2], x.shape[3])
         if ctx.has_exp and x_up:
             # the expand conv ran at half resolution: its gradients do too (dz summed over each 2x2 block first)
-            dzh = ops.upsample2_bwd(dz) if (need_we or need_x) else None
+            if dzh is None:
+                dzh = ops.upsample2_bwd(dz) if (need_we or need_x) else None
             if need_we:
                 dwe = ops.conv2d_wgrad(x, dzh, 1)
             if need_x:
@@ -245,8 +252,14 @@ class ResBlockFn(torch.autograd.Function):
                     dx = ops.upsample2_bwd(ops.conv2d_fwd(da, packed(w1, 1), x.shape[1], 3))
                 ops.conv2d_fwd(dzh, packed(w_exp, 1), x.shape[1], 1, out=dx, accumulate=True)
         elif up_dg and need_x:
-            dx = ops.upsample2_bwd(dz)  # identity branch, already at low resolution
+            dx = dzh if dzh is not None else ops.upsample2_bwd(dz)  # identity branch, already at low resolution
             ops.conv2d_up_dgrad(da, packed(w1, 0), x.shape[1], out=dx, accumulate=True)
+        elif x_up and dzh is not None and dz is None:
+            # identity skip behind an Upsample on a map the phase kernel does not take: reduce conv1's full-resolution
+            # data gradient, then add the (already reduced) skip gradient
+            if need_x:
+                dx = ops.upsample2_bwd(ops.conv2d_fwd(da, packed(w1, 1), x.shape[1], 3))
+                ops.add_(dx, dzh)
         else:
             if ctx.has_exp:
                 if need_we:

@@ -471,6 +471,25 @@ def bn_apply_act_pool(x, res, mean, invstd, gamma, beta, slope=LRELU_SLOPE, want
     return y, yp
 
 
+def bn_bwd_dzsum_supported(x):
+    return SYNC_BN is None and not (x.shape[2] & 1) and not (x.shape[3] & 3)
+
+
+def bn_bwd_dzsum(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_param_grads=True):
+    """act_mode-1 BatchNorm(+residual+LeakyReLU) backward -> dx, dz_half (2x2 block sums of the residual-branch
+    gradient, [B, C, H/2, W/2]), dgamma, dbeta"""
+    _require(dy, y, x, mean, invstd, gamma)
+    B, C, H, W = x.shape
+    ws = workspace(_lib.load().sivae_bn_workspace_bytes(B, C, H * W), x.device)
+    dx = torch.empty_like(x)
+    dzh = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
+    _lib.call("sivae_bn_bwd_dzsum", _p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), float(slope), _p(dx), _p(dzh),
+              _p(dgamma), _p(dbeta), B, C, H, W, _p(ws), ws.numel(), _s())
+    return dx, dzh, dgamma, dbeta
+
+
 def bn_bwd(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_dz=False, want_param_grads=True, beta=None,
            act_mode=None, dy_pooled=False):
     """-> dx, dz (or None), dgamma, dbeta (or None, None).

@@ -503,6 +503,30 @@ def check_space_to_depth():
     return [("space_to_depth2", float((out - ref).abs().max()), 0.0)]
 
 
+def check_bn_bwd_dzsum():
+    """act_mode-1 BN backward returning the residual-branch gradient as 2x2 block sums"""
+    from sivae_hip import ops
+    res = []
+    for (B, C, H, W) in [(3, 8, 8, 16), (2, 5, 12, 8), (2, 16, 32, 32)]:
+        x, r = _rand(B, C, H, W, seed=1), _rand(B, C, H, W, seed=2)
+        gamma, beta = _rand(C, seed=8).abs() + 0.5, _rand(C, seed=9)
+        dy = _rand(B, C, H, W, seed=4)
+        xt, rt = x.clone().requires_grad_(), r.clone().requires_grad_()
+        gt, bt = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+        y = F.leaky_relu(F.batch_norm(xt, None, None, gt, bt, True, 0.1, 1e-5) + rt, 0.2)
+        y.backward(dy)
+        mean = x.mean((0, 2, 3))
+        invstd = 1.0 / torch.sqrt(x.var((0, 2, 3), unbiased=False) + 1e-5)
+        dx, dzh, dg, db = ops.bn_bwd_dzsum(_d(dy), _d(y.detach()), _d(x), _d(mean), _d(invstd), _d(gamma), 0.2)
+        ref_dzh = 4.0 * F.avg_pool2d(rt.grad, 2)
+        tag = "(%d,%d,%d,%d)" % (B, C, H, W)
+        res.append(("bn_bwd_dzsum_dx" + tag, _err(dx, xt.grad), 2e-5))
+        res.append(("bn_bwd_dzsum_dzh" + tag, _err(dzh, ref_dzh), 1e-5))
+        res.append(("bn_bwd_dzsum_dgamma" + tag, _err(dg, gt.grad), 2e-5))
+        res.append(("bn_bwd_dzsum_dbeta" + tag, _err(db, bt.grad), 2e-5))
+    return res
+
+
 def check_bn_apply_pool():
     """BN-apply (+ residual) + LeakyReLU + AvgPool2d(2) in one pass"""
     from sivae_hip import ops
@@ -651,6 +675,7 @@ def all_checks():
     checks.append(("input_u8", check_input_u8))
     checks.append(("bn_bwd_pooled", check_bn_bwd_pooled))
     checks.append(("bn_apply_pool", check_bn_apply_pool))
+    checks.append(("bn_bwd_dzsum", check_bn_bwd_dzsum))
     checks.append(("space_to_depth", check_space_to_depth))
     checks.append(("bn_apply_resup", check_bn_apply_resup))
     checks.append(("losses", check_losses))
