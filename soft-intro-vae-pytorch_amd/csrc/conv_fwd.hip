@@ -227,18 +227,20 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) conv_fwd_kernel(ConvFwdAr
   }
 #undef SIVAE_LOAD_CHUNK
 
-  // ---- epilogue: bias / accumulate / store, optional BatchNorm partial statistics
+  // ---- epilogue: bias / accumulate / store, optional BatchNorm partial statistics.  Stores go through a buffer
+  // descriptor of this tile's images with 32-bit offsets; a pixel or channel outside the tensor gets an out-of-range
+  // offset and its store is dropped — no exec-mask branches, no 64-bit address arithmetic per element.
+  const __amdgpu_buffer_rsrc_t yrsrc =
+      make_rsrc(a.y + (size_t)b0 * a.Co * HW, (unsigned long long)nb_here * a.Co * HW * 4ull);
   unsigned y_off[WN];
-  bool y_ok[WN];
 #pragma unroll
   for (int n = 0; n < WN; ++n) {
     const int m_pix = (wvn * WN + n) * 32 + l31;
     const int cc = m_pix & (TW - 1);
     const int rr = (m_pix >> a.tw_log2) & (TH - 1);
     const int tb = m_pix >> (a.tw_log2 + a.th_log2);
-    const int b = b0 + tb, r = r0 + rr, c = c0 + cc;
-    y_ok[n] = (b < a.B) && (r < H) && (c < W);
-    y_off[n] = ((unsigned)b * a.Co * H + r) * W + c;
+    const int r = r0 + rr, c = c0 + cc;
+    y_off[n] = (tb < nb_here && r < H && c < W) ? (unsigned)((tb * a.Co * H + r) * W + c) * 4u : SIVAE_OOB;
   }
   float* red = smem;  // reuse LDS: [WVN][TCO][2]
   const bool want_stats = a.stats != nullptr;
@@ -250,17 +252,17 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) conv_fwd_kernel(ConvFwdAr
       const int chn = co0 + col;
       const bool ch_ok = chn < a.Co;
       const float bias = (a.bias != nullptr && ch_ok) ? a.bias[chn] : 0.f;
+      const unsigned choff = (unsigned)chn * (unsigned)HW * 4u;
       float s = 0.f, q = 0.f;
 #pragma unroll
       for (int n = 0; n < WN; ++n) {
         float v = acc[m][n][r] + bias;
-        if (ch_ok && y_ok[n]) {
-          float* dst = a.y + ((size_t)y_off[n] + (size_t)chn * HW);
-          if (a.accumulate) v += *dst;
-          *dst = v;
-          s += v;
-          q += v * v;
-        }
+        const bool ok = ch_ok && y_off[n] != SIVAE_OOB;
+        const unsigned off = ok ? y_off[n] + choff : SIVAE_OOB;
+        if (a.accumulate) v += buf_load_f32(yrsrc, off, 0u);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrsrc, (int)off, 0, 0);
+        s += ok ? v : 0.f;
+        q += ok ? v * v : 0.f;
       }
       if (want_stats) {
         s = half_wave_sum(s);
@@ -379,6 +381,7 @@ extern "C" int sivae_conv2d_fwd(const float* x, const float* wp, float* y, const
   // one image of x (Ci*H*W floats) must be addressable with 32-bit byte offsets (tiles spanning
   // several images only exist for images smaller than a tile)
   if ((long long)Ci * hw * 4 >= 0x7fffffffLL) return SIVAE_ERR_RANGE;
+  if ((long long)Co * hw * 4 >= 0x3fffffffLL) return SIVAE_ERR_RANGE;  // (32-bit store offsets inside a tile's images)
   ConvFwdArgs a;
   a.x = x;
   a.wp = wp;
