@@ -99,23 +99,25 @@ __global__ void __launch_bounds__(64) bn_finalize_kernel(const double* __restric
 }
 
 // Finalize for the conv-epilogue partials ([S][C][2] floats, S = number of pixel tiles, can be 10^4+):
-// one block per channel, threads stride over tiles, fixed-shape fp64 tree -> deterministic.
-__global__ void __launch_bounds__(256) bn_finalize_conv_kernel(const float* __restrict__ part, int S, int C,
+// one block per channel (NT = 1024 threads when there are thousands of tiles, so a channel's strided walk is
+// spread over 16 waves), threads stride over tiles, fixed-shape fp64 tree -> deterministic.
+template <int NT>
+__global__ void __launch_bounds__(NT) bn_finalize_conv_kernel(const float* __restrict__ part, int S, int C,
                                                                double count, float eps, float momentum,
                                                                float* running_mean, float* running_var,
                                                                long long* num_batches_tracked,
                                                                float* __restrict__ mean_out,
                                                                float* __restrict__ invstd_out) {
-  __shared__ double red[4];
+  __shared__ double red[NT / 64];
   const int c = blockIdx.x;
   double sum = 0.0, sq = 0.0;
-  for (int s = threadIdx.x; s < S; s += 256) {
+  for (int s = threadIdx.x; s < S; s += NT) {
     const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)s * C + c) * 2);
     sum += (double)v.x;
     sq += (double)v.y;
   }
-  sum = block_sum<256>(sum, red);
-  sq = block_sum<256>(sq, red);
+  sum = block_sum<NT>(sum, red);
+  sq = block_sum<NT>(sq, red);
   if (threadIdx.x != 0) return;
   if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
   const double mean = sum / count;
@@ -163,9 +165,14 @@ extern "C" int sivae_bn_stats_from_conv(const float* partials, int n_tiles, int 
   if (!partials || !mean_out || !invstd_out) return SIVAE_ERR_NULL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return SIVAE_ERR_NULL;
   if (B <= 0 || C <= 0 || HW <= 0 || n_tiles <= 0) return SIVAE_ERR_SHAPE;
-  hipLaunchKernelGGL(bn_finalize_conv_kernel, dim3(C), dim3(256), 0, stream, partials, n_tiles, C,
-                     (double)B * HW, eps, momentum, running_mean, running_var, num_batches_tracked, mean_out,
-                     invstd_out);
+  if (n_tiles >= 4096)
+    hipLaunchKernelGGL((bn_finalize_conv_kernel<1024>), dim3(C), dim3(1024), 0, stream, partials, n_tiles, C,
+                       (double)B * HW, eps, momentum, running_mean, running_var, num_batches_tracked, mean_out,
+                       invstd_out);
+  else
+    hipLaunchKernelGGL((bn_finalize_conv_kernel<256>), dim3(C), dim3(256), 0, stream, partials, n_tiles, C,
+                       (double)B * HW, eps, momentum, running_mean, running_var, num_batches_tracked, mean_out,
+                       invstd_out);
   return sivae_launch_status();
 }
 

@@ -101,6 +101,50 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return t;
 }
 
+// ---- out[e] = sum_s part[s][e] for split-K style workspaces ([n_slices][numel] floats) ----
+// A block owns 64 consecutive elements; its YL wave-rows each walk every YL-th slice with four independent
+// accumulators (so 4*YL loads per element are in flight instead of one), then the rows are folded through LDS in
+// row order.  The summation order depends only on (n_slices, YL) -> deterministic.
+template <int YL>
+__global__ void __launch_bounds__(64 * YL) slice_reduce_rows_kernel(const float* __restrict__ part,
+                                                                    float* __restrict__ out, int n_slices,
+                                                                    size_t numel) {
+  __shared__ float red[YL][64];
+  const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+  const size_t i = (size_t)blockIdx.x * 64 + x;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < numel) {
+    const float* p = part + i;
+    int k = y;
+    for (; k + 3 * YL < n_slices; k += 4 * YL) {
+      s0 += p[(size_t)k * numel];
+      s1 += p[(size_t)(k + YL) * numel];
+      s2 += p[(size_t)(k + 2 * YL) * numel];
+      s3 += p[(size_t)(k + 3 * YL) * numel];
+    }
+    for (; k < n_slices; k += YL) s0 += p[(size_t)k * numel];
+  }
+  red[y][x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (y == 0 && i < numel) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < YL; ++j) s += red[j][x];
+    out[i] = s;
+  }
+}
+
+static inline void sivae_launch_slice_reduce(const float* part, float* out, int n_slices, size_t numel,
+                                             hipStream_t stream) {
+  const unsigned nb = (unsigned)((numel + 63) / 64);
+  if (n_slices >= 64)
+    hipLaunchKernelGGL((slice_reduce_rows_kernel<16>), dim3(nb), dim3(1024), 0, stream, part, out, n_slices, numel);
+  else if (n_slices >= 8)
+    hipLaunchKernelGGL((slice_reduce_rows_kernel<4>), dim3(nb), dim3(256), 0, stream, part, out, n_slices, numel);
+  else
+    hipLaunchKernelGGL((slice_reduce_rows_kernel<1>), dim3(nb), dim3(64), 0, stream, part, out, n_slices, numel);
+}
+
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 // same function for 0 <= slope <= 1 in two VALU ops (v_mul + v_max) instead of compare / multiply / select
 __device__ __forceinline__ float lrelu01(float v, float slope) { return fmaxf(v, v * slope); }

@@ -342,15 +342,6 @@ __global__ void __launch_bounds__(256, 2) conv5_edge_wgrad_kernel(Conv5WgradArgs
   }
 }
 
-__global__ void __launch_bounds__(256) conv5_slice_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                                 int n_slices, int numel) {
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < numel; i += gridDim.x * 256) {
-    float s = 0.f;
-    for (int k = 0; k < n_slices; ++k) s += part[(size_t)k * numel + i];
-    out[i] = s;
-  }
-}
-
 namespace {
 struct EdgePlan { int nrow4, ncol32, n_tiles, tps, n_slices, nblkx; };
 static EdgePlan edge_plan(int B, int Cbig, int H, int W) {
@@ -404,7 +395,6 @@ extern "C" int sivae_conv5_edge_wgrad(const float* x, const float* dy, float* dw
     hipLaunchKernelGGL((conv5_edge_wgrad_kernel<false>), grid, dim3(256), lds, stream, a);
   }
   const int numel = Co * Ci * 25;
-  hipLaunchKernelGGL(conv5_slice_reduce_kernel, dim3(cdiv(numel, 256)), dim3(256), 0, stream,
-                     (const float*)workspace, dw, p.n_slices, numel);
+  sivae_launch_slice_reduce((const float*)workspace, dw, p.n_slices, (size_t)numel, stream);
   return sivae_launch_status();
 }

@@ -234,18 +234,6 @@ __global__ void __launch_bounds__(WVM* WVN * 64, 2) conv_wgrad_kernel(ConvWgradA
     }
 }
 
-// out[e] = sum_s part[s][e]   (fixed order -> deterministic)
-__global__ void __launch_bounds__(256) slice_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                           int n_slices, size_t numel) {
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * 256;
-  for (; i < numel; i += stride) {
-    float s = 0.f;
-    for (int k = 0; k < n_slices; ++k) s += part[(size_t)k * numel + i];
-    out[i] = s;
-  }
-}
-
 namespace {
 
 struct WgradPlan {
@@ -369,9 +357,6 @@ extern "C" int sivae_conv2d_wgrad(const float* x, const float* dy, float* dw, co
   else rc = launch_wgrad<5, 1, 1, 1, 2, 1, 2>(a, p, stream);                // co64 x ci32, 2 waves
   if (rc != SIVAE_OK) return rc;
 
-  int nb = cdiv((long long)numel, 256);
-  if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(slice_reduce_kernel, dim3(nb), dim3(256), 0, stream, (const float*)workspace, dw,
-                     p.n_slices, numel);
+  sivae_launch_slice_reduce((const float*)workspace, dw, p.n_slices, numel, stream);
   return sivae_launch_status();
 }

@@ -47,6 +47,8 @@ CONV_SHAPES = [
     (2, 64, 128, 32, 32, 1),
     (2, 128, 64, 16, 16, 1),
     (3, 100, 40, 8, 8, 1),
+    (9, 40, 72, 64, 64, 1),    # 144 split-K slices -> 16-row slice reduce with a ragged tail
+    (5, 64, 96, 48, 48, 1),    # 45 slices -> 4-row slice reduce with a ragged tail
     (3, 3, 64, 32, 32, 5),     # encoder stem
     (2, 64, 3, 32, 32, 5),     # decoder predict
     (2, 1, 64, 28, 28, 5),
