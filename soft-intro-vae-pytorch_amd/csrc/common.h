@@ -85,6 +85,22 @@ __device__ __forceinline__ float half_wave_sum(float v) {
   for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// The same sum in five DPP-modified VALU adds (no ds_bpermute traffic, no lgkmcnt waits): quad butterflies, the two
+// row mirrors, then row_bcast15 folds row 0 into row 1 (and row 2 into row 3).  The total is valid ONLY in the
+// upper 16 lanes of each half wave (lane & 16) — the conv epilogues let lane 31 of the half write it.
+// Must be called with the whole wave active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float half_wave_sum_hi(float v) {
+  v += dpp_mov_f32<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov_f32<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov_f32<0x141, 0xf>(v);  // row_half_mirror
+  v += dpp_mov_f32<0x140, 0xf>(v);  // row_mirror
+  v += dpp_mov_f32<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+  return v;
+}
 
 // Block-wide sum of doubles for blocks of NT threads (NT multiple of 64, <= 1024).
 // `red` must hold NT/64 doubles of LDS. Result valid in every thread.

@@ -265,9 +265,9 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) conv_fwd_kernel(ConvFwdAr
         q += ok ? v * v : 0.f;
       }
       if (want_stats) {
-        s = half_wave_sum(s);
-        q = half_wave_sum(q);
-        if (l31 == 0) {
+        s = half_wave_sum_hi(s);
+        q = half_wave_sum_hi(q);
+        if (l31 == 31) {
           red[(wvn * TCO + col) * 2 + 0] = s;
           red[(wvn * TCO + col) * 2 + 1] = q;
         }

@@ -59,6 +59,12 @@ struct WinoArgs {
 };
 
 #define WINO_CK 16
+// Two blocks share a CU (two waves per SIMD).  While one is in its MFMA phase — 64-cycle matrix instructions with
+// plenty of issue slack — the other's serial tail (output transform, LDS exchange, stores, next item's first
+// loads) runs at raised wave priority so that it is back in ITS MFMA phase sooner: +2-3% on the 64..128-channel
+// layers; raising the MFMA phase instead measured +-0.
+#define WINO_EPI_PRIO_UP __builtin_amdgcn_s_setprio(1);
+#define WINO_EPI_PRIO_DOWN __builtin_amdgcn_s_setprio(0);
 #define WINO_EX_FLOATS (2 * 4 * 2 * 16 * 64)  // output-transform exchange area (64 KB), aliases the halo buffers
 #define WINO_TCO 64
 
@@ -122,6 +128,8 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
   const int teff = tid % NPOS;
   const int xtb = teff / (LH * LWU), xrr = (teff / LWU) % LH, xcc = teff % LWU;
   float xmask = 0.f;  // 1 inside the image, 0 on the zero padding (applied after the fused BatchNorm+LeakyReLU)
+  const f32x2 pslope2 = {a.pro_slope, a.pro_slope};
+#define xmask2 (f32x2{xmask, xmask})
   const int xl = xtb * PLANE_IMG + xrr * RS + (xcc & 1) * PH + (xcc >> 1);
   int nb_here;  // images of this item that exist (TB == 2 and odd batch: the last item has one)
 #define WINO_SETUP(ITEM)                                                 \
@@ -182,17 +190,25 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
   }
 #define WINO_STORE_X(CH, BUF)                                            \
   {                                                                      \
-    _Pragma("unroll") for (int ck = 0; ck < CK; ++ck) {                  \
-      const int ci = (CH)*CK + ck;                                       \
-      const bool ci_ok = ci < a.Ci;                                      \
-      float v = xr[ck];                                                  \
-      if (PRO) { /* padded channels carry {0,0,0} parameters -> 0 */      \
-        const float4 pp = pro4[ci];                                      \
-        v = lrelu01((v - pp.x) * pp.y + pp.z, a.pro_slope) * xmask;      \
-      } else {                                                           \
-        v = ci_ok ? v : 0.f;                                             \
+    if (PRO) { /* two channels per packed-fp32 op; padded channels carry all-zero parameters -> 0 */ \
+      _Pragma("unroll") for (int cp = 0; cp < CK / 2; ++cp) {            \
+        const float4 p0 = pro4[(CH)*CK + 2 * cp];     /* mean0 mean1 scale0 scale1 */ \
+        const float4 p1 = pro4[(CH)*CK + 2 * cp + 1]; /* beta0 beta1 */   \
+        f32x2 v = {xr[2 * cp], xr[2 * cp + 1]};                          \
+        const f32x2 pm = {p0.x, p0.y}, ps = {p0.z, p0.w}, pb = {p1.x, p1.y}; \
+        v = (v - pm) * ps + pb;                                          \
+        const f32x2 u = v * pslope2;                                     \
+        v.x = fmaxf(v.x, u.x);                                           \
+        v.y = fmaxf(v.y, u.y);                                           \
+        v = v * xmask2;                                                  \
+        xs[(BUF)*XBUF + (2 * cp) * PLANE + xl] = v.x;                    \
+        xs[(BUF)*XBUF + (2 * cp + 1) * PLANE + xl] = v.y;                \
       }                                                                  \
-      xs[(BUF)*XBUF + ck * PLANE + xl] = v;                              \
+    } else {                                                             \
+      _Pragma("unroll") for (int ck = 0; ck < CK; ++ck) {                \
+        const int ci = (CH)*CK + ck;                                     \
+        xs[(BUF)*XBUF + ck * PLANE + xl] = ci < a.Ci ? xr[ck] : 0.f;     \
+      }                                                                  \
     }                                                                    \
   }
   // raw halo reads of k-step KK (two columns x four rows) — issued one k-step ahead of their use so the LDS
@@ -314,9 +330,9 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
       }                                                                  \
       if (a.stats != nullptr) {                                          \
         const int chn = e_co0 + (p >> 4) * 32 + (p & 3) + 8 * ((p & 15) >> 2) + 4 * hh; \
-        const float s = half_wave_sum(ssum);                             \
-        const float q = half_wave_sum(ssq);                              \
-        if (l31 == 0 && chn < a.Co) {                                    \
+        const float s = half_wave_sum_hi(ssum);                          \
+        const float q = half_wave_sum_hi(ssq);                           \
+        if (l31 == 31 && chn < a.Co) {                                   \
           float* dst = a.stats + ((size_t)e_pt * a.Co + chn) * 2;        \
           dst[0] = s;                                                    \
           dst[1] = q;                                                    \
@@ -331,9 +347,16 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
   // phase overwrites it with chunk ch+2.
   const int nchunks = a.Ci_pad / CK;
   if (PRO) {
+    // pro4[2p] = {mean, mean', scale, scale'}, pro4[2p + 1] = {beta, beta', 0, 0} of the channel pair (2p, 2p + 1)
     for (int c = tid; c < a.Ci_pad; c += NT) {
-      pro4[c] = c < a.Ci ? make_float4(a.pro_mean[c], a.pro_invstd[c] * a.pro_gamma[c], a.pro_beta[c], 0.f)
-                         : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int c0_ = c & ~1, c1_ = c | 1;
+      const bool k0 = c0_ < a.Ci, k1 = c1_ < a.Ci;
+      if ((c & 1) == 0)
+        pro4[c] = make_float4(k0 ? a.pro_mean[c0_] : 0.f, k1 ? a.pro_mean[c1_] : 0.f,
+                              k0 ? a.pro_invstd[c0_] * a.pro_gamma[c0_] : 0.f,
+                              k1 ? a.pro_invstd[c1_] * a.pro_gamma[c1_] : 0.f);
+      else
+        pro4[c] = make_float4(k0 ? a.pro_beta[c0_] : 0.f, k1 ? a.pro_beta[c1_] : 0.f, 0.f, 0.f);
     }
     __syncthreads();
   }
@@ -358,6 +381,7 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
     }
     if (ch < nchunks) WINO_MMA(ch, 0, false)
 
+    WINO_EPI_PRIO_UP
     // coordinates of the item just accumulated; then put the next item's first loads in flight
     const int e_pt = pt, e_b = b, e_nb = nb_here, e_r0 = r0, e_c0 = c0, e_co0 = co0;
     const int next = item + (int)gridDim.x;
@@ -377,6 +401,7 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) WINO_LOAD_A(kk, kk)
     }
+    WINO_EPI_PRIO_DOWN
     if (!has_next) break;
     item = next;
   }
@@ -389,6 +414,7 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
 #undef WINO_KSTEP
 #undef WINO_READ
 #undef WINO_STEP
+#undef xmask2
 
 }
 

@@ -223,6 +223,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_kernel(WinoUpArgs a) {
     }
     if (ch < nchunks) WUP_MMA(ch, 0, false)
 
+    __builtin_amdgcn_s_setprio(1);  // serial tail at raised priority (see conv_wino.hip)
     const int e_pt = pt, e_b = b, e_r0 = r0, e_c0 = c0, e_co0 = co0;
     const int next = item + (int)gridDim.x;
     const bool has_next = next < n_items;
@@ -262,9 +263,9 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_kernel(WinoUpArgs a) {
           float s = (ok00 ? y00 : 0.f) + (ok01 ? y01 : 0.f) + (ok10 ? y10 : 0.f) + (ok11 ? y11 : 0.f);
           float q = (ok00 ? y00 * y00 : 0.f) + (ok01 ? y01 * y01 : 0.f) + (ok10 ? y10 * y10 : 0.f) +
                     (ok11 ? y11 * y11 : 0.f);
-          s = half_wave_sum(s);
-          q = half_wave_sum(q);
-          if (l31 == 0 && cok) {
+          s = half_wave_sum_hi(s);
+          q = half_wave_sum_hi(q);
+          if (l31 == 31 && cok) {
             float* dst = a.stats + ((size_t)(e_pt * 4 + wave) * a.Co + chn) * 2;
             dst[0] = s;
             dst[1] = q;
@@ -272,6 +273,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_kernel(WinoUpArgs a) {
         }
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     if (!has_next) break;
     item = next;
   }

@@ -216,6 +216,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_dgrad_kernel(WinoUpDgArgs
     }
     if (q < nchunks) WUD_MMA(q, 0, false)
 
+    __builtin_amdgcn_s_setprio(1);  // serial tail at raised priority (see conv_wino.hip)
     const int e_b = b, e_r0 = r0, e_c0 = c0, e_n0 = n0;
     const int next = item + (int)gridDim.x;
     const bool has_next = next < n_items;
@@ -277,6 +278,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_dgrad_kernel(WinoUpDgArgs
       if (KS2) __syncthreads();  // the reduction area aliases the halo buffers of the next item
     }
     if (has_next && !early) WUD_PREFETCH(next)
+    __builtin_amdgcn_s_setprio(0);
     if (!has_next) break;
     item = next;
   }

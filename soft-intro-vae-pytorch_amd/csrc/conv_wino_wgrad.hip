@@ -82,6 +82,7 @@ __global__ void __launch_bounds__(NGI * 256, 2) wino_wgrad_kernel(WinoWgArgs a) 
   const int xpos = (tid & 127) < NPOSX ? (tid & 127) : (tid & 127) - NPOSX;
   const int xrr = xpos / LWX, xcc = xpos % LWX;
   float xmask = 0.f;
+  const f32x2 pslope2 = {a.pro_slope, a.pro_slope};
   const int ypy = lane >> 4, ypx = lane & 15;
 
   // ---- operand bases.  k-step kk = tile pair (ty = kk >> 2, tx = 2*(kk & 3) + hh)
@@ -142,13 +143,22 @@ __global__ void __launch_bounds__(NGI * 256, 2) wino_wgrad_kernel(WinoWgArgs a) 
   }
 #define WG_STORE(BUF)                                                                               \
   {                                                                                                 \
-    _Pragma("unroll") for (int q = 0; q < XQ; ++q) {                                                \
-      float v = xr[q];                                                                              \
-      if (PRO) {                                                                                    \
-        const float4 pp = pro4[xsub + NSUB * q];                                                    \
-        v = lrelu01((v - pp.x) * pp.y + pp.z, a.pro_slope) * xmask;                                 \
+    if (PRO) { /* two channels per packed-fp32 op */                                                \
+      _Pragma("unroll") for (int pq = 0; pq < XQ / 2; ++pq) {                                       \
+        const float4 p0 = pro4[2 * (pq * NSUB + xsub)];     /* mean mean' scale scale' */           \
+        const float4 p1 = pro4[2 * (pq * NSUB + xsub) + 1]; /* beta beta' */                        \
+        f32x2 v = {xr[2 * pq], xr[2 * pq + 1]};                                                     \
+        const f32x2 pm = {p0.x, p0.y}, ps = {p0.z, p0.w}, pb = {p1.x, p1.y};                        \
+        v = (v - pm) * ps + pb;                                                                     \
+        const f32x2 u = v * pslope2;                                                                \
+        v.x = fmaxf(v.x, u.x);                                                                      \
+        v.y = fmaxf(v.y, u.y);                                                                      \
+        v = v * f32x2{xmask, xmask};                                                                \
+        xs[(BUF)*XBUF + (xsub + NSUB * (2 * pq)) * XP + xpos] = v.x;                                \
+        xs[(BUF)*XBUF + (xsub + NSUB * (2 * pq + 1)) * XP + xpos] = v.y;                            \
       }                                                                                             \
-      xs[(BUF)*XBUF + (xsub + NSUB * q) * XP + xpos] = v;                                           \
+    } else {                                                                                        \
+      _Pragma("unroll") for (int q = 0; q < XQ; ++q) xs[(BUF)*XBUF + (xsub + NSUB * q) * XP + xpos] = xr[q]; \
     }                                                                                               \
     _Pragma("unroll") for (int q = 0; q < YQ; ++q) dys[(BUF)*YBUF + (wave + NW * q) * YP + lane] = yr[q]; \
   }
@@ -212,10 +222,17 @@ __global__ void __launch_bounds__(NGI * 256, 2) wino_wgrad_kernel(WinoWgArgs a) 
   }
 
   if (PRO) {
+    // pair table: entry e = pq * NSUB + xsub holds the channels (xsub + NSUB*2pq, xsub + NSUB*(2pq+1)) a thread
+    // stages in its registers xr[2pq], xr[2pq+1]:  pro4[2e] = {mean, mean', scale, scale'}, pro4[2e+1] = {beta, beta'}
     if (tid < CIT) {
-      const int ci = ci0 + tid;
-      const int cc = ci < a.Ci ? ci : a.Ci - 1;
-      pro4[tid] = make_float4(a.pro_mean[cc], a.pro_invstd[cc] * a.pro_gamma[cc], a.pro_beta[cc], 0.f);
+      const int e = tid >> 1, pq = e / NSUB, xs_ = e % NSUB;
+      const int ca_ = ci0 + xs_ + NSUB * (2 * pq), cb_ = ca_ + NSUB;
+      const int c0_ = ca_ < a.Ci ? ca_ : a.Ci - 1, c1_ = cb_ < a.Ci ? cb_ : a.Ci - 1;
+      if ((tid & 1) == 0)
+        pro4[tid] = make_float4(a.pro_mean[c0_], a.pro_mean[c1_], a.pro_invstd[c0_] * a.pro_gamma[c0_],
+                                a.pro_invstd[c1_] * a.pro_gamma[c1_]);
+      else
+        pro4[tid] = make_float4(a.pro_beta[c0_], a.pro_beta[c1_], 0.f, 0.f);
     }
     __syncthreads();
   }

@@ -23,7 +23,11 @@ def timeit(fn, reps=5):
     return s.elapsed_time(e) / reps
 
 print("variant fwd3=%s wgrad3=%s B=%d" % (os.environ.get("SIVAE_FWD3_VARIANT", "0"), os.environ.get("SIVAE_WGRAD3_VARIANT", "0"), B))
+KS_ONLY = int(os.environ.get("BENCH_KS", "0"))
+WINO_ONLY = bool(os.environ.get("BENCH_WINO_ONLY"))
 for (Ci, Co, H, ks) in SHAPES:
+    if KS_ONLY and ks != KS_ONLY:
+        continue
     x = torch.randn(B, Ci, H, H, device="cuda")
     dy = torch.randn(B, Co, H, H, device="cuda")
     w = torch.randn(Co, Ci, ks, ks, device="cuda") / (Ci * ks * ks) ** 0.5
@@ -31,8 +35,9 @@ for (Ci, Co, H, ks) in SHAPES:
     fl = 2.0 * B * H * H * Ci * Co * ks * ks
     out = "%4d->%-4d @%-3d k%d :" % (Ci, Co, H, ks)
     if "fwd" in what:
-        t = timeit(lambda: ops.conv2d_fwd(x, wp, Co, ks, want_stats=True))
-        out += "  fwd %7.3f ms %6.1f TF" % (t, fl / t / 1e9)
+        if not WINO_ONLY:
+            t = timeit(lambda: ops.conv2d_fwd(x, wp, Co, ks, want_stats=True))
+            out += "  fwd %7.3f ms %6.1f TF" % (t, fl / t / 1e9)
         if ks == 3 and H >= 16:
             wq = ops.PackedW(w, 0)
             pro = None
@@ -65,10 +70,14 @@ for (Ci, Co, H, ks) in SHAPES:
         ops.WINO_UP = True
         out += "  up-wgrad F(2,2) %7.3f ms %6.1f TF(alg) | F(2,3)+upsample %7.3f ms %6.1f TF(alg)" % (
             t, fl / t / 1e9, t2, fl / t2 / 1e9)
-    if "wgrad" in what:
-        t = timeit(lambda: ops.conv2d_wgrad(x, dy, ks))
+    if "wgrad" in what.split(","):
+        prow = None
+        if os.environ.get("BENCH_PRO") and ks == 3:
+            prow = (torch.zeros(Ci, device="cuda"), torch.ones(Ci, device="cuda"), torch.ones(Ci, device="cuda"),
+                    torch.zeros(Ci, device="cuda"), 0.2)
+        t = timeit(lambda: ops.conv2d_wgrad(x, dy, ks, pro=prow))
         out += "  wgrad %7.3f ms %6.1f TF" % (t, fl / t / 1e9)
-        if ks == 3 and H >= 16 and ops.WINO_WGRAD:
+        if ks == 3 and H >= 16 and ops.WINO_WGRAD and not WINO_ONLY:
             ops.WINO_WGRAD = False
             t = timeit(lambda: ops.conv2d_wgrad(x, dy, ks))
             ops.WINO_WGRAD = True
