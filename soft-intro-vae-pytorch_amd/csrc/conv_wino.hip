@@ -498,15 +498,6 @@ extern "C" int sivae_conv2d_wino_num_px_tiles(int B, int H, int W) {
   return B * cdiv(H, pxh) * cdiv(W, pxw);
 }
 
-static int wino_variant() {  // experiment switch (tools/bench_conv.py): SIVAE_WINO_VARIANT=2 -> 8-wave <NG=2,WM=1> blocks
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("SIVAE_WINO_VARIANT");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
-
 // persistent grid: two co-resident blocks per CU
 static int wino_grid_blocks() {
   static int g = 0;
@@ -597,7 +588,6 @@ static int wino_fwd_impl(const float* x, const float* up, float* y, const float*
   // 268 TF algorithmic on 512->512 @32x32; the 8-wave <NG=2,WM=1> split measured 106 TF)
   if (W == 8) return wino_launch<2, 2, 1, 2>(a, stream);  // 8x8 maps: 2 images x 4x4 tiles per block
   if (W == 4) return wino_launch<1, 1, 1, 2>(a, stream);  // 4x4 maps: 4 images x 2x2 tiles per block
-  if (wino_variant() == 2) return wino_wide(W) ? wino_launch<1, 4, 2, 1>(a, stream) : wino_launch<2, 3, 2, 1>(a, stream);
   return wino_wide(W) ? wino_launch<1, 4, 1, 2>(a, stream) : wino_launch<2, 3, 1, 2>(a, stream);
 }
 
