@@ -204,6 +204,22 @@ int sivae_bn_apply_act_pool(const float* x, const float* res, const float* mean,
 int sivae_bn_apply_act_resup(const float* x, const float* res_half, const float* mean, const float* invstd,
                              const float* gamma, const float* beta, float slope, float* y, int B, int C, int H, int W,
                              sivae_stream_t stream);
+/* LeakyReLU sign mask (1 bit per element: pre-activation > 0; element e -> bit e&7 of byte e>>3).  The apply pass
+ * of "LeakyReLU(BN(x) + res)" (ResidualBlock output, train_soft_intro_vae.py:71-74) writes it next to its output and
+ * the backward reads it instead of the saved output: 1/32 of a tensor per backward pass, and an encoder block
+ * (output consumed only through the AvgPool2d behind it, :95-99) never writes its full-resolution output.
+ *   y_pooled != NULL: + AvgPool2d(2), y may be NULL; res_up != 0: res is [B][C][H/2][W/2] read through
+ *   Upsample(2,'nearest') addressing (:155).  mask: sivae_bn_signmask_bytes() bytes.  H even, W % 8 == 0. */
+size_t sivae_bn_signmask_bytes(int B, int C, int HW);
+int sivae_bn_apply_act_signmask(const float* x, const float* res, int res_up, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, float slope, float* y, float* y_pooled,
+                                unsigned char* mask, int B, int C, int H, int W, sivae_stream_t stream);
+/* backward with the sign from that mask.  dy_pooled != 0: dy is the gradient of AvgPool2d(2)(output) at half
+ * resolution; dz_sum != 0: dz_out = 2x2 block sums of the residual-branch gradient [B][C][H/2][W/2] (not both). */
+int sivae_bn_bwd_signmask(const float* dy, const unsigned char* mask, const float* x, const float* mean,
+                          const float* invstd, const float* gamma, float slope, float* dx, float* dz_out,
+                          float* dgamma, float* dbeta, int B, int C, int H, int W, int dy_pooled, int dz_sum,
+                          void* workspace, size_t workspace_bytes, sivae_stream_t stream);
 /* backward of the above: dz = dy*(s>0?1:slope); dx = BN backward of dz; dz_out (optional) = gradient
  * of the residual branch; dgamma/dbeta optional.  act_mode selects where the LeakyReLU sign s comes from:
  *   0 no activation, 1 the saved OUTPUT y (valid since slope > 0), 2 recomputed from x (needs beta; used

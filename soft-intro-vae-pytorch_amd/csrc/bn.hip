@@ -32,6 +32,28 @@ static SlicePlan plan_slices(long long n_per_ch, int C) {
 
 }  // namespace
 
+// ---- LeakyReLU sign mask: 1 bit per element (set = pre-activation > 0), element e -> bit (e & 7) of byte e >> 3.
+// A thread owns one float4 = one nibble; the even lane of each lane pair writes the byte (its nibble | the odd
+// lane's << 4, fetched with one DPP quad_perm move — the whole wave must be active at the call).  The backward of
+// "LeakyReLU(BN(c) + skip)" then reads 1/32 of a tensor for the sign instead of the saved output (and an encoder
+// block, whose output is only consumed through the AvgPool2d behind it, never writes that output at all).
+__device__ __forceinline__ unsigned sign_nibble(const float4 v) {
+  return (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+}
+__device__ __forceinline__ unsigned pair_nibbles(unsigned nib) {
+  const unsigned other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0xB1, 0xf, 0xf, true);  // lane ^ 1
+  return nib | (other << 4);
+}
+__device__ __forceinline__ unsigned load_nibble(const unsigned char* __restrict__ mask, size_t i4) {
+  return ((unsigned)mask[i4 >> 1] >> (unsigned)((i4 & 1) * 4)) & 0xfu;
+}
+__device__ __forceinline__ void apply_nibble(float* gz, unsigned nib, float slope) {
+  gz[0] = (nib & 1u) ? gz[0] : gz[0] * slope;
+  gz[1] = (nib & 2u) ? gz[1] : gz[1] * slope;
+  gz[2] = (nib & 4u) ? gz[2] : gz[2] * slope;
+  gz[3] = (nib & 8u) ? gz[3] : gz[3] * slope;
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward statistics
 // ------------------------------------------------------------------------------------------------
@@ -273,25 +295,37 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float slope,
-                                                       float* __restrict__ y, int C, int HW, size_t numel) {
+                                                       float* __restrict__ y, unsigned char* __restrict__ mask,
+                                                       int C, int HW, size_t numel) {
   const size_t stride = (size_t)gridDim.x * 256;
   if (VEC) {
     const size_t n4 = numel >> 2;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-      const size_t e = i << 2;
-      const int c = (int)((e / HW) % C);
-      const float m = mean[c], g = invstd[c] * gamma[c], bt = beta[c];
-      float4 v = reinterpret_cast<const float4*>(x)[i];
-      v.x = (v.x - m) * g + bt;
-      v.y = (v.y - m) * g + bt;
-      v.z = (v.z - m) * g + bt;
-      v.w = (v.w - m) * g + bt;
-      if (HAS_RES) {
-        const float4 r = reinterpret_cast<const float4*>(res)[i];
-        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    // (block-uniform trip count: the sign-mask lane exchange needs the whole wave)
+    for (size_t base = (size_t)blockIdx.x * 256; base < n4; base += stride) {
+      const size_t i = base + threadIdx.x;
+      const bool ok = i < n4;
+      unsigned nib = 0;
+      if (ok) {
+        const size_t e = i << 2;
+        const int c = (int)((e / HW) % C);
+        const float m = mean[c], g = invstd[c] * gamma[c], bt = beta[c];
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        v.x = (v.x - m) * g + bt;
+        v.y = (v.y - m) * g + bt;
+        v.z = (v.z - m) * g + bt;
+        v.w = (v.w - m) * g + bt;
+        if (HAS_RES) {
+          const float4 r = reinterpret_cast<const float4*>(res)[i];
+          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        nib = sign_nibble(v);
+        v.x = lrelu(v.x, slope); v.y = lrelu(v.y, slope); v.z = lrelu(v.z, slope); v.w = lrelu(v.w, slope);
+        reinterpret_cast<float4*>(y)[i] = v;
       }
-      v.x = lrelu(v.x, slope); v.y = lrelu(v.y, slope); v.z = lrelu(v.z, slope); v.w = lrelu(v.w, slope);
-      reinterpret_cast<float4*>(y)[i] = v;
+      if (mask != nullptr) {
+        const unsigned byte = pair_nibbles(nib);
+        if (ok && !(threadIdx.x & 1)) mask[i >> 1] = (unsigned char)byte;
+      }
     }
   } else {
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < numel; e += stride) {
@@ -303,20 +337,21 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
   }
 }
 
-extern "C" int sivae_bn_apply_act(const float* x, const float* res, const float* mean, const float* invstd,
-                                  const float* gamma, const float* beta, float slope, float* y, int B, int C,
-                                  int HW, hipStream_t stream) {
+static int bn_apply_impl(const float* x, const float* res, const float* mean, const float* invstd,
+                         const float* gamma, const float* beta, float slope, float* y, unsigned char* mask, int B,
+                         int C, int HW, hipStream_t stream) {
   if (!x || !mean || !invstd || !gamma || !beta || !y) return SIVAE_ERR_NULL;
   if (B <= 0 || C <= 0 || HW <= 0) return SIVAE_ERR_SHAPE;
   const size_t numel = (size_t)B * C * HW;
   const bool vec = (HW & 3) == 0;
+  if (mask && !vec) return SIVAE_ERR_SHAPE;
   long long work = vec ? (long long)(numel >> 2) : (long long)numel;
   int nb = cdiv(work, 256);
   if (nb > 8192) nb = 8192;
   if (nb < 1) nb = 1;
 #define LAUNCH(R, V) \
   hipLaunchKernelGGL((bn_apply_kernel<R, V>), dim3(nb), dim3(256), 0, stream, x, res, mean, invstd, gamma, beta, \
-                     slope, y, C, HW, numel)
+                     slope, y, mask, C, HW, numel)
   if (res) {
     if (vec) LAUNCH(true, true); else LAUNCH(true, false);
   } else {
@@ -324,6 +359,12 @@ extern "C" int sivae_bn_apply_act(const float* x, const float* res, const float*
   }
 #undef LAUNCH
   return sivae_launch_status();
+}
+
+extern "C" int sivae_bn_apply_act(const float* x, const float* res, const float* mean, const float* invstd,
+                                  const float* gamma, const float* beta, float slope, float* y, int B, int C,
+                                  int HW, hipStream_t stream) {
+  return bn_apply_impl(x, res, mean, invstd, gamma, beta, slope, y, nullptr, B, C, HW, stream);
 }
 
 // Same op with the residual stored at HALF resolution and read through nn.Upsample(2,'nearest') addressing
@@ -334,30 +375,42 @@ __global__ void __launch_bounds__(256) bn_apply_resup_kernel(const float* __rest
                                                              const float* __restrict__ invstd,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float slope,
-                                                             float* __restrict__ y, int C, int H, int W, size_t numel) {
+                                                             float* __restrict__ y, unsigned char* __restrict__ mask,
+                                                             int C, int H, int W, size_t numel) {
   const size_t stride = (size_t)gridDim.x * 256;
   const int W4 = W >> 2, Hs = H >> 1, Ws = W >> 1;
   const size_t n4 = numel >> 2;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-    const int w4 = (int)(i % W4);
-    size_t t = i / W4;
-    const int h = (int)(t % H);
-    t /= H;  // b*C + c
-    const int c = (int)(t % C);
-    const float m = mean[c], g = invstd[c] * gamma[c], bt = beta[c];
-    float4 v = reinterpret_cast<const float4*>(x)[i];
-    const float2 r = *reinterpret_cast<const float2*>(res + (t * Hs + (h >> 1)) * Ws + 2 * w4);
-    v.x = lrelu((v.x - m) * g + bt + r.x, slope);
-    v.y = lrelu((v.y - m) * g + bt + r.x, slope);
-    v.z = lrelu((v.z - m) * g + bt + r.y, slope);
-    v.w = lrelu((v.w - m) * g + bt + r.y, slope);
-    reinterpret_cast<float4*>(y)[i] = v;
+  for (size_t base = (size_t)blockIdx.x * 256; base < n4; base += stride) {
+    const size_t i = base + threadIdx.x;
+    const bool ok = i < n4;
+    unsigned nib = 0;
+    if (ok) {
+      const int w4 = (int)(i % W4);
+      size_t t = i / W4;
+      const int h = (int)(t % H);
+      t /= H;  // b*C + c
+      const int c = (int)(t % C);
+      const float m = mean[c], g = invstd[c] * gamma[c], bt = beta[c];
+      float4 v = reinterpret_cast<const float4*>(x)[i];
+      const float2 r = *reinterpret_cast<const float2*>(res + (t * Hs + (h >> 1)) * Ws + 2 * w4);
+      v.x = (v.x - m) * g + bt + r.x;
+      v.y = (v.y - m) * g + bt + r.x;
+      v.z = (v.z - m) * g + bt + r.y;
+      v.w = (v.w - m) * g + bt + r.y;
+      nib = sign_nibble(v);
+      v.x = lrelu(v.x, slope); v.y = lrelu(v.y, slope); v.z = lrelu(v.z, slope); v.w = lrelu(v.w, slope);
+      reinterpret_cast<float4*>(y)[i] = v;
+    }
+    if (mask != nullptr) {
+      const unsigned byte = pair_nibbles(nib);
+      if (ok && !(threadIdx.x & 1)) mask[i >> 1] = (unsigned char)byte;
+    }
   }
 }
 
-extern "C" int sivae_bn_apply_act_resup(const float* x, const float* res_half, const float* mean, const float* invstd,
-                                        const float* gamma, const float* beta, float slope, float* y, int B, int C,
-                                        int H, int W, hipStream_t stream) {
+static int bn_apply_resup_impl(const float* x, const float* res_half, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, float slope, float* y, unsigned char* mask,
+                               int B, int C, int H, int W, hipStream_t stream) {
   if (!x || !res_half || !mean || !invstd || !gamma || !beta || !y) return SIVAE_ERR_NULL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 3)) return SIVAE_ERR_SHAPE;
   const size_t numel = (size_t)B * C * H * W;
@@ -365,8 +418,14 @@ extern "C" int sivae_bn_apply_act_resup(const float* x, const float* res_half, c
   if (nb > 8192) nb = 8192;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(bn_apply_resup_kernel, dim3(nb), dim3(256), 0, stream, x, res_half, mean, invstd, gamma, beta,
-                     slope, y, C, H, W, numel);
+                     slope, y, mask, C, H, W, numel);
   return sivae_launch_status();
+}
+
+extern "C" int sivae_bn_apply_act_resup(const float* x, const float* res_half, const float* mean, const float* invstd,
+                                        const float* gamma, const float* beta, float slope, float* y, int B, int C,
+                                        int H, int W, hipStream_t stream) {
+  return bn_apply_resup_impl(x, res_half, mean, invstd, gamma, beta, slope, y, nullptr, B, C, H, W, stream);
 }
 
 // Same op, also writing AvgPool2d(2) of the result (the pool that follows every encoder block and the stem,
@@ -378,54 +437,102 @@ __global__ void __launch_bounds__(256) bn_apply_pool_kernel(const float* __restr
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float slope,
-                                                            float* __restrict__ y, float* __restrict__ yp, int C, int H,
-                                                            int W, size_t n_quads) {
+                                                            float* __restrict__ y, float* __restrict__ yp,
+                                                            unsigned char* __restrict__ mask, int C, int H, int W,
+                                                            size_t n_quads) {
   const size_t stride = (size_t)gridDim.x * 256;
   const int W4 = W >> 2, H2 = H >> 1;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_quads; i += stride) {
-    const int w4 = (int)(i % W4);
-    size_t t = i / W4;
-    const int h2 = (int)(t % H2);
-    t /= H2;  // b*C + c
-    const int c = (int)(t % C);
-    const float m = mean[c], g = invstd[c] * gamma[c], bt = beta[c];
-    const size_t o0 = (t * H + 2 * h2) * (size_t)W + 4 * w4, o1 = o0 + W;
-    float4 a = *reinterpret_cast<const float4*>(x + o0), b = *reinterpret_cast<const float4*>(x + o1);
-    a.x = (a.x - m) * g + bt; a.y = (a.y - m) * g + bt; a.z = (a.z - m) * g + bt; a.w = (a.w - m) * g + bt;
-    b.x = (b.x - m) * g + bt; b.y = (b.y - m) * g + bt; b.z = (b.z - m) * g + bt; b.w = (b.w - m) * g + bt;
-    if (HAS_RES) {
-      const float4 ra = *reinterpret_cast<const float4*>(res + o0), rb = *reinterpret_cast<const float4*>(res + o1);
-      a.x += ra.x; a.y += ra.y; a.z += ra.z; a.w += ra.w;
-      b.x += rb.x; b.y += rb.y; b.z += rb.z; b.w += rb.w;
+  for (size_t base = (size_t)blockIdx.x * 256; base < n_quads; base += stride) {
+    const size_t i = base + threadIdx.x;
+    const bool ok = i < n_quads;
+    unsigned nib0 = 0, nib1 = 0;
+    size_t m0 = 0, m1 = 0;
+    if (ok) {
+      const int w4 = (int)(i % W4);
+      size_t t = i / W4;
+      const int h2 = (int)(t % H2);
+      t /= H2;  // b*C + c
+      const int c = (int)(t % C);
+      const float m = mean[c], g = invstd[c] * gamma[c], bt = beta[c];
+      const size_t o0 = (t * H + 2 * h2) * (size_t)W + 4 * w4, o1 = o0 + W;
+      float4 a = *reinterpret_cast<const float4*>(x + o0), b = *reinterpret_cast<const float4*>(x + o1);
+      a.x = (a.x - m) * g + bt; a.y = (a.y - m) * g + bt; a.z = (a.z - m) * g + bt; a.w = (a.w - m) * g + bt;
+      b.x = (b.x - m) * g + bt; b.y = (b.y - m) * g + bt; b.z = (b.z - m) * g + bt; b.w = (b.w - m) * g + bt;
+      if (HAS_RES) {
+        const float4 ra = *reinterpret_cast<const float4*>(res + o0), rb = *reinterpret_cast<const float4*>(res + o1);
+        a.x += ra.x; a.y += ra.y; a.z += ra.z; a.w += ra.w;
+        b.x += rb.x; b.y += rb.y; b.z += rb.z; b.w += rb.w;
+      }
+      nib0 = sign_nibble(a);
+      nib1 = sign_nibble(b);
+      m0 = o0 >> 3;  // (W % 8 == 0 with a mask: the lane pair (w4, w4 ^ 1) shares one byte per row)
+      m1 = o1 >> 3;
+      a.x = lrelu(a.x, slope); a.y = lrelu(a.y, slope); a.z = lrelu(a.z, slope); a.w = lrelu(a.w, slope);
+      b.x = lrelu(b.x, slope); b.y = lrelu(b.y, slope); b.z = lrelu(b.z, slope); b.w = lrelu(b.w, slope);
+      if (y != nullptr) {
+        *reinterpret_cast<float4*>(y + o0) = a;
+        *reinterpret_cast<float4*>(y + o1) = b;
+      }
+      // same summation order as avgpool2_fwd_kernel: ((row0.l + row0.r) + (row1.l + row1.r)) * 0.25
+      *reinterpret_cast<float2*>(yp + (t * H2 + h2) * (size_t)(W >> 1) + 2 * w4) =
+          make_float2(((a.x + a.y) + (b.x + b.y)) * 0.25f, ((a.z + a.w) + (b.z + b.w)) * 0.25f);
     }
-    a.x = lrelu(a.x, slope); a.y = lrelu(a.y, slope); a.z = lrelu(a.z, slope); a.w = lrelu(a.w, slope);
-    b.x = lrelu(b.x, slope); b.y = lrelu(b.y, slope); b.z = lrelu(b.z, slope); b.w = lrelu(b.w, slope);
-    if (y != nullptr) {
-      *reinterpret_cast<float4*>(y + o0) = a;
-      *reinterpret_cast<float4*>(y + o1) = b;
+    if (mask != nullptr) {
+      const unsigned byte0 = pair_nibbles(nib0), byte1 = pair_nibbles(nib1);
+      if (ok && !(threadIdx.x & 1)) {
+        mask[m0] = (unsigned char)byte0;
+        mask[m1] = (unsigned char)byte1;
+      }
     }
-    // same summation order as avgpool2_fwd_kernel: ((row0.l + row0.r) + (row1.l + row1.r)) * 0.25
-    *reinterpret_cast<float2*>(yp + (t * H2 + h2) * (size_t)(W >> 1) + 2 * w4) =
-        make_float2(((a.x + a.y) + (b.x + b.y)) * 0.25f, ((a.z + a.w) + (b.z + b.w)) * 0.25f);
   }
 }
 
-extern "C" int sivae_bn_apply_act_pool(const float* x, const float* res, const float* mean, const float* invstd,
-                                       const float* gamma, const float* beta, float slope, float* y, float* y_pooled,
-                                       int B, int C, int H, int W, hipStream_t stream) {
+static int bn_apply_pool_impl(const float* x, const float* res, const float* mean, const float* invstd,
+                              const float* gamma, const float* beta, float slope, float* y, float* y_pooled,
+                              unsigned char* mask, int B, int C, int H, int W, hipStream_t stream) {
   if (!x || !mean || !invstd || !gamma || !beta || !y_pooled) return SIVAE_ERR_NULL;  // y may be NULL: pooled only
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 3)) return SIVAE_ERR_SHAPE;
+  if (mask && (W & 7)) return SIVAE_ERR_SHAPE;
   const size_t n_quads = (size_t)B * C * (H >> 1) * (W >> 2);
   int nb = cdiv((long long)n_quads, 256 * 2);
   if (nb > 8192) nb = 8192;
   if (nb < 1) nb = 1;
   if (res)
     hipLaunchKernelGGL(bn_apply_pool_kernel<true>, dim3(nb), dim3(256), 0, stream, x, res, mean, invstd, gamma, beta,
-                       slope, y, y_pooled, C, H, W, n_quads);
+                       slope, y, y_pooled, mask, C, H, W, n_quads);
   else
     hipLaunchKernelGGL(bn_apply_pool_kernel<false>, dim3(nb), dim3(256), 0, stream, x, res, mean, invstd, gamma, beta,
-                       slope, y, y_pooled, C, H, W, n_quads);
+                       slope, y, y_pooled, mask, C, H, W, n_quads);
   return sivae_launch_status();
+}
+
+extern "C" int sivae_bn_apply_act_pool(const float* x, const float* res, const float* mean, const float* invstd,
+                                       const float* gamma, const float* beta, float slope, float* y, float* y_pooled,
+                                       int B, int C, int H, int W, hipStream_t stream) {
+  return bn_apply_pool_impl(x, res, mean, invstd, gamma, beta, slope, y, y_pooled, nullptr, B, C, H, W, stream);
+}
+
+// ---- the three apply flavours with the LeakyReLU sign mask as an extra output (see sign_nibble above):
+//   y_pooled != NULL : BatchNorm + residual + LeakyReLU + AvgPool2d(2); y (full resolution) may be NULL
+//   res_up != 0      : residual at half resolution, read through Upsample(2,'nearest') addressing
+//   otherwise        : plain apply.           mask: sivae_bn_signmask_bytes(B, C, H*W) bytes.  H even, W % 8 == 0.
+extern "C" size_t sivae_bn_signmask_bytes(int B, int C, int HW) {
+  if (B <= 0 || C <= 0 || HW <= 0) return 0;
+  return ((size_t)B * C * HW + 7) / 8;
+}
+
+extern "C" int sivae_bn_apply_act_signmask(const float* x, const float* res, int res_up, const float* mean,
+                                           const float* invstd, const float* gamma, const float* beta, float slope,
+                                           float* y, float* y_pooled, unsigned char* mask, int B, int C, int H, int W,
+                                           hipStream_t stream) {
+  if (!mask) return SIVAE_ERR_NULL;
+  if (H <= 0 || W <= 0 || (H & 1) || (W & 7)) return SIVAE_ERR_SHAPE;
+  if (y_pooled) {
+    if (res_up) return SIVAE_ERR_MODE;
+    return bn_apply_pool_impl(x, res, mean, invstd, gamma, beta, slope, y, y_pooled, mask, B, C, H, W, stream);
+  }
+  if (res_up) return bn_apply_resup_impl(x, res, mean, invstd, gamma, beta, slope, y, mask, B, C, H, W, stream);
+  return bn_apply_impl(x, res, mean, invstd, gamma, beta, slope, y, mask, B, C, H * W, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -455,7 +562,7 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ beta, float slope,
                                                              double* __restrict__ part, int C, int HW,
                                                              long long n_per_ch, long long slice_len, int S,
-                                                             int pool_w) {
+                                                             int pool_w, const unsigned char* __restrict__ mask) {
   __shared__ double red[4];
   const int c = blockIdx.x, s = blockIdx.y;
   const long long n0 = (long long)s * slice_len;
@@ -482,6 +589,8 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float* __rest
         gz[1] = ((xv.y - m) * gsc + bt) > 0.f ? gz[1] : gz[1] * slope;
         gz[2] = ((xv.z - m) * gsc + bt) > 0.f ? gz[2] : gz[2] * slope;
         gz[3] = ((xv.w - m) * gsc + bt) > 0.f ? gz[3] : gz[3] * slope;
+      } else if (ACT == 3) {
+        apply_nibble(gz, load_nibble(mask, o >> 2), slope);
       }
       const float xh[4] = {(xv.x - m) * is, (xv.y - m) * is, (xv.z - m) * is, (xv.w - m) * is};
 #pragma unroll
@@ -533,7 +642,8 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const float* __restrict_
                                                         const float* __restrict__ beta,
                                                         const float* __restrict__ coef, float slope,
                                                         float* __restrict__ dx, float* __restrict__ dz_out, int C,
-                                                        int HW, size_t numel, int pool_w) {
+                                                        int HW, size_t numel, int pool_w,
+                                                        const unsigned char* __restrict__ mask) {
   const size_t stride = (size_t)gridDim.x * 256;
   if (VEC) {
     const size_t n4 = numel >> 2;
@@ -556,6 +666,8 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const float* __restrict_
         gz[1] = ((xv.y - m) * gs + bt) > 0.f ? gz[1] : gz[1] * slope;
         gz[2] = ((xv.z - m) * gs + bt) > 0.f ? gz[2] : gz[2] * slope;
         gz[3] = ((xv.w - m) * gs + bt) > 0.f ? gz[3] : gz[3] * slope;
+      } else if (ACT == 3) {
+        apply_nibble(gz, load_nibble(mask, i), slope);
       }
       float4 o;
       o.x = gs * (gz[0] - c1 - (xv.x - m) * is * c2);
@@ -582,6 +694,7 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const float* __restrict_
 // 2x2 BLOCK SUM at half resolution — the adjoint of the nn.Upsample (:155) the block's input went through — instead of
 // the full-resolution tensor: in the decoder dz is only ever consumed through that sum (identity skip, or the 1x1
 // expand conv that runs at half resolution).  One thread = 2 rows x 4 columns; H even, W % 4 == 0.
+template <bool MASK>
 __global__ void __launch_bounds__(256) bn_bwd_dx_dzsum_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                               const float* __restrict__ x,
                                                               const float* __restrict__ mean,
@@ -589,7 +702,8 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_dzsum_kernel(const float* __res
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ coef, float slope,
                                                               float* __restrict__ dx, float* __restrict__ dz_half, int C,
-                                                              int H, int W, size_t n_quads) {
+                                                              int H, int W, size_t n_quads,
+                                                              const unsigned char* __restrict__ mask) {
   const size_t stride = (size_t)gridDim.x * 256;
   const int W4 = W >> 2, H2 = H >> 1;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_quads; i += stride) {
@@ -606,10 +720,16 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_dzsum_kernel(const float* __res
     for (int rr = 0; rr < 2; ++rr) {
       const size_t o = o0 + (size_t)rr * W;
       const float4 g = *reinterpret_cast<const float4*>(dy + o);
-      const float4 yv = *reinterpret_cast<const float4*>(y + o);
       const float4 xv = *reinterpret_cast<const float4*>(x + o);
-      const float gz0 = yv.x > 0.f ? g.x : g.x * slope, gz1 = yv.y > 0.f ? g.y : g.y * slope;
-      const float gz2 = yv.z > 0.f ? g.z : g.z * slope, gz3 = yv.w > 0.f ? g.w : g.w * slope;
+      float gzv[4] = {g.x, g.y, g.z, g.w};
+      if (MASK) {
+        apply_nibble(gzv, load_nibble(mask, o >> 2), slope);
+      } else {
+        const float4 yv = *reinterpret_cast<const float4*>(y + o);
+        gzv[0] = yv.x > 0.f ? g.x : g.x * slope; gzv[1] = yv.y > 0.f ? g.y : g.y * slope;
+        gzv[2] = yv.z > 0.f ? g.z : g.z * slope; gzv[3] = yv.w > 0.f ? g.w : g.w * slope;
+      }
+      const float gz0 = gzv[0], gz1 = gzv[1], gz2 = gzv[2], gz3 = gzv[3];
       float4 d;
       d.x = gs * (gz0 - c1 - (xv.x - m) * is * c2);
       d.y = gs * (gz1 - c1 - (xv.y - m) * is * c2);
@@ -632,10 +752,12 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_dzsum_kernel(const float* __res
 static int bn_bwd_impl(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
                        const float* gamma, const float* beta, int act_mode, float slope, float* dx, float* dz_out,
                        float* dgamma, float* dbeta, int B, int C, int HW, int pool_w, void* workspace,
-                       size_t workspace_bytes, hipStream_t stream, int dzsum_w = 0) {
+                       size_t workspace_bytes, hipStream_t stream, int dzsum_w = 0,
+                       const unsigned char* mask = nullptr) {
   if (!dy || !x || !mean || !invstd || !gamma || !dx) return SIVAE_ERR_NULL;
-  if (act_mode < 0 || act_mode > 2) return SIVAE_ERR_MODE;
+  if (act_mode < 0 || act_mode > 3) return SIVAE_ERR_MODE;
   if (act_mode == 1 && !y) return SIVAE_ERR_NULL;
+  if (act_mode == 3 && (!mask || (HW & 3))) return SIVAE_ERR_NULL;  // sign from the 1-bit mask (float4 path only)
   if (act_mode == 2 && !beta) return SIVAE_ERR_NULL;
   if (B <= 0 || C <= 0 || HW <= 0) return SIVAE_ERR_SHAPE;
   if (!workspace || workspace_bytes < sivae_bn_workspace_bytes(B, C, HW)) return SIVAE_ERR_WORKSPACE;
@@ -645,8 +767,8 @@ static int bn_bwd_impl(const float* dy, const float* y, const float* x, const fl
   float* coef = (float*)(part + (size_t)C * p.S * 2);
 #define LAUNCHP(A) \
   hipLaunchKernelGGL((bn_bwd_partial_kernel<A>), dim3(C, p.S), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma, \
-                     beta, slope, part, C, HW, n, p.len, p.S, pool_w)
-  if (act_mode == 0) LAUNCHP(0); else if (act_mode == 1) LAUNCHP(1); else LAUNCHP(2);
+                     beta, slope, part, C, HW, n, p.len, p.S, pool_w, mask)
+  if (act_mode == 0) LAUNCHP(0); else if (act_mode == 1) LAUNCHP(1); else if (act_mode == 2) LAUNCHP(2); else LAUNCHP(3);
 #undef LAUNCHP
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, (const double*)part, p.S, C,
                      (double)n, dgamma, dbeta, coef);
@@ -657,8 +779,12 @@ static int bn_bwd_impl(const float* dy, const float* y, const float* x, const fl
     int nq = cdiv((long long)n_quads, 256 * 2);
     if (nq > 8192) nq = 8192;
     if (nq < 1) nq = 1;
-    hipLaunchKernelGGL(bn_bwd_dx_dzsum_kernel, dim3(nq), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma,
-                       (const float*)coef, slope, dx, dz_out, C, H_, W_, n_quads);
+    if (act_mode == 3)
+      hipLaunchKernelGGL(bn_bwd_dx_dzsum_kernel<true>, dim3(nq), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma,
+                         (const float*)coef, slope, dx, dz_out, C, H_, W_, n_quads, mask);
+    else
+      hipLaunchKernelGGL(bn_bwd_dx_dzsum_kernel<false>, dim3(nq), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma,
+                         (const float*)coef, slope, dx, dz_out, C, H_, W_, n_quads, mask);
     return sivae_launch_status();
   }
   const bool vec = (HW & 3) == 0;
@@ -668,12 +794,13 @@ static int bn_bwd_impl(const float* dy, const float* y, const float* x, const fl
   if (nb < 1) nb = 1;
 #define LAUNCH(A, Z, V) \
   hipLaunchKernelGGL((bn_bwd_dx_kernel<A, Z, V>), dim3(nb), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma, \
-                     beta, (const float*)coef, slope, dx, dz_out, C, HW, numel, pool_w)
+                     beta, (const float*)coef, slope, dx, dz_out, C, HW, numel, pool_w, mask)
 #define LAUNCH_A(A) \
   { if (hz) { if (vec) LAUNCH(A, true, true); else LAUNCH(A, true, false); } \
     else { if (vec) LAUNCH(A, false, true); else LAUNCH(A, false, false); } }
   const bool hz = dz_out != nullptr;
-  if (act_mode == 0) LAUNCH_A(0) else if (act_mode == 1) LAUNCH_A(1) else LAUNCH_A(2)
+  if (act_mode == 0) LAUNCH_A(0) else if (act_mode == 1) LAUNCH_A(1) else if (act_mode == 2) LAUNCH_A(2)
+  else { if (hz) LAUNCH(3, true, true); else LAUNCH(3, false, true); }
 #undef LAUNCH_A
 #undef LAUNCH
   return sivae_launch_status();
@@ -709,6 +836,22 @@ extern "C" int sivae_bn_bwd_pooled_dy(const float* dy_half, const float* y, cons
   if (H <= 0 || W <= 0 || (H & 1) || (W & 3)) return SIVAE_ERR_SHAPE;
   return bn_bwd_impl(dy_half, y, x, mean, invstd, gamma, beta, act_mode, slope, dx, dz_out, dgamma, dbeta, B, C, H * W,
                      W, workspace, workspace_bytes, stream);
+}
+
+// Backward of "LeakyReLU(BN(x) + res)" with the LeakyReLU sign taken from the 1-bit mask the apply pass wrote
+// (sivae_bn_apply_act_signmask) — 1/32 of a tensor per pass instead of the saved output.  dy_pooled != 0: dy is
+// the gradient of AvgPool2d(2)(output) at half resolution; dz_sum != 0: dz_out is the 2x2 block sum of the
+// residual-branch gradient ([B][C][H/2][W/2]); not both.  H even, W % 8 == 0.
+extern "C" int sivae_bn_bwd_signmask(const float* dy, const unsigned char* mask, const float* x, const float* mean,
+                                     const float* invstd, const float* gamma, float slope, float* dx, float* dz_out,
+                                     float* dgamma, float* dbeta, int B, int C, int H, int W, int dy_pooled, int dz_sum,
+                                     void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (!mask) return SIVAE_ERR_NULL;
+  if (H <= 0 || W <= 0 || (H & 1) || (W & 7)) return SIVAE_ERR_SHAPE;
+  if (dy_pooled && dz_sum) return SIVAE_ERR_MODE;
+  if (dz_sum && !dz_out) return SIVAE_ERR_NULL;
+  return bn_bwd_impl(dy, nullptr, x, mean, invstd, gamma, nullptr, 3, slope, dx, dz_out, dgamma, dbeta, B, C, H * W,
+                     dy_pooled ? W : 0, workspace, workspace_bytes, stream, dz_sum ? W : 0, mask);
 }
 
 // ---- backward whose first reduction was done by the producer of dy (sivae_conv2d_wino_dgrad_bnbwd): per-tile
@@ -754,10 +897,10 @@ extern "C" int sivae_bn_bwd_from_partials(const float* dy, const float* x, const
   float* dz_out = nullptr;
   if (vec)
     hipLaunchKernelGGL((bn_bwd_dx_kernel<2, false, true>), dim3(nb), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma,
-                       beta, (const float*)coef, slope, dx, dz_out, C, HW, numel, 0);
+                       beta, (const float*)coef, slope, dx, dz_out, C, HW, numel, 0, (const unsigned char*)nullptr);
   else
     hipLaunchKernelGGL((bn_bwd_dx_kernel<2, false, false>), dim3(nb), dim3(256), 0, stream, dy, y, x, mean, invstd,
-                       gamma, beta, (const float*)coef, slope, dx, dz_out, C, HW, numel, 0);
+                       gamma, beta, (const float*)coef, slope, dx, dz_out, C, HW, numel, 0, (const unsigned char*)nullptr);
   return sivae_launch_status();
 }
 
@@ -804,7 +947,7 @@ extern "C" int sivae_bn_bwd_reduce(const float* dy, const float* y, const float*
   double* part = (double*)workspace;
 #define LAUNCHP(A) \
   hipLaunchKernelGGL((bn_bwd_partial_kernel<A>), dim3(C, p.S), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma, \
-                     beta, slope, part, C, HW, n, p.len, p.S, 0)
+                     beta, slope, part, C, HW, n, p.len, p.S, 0, (const unsigned char*)nullptr)
   if (act_mode == 0) LAUNCHP(0); else if (act_mode == 1) LAUNCHP(1); else LAUNCHP(2);
 #undef LAUNCHP
   hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, (const double*)part, p.S, C, sums);
@@ -834,7 +977,7 @@ extern "C" int sivae_bn_bwd_apply(const float* dy, const float* y, const float* 
   if (nb < 1) nb = 1;
 #define LAUNCH(A, Z, V) \
   hipLaunchKernelGGL((bn_bwd_dx_kernel<A, Z, V>), dim3(nb), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma, \
-                     beta, (const float*)coef, slope, dx, dz_out, C, HW, numel, 0)
+                     beta, (const float*)coef, slope, dx, dz_out, C, HW, numel, 0, (const unsigned char*)nullptr)
 #define LAUNCH_A(A) \
   { if (hz) { if (vec) LAUNCH(A, true, true); else LAUNCH(A, true, false); } \
     else { if (vec) LAUNCH(A, false, true); else LAUNCH(A, false, false); } }

@@ -173,13 +173,23 @@ class ResBlockFn(torch.autograd.Function):
             c, p2 = ops.conv2d_fwd(h, packed(w2, 0), Co, 3, pro=pro1), None
         mean2, invstd2 = _stats(p2, B, Co, H * W, st2)
         fused = None
-        if post == "pool" and not (x_up and w_exp is None):
-            fused = ops.bn_apply_act_pool(c, idt, mean2, invstd2, g2.detach(), b2.detach(), SLOPE)
-        if fused is not None:
-            out, y = fused  # BatchNorm + residual + LeakyReLU and the AvgPool2d that follows, one pass
+        pool_fusable = post == "pool" and not (x_up and w_exp is None)
+        if st1.training and st2.training and ops.bn_signmask_supported(c):
+            # the backward takes the LeakyReLU sign from a 1-bit mask written here, not from the output: `out` below
+            # is that mask (uint8), and a pooled block never writes its full-resolution output
+            full, y, out = ops.bn_apply_act_signmask(c, idt, mean2, invstd2, g2.detach(), b2.detach(), SLOPE,
+                                                     res_up=x_up, pool=pool_fusable, want_full=not pool_fusable)
+            if not pool_fusable:
+                y = _post_fwd(full, post)
+            del full
         else:
-            out = ops.bn_apply_act(c, idt, mean2, invstd2, g2.detach(), b2.detach(), SLOPE, res_up=x_up)
-            y = _post_fwd(out, post)
+            if pool_fusable:
+                fused = ops.bn_apply_act_pool(c, idt, mean2, invstd2, g2.detach(), b2.detach(), SLOPE)
+            if fused is not None:
+                out, y = fused  # BatchNorm + residual + LeakyReLU and the AvgPool2d that follows, one pass
+            else:
+                out = ops.bn_apply_act(c, idt, mean2, invstd2, g2.detach(), b2.detach(), SLOPE, res_up=x_up)
+                y = _post_fwd(out, post)
         if cache is not None:
             cache.update(a=a, h=h, c=c, out=out, mean1=mean1, invstd1=invstd1, mean2=mean2, invstd2=invstd2, y=y)
         ctx.post = post
@@ -201,7 +211,19 @@ class ResBlockFn(torch.autograd.Function):
         # BN2 + residual + LeakyReLU; the AvgPool2d that follows an encoder block is undone while reading dy
         x_up = ctx.x_up
         dzh = None  # 2x2 block sums of dz: all a block behind an Upsample ever needs of it
-        if x_up and ctx.post != "pool" and ops.bn_bwd_dzsum_supported(c):
+        if out.dtype == torch.uint8:  # `out` is the LeakyReLU sign mask (1 bit per element)
+            if ctx.post == "pool" and not (x_up and not ctx.has_exp):
+                dc, dz, dg2, db2 = ops.bn_bwd_signmask(dy.contiguous(), out, c, mean2, invstd2, g2, SLOPE,
+                                                       dy_pooled=True, want_param_grads=need_bn2)
+            else:
+                d_out = _post_bwd(dy.contiguous(), ctx.post, c.shape)
+                want_sum = x_up and ctx.post != "pool"
+                dc, dz, dg2, db2 = ops.bn_bwd_signmask(d_out, out, c, mean2, invstd2, g2, SLOPE, dz_sum=want_sum,
+                                                       want_param_grads=need_bn2)
+                if want_sum:
+                    dzh, dz = dz, None
+                del d_out
+        elif x_up and ctx.post != "pool" and ops.bn_bwd_dzsum_supported(c):
             d_out = _post_bwd(dy.contiguous(), ctx.post, out.shape)
             dc, dzh, dg2, db2 = ops.bn_bwd_dzsum(d_out, out, c, mean2, invstd2, g2, SLOPE, want_param_grads=need_bn2)
             dz = None

@@ -151,6 +151,9 @@ WINO_UP = os.environ.get("SIVAE_WINO_UP", "1") != "0"  # phase-decomposed F(2x2,
 # next-item prefetch, which costs more than the 14 ms reduction pass it removes) -> off by default.
 FUSE_BN_BWD = os.environ.get("SIVAE_FUSE_BN_BWD", "0") == "1"
 WINO_WGRAD = os.environ.get("SIVAE_WINO_WGRAD", os.environ.get("SIVAE_WINO", "1")) != "0"
+# 1-bit LeakyReLU sign mask written by the block's last BatchNorm pass and read by its backward instead of the saved
+# output (SIVAE_SIGNMASK=0: the backward reads the output tensor again)
+SIGNMASK = os.environ.get("SIVAE_SIGNMASK", "1") != "0"
 
 
 class PackedW:
@@ -469,6 +472,49 @@ def bn_apply_act_pool(x, res, mean, invstd, gamma, beta, slope=LRELU_SLOPE, want
     _lib.call("sivae_bn_apply_act_pool", _p(x), _p(res), _p(mean), _p(invstd), _p(gamma), _p(beta), float(slope),
               _p(y), _p(yp), B, C, H, W, _s())
     return y, yp
+
+
+def bn_signmask_supported(x):
+    """the 1-bit LeakyReLU sign mask path: local BatchNorm, H even, W % 8 == 0"""
+    return SIGNMASK and SYNC_BN is None and x.dim() == 4 and not (x.shape[2] & 1) and not (x.shape[3] & 7)
+
+
+def bn_apply_act_signmask(x, res, mean, invstd, gamma, beta, slope=LRELU_SLOPE, res_up=False, pool=False,
+                          want_full=True):
+    """LeakyReLU(BN(x) + res) -> (y, y_pooled, mask): y is None with want_full=False (pool only), y_pooled is None
+    without pool; mask = the activation's sign bits (uint8, 1 bit per element) for bn_bwd_signmask"""
+    _require(x, res, mean, invstd, gamma, beta)
+    B, C, H, W = x.shape
+    assert pool or want_full
+    y = torch.empty_like(x) if want_full else None
+    yp = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device) if pool else None
+    mask = torch.empty(_lib.load().sivae_bn_signmask_bytes(B, C, H * W), dtype=torch.uint8, device=x.device)
+    _lib.call("sivae_bn_apply_act_signmask", _p(x), _p(res), int(bool(res_up)), _p(mean), _p(invstd), _p(gamma),
+              _p(beta), float(slope), _p(y), _p(yp), _p(mask), B, C, H, W, _s())
+    return y, yp, mask
+
+
+def bn_bwd_signmask(dy, mask, x, mean, invstd, gamma, slope=LRELU_SLOPE, dy_pooled=False, dz_sum=False,
+                    want_dz=True, want_param_grads=True):
+    """backward of bn_apply_act_signmask -> dx, dz (full resolution, or its 2x2 block sums with dz_sum), dgamma,
+    dbeta.  dy_pooled: dy is the gradient of the pooled output."""
+    _require(dy, x, mean, invstd, gamma)
+    B, C, H, W = x.shape
+    if mask.dtype != torch.uint8 or not mask.is_cuda or mask.numel() < _lib.load().sivae_bn_signmask_bytes(B, C, H * W):
+        raise TypeError("sivae_hip: bn_bwd_signmask needs the uint8 device mask bn_apply_act_signmask returned")
+    ws = workspace(_lib.load().sivae_bn_workspace_bytes(B, C, H * W), x.device)
+    dx = torch.empty_like(x)
+    dz = None
+    if dz_sum:
+        dz = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    elif want_dz:
+        dz = torch.empty_like(x)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
+    _lib.call("sivae_bn_bwd_signmask", _p(dy), _p(mask), _p(x), _p(mean), _p(invstd), _p(gamma), float(slope), _p(dx),
+              _p(dz), _p(dgamma), _p(dbeta), B, C, H, W, int(bool(dy_pooled)), int(bool(dz_sum)), _p(ws), ws.numel(),
+              _s())
+    return dx, dz, dgamma, dbeta
 
 
 def bn_bwd_dzsum_supported(x):

@@ -529,6 +529,66 @@ def check_bn_bwd_dzsum():
     return res
 
 
+def check_bn_signmask():
+    """the 1-bit LeakyReLU sign mask path of 'LeakyReLU(BN(c) + res)': outputs and mask of the three apply flavours
+    (plain / half-resolution residual / + AvgPool2d, with and without the full-resolution output), and the three
+    backward flavours (dz, 2x2 block-summed dz, pooled dy) against the saved-output kernels (must agree bit for bit:
+    same arithmetic, only the source of the sign differs)"""
+    from sivae_hip import ops
+    res_ = []
+    for (B, C, H, W) in [(3, 8, 8, 16), (2, 5, 6, 24), (2, 16, 32, 32), (1, 3, 2, 8)]:
+        tag = "(%d,%d,%d,%d)" % (B, C, H, W)
+        x = _d(_rand(B, C, H, W, seed=1))
+        res = _d(_rand(B, C, H, W, seed=2))
+        resh = _d(_rand(B, C, H // 2, W // 2, seed=3))
+        gamma, beta = _d(_rand(C, seed=8).abs() + 0.5), _d(_rand(C, seed=9))
+        dy = _d(_rand(B, C, H, W, seed=4))
+        dyh = _d(_rand(B, C, H // 2, W // 2, seed=5))
+        mean, invstd = ops.bn_stats(x)
+        assert ops.bn_signmask_supported(x)
+
+        def bits(mask):
+            m = mask.cpu().numpy()
+            import numpy as np
+            return torch.from_numpy(np.unpackbits(m, bitorder="little")[: B * C * H * W].astype("float32")).view(B, C, H, W)
+
+        # plain
+        y_ref = ops.bn_apply_act(x, res, mean, invstd, gamma, beta, 0.2)
+        y, yp, mask = ops.bn_apply_act_signmask(x, res, mean, invstd, gamma, beta, 0.2)
+        res_.append(("signmask_apply" + tag, float((y - y_ref).abs().max()), 0.0))
+        res_.append(("signmask_bits" + tag, float((bits(mask) - (y_ref > 0).float().cpu()).abs().max()), 0.0))
+        dx_ref, dz_ref, dg_ref, db_ref = ops.bn_bwd(dy, y_ref, x, mean, invstd, gamma, 0.2, want_dz=True, act_mode=1)
+        dx, dz, dg, db = ops.bn_bwd_signmask(dy, mask, x, mean, invstd, gamma, 0.2)
+        for n_, a_, b_ in (("dx", dx, dx_ref), ("dz", dz, dz_ref), ("dgamma", dg, dg_ref), ("dbeta", db, db_ref)):
+            res_.append(("signmask_bwd_%s%s" % (n_, tag), float((a_ - b_).abs().max()), 0.0))
+        # pooled dy
+        dx_ref, dz_ref, dg_ref, db_ref = ops.bn_bwd(dyh, y_ref, x, mean, invstd, gamma, 0.2, want_dz=True, act_mode=1,
+                                                    dy_pooled=True)
+        dx, dz, dg, db = ops.bn_bwd_signmask(dyh, mask, x, mean, invstd, gamma, 0.2, dy_pooled=True)
+        for n_, a_, b_ in (("dx", dx, dx_ref), ("dz", dz, dz_ref), ("dgamma", dg, dg_ref), ("dbeta", db, db_ref)):
+            res_.append(("signmask_bwd_pooled_%s%s" % (n_, tag), float((a_ - b_).abs().max()), 0.0))
+        # + AvgPool2d, with and without the full-resolution output
+        for want_full in (True, False):
+            y2, yp2, mask2 = ops.bn_apply_act_signmask(x, res, mean, invstd, gamma, beta, 0.2, pool=True,
+                                                       want_full=want_full)
+            y_p, yp_p = ops.bn_apply_act_pool(x, res, mean, invstd, gamma, beta, 0.2)
+            res_.append(("signmask_pool%d_yp%s" % (want_full, tag), float((yp2 - yp_p).abs().max()), 0.0))
+            res_.append(("signmask_pool%d_bits%s" % (want_full, tag),
+                         float((bits(mask2) - (y_ref > 0).float().cpu()).abs().max()), 0.0))
+            if want_full:
+                res_.append(("signmask_pool_y" + tag, float((y2 - y_p).abs().max()), 0.0))
+        # half-resolution residual + block-summed dz
+        y_ref = ops.bn_apply_act(x, resh, mean, invstd, gamma, beta, 0.2, res_up=True)
+        y, _, mask = ops.bn_apply_act_signmask(x, resh, mean, invstd, gamma, beta, 0.2, res_up=True)
+        res_.append(("signmask_resup" + tag, float((y - y_ref).abs().max()), 0.0))
+        res_.append(("signmask_resup_bits" + tag, float((bits(mask) - (y_ref > 0).float().cpu()).abs().max()), 0.0))
+        dx_ref, dzh_ref, dg_ref, db_ref = ops.bn_bwd_dzsum(dy, y_ref, x, mean, invstd, gamma, 0.2)
+        dx, dzh, dg, db = ops.bn_bwd_signmask(dy, mask, x, mean, invstd, gamma, 0.2, dz_sum=True)
+        for n_, a_, b_ in (("dx", dx, dx_ref), ("dzh", dzh, dzh_ref), ("dgamma", dg, dg_ref), ("dbeta", db, db_ref)):
+            res_.append(("signmask_bwd_dzsum_%s%s" % (n_, tag), float((a_ - b_).abs().max()), 0.0))
+    return res_
+
+
 def check_bn_apply_pool():
     """BN-apply (+ residual) + LeakyReLU + AvgPool2d(2) in one pass"""
     from sivae_hip import ops
@@ -678,6 +738,7 @@ def all_checks():
     checks.append(("bn_bwd_pooled", check_bn_bwd_pooled))
     checks.append(("bn_apply_pool", check_bn_apply_pool))
     checks.append(("bn_bwd_dzsum", check_bn_bwd_dzsum))
+    checks.append(("bn_signmask", check_bn_signmask))
     checks.append(("space_to_depth", check_space_to_depth))
     checks.append(("bn_apply_resup", check_bn_apply_resup))
     checks.append(("losses", check_losses))
