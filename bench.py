@@ -247,8 +247,9 @@ def main():
                             mfma_issued_tflops_per_gpu=round(issued * per * args.steps / dt / 1e12, 2),
                             mfma_issued_frac=round(issued * per * args.steps / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4))
     out = {
-        "metric": "training images/sec (whole node) at 256x256 bs128" if args.config == "celeb256"
-        else "training images/sec (whole node)",
+        # BASELINE.json's metric is quoted at 256x256 with 128 images per GPU; any other run says what it ran
+        "metric": "training images/sec (whole node) at 256x256 bs128" if (args.config == "celeb256" and per == 128)
+        else "training images/sec (whole node) at %dx%d bs%d" % (image_size, image_size, per),
         "value": round(value, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",

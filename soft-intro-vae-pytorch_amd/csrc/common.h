@@ -208,6 +208,16 @@ __device__ __forceinline__ float2 buf_load_f32x2(__amdgpu_buffer_rsrc_t r, unsig
 __device__ __forceinline__ unsigned fastdiv(unsigned e, unsigned magic) { return magic ? __umulhi(e, magic) : e; }
 #endif
 
+// SIVAE_XCD_REMAP=0 switches the XCD-aware block order of the weight-gradient kernels off (A/B switch)
+static inline int sivae_xcd_remap() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SIVAE_XCD_REMAP");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
 // Raise a kernel's dynamic-LDS limit once per high-water mark instead of on every launch: keeps the attribute call
 // out of the launch path and, after an eager warm-up has seen the kernel, out of HIP-graph stream captures.
 static inline int sivae_ensure_lds(const void* kern, size_t lds, size_t* high_water) {

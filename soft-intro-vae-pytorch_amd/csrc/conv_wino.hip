@@ -47,6 +47,7 @@ struct WinoArgs {
   int accumulate;
   int upsample;
   int n_items;
+  int xcd_group;  // 1: start items grouped per XCD (see the kernel)
   // optional: the output y is the gradient flowing into LeakyReLU(BatchNorm(bnb_x)) (the data gradient of conv2 feeding
   // BatchNorm-1's backward): the `stats` partials then hold {sum g, sum g * xhat}, g = y * LeakyReLU'(z), instead of
   // {sum y, sum y^2} — the first reduction pass of the BatchNorm backward disappears
@@ -117,7 +118,12 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
   // transform of the current one, so launch latency, address set-up and the first HBM round trip are paid
   // once per block instead of once per 128 output pixels.
   const int n_items = a.n_items;
+  // Consecutive blockIdx go round-robin to the 8 XCDs.  With xcd_group the block on XCD x, slot j starts at item
+  // x * (grid / 8) + j: the co-tiles of one pixel tile (consecutive items) then run on ONE XCD and share the halo in its
+  // L2.  Only for layers whose whole U (all co-tiles) fits an L2 next to the halos; with 8 co-tiles of 2 MB each the
+  // plain order is the better one (co-tile c = XCD c keeps ONE U slab resident).
   int item = blockIdx.x;
+  if (a.xcd_group) item = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
   int pt, b, r0, c0, co0;
   __amdgpu_buffer_rsrc_t xrsrc;
   const __amdgpu_buffer_rsrc_t ursrc = make_rsrc(a.up, 16ull * a.Ci_pad * a.Co_pad * 4ull);
@@ -537,6 +543,8 @@ static int wino_launch(WinoArgs& a, hipStream_t stream) {
   }
   a.n_items = (int)nblk;
   const int grid = nblk < wino_grid_blocks() ? (int)nblk : wino_grid_blocks();
+  a.xcd_group = (sivae_xcd_remap() && a.n_co_tiles > 1 && !(grid & 7) &&
+                 (size_t)a.Ci_pad * a.Co_pad * 64 <= (size_t)2 << 20) ? 1 : 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NG * 256), lds, stream, a);
   return sivae_launch_status();
 }

@@ -27,6 +27,7 @@ struct WinoUpWgArgs {
   int Ci_pad, Co_pad;
   int nrh, nrw, nstages, sps;
   int n_co_tiles, n_ci_tiles;
+  int nblk, xcd_remap;
 };
 
 #define WUW_COT 32
@@ -51,7 +52,15 @@ __global__ void __launch_bounds__(512, 2) wino_up_wgrad_kernel(WinoUpWgArgs a) {
   const int Hs = a.Hs, Ws = a.Ws, HWs = Hs * Ws, H = 2 * Hs, W = 2 * Ws, HW = H * W;
 
   const int ntiles = a.n_co_tiles * a.n_ci_tiles;
-  const int tile = blockIdx.x % ntiles, slice = blockIdx.x / ntiles;
+  // XCD-aware block order: consecutive blockIdx go round-robin to the 8 XCDs, so logical block L = xcd * M + j puts the
+  // (co, ci) tiles of one pixel slice on ONE XCD at the same time — they read the same x / dY stages, which then come
+  // out of that XCD's L2 once instead of once per XCD
+  int lb = (int)blockIdx.x;
+  if (a.xcd_remap) {
+    lb = (lb & 7) * ((int)gridDim.x >> 3) + (lb >> 3);
+    if (lb >= a.nblk) return;
+  }
+  const int tile = lb % ntiles, slice = lb / ntiles;
   const int ci0 = (tile % a.n_ci_tiles) * WUW_CIT, co0 = (tile / a.n_ci_tiles) * WUW_COT;
   const int s_begin = slice * a.sps;
   const int s_end = (s_begin + a.sps < a.nstages) ? (s_begin + a.sps) : a.nstages;
@@ -340,7 +349,9 @@ extern "C" int sivae_conv2d_wino_up_wgrad(const float* x_half, const float* dy, 
     const int rc_lds = sivae_ensure_lds(reinterpret_cast<const void*>(wino_up_wgrad_kernel), lds, &lds_hwm);
     if (rc_lds != SIVAE_OK) return rc_lds;
   }
-  hipLaunchKernelGGL(wino_up_wgrad_kernel, dim3((unsigned)nblk), dim3(512), lds, stream, a);
+  a.nblk = (int)nblk;
+  a.xcd_remap = sivae_xcd_remap();
+  hipLaunchKernelGGL(wino_up_wgrad_kernel, dim3((unsigned)(a.xcd_remap ? (nblk + 7) / 8 * 8 : nblk)), dim3(512), lds, stream, a);
   rc = sivae_launch_status();
   if (rc != SIVAE_OK) return rc;
   const int n_cic = (Ci + 63) / 64;

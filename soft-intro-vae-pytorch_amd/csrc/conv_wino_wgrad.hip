@@ -41,6 +41,7 @@ struct WinoWgArgs {
   int nrh, nrw, nstages, sps;
   int n_co_tiles, n_ci_tiles;
   int upsample;
+  int nblk, xcd_remap;
 };
 
 template <bool PRO, int NGI>
@@ -70,7 +71,15 @@ __global__ void __launch_bounds__(NGI * 256, 2) wino_wgrad_kernel(WinoWgArgs a) 
   const int HWs = Hs * Ws;
 
   const int ntiles = a.n_co_tiles * a.n_ci_tiles;
-  const int tile = blockIdx.x % ntiles, slice = blockIdx.x / ntiles;
+  // XCD-aware block order: consecutive blockIdx go round-robin to the 8 XCDs, so logical block L = xcd * M + j puts the
+  // (co, ci) tiles of one pixel slice on ONE XCD at the same time — they read the same x / dY stages, which then come
+  // out of that XCD's L2 once instead of once per XCD
+  int lb = (int)blockIdx.x;
+  if (a.xcd_remap) {
+    lb = (lb & 7) * ((int)gridDim.x >> 3) + (lb >> 3);
+    if (lb >= a.nblk) return;
+  }
+  const int tile = lb % ntiles, slice = lb / ntiles;
   const int ci0 = (tile % a.n_ci_tiles) * CIT, co0 = (tile / a.n_ci_tiles) * COT;
   const int s_begin = slice * a.sps;
   const int s_end = (s_begin + a.sps < a.nstages) ? (s_begin + a.sps) : a.nstages;
@@ -403,7 +412,9 @@ extern "C" int sivae_conv2d_wino_wgrad(const float* x, const float* dy, float* d
     const int rc_lds = sivae_ensure_lds(reinterpret_cast<const void*>(kern), lds, &lds_hwm[pro_mean ? 1 : 0]);
     if (rc_lds != SIVAE_OK) return rc_lds;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(WG_NGI * 256), lds, stream, a);
+  a.nblk = (int)nblk;
+  a.xcd_remap = sivae_xcd_remap();
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.xcd_remap ? (nblk + 7) / 8 * 8 : nblk)), dim3(WG_NGI * 256), lds, stream, a);
   rc = sivae_launch_status();
   if (rc != SIVAE_OK) return rc;
   const int n_cic = (Ci + 63) / 64;

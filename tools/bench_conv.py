@@ -36,8 +36,14 @@ for (Ci, Co, H, ks) in SHAPES:
     out = "%4d->%-4d @%-3d k%d :" % (Ci, Co, H, ks)
     if "fwd" in what:
         if not WINO_ONLY:
-            t = timeit(lambda: ops.conv2d_fwd(x, wp, Co, ks, want_stats=True))
-            out += "  fwd %7.3f ms %6.1f TF" % (t, fl / t / 1e9)
+            t = timeit(lambda: ops.conv2d_fwd(x, wp, Co, ks, want_stats=(ks != 1)))  # (conv_expand has no BatchNorm)
+            gbs = (B * (Ci + Co) * H * H * 4) / t / 1e6
+            out += "  fwd %7.3f ms %6.1f TF %5.0f GB/s" % (t, fl / t / 1e9, gbs)
+            if ks == 1:
+                yb = torch.randn(B, Co, H, H, device="cuda")
+                t = timeit(lambda: ops.conv2d_fwd(x, wp, Co, ks, out=yb, accumulate=True))
+                out += "  +acc %7.3f ms %5.0f GB/s" % (t, (B * (Ci + 2 * Co) * H * H * 4) / t / 1e6)
+                del yb
         if ks == 3 and H >= 16:
             wq = ops.PackedW(w, 0)
             pro = None
