@@ -308,6 +308,12 @@ int sivae_adam_step_dev(float* param, const float* grad, float* exp_avg, float* 
 int sivae_u8_to_f32(const unsigned char* src, float* dst, const int* flip, int B, int C, int H, int W, int nhwc,
                     float scale, sivae_stream_t stream);
 
+/* ---- output side -----------------------------------------------------------------------------
+ * generated images fp32 -> uint8 with the reference's quantisation for the FID network
+ * (metrics/fid_score.py:247-249: np.clip(images * 255, 0, 255).astype(np.uint8)): dst = trunc(clamp(src*scale, 0, 255)).
+ * src and dst 16-byte aligned. */
+int sivae_f32_to_u8(const float* src, unsigned char* dst, size_t numel, float scale, sivae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -217,3 +217,48 @@ extern "C" int sivae_u8_to_f32(const unsigned char* src, float* dst, const int* 
   hipLaunchKernelGGL(u8_to_f32_kernel, dim3(nb), dim3(256), 0, stream, src, dst, flip, C, H, W, nhwc, scale, numel);
   return sivae_launch_status();
 }
+
+// ---- output side: generated images fp32 NCHW -> uint8, the quantisation the reference applies to every
+// sample batch before the FID network sees it (metrics/fid_score.py:247-249: np.clip(images * 255, 0, 255)
+// .astype(np.uint8) — clip, then truncate toward zero; NaN -> 0 here).  16 elements per thread, 16-byte stores.
+__global__ void __launch_bounds__(256) f32_to_u8_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst,
+                                                        float scale, size_t numel) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  const size_t n16 = numel >> 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) {
+    unsigned w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = reinterpret_cast<const float4*>(src)[i * 4 + q];
+      const float f[4] = {v.x, v.y, v.z, v.w};
+      unsigned word = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float t = f[k] * scale;
+        t = t > 0.f ? t : 0.f;  // (also NaN -> 0)
+        t = t < 255.f ? t : 255.f;
+        word |= (unsigned)(int)t << (8 * k);
+      }
+      w[q] = word;
+    }
+    reinterpret_cast<uint4*>(dst)[i] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  // ragged tail
+  for (size_t e = (n16 << 4) + (size_t)blockIdx.x * 256 + threadIdx.x; e < numel; e += stride) {
+    float t = src[e] * scale;
+    t = t > 0.f ? t : 0.f;
+    t = t < 255.f ? t : 255.f;
+    dst[e] = (unsigned char)(int)t;
+  }
+}
+
+extern "C" int sivae_f32_to_u8(const float* src, unsigned char* dst, size_t numel, float scale, hipStream_t stream) {
+  if (!src || !dst) return SIVAE_ERR_NULL;
+  if (numel == 0) return SIVAE_ERR_SHAPE;
+  if ((((uintptr_t)src) & 15u) || (((uintptr_t)dst) & 15u)) return SIVAE_ERR_SHAPE;  // 16-byte vector accesses
+  int nb = cdiv((long long)((numel >> 4) + 1), 256);
+  if (nb > 8192) nb = 8192;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(f32_to_u8_kernel, dim3(nb), dim3(256), 0, stream, src, dst, scale, numel);
+  return sivae_launch_status();
+}

@@ -82,6 +82,15 @@ def u8_to_f32(src, flip=None, nhwc=False, scale=1.0 / 255.0):
     return dst
 
 
+def f32_to_u8(src, scale=255.0):
+    """fp32 images -> uint8 the way the reference quantises generated batches (clip(x*255, 0, 255) truncated)"""
+    if not src.is_cuda or src.dtype != torch.float32 or not src.is_contiguous():
+        raise TypeError("sivae_hip.f32_to_u8: expected a contiguous float32 ROCm tensor")
+    dst = torch.empty(src.shape, dtype=torch.uint8, device=src.device)
+    _lib.call("sivae_f32_to_u8", _p(src), _p(dst), src.numel(), float(scale), _s())
+    return dst
+
+
 def _require(*tensors):
     for t in tensors:
         if t is None:

@@ -689,6 +689,23 @@ def check_input_u8():
     return res
 
 
+def check_output_u8():
+    """fp32 -> uint8 quantisation of generated images: np.clip(x * 255, 0, 255).astype(np.uint8) (bit-exact)"""
+    import numpy as np
+    from sivae_hip import ops
+    g = torch.Generator().manual_seed(11)
+    res = []
+    for shape in [(4, 3, 32, 32), (2, 3, 5, 7), (1, 1, 28, 28), (3, 3, 64, 64)]:
+        x = torch.rand(shape, generator=g) * 1.4 - 0.2
+        x.view(-1)[:6] = torch.tensor([0.0, 1.0, 254.9999 / 255.0, -0.0, 1.0 + 1e-7, 0.5])
+        ref = np.clip(x.numpy() * 255, 0, 255).astype(np.uint8)
+        out = ops.f32_to_u8(x.to(DEV)).cpu().numpy()
+        res.append(("f32_to_u8%s" % (shape,), float(np.abs(out.astype(np.int32) - ref.astype(np.int32)).max()), 0.0))
+    x = torch.full((32,), float("nan"))
+    res.append(("f32_to_u8_nan", float(ops.f32_to_u8(x.to(DEV)).max()), 0.0))
+    return res
+
+
 def all_checks():
     """-> list of (label, thunk) ; every thunk returns a list of (name, err, tol)"""
     checks = []
@@ -739,6 +756,7 @@ def all_checks():
     checks.append(("bn_apply_pool", check_bn_apply_pool))
     checks.append(("bn_bwd_dzsum", check_bn_bwd_dzsum))
     checks.append(("bn_signmask", check_bn_signmask))
+    checks.append(("output_u8", check_output_u8))
     checks.append(("space_to_depth", check_space_to_depth))
     checks.append(("bn_apply_resup", check_bn_apply_resup))
     checks.append(("losses", check_losses))

@@ -301,3 +301,52 @@ def test_size_independent_properties_at_full_batch_shapes():
         out = ops.bn_apply_act(fx2, None, mean, invstd, ones, torch.zeros(Co, device=dev), 1.0)
         assert float(out.mean((0, 2, 3)).abs().max()) < 1e-4
         assert float((out.var((0, 2, 3), unbiased=False) - 1).abs().max()) < 1e-3
+
+
+def test_eval_mode_inference_and_generation_vs_oracle():
+    """Output side: eval-mode BatchNorm (running statistics) through the same kernels — encoder mu/logvar,
+    deterministic reconstruction and model.sample against the CPU oracle with training=False; running buffers untouched;
+    sivae_hip.infer.generate reproduces model.sample + the reference's uint8 quantisation (fid_score.py:241-250)."""
+    import train_soft_intro_vae as T
+    from oracle import sivae_oracle as O
+    from sivae_hip import infer, rng
+    dev = torch.device("cuda", 0)
+    channels, image_size, zdim, B = [16, 32, 64], 32, 24, 6
+    torch.manual_seed(3)
+    model = T.SoftIntroVAE(cdim=3, zdim=zdim, channels=channels, image_size=image_size).to(dev).train()
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for _ in range(3):  # move the running statistics away from their initial values
+            model(torch.rand(B, 3, image_size, image_size, generator=g).to(dev))
+    model.eval()
+    P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    x = torch.rand(B, 3, image_size, image_size, generator=g)
+    z = torch.randn(B, zdim, generator=g)
+    with torch.no_grad():
+        mu, logvar, zz, rec = model(x.to(dev), deterministic=True)
+        smp = model.sample(z.to(dev))
+        mu_o, logvar_o = O.encode(P, x, channels, image_size, training=False)
+        rec_o = O.decode(P, mu_o, channels, image_size, training=False)
+        smp_o = O.decode(P, z, channels, image_size, training=False)
+    assert _rel(mu, mu_o) <= TOL and _rel(logvar, logvar_o) <= TOL
+    assert _rel(zz, mu_o) <= TOL
+    assert _rel(rec, rec_o) <= TOL and _rel(smp, smp_o) <= TOL
+    for k, v in model.state_dict().items():  # eval mode leaves every buffer alone
+        if k.endswith(BUFS):
+            assert torch.equal(v.cpu(), P[k]), k
+    # generation loop: same Philox stream -> same noise -> generate == quantised model.sample
+    st = rng.PhiloxStream(7, 0)
+    batches = list(infer.generate(model, 10, batch_size=4, stream=st))
+    assert len(batches) == 3 and all(b.dtype == torch.uint8 and b.shape == (4, 3, image_size, image_size) for b in batches)
+    st2 = rng.PhiloxStream(7, 0)
+    with torch.no_grad():
+        ref0 = model.sample(st2.randn((4, zdim), dev))
+    expect = np.clip(ref0.cpu().numpy() * 255, 0, 255).astype(np.uint8)
+    assert np.array_equal(batches[0].cpu().numpy(), expect)
+    assert not model.training  # mode restored
+    assert _rel(infer.reconstruct(model, x.to(dev)), rec_o) <= TOL
+    # train-mode generation (the reference's FID loop leaves the VAE in train mode): BatchNorm buffers move, mode restored
+    raw = list(infer.generate(model, 4, batch_size=4, as_uint8=False, eval_mode=False, stream=rng.PhiloxStream(7, 0)))[0]
+    assert raw.dtype == torch.float32 and not model.training
+    nbt = "decoder.main.res_in_4.bn1.num_batches_tracked"
+    assert int(model.state_dict()[nbt]) == int(P[nbt]) + 1
