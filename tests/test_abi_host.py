@@ -45,6 +45,29 @@ def test_argument_errors_use_documented_codes():
     assert L.sivae_pack_conv_weight(one, one, 4, 4, 3, 5, null) == -6
 
 
+def test_round1_late_entry_points_validate_arguments():
+    """sign-mask BatchNorm passes, the uint8 output quantisation and the Winograd shape predicates: pure host checks
+    (every call returns before any kernel launch)"""
+    L = lib.load()
+    null = None
+    one = ctypes.c_void_p(16)
+    assert L.sivae_bn_signmask_bytes(2, 3, 16) == 12 and L.sivae_bn_signmask_bytes(1, 1, 4) == 1
+    assert L.sivae_bn_signmask_bytes(0, 3, 16) == 0
+    # mask missing / W % 8 != 0 / pooled output together with a half-resolution residual
+    assert L.sivae_bn_apply_act_signmask(one, one, 0, one, one, one, one, 0.2, one, null, null, 1, 1, 4, 8, null) == -1
+    assert L.sivae_bn_apply_act_signmask(one, one, 0, one, one, one, one, 0.2, one, null, one, 1, 1, 4, 12, null) == -2
+    assert L.sivae_bn_apply_act_signmask(one, one, 1, one, one, one, one, 0.2, one, one, one, 1, 1, 4, 8, null) == -6
+    assert L.sivae_bn_bwd_signmask(one, null, one, one, one, one, 0.2, one, null, null, null, 1, 1, 4, 8, 0, 0, one, 1 << 20, null) == -1
+    assert L.sivae_bn_bwd_signmask(one, one, one, one, one, one, 0.2, one, one, null, null, 1, 1, 4, 8, 1, 1, one, 1 << 20, null) == -6
+    assert L.sivae_bn_bwd_signmask(one, one, one, one, one, one, 0.2, one, null, null, null, 1, 1, 3, 8, 0, 0, one, 1 << 20, null) == -2
+    assert L.sivae_f32_to_u8(null, one, 16, 255.0, null) == -1
+    assert L.sivae_f32_to_u8(one, one, 0, 255.0, null) == -2
+    assert L.sivae_f32_to_u8(ctypes.c_void_p(20), one, 16, 255.0, null) == -2  # 16-byte alignment
+    assert L.sivae_conv2d_wino_supported(256, 256) == 1 and L.sivae_conv2d_wino_supported(4, 4) == 1
+    assert L.sivae_conv2d_wino_supported(7, 7) == 0 and L.sivae_conv2d_wino_supported(28, 28) == 1
+    assert L.sivae_conv2d_wino_up_supported(16, 32) == 1 and L.sivae_conv2d_wino_up_supported(8, 8) == 0
+
+
 def test_workspace_and_padding_queries():
     L = lib.load()
     assert L.sivae_conv_ck(3) == 8 and L.sivae_conv_ck(1) == 32 and L.sivae_conv_ck(5) == 4
