@@ -314,6 +314,55 @@ int sivae_u8_to_f32(const unsigned char* src, float* dst, const int* flip, int B
  * src and dst 16-byte aligned. */
 int sivae_f32_to_u8(const float* src, unsigned char* dst, size_t numel, float scale, sivae_stream_t stream);
 
+/* ---- bf16 mode (config 3 of BASELINE.json: "CelebA 128x128 ... bf16") -----------------------------------------
+ * The reference trains in fp32 only (soft_intro_vae/train_soft_intro_vae.py:376-440 has no autocast / GradScaler), so
+ * this mode is build-defined: activations and activation gradients are stored in bf16, the convolutions run on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation, BatchNorm statistics / parameter gradients / master weights / Adam
+ * stay fp32, the loss kernels above stay fp32 (Decoder.predict writes fp32 NCHW).
+ * Activation layout ("blocked NCHW"): x[b][c/8][h][w][c%8] bf16, channel count padded to a multiple of 16 with zeros
+ * (sivae_bf16_cblocks(C) 8-channel blocks).  Same nn.Conv2d / nn.BatchNorm2d / nn.LeakyReLU / nn.AvgPool2d /
+ * nn.Upsample call sites as the fp32 entry points above (:51-75, :88-99, :153-159). */
+int sivae_bf16_cblocks(int C);
+/* fp32 NCHW <-> blocked bf16 (padded channels written as 0; `scale` multiplies on the way in) */
+int sivae_bf16_from_f32_nchw(const float* src, void* dst, int B, int C, int H, int W, float scale,
+                             sivae_stream_t stream);
+int sivae_bf16_to_f32_nchw(const void* src, float* dst, int B, int C, int H, int W, sivae_stream_t stream);
+/* fp32 master weight [Co][Ci][ks][ks] -> bf16 MFMA-operand slabs; mode 0 forward, mode 1 data gradient */
+size_t sivae_bf16_pack_conv_weight_bytes(int Co, int Ci, int ks, int mode);
+int sivae_bf16_pack_conv_weight(const float* w, void* wp, int Co, int Ci, int ks, int mode, sivae_stream_t stream);
+/* y (+)= conv(x', wp) + bias with the fusions of sivae_conv2d_fwd (producer BatchNorm+LeakyReLU prologue — 3x3 only —,
+ * upsample addressing, {sum, sumsq} partials of the rounded output, accumulate).  out_f32_nchw != 0: y is float
+ * [B][Co][H][W] (Co <= 32, no stats: Decoder.predict :159).  stats_partial has sivae_bf16_conv2d_num_px_tiles rows and
+ * feeds sivae_bn_stats_from_conv unchanged.  The data gradient is this function on dy with the mode-1 pack. */
+int sivae_bf16_conv2d_num_px_tiles(int B, int Co, int H, int W);
+int sivae_bf16_conv2d_fwd(const void* x, const void* wp, void* y, const float* bias, const float* pro_mean,
+                          const float* pro_invstd, const float* pro_gamma, const float* pro_beta, float pro_slope,
+                          float* stats_partial, int B, int Ci, int Co, int H, int W, int ks, int upsample,
+                          int accumulate, int out_f32_nchw, sivae_stream_t stream);
+/* dw [Co][Ci][ks][ks] fp32 = weight gradient (aten::convolution_backward, weight half); x' as above (prologue 3x3
+ * only, upsample addressing); deterministic two-pass reduction over pixel slices */
+size_t sivae_bf16_conv2d_wgrad_workspace_bytes(int B, int Ci, int Co, int H, int W, int ks);
+int sivae_bf16_conv2d_wgrad(const void* x, const void* dy, float* dw, const float* pro_mean, const float* pro_invstd,
+                            const float* pro_gamma, const float* pro_beta, float pro_slope, int B, int Ci, int Co,
+                            int H, int W, int ks, int upsample, void* workspace, size_t workspace_bytes,
+                            sivae_stream_t stream);
+/* y = LeakyReLU((x-mean)*invstd*gamma+beta + res): res NULL, same shape, or (res_up) [B][C][H/2][W/2] read through
+ * nearest-2x addressing; y and/or y_pool = AvgPool2d(2)(y) are written (either may be NULL, not both) */
+int sivae_bf16_bn_apply_act(const void* x, const void* res, int res_up, const float* mean, const float* invstd,
+                            const float* gamma, const float* beta, float slope, void* y, void* y_pool, int B, int C,
+                            int H, int W, sivae_stream_t stream);
+/* backward of the above: dy (or, dy_pooled, the gradient of y_pool), activation sign from y or — y NULL — recomputed
+ * from x (no residual; needs beta); dx, dz = gradient of the residual branch (NULL to skip; dz_sum: its 2x2 block
+ * sums [B][C][H/2][W/2]), dgamma / dbeta (NULL to skip) */
+size_t sivae_bf16_bn_bwd_workspace_bytes(int B, int C, int H, int W);
+int sivae_bf16_bn_bwd(const void* dy, int dy_pooled, const void* y, const void* x, const float* mean,
+                      const float* invstd, const float* gamma, const float* beta, float slope, void* dx, void* dz,
+                      int dz_sum, float* dgamma, float* dbeta, int B, int C, int H, int W, void* workspace,
+                      size_t workspace_bytes, sivae_stream_t stream);
+int sivae_bf16_upsample2_fwd(const void* x, void* y, int B, int C, int Hs, int Ws, sivae_stream_t stream);
+int sivae_bf16_upsample2_bwd(const void* dy, void* dx, int B, int C, int Hs, int Ws, sivae_stream_t stream);
+int sivae_bf16_add_inplace(void* y, const void* x, size_t nvec, sivae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

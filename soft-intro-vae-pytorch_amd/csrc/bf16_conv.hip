@@ -1,0 +1,507 @@
+// bf16 implicit-GEMM stride-1 "same" convolution for gfx950 on v_mfma_f32_32x32x16_bf16 (fp32 accumulate): forward
+// and — fed the flipped/transposed weight pack — data gradient of the nn.Conv2d(k in {1,3,5}) layers of
+// soft_intro_vae/train_soft_intro_vae.py:51-61,89,159 in the build-defined bf16 mode of config 3 (BASELINE.json
+// configs[2]).  The reference has no mixed precision; the mode's contract is: bf16 activation / gradient storage in the
+// blocked layout of bf16_common.h, bf16 operands, fp32 accumulation, fp32 BatchNorm statistics, fp32 master weights.
+//
+//   D[co][pixel] = sum_{tap, ci} W[co][tap][ci] * X[pixel + tap][ci]
+//
+// MFMA roles: A = weights (row = output channel, 8 consecutive input channels per lane), B = activations (col = pixel,
+// the same 8 input channels) — one ds_read_b128 per operand, every tap a 16-byte-aligned shift inside the halo tile.
+// LDS per block:  ws[TAPS][CKS][2][TCO]  16-byte vectors: the weight slab of the current 16*CKS-channel chunk, already
+//                                        in operand order in HBM (sivae_bf16_pack_conv_weight) -> a straight copy
+//                 xs[2*CKS][plane]       16-byte vectors: zero-padded halo tile of the chunk's 8-channel blocks
+// Accumulator register r of a lane is output channel (r&3) + 8*(r>>2) + 4*(lane>>5) of pixel lane&31, so the four
+// registers of a group are 4 consecutive channels of one pixel = one 8-byte store into the blocked output; lanes l and
+// l+32 complete the pixel's 16-byte vector.
+//
+// Fusions (runtime flags unless noted): producer BatchNorm + LeakyReLU applied while the halo tile is staged (PRO),
+// nearest-2x upsample addressing of x, bias, y += result, per-channel {sum, sumsq} partials of the ROUNDED output for
+// the consumer BatchNorm, fp32 NCHW output (OUTF32: Decoder.predict feeds the fp32 loss kernels).
+#include "bf16_common.h"
+#include <stdlib.h>
+
+struct Bf16ConvArgs {
+  const void* x;   // bf16 blocked [B][Cib][Hs][Ws][8]
+  const void* wp;  // packed bf16 [n_co_tiles][nchunks][TAPS][CKS][2][TCO][8]
+  void* y;         // bf16 blocked [B][Cob][H][W][8], or float [B][Co][H][W] (OUTF32)
+  const float* bias;
+  const float* pro_mean;
+  const float* pro_invstd;
+  const float* pro_gamma;
+  const float* pro_beta;
+  float pro_slope;
+  float* stats;  // [n_px_tiles][Co][2] or null
+  int B, Ci, Co, H, W;
+  int Cib, Cob;  // 8-channel blocks of x / y in storage
+  int tb_log2, th_log2, tw_log2;
+  int ntb, nth, ntw;
+  int n_co_tiles, nchunks;
+  int accumulate, upsample;
+};
+
+template <int KS, int WM, int WN, int WVM, int WVN, int CKS, int MAXV, bool PRO, bool OUTF32, int MINW>
+__global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16ConvArgs a) {
+  constexpr int P = KS / 2;
+  constexpr int NT = WVM * WVN * 64;
+  constexpr int TCO = WVM * WM * 32;
+  constexpr int TAPS = KS * KS;
+  constexpr int NCB = 2 * CKS;
+  constexpr int NW = TAPS * CKS * 2 * TCO;  // 16-byte weight vectors per chunk
+  constexpr int NWQ = (NW + NT - 1) / NT;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4_t* ws = reinterpret_cast<u32x4_t*>(smem_raw);
+  u32x4_t* xs = ws + NW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int wvm = wave / WVN, wvn = wave % WVN;
+
+  const int TW = 1 << a.tw_log2, TH = 1 << a.th_log2, TB = 1 << a.tb_log2;
+  const int LW = TW + 2 * P, LH = TH + 2 * P;
+  const int plane = TB * LH * LW;
+  const int nvec = NCB * plane;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int Hs = a.upsample ? (H >> 1) : H, Ws = a.upsample ? (W >> 1) : W;
+  const int HWs = Hs * Ws;
+  float* ps = reinterpret_cast<float*>(xs + nvec);  // [Cib][16]: 8 scales, 8 shifts per channel block (PRO)
+
+  const int bid = blockIdx.x;
+  const int co_tile = bid % a.n_co_tiles;
+  const int pt = bid / a.n_co_tiles;
+  const int tw_i = pt % a.ntw;
+  const int t2 = pt / a.ntw;
+  const int th_i = t2 % a.nth;
+  const int tb_i = t2 / a.nth;
+  const int b0 = tb_i << a.tb_log2, r0 = th_i << a.th_log2, c0 = tw_i << a.tw_log2;
+  const int co0 = co_tile * TCO;
+
+  int nb_here = a.B - b0;
+  if (nb_here > TB) nb_here = TB;
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      make_rsrc(reinterpret_cast<const unsigned char*>(a.x) + (size_t)b0 * a.Cib * HWs * 16,
+                (unsigned long long)nb_here * a.Cib * HWs * 16ull);
+  const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(a.wp, (unsigned long long)NW * 16ull);
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.wp);
+
+  if (PRO) {
+    for (int c = tid; c < a.Cib * 8; c += NT) {
+      float sc = 0.f, sh = 0.f;
+      if (c < a.Ci) {
+        sc = a.pro_invstd[c] * a.pro_gamma[c];
+        sh = a.pro_beta[c] - a.pro_mean[c] * sc;
+      }
+      ps[(c >> 3) * 16 + (c & 7)] = sc;
+      ps[(c >> 3) * 16 + 8 + (c & 7)] = sh;
+    }
+  }
+
+  // ---- staging map of the halo tile: this thread owns vectors tid + p*NT of [NCB][plane]
+  unsigned xo[MAXV];
+  int xcb[MAXV];
+#pragma unroll
+  for (int p = 0; p < MAXV; ++p) {
+    const int v = tid + p * NT;
+    unsigned off = SIVAE_OOB;
+    int cbl = 0;
+    if (v < nvec) {
+      cbl = v / plane;
+      const int pos = v - cbl * plane;
+      const int cc = pos % LW;
+      const int t = pos / LW;
+      const int rr = t % LH;
+      const int tb = t / LH;
+      const int r = r0 + rr - P, c = c0 + cc - P;
+      if (tb < nb_here && r >= 0 && r < H && c >= 0 && c < W) {
+        const int rs = a.upsample ? (r >> 1) : r, cs = a.upsample ? (c >> 1) : c;
+        off = ((((unsigned)tb * a.Cib + cbl) * Hs + rs) * Ws + cs) * 16u;
+      }
+    }
+    xo[p] = off;
+    xcb[p] = cbl;
+  }
+  unsigned wo[NWQ];
+#pragma unroll
+  for (int q = 0; q < NWQ; ++q) {
+    const int idx = tid + q * NT;
+    wo[q] = (NW % NT == 0 || idx < NW) ? (unsigned)idx * 16u : SIVAE_OOB;
+  }
+
+  const int a_base = hh * TCO + wvm * WM * 32 + l31;
+  int b_base[WN];
+#pragma unroll
+  for (int n = 0; n < WN; ++n) {
+    const int m_pix = (wvn * WN + n) * 32 + l31;
+    const int cc = m_pix & (TW - 1);
+    const int rr = (m_pix >> a.tw_log2) & (TH - 1);
+    const int tb = m_pix >> (a.tw_log2 + a.th_log2);
+    b_base[n] = hh * plane + (tb * LH + rr) * LW + cc;
+  }
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int m = 0; m < WM; ++m)
+#pragma unroll
+    for (int n = 0; n < WN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  u32x4_t wr[NWQ];
+  u32x4_t xr[MAXV];
+
+#define SIVAE_LOAD_CHUNK(CH)                                                                                   \
+  {                                                                                                            \
+    const __amdgpu_buffer_rsrc_t wr_c =                                                                        \
+        make_rsrc(wbase + ((size_t)co_tile * a.nchunks + (CH)) * (size_t)NW * 16, (unsigned long long)NW * 16ull); \
+    _Pragma("unroll") for (int q = 0; q < NWQ; ++q) wr[q] = buf_load_u32x4(wr_c, wo[q], 0u);                   \
+    const unsigned xsoff = (unsigned)(CH) * (unsigned)(NCB * 16) * (unsigned)HWs;                              \
+    _Pragma("unroll") for (int p = 0; p < MAXV; ++p) xr[p] = buf_load_u32x4(xrsrc, xo[p], xsoff);              \
+  }
+  (void)wrsrc;
+
+  SIVAE_LOAD_CHUNK(0)
+  if (PRO) __syncthreads();
+  for (int ch = 0; ch < a.nchunks; ++ch) {
+#pragma unroll
+    for (int q = 0; q < NWQ; ++q) {
+      const int idx = tid + q * NT;
+      if (NW % NT == 0 || idx < NW) ws[idx] = wr[q];
+    }
+#pragma unroll
+    for (int p = 0; p < MAXV; ++p) {
+      const int v = tid + p * NT;
+      u32x4_t q = xr[p];
+      if (PRO) {
+        float f[8];
+        unpack8(q, f);
+        const float* pp = ps + (ch * NCB + xcb[p]) * 16;
+        const bool in = xo[p] != SIVAE_OOB;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = in ? lrelu01(f[e] * pp[e] + pp[8 + e], a.pro_slope) : 0.f;
+        q = pack8(f);
+      }
+      if (v < nvec) xs[v] = q;
+    }
+    __syncthreads();
+    if (ch + 1 < a.nchunks) SIVAE_LOAD_CHUNK(ch + 1)
+
+#pragma unroll
+    for (int ks = 0; ks < CKS; ++ks) {
+#pragma unroll
+      for (int kh = 0; kh < KS; ++kh) {
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
+          const int tap = kh * KS + kw;
+          bf16x8_t av[WM], bv[WN];
+#pragma unroll
+          for (int m = 0; m < WM; ++m)
+            av[m] = __builtin_bit_cast(bf16x8_t, ws[a_base + (tap * CKS + ks) * 2 * TCO + m * 32]);
+          const int soff = ks * 2 * plane + kh * LW + kw;
+#pragma unroll
+          for (int n = 0; n < WN; ++n) bv[n] = __builtin_bit_cast(bf16x8_t, xs[b_base[n] + soff]);
+#pragma unroll
+          for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m], bv[n], acc[m][n], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#undef SIVAE_LOAD_CHUNK
+
+  // ---- epilogue
+  int px_ok[WN];
+  unsigned y_off[WN];
+#pragma unroll
+  for (int n = 0; n < WN; ++n) {
+    const int m_pix = (wvn * WN + n) * 32 + l31;
+    const int cc = m_pix & (TW - 1);
+    const int rr = (m_pix >> a.tw_log2) & (TH - 1);
+    const int tb = m_pix >> (a.tw_log2 + a.th_log2);
+    const int r = r0 + rr, c = c0 + cc;
+    px_ok[n] = (tb < nb_here && r < H && c < W) ? 1 : 0;
+    if (OUTF32)
+      y_off[n] = px_ok[n] ? (unsigned)((tb * a.Co * H + r) * W + c) * 4u : SIVAE_OOB;
+    else
+      y_off[n] = px_ok[n] ? (unsigned)((tb * a.Cob * H + r) * W + c) * 16u + (unsigned)hh * 8u : SIVAE_OOB;
+  }
+  float* red = reinterpret_cast<float*>(smem_raw);  // [WVN][TCO][2]
+  const bool want_stats = a.stats != nullptr;
+
+  if (OUTF32) {
+    const __amdgpu_buffer_rsrc_t yrsrc = make_rsrc(reinterpret_cast<float*>(a.y) + (size_t)b0 * a.Co * HW,
+                                                   (unsigned long long)nb_here * a.Co * HW * 4ull);
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int chn = co0 + (wvm * WM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const bool ch_ok = chn < a.Co;
+        const float bias = (a.bias != nullptr && ch_ok) ? a.bias[chn] : 0.f;
+        const unsigned choff = (unsigned)chn * (unsigned)HW * 4u;
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+          const unsigned off = (ch_ok && px_ok[n]) ? y_off[n] + choff : SIVAE_OOB;
+          float v = acc[m][n][r] + bias;
+          if (a.accumulate) v += buf_load_f32(yrsrc, off, 0u);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrsrc, (int)off, 0, 0);
+        }
+      }
+    }
+    return;
+  }
+
+  const __amdgpu_buffer_rsrc_t yrsrc = make_rsrc(reinterpret_cast<unsigned char*>(a.y) + (size_t)b0 * a.Cob * HW * 16,
+                                                 (unsigned long long)nb_here * a.Cob * HW * 16ull);
+#pragma unroll
+  for (int m = 0; m < WM; ++m) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col0 = (wvm * WM + m) * 32 + 8 * g + 4 * hh;  // first of this lane's 4 channels, within the tile
+      const int cb = (co0 >> 3) + (wvm * WM + m) * 4 + g;
+      const bool cb_ok = cb < a.Cob;
+      float bias[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        bias[e] = (a.bias != nullptr && co0 + col0 + e < a.Co) ? a.bias[co0 + col0 + e] : 0.f;
+      float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+      const unsigned cboff = (unsigned)cb * (unsigned)HW * 16u;
+#pragma unroll
+      for (int n = 0; n < WN; ++n) {
+        const unsigned off = (cb_ok && px_ok[n]) ? y_off[n] + cboff : SIVAE_OOB;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[m][n][4 * g + e] + bias[e];
+        if (a.accumulate) {
+          const u32x2_t old = __builtin_amdgcn_raw_buffer_load_b64(yrsrc, (int)off, 0, 0);
+          v[0] += bf16_lo(old[0]);
+          v[1] += bf16_hi(old[0]);
+          v[2] += bf16_lo(old[1]);
+          v[3] += bf16_hi(old[1]);
+        }
+        u32x2_t o;
+        o[0] = pack_bf16(v[0], v[1]);
+        o[1] = pack_bf16(v[2], v[3]);
+        __builtin_amdgcn_raw_buffer_store_b64(o, yrsrc, (int)off, 0, 0);
+        if (want_stats) {
+          const float w0 = bf16_lo(o[0]), w1 = bf16_hi(o[0]), w2 = bf16_lo(o[1]), w3 = bf16_hi(o[1]);
+          const float okf = px_ok[n] ? 1.f : 0.f;
+          s[0] += okf * w0;
+          s[1] += okf * w1;
+          s[2] += okf * w2;
+          s[3] += okf * w3;
+          q[0] += okf * w0 * w0;
+          q[1] += okf * w1 * w1;
+          q[2] += okf * w2 * w2;
+          q[3] += okf * w3 * w3;
+        }
+      }
+      if (want_stats) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float ss = half_wave_sum_hi(s[e]);
+          const float qq = half_wave_sum_hi(q[e]);
+          if (l31 == 31) {
+            red[(wvn * TCO + col0 + e) * 2 + 0] = ss;
+            red[(wvn * TCO + col0 + e) * 2 + 1] = qq;
+          }
+        }
+      }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    for (int c = tid; c < TCO; c += NT) {
+      if (co0 + c < a.Co) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < WVN; ++w) {
+          s += red[(w * TCO + c) * 2 + 0];
+          q += red[(w * TCO + c) * 2 + 1];
+        }
+        float* dst = a.stats + ((size_t)pt * a.Co + co0 + c) * 2;
+        dst[0] = s;
+        dst[1] = q;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight pack: fp32 master weights [Co][Ci][KS][KS] -> bf16 operand slabs
+//   wp[co_tile][chunk][tap][ks][hh][TCO][8]   (input channel = (chunk*CKS + ks)*16 + hh*8 + e)
+// mode 0: forward operand; mode 1: data-gradient operand (output channels = the conv's input channels, taps flipped)
+// ------------------------------------------------------------------------------------------------
+__global__ void bf16_pack_conv_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Co,
+                                             int Ci, int KS, int mode, int TCO, int CKS, int nchunks,
+                                             size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  // outputs / inputs of the GEMM this pack feeds
+  const int N_out = mode == 0 ? Co : Ci, N_in = mode == 0 ? Ci : Co;
+  const int TAPS = KS * KS;
+  size_t t = i;
+  const int e = (int)(t % 8);
+  t /= 8;
+  const int o = (int)(t % TCO);
+  t /= TCO;
+  const int hh = (int)(t % 2);
+  t /= 2;
+  const int ks = (int)(t % CKS);
+  t /= CKS;
+  const int tap = (int)(t % TAPS);
+  t /= TAPS;
+  const int chunk = (int)(t % nchunks);
+  const int co_tile = (int)(t / nchunks);
+  const int oc = co_tile * TCO + o;
+  const int ic = (chunk * CKS + ks) * 16 + hh * 8 + e;
+  float v = 0.f;
+  if (oc < N_out && ic < N_in) {
+    const int kh = tap / KS, kw = tap % KS;
+    if (mode == 0)
+      v = w[(((size_t)oc * Ci + ic) * KS + kh) * KS + kw];
+    else
+      v = w[(((size_t)ic * Ci + oc) * KS + (KS - 1 - kh)) * KS + (KS - 1 - kw)];
+  }
+  const unsigned u = pack_bf16(v, 0.f);
+  wp[i] = (unsigned short)(u & 0xffffu);
+}
+
+namespace {
+
+struct Bf16Cfg {
+  int TCO, TPX, CKS;
+};
+// tile configuration by (ks, output channels, input channels) — shared by the pack and the launch
+Bf16Cfg bf16_cfg(int ks, int n_out, int n_in) {
+  Bf16Cfg c;
+  c.TCO = n_out <= 32 ? 32 : (n_out <= 64 ? 64 : 128);
+  c.TPX = n_out <= 64 ? 256 : 128;
+  c.CKS = (ks == 1 && (bf16_cblocks(n_in) % 8) == 0) ? 4 : 1;
+  return c;
+}
+
+template <int KS, int WM, int WN, int WVM, int WVN, int CKS, int MAXV, bool PRO, bool OUTF32, int MINW>
+int launch_cfg(Bf16ConvArgs& a, hipStream_t stream) {
+  constexpr int TCO = WVM * WM * 32;
+  constexpr int TPX = WVN * WN * 32;
+  constexpr int NT = WVM * WVN * 64;
+  constexpr int P = KS / 2;
+  constexpr int NW = KS * KS * CKS * 2 * TCO;
+  TileGeom g = make_tile_geom(a.B, a.H, a.W, TPX);
+  a.tb_log2 = g.tb_log2;
+  a.th_log2 = g.th_log2;
+  a.tw_log2 = g.tw_log2;
+  a.ntb = g.ntb;
+  a.nth = g.nth;
+  a.ntw = g.ntw;
+  a.n_co_tiles = cdiv(a.Co, TCO);
+  a.nchunks = a.Cib / (2 * CKS);
+  const int plane = (1 << g.tb_log2) * ((1 << g.th_log2) + 2 * P) * ((1 << g.tw_log2) + 2 * P);
+  if (2 * CKS * plane > MAXV * NT) return SIVAE_ERR_SHAPE;
+  size_t lds = (size_t)(NW + 2 * CKS * plane) * 16 + (PRO ? (size_t)a.Cib * 64 : 0);
+  const size_t red = (size_t)WVN * TCO * 2 * sizeof(float);
+  if (lds < red) lds = red;
+  const long long nblk = (long long)a.n_co_tiles * g.ntb * g.nth * g.ntw;
+  if (nblk > 0x7fffffffLL) return SIVAE_ERR_RANGE;
+  auto kern = bf16_conv_kernel<KS, WM, WN, WVM, WVN, CKS, MAXV, PRO, OUTF32, MINW>;
+  static size_t lds_hwm = 0;
+  const int rc_lds = sivae_ensure_lds(reinterpret_cast<const void*>(kern), lds, &lds_hwm);
+  if (rc_lds != SIVAE_OK) return rc_lds;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NT), lds, stream, a);
+  return sivae_launch_status();
+}
+
+template <int KS, int CKS, int MAXV, bool PRO, bool OUTF32>
+int launch_by_co(Bf16ConvArgs& a, int TCO, hipStream_t stream) {
+  if (TCO == 32) return launch_cfg<KS, 1, 2, 1, 4, CKS, MAXV, PRO, OUTF32, 2>(a, stream);
+  if (OUTF32) return SIVAE_ERR_SHAPE;  // fp32 NCHW output exists for the RGB-side `predict` conv only
+  if constexpr (!OUTF32) {
+    if (TCO == 64) return launch_cfg<KS, 2, 2, 1, 4, CKS, MAXV, PRO, false, 2>(a, stream);
+    return launch_cfg<KS, 2, 2, 2, 2, CKS, MAXV, PRO, false, 2>(a, stream);
+  }
+  return SIVAE_ERR_SHAPE;
+}
+
+}  // namespace
+
+extern "C" int sivae_bf16_cblocks(int C) { return C <= 0 ? SIVAE_ERR_SHAPE : bf16_cblocks(C); }
+
+extern "C" size_t sivae_bf16_pack_conv_weight_bytes(int Co, int Ci, int ks, int mode) {
+  if (Co <= 0 || Ci <= 0 || (ks != 1 && ks != 3 && ks != 5) || (mode != 0 && mode != 1)) return 0;
+  const int n_out = mode == 0 ? Co : Ci, n_in = mode == 0 ? Ci : Co;
+  const Bf16Cfg c = bf16_cfg(ks, n_out, n_in);
+  const int nchunks = bf16_cblocks(n_in) / (2 * c.CKS);
+  return (size_t)cdiv(n_out, c.TCO) * nchunks * ks * ks * c.CKS * 2 * c.TCO * 16;
+}
+
+extern "C" int sivae_bf16_pack_conv_weight(const float* w, void* wp, int Co, int Ci, int ks, int mode,
+                                           hipStream_t stream) {
+  if (!w || !wp) return SIVAE_ERR_NULL;
+  const size_t bytes = sivae_bf16_pack_conv_weight_bytes(Co, Ci, ks, mode);
+  if (bytes == 0) return (ks != 1 && ks != 3 && ks != 5) ? SIVAE_ERR_KSIZE : SIVAE_ERR_SHAPE;
+  const int n_out = mode == 0 ? Co : Ci, n_in = mode == 0 ? Ci : Co;
+  const Bf16Cfg c = bf16_cfg(ks, n_out, n_in);
+  const int nchunks = bf16_cblocks(n_in) / (2 * c.CKS);
+  const size_t total = bytes / 2;
+  hipLaunchKernelGGL(bf16_pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w,
+                     reinterpret_cast<unsigned short*>(wp), Co, Ci, ks, mode, c.TCO, c.CKS, nchunks, total);
+  return sivae_launch_status();
+}
+
+extern "C" int sivae_bf16_conv2d_num_px_tiles(int B, int Co, int H, int W) {
+  if (B <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
+  const Bf16Cfg c = bf16_cfg(3, Co, 16);
+  TileGeom g = make_tile_geom(B, H, W, c.TPX);
+  return g.ntb * g.nth * g.ntw;
+}
+
+extern "C" int sivae_bf16_conv2d_fwd(const void* x, const void* wp, void* y, const float* bias, const float* pro_mean,
+                                     const float* pro_invstd, const float* pro_gamma, const float* pro_beta,
+                                     float pro_slope, float* stats_partial, int B, int Ci, int Co, int H, int W, int ks,
+                                     int upsample, int accumulate, int out_f32_nchw, hipStream_t stream) {
+  if (!x || !wp || !y) return SIVAE_ERR_NULL;
+  if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
+  if (ks != 1 && ks != 3 && ks != 5) return SIVAE_ERR_KSIZE;
+  if (upsample && ((H & 1) || (W & 1))) return SIVAE_ERR_SHAPE;
+  if (pro_mean && (!pro_invstd || !pro_gamma || !pro_beta)) return SIVAE_ERR_NULL;
+  if (pro_mean && ks != 3) return SIVAE_ERR_MODE;  // the producer-BatchNorm prologue exists on the 3x3 kernel (conv2)
+  if (out_f32_nchw && (stats_partial || Co > 32)) return SIVAE_ERR_MODE;
+  const long long hw = (long long)H * W;
+  const int Cib = bf16_cblocks(Ci), Cob = bf16_cblocks(Co);
+  if ((long long)Cib * hw * 16 >= 0x7fffffffLL || (long long)Cob * hw * 16 >= 0x3fffffffLL) return SIVAE_ERR_RANGE;
+  Bf16ConvArgs a;
+  a.x = x;
+  a.wp = wp;
+  a.y = y;
+  a.bias = bias;
+  a.pro_mean = pro_mean;
+  a.pro_invstd = pro_invstd;
+  a.pro_gamma = pro_gamma;
+  a.pro_beta = pro_beta;
+  a.pro_slope = pro_slope;
+  a.stats = stats_partial;
+  a.B = B;
+  a.Ci = Ci;
+  a.Co = Co;
+  a.H = H;
+  a.W = W;
+  a.Cib = Cib;
+  a.Cob = Cob;
+  a.accumulate = accumulate;
+  a.upsample = upsample;
+  const Bf16Cfg c = bf16_cfg(ks, Co, Ci);
+  if (ks == 3) {
+    if (pro_mean) return launch_by_co<3, 1, 5, true, false>(a, c.TCO, stream);
+    return launch_by_co<3, 1, 5, false, false>(a, c.TCO, stream);
+  }
+  if (ks == 1) {
+    if (c.CKS == 4) return launch_by_co<1, 4, 8, false, false>(a, c.TCO, stream);
+    return launch_by_co<1, 1, 2, false, false>(a, c.TCO, stream);
+  }
+  if (out_f32_nchw) return launch_by_co<5, 1, 4, false, true>(a, c.TCO, stream);
+  return launch_by_co<5, 1, 4, false, false>(a, c.TCO, stream);
+}

@@ -108,8 +108,10 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-def _s():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _s(t=None):
+    """HIP stream the launch goes to: torch's current stream of the TENSOR's device (the drop-in entry points also
+    make that device current, so legacy `_s()` calls agree with it)"""
+    return ctypes.c_void_p(torch.cuda.current_stream(None if t is None else t.device).cuda_stream)
 
 
 def workspace(nbytes, device):

@@ -1,0 +1,189 @@
+"""Tensor-level wrappers over the bf16-mode entry points of libsivae_hip (sivae_bf16_*; no autograd here — see
+`functional16.py`).
+
+Activations are torch.bfloat16 tensors of shape [B, C16/8, H, W, 8] ("blocked NCHW": 8 consecutive channels per pixel
+vector, channel count padded to a multiple of 16 with zeros — bf16_common.h).  Statistics, BatchNorm parameters and their
+gradients, weights and weight gradients are float32.  Like `ops`, everything launches on torch's current stream of the
+tensor's device and there is no CPU path.
+"""
+import torch
+
+from . import lib as _lib
+from . import ops
+
+_p, _s = ops._p, ops._s
+LRELU_SLOPE = ops.LRELU_SLOPE
+TIMER_KEYS = True
+
+
+def cblocks(C):
+    return ((C + 15) // 16) * 2
+
+
+def _req16(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("sivae_hip: tensor is on %s — the bf16 kernels need a ROCm device tensor and have no "
+                               "CPU fallback" % t.device)
+        if t.dtype != torch.bfloat16 or t.dim() != 5 or t.shape[-1] != 8 or (t.shape[1] & 1):
+            raise TypeError("sivae_hip: expected a blocked bfloat16 activation [B, C16/8, H, W, 8], got %s %s"
+                            % (t.dtype, tuple(t.shape)))
+        if not t.is_contiguous():
+            raise ValueError("sivae_hip: tensor must be contiguous")
+
+
+def empty_blocked(B, C, H, W, device):
+    return torch.empty((B, cblocks(C), H, W, 8), dtype=torch.bfloat16, device=device)
+
+
+def from_f32(x, scale=1.0):
+    """fp32 NCHW -> blocked bf16 (padded channels zero)"""
+    ops._require(x)
+    B, C, H, W = x.shape
+    y = empty_blocked(B, C, H, W, x.device)
+    _lib.call("sivae_bf16_from_f32_nchw", _p(x), _p(y), B, C, H, W, float(scale), _s(x))
+    return y
+
+
+def to_f32(xb, C):
+    """blocked bf16 -> fp32 NCHW with C channels"""
+    _req16(xb)
+    B, Cb, H, W, _ = xb.shape
+    assert cblocks(C) == Cb
+    y = torch.empty((B, C, H, W), dtype=torch.float32, device=xb.device)
+    _lib.call("sivae_bf16_to_f32_nchw", _p(xb), _p(y), B, C, H, W, _s(xb))
+    return y
+
+
+class PackedW16:
+    """bf16 MFMA-operand slabs of one fp32 master weight (mode 0 forward, 1 data gradient)"""
+
+    def __init__(self, w, mode):
+        ops._require(w)
+        if w.dim() == 2:
+            Co, Ci, ks = w.shape[0], w.shape[1], 1
+        else:
+            Co, Ci, ks = w.shape[0], w.shape[1], w.shape[2]
+        self.Co, self.Ci, self.ks, self.mode = Co, Ci, ks, mode
+        nbytes = _lib.load().sivae_bf16_pack_conv_weight_bytes(Co, Ci, ks, mode)
+        if nbytes == 0:
+            raise _lib.SivaeError("sivae_bf16_pack_conv_weight_bytes", -3)
+        self.data = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
+        _lib.call("sivae_bf16_pack_conv_weight", _p(w), _p(self.data), Co, Ci, ks, mode, _s(w))
+
+
+def conv2d(x, wp, Ci, Co, ks, bias=None, pro=None, upsample=False, want_stats=False, out=None, accumulate=False,
+           out_f32=False):
+    """x blocked [B, Cib, Hs, Ws, 8] -> y blocked [B, Cob, H, W, 8] (or fp32 NCHW [B, Co, H, W] with out_f32).
+    wp: PackedW16 of the layer (mode 0: forward, Ci/Co the conv's; mode 1: data gradient, Ci/Co swapped by the
+    caller).  pro = (mean, invstd, gamma, beta, slope): producer BatchNorm + LeakyReLU fused into the load (3x3)."""
+    _req16(x, None if out_f32 else out)
+    B, Cib, Hs, Ws, _ = x.shape
+    assert Cib == cblocks(Ci), (Cib, Ci)
+    H, W = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
+    L = _lib.load()
+    if out is not None:
+        y = out
+    elif out_f32:
+        y = torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
+    else:
+        y = empty_blocked(B, Co, H, W, x.device)
+    stats = None
+    if want_stats:
+        stats = torch.empty((L.sivae_bf16_conv2d_num_px_tiles(B, Co, H, W), Co, 2), dtype=torch.float32,
+                            device=x.device)
+    pm = pi = pg = pb = None
+    slope = 1.0
+    if pro is not None:
+        pm, pi, pg, pb, slope = pro
+        ops._require(pm, pi, pg, pb)
+    ops._require(bias)
+    t0 = ops.TIMER.begin() if ops.TIMER is not None else None
+    _lib.call("sivae_bf16_conv2d_fwd", _p(x), _p(wp.data), _p(y), _p(bias), _p(pm), _p(pi), _p(pg), _p(pb),
+              float(slope), _p(stats), B, Ci, Co, H, W, ks, int(bool(upsample)), int(bool(accumulate)),
+              int(bool(out_f32)), _s(x))
+    if t0 is not None:
+        ops.TIMER.end("bf16_conv_kernel<%d,%s>" % (ks, "co32" if Co <= 32 else ("co64" if Co <= 64 else "co128")),
+                      2.0 * B * H * W * Co * Ci * ks * ks, t0)
+    return (y, stats) if want_stats else y
+
+
+def conv2d_wgrad(x, dy, Ci, Co, ks, pro=None, upsample=False):
+    """-> dW fp32 [Co, Ci, ks, ks]"""
+    _req16(x, dy)
+    B, Cob, H, W, _ = dy.shape
+    assert Cob == cblocks(Co) and x.shape[1] == cblocks(Ci)
+    L = _lib.load()
+    ws = ops.workspace(L.sivae_bf16_conv2d_wgrad_workspace_bytes(B, Ci, Co, H, W, ks), x.device)
+    dw = torch.empty((Co, Ci, ks, ks), dtype=torch.float32, device=x.device)
+    pm = pi = pg = pb = None
+    slope = 1.0
+    if pro is not None:
+        pm, pi, pg, pb, slope = pro
+        ops._require(pm, pi, pg, pb)
+    t0 = ops.TIMER.begin() if ops.TIMER is not None else None
+    _lib.call("sivae_bf16_conv2d_wgrad", _p(x), _p(dy), _p(dw), _p(pm), _p(pi), _p(pg), _p(pb), float(slope), B, Ci,
+              Co, H, W, ks, int(bool(upsample)), _p(ws), ws.numel(), _s(x))
+    if t0 is not None:
+        ops.TIMER.end("bf16_wgrad_kernel<%d>" % ks, 2.0 * B * H * W * Co * Ci * ks * ks, t0)
+    return dw
+
+
+def bn_apply_act(x, res, mean, invstd, gamma, beta, C, slope=LRELU_SLOPE, res_up=False, want_full=True, pool=False):
+    """LeakyReLU(BN(x) + res) -> (y or None, AvgPool2d(2)(y) or None)"""
+    _req16(x, res)
+    ops._require(mean, invstd, gamma, beta)
+    B, Cb, H, W, _ = x.shape
+    assert want_full or pool
+    y = torch.empty_like(x) if want_full else None
+    yp = torch.empty((B, Cb, H // 2, W // 2, 8), dtype=torch.bfloat16, device=x.device) if pool else None
+    _lib.call("sivae_bf16_bn_apply_act", _p(x), _p(res), int(bool(res_up)), _p(mean), _p(invstd), _p(gamma), _p(beta),
+              float(slope), _p(y), _p(yp), B, C, H, W, _s(x))
+    return y, yp
+
+
+def bn_bwd(dy, y, x, mean, invstd, gamma, beta, C, slope=LRELU_SLOPE, dy_pooled=False, want_dz=False, dz_sum=False,
+           want_param_grads=True):
+    """-> dx, dz (full resolution, its 2x2 block sums with dz_sum, or None), dgamma, dbeta.
+    y: the saved block output (sign of the activation), or None to recompute the sign from x (needs beta)."""
+    _req16(dy, y, x)
+    ops._require(mean, invstd, gamma, beta)
+    B, Cb, H, W, _ = x.shape
+    ws = ops.workspace(_lib.load().sivae_bf16_bn_bwd_workspace_bytes(B, C, H, W), x.device)
+    dx = torch.empty_like(x)
+    dz = None
+    if dz_sum:
+        dz = torch.empty((B, Cb, H // 2, W // 2, 8), dtype=torch.bfloat16, device=x.device)
+    elif want_dz:
+        dz = torch.empty_like(x)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
+    _lib.call("sivae_bf16_bn_bwd", _p(dy), int(bool(dy_pooled)), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma),
+              _p(beta), float(slope), _p(dx), _p(dz), int(bool(dz_sum)), _p(dgamma), _p(dbeta), B, C, H, W, _p(ws),
+              ws.numel(), _s(x))
+    return dx, dz, dgamma, dbeta
+
+
+def upsample2_fwd(x, C):
+    _req16(x)
+    B, Cb, H, W, _ = x.shape
+    y = torch.empty((B, Cb, 2 * H, 2 * W, 8), dtype=torch.bfloat16, device=x.device)
+    _lib.call("sivae_bf16_upsample2_fwd", _p(x), _p(y), B, C, H, W, _s(x))
+    return y
+
+
+def upsample2_bwd(dy, C):
+    _req16(dy)
+    B, Cb, H2, W2, _ = dy.shape
+    dx = torch.empty((B, Cb, H2 // 2, W2 // 2, 8), dtype=torch.bfloat16, device=dy.device)
+    _lib.call("sivae_bf16_upsample2_bwd", _p(dy), _p(dx), B, C, H2 // 2, W2 // 2, _s(dy))
+    return dx
+
+
+def add_(y, x):
+    _req16(y, x)
+    assert y.shape == x.shape
+    _lib.call("sivae_bf16_add_inplace", _p(y), _p(x), y.numel() // 8, _s(y))
+    return y

@@ -1,0 +1,351 @@
+"""Kernel-level parity checks of the bf16 mode (sivae_bf16_* entry points) against stock torch on the CPU in fp64.
+
+The reference op is evaluated in fp64 on the SAME bf16-rounded operands the kernel consumes, so what is measured is
+the kernel's own arithmetic (fp32 accumulation order, the final rounding to bf16), not the cost of the format:
+  * fp32 outputs (weight gradients, Decoder.predict's fp32 output, BatchNorm partial sums / parameter gradients):
+    err = max|hip - ref| / max|ref| <= 2e-5
+  * bf16 outputs: one rounding to 8 mantissa bits -> <= 2^-8 of the element; checked as max|hip - ref| / max|ref| <= 6e-3
+    plus element-wise |hip - ref| <= 2^-7 |ref| + 1e-3 max|ref|
+Used by tests/test_kernels16_gpu.py (pytest -m gpu) and `python tests/kernel_checks16.py [filter...]`.
+"""
+import sys
+import traceback
+
+import torch
+import torch.nn.functional as F
+
+DEV = "cuda"
+TOL_F32 = 2e-5
+TOL_BF16 = 6e-3
+SLOPE = 0.2
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64) * scale
+
+
+def _r16(t):
+    """round to bf16, return fp64"""
+    return t.float().bfloat16().double()
+
+
+def cblocks(C):
+    return ((C + 15) // 16) * 2
+
+
+def to_blocked(x):
+    """[B, C, H, W] (any float dtype) -> blocked bf16 [B, Cb, H, W, 8] on the CPU"""
+    B, C, H, W = x.shape
+    Cb = cblocks(C)
+    xp = torch.zeros(B, Cb * 8, H, W, dtype=torch.float32)
+    xp[:, :C] = x.float()
+    return xp.view(B, Cb, 8, H, W).permute(0, 1, 3, 4, 2).contiguous().bfloat16()
+
+
+def from_blocked(xb, C):
+    """blocked bf16 [B, Cb, H, W, 8] (any device) -> fp64 [B, C, H, W] on the CPU"""
+    xb = xb.detach().cpu().float()
+    B, Cb, H, W, _ = xb.shape
+    return xb.permute(0, 1, 4, 2, 3).reshape(B, Cb * 8, H, W)[:, :C].double()
+
+
+def _err(a, ref):
+    a = a.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    if a.shape != ref.shape or not torch.isfinite(a).all():
+        return float("inf")
+    return float((a - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def _err16(a, ref):
+    """bf16 output: max-norm error, made inf when an element misses the element-wise rounding bound"""
+    a = a.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    if a.shape != ref.shape or not torch.isfinite(a).all():
+        return float("inf")
+    m = float(ref.abs().max()) + 1e-30
+    if bool(((a - ref).abs() > ref.abs() * 2.0 ** -7 + 1e-3 * m).any()):
+        return float("inf")
+    return float((a - ref).abs().max() / m)
+
+
+def _padded_zero(xb, C):
+    """the padded channels of a blocked tensor must be exactly zero"""
+    xb = xb.detach().cpu().float()
+    B, Cb, H, W, _ = xb.shape
+    full = xb.permute(0, 1, 4, 2, 3).reshape(B, Cb * 8, H, W)
+    return float(full[:, C:].abs().max()) if Cb * 8 > C else 0.0
+
+
+CONV16_SHAPES = [
+    # (B, Ci, Co, H, W, ks)
+    (2, 64, 128, 32, 32, 3),
+    (2, 128, 64, 16, 16, 3),
+    (3, 64, 64, 64, 64, 3),
+    (4, 160, 136, 8, 8, 3),   # channel counts that are not multiples of the tiles
+    (8, 512, 512, 4, 4, 3),   # long K loop, four images per pixel tile
+    (5, 16, 32, 8, 8, 3),     # Co <= 32 configuration
+    (2, 24, 16, 12, 20, 3),   # ragged tiles, padded channels (24 -> 32, 16)
+    (2, 64, 64, 28, 28, 3),
+    (2, 64, 128, 32, 32, 1),
+    (2, 128, 64, 16, 16, 1),
+    (3, 48, 40, 8, 8, 1),     # 1x1 with 16-channel chunks
+    (3, 3, 64, 32, 32, 5),    # encoder stem
+    (2, 64, 3, 32, 32, 5),    # decoder predict
+    (2, 1, 64, 28, 28, 5),
+]
+
+
+def check_convert():
+    from sivae_hip import ops16
+    res = []
+    for shape in [(2, 3, 8, 8), (3, 64, 16, 16), (2, 40, 4, 4), (1, 512, 4, 4)]:
+        x = _rand(*shape, seed=1)
+        xb = ops16.from_f32(x.float().to(DEV))
+        res.append(("from_f32%s" % (shape,), _err(xb.cpu().float(), to_blocked(x).float()), 0.0))
+        back = ops16.to_f32(xb, shape[1])
+        res.append(("to_f32%s" % (shape,), _err(back, _r16(x)), 0.0))
+    return res
+
+
+def check_conv(shape, bias=False, stats=False, out_f32=False):
+    from sivae_hip import ops16
+    B, Ci, Co, H, W, ks = shape
+    x = _r16(_rand(B, Ci, H, W, seed=1))
+    w = _rand(Co, Ci, ks, ks, seed=2, scale=1.0 / (Ci * ks * ks) ** 0.5)
+    b = _rand(Co, seed=3) if bias else None
+    ref = F.conv2d(x, _r16(w), b.float().double() if bias else None, padding=ks // 2)
+    wp = ops16.PackedW16(w.float().to(DEV), 0)
+    out = ops16.conv2d(to_blocked(x).to(DEV), wp, Ci, Co, ks, bias=None if b is None else b.float().to(DEV),
+                       want_stats=stats, out_f32=out_f32)
+    res = []
+    tag = "conv16%s%s%s" % (shape, "+bias" if bias else "", "+f32out" if out_f32 else "")
+    if stats:
+        y, part = out
+        yr = from_blocked(y, Co)  # statistics are those of the ROUNDED output
+        s = part.double().cpu().sum(0)
+        res.append((tag + " sum", _err(s[:, 0], yr.sum((0, 2, 3))), TOL_F32 * 5))
+        res.append((tag + " sumsq", _err(s[:, 1], (yr * yr).sum((0, 2, 3))), TOL_F32 * 5))
+    else:
+        y = out
+    if out_f32:
+        res.append((tag, _err(y, ref), TOL_F32))
+    else:
+        res.append((tag, _err16(from_blocked(y, Co), ref), TOL_BF16))
+        res.append((tag + " pad", _padded_zero(y, Co), 0.0))
+    return res
+
+
+def check_conv_dgrad(shape):
+    from sivae_hip import ops16
+    B, Ci, Co, H, W, ks = shape
+    dy = _r16(_rand(B, Co, H, W, seed=4))
+    w = _rand(Co, Ci, ks, ks, seed=2, scale=1.0 / (Ci * ks * ks) ** 0.5)
+    ref = F.conv_transpose2d(dy, _r16(w), padding=ks // 2)
+    wp = ops16.PackedW16(w.float().to(DEV), 1)
+    dx = ops16.conv2d(to_blocked(dy).to(DEV), wp, Co, Ci, ks)
+    return [("dgrad16%s" % (shape,), _err16(from_blocked(dx, Ci), ref), TOL_BF16)]
+
+
+def check_conv_wgrad(shape, pro=False, upsample=False):
+    from sivae_hip import ops16
+    B, Ci, Co, H, W, ks = shape
+    Hs, Ws = (H // 2, W // 2) if upsample else (H, W)
+    x = _r16(_rand(B, Ci, Hs, Ws, seed=1))
+    dy = _r16(_rand(B, Co, H, W, seed=4))
+    xin = x
+    prot = None
+    if pro:
+        mean, var = _rand(Ci, seed=5, scale=0.3), _rand(Ci, seed=6).abs() + 0.5
+        gamma, beta = _rand(Ci, seed=7, scale=0.5) + 1.0, _rand(Ci, seed=8, scale=0.2)
+        invstd = (var + 1e-5).rsqrt()
+        sc = (invstd.float() * gamma.float()).double()
+        sh = (beta.float() - mean.float() * sc.float()).double()
+        xin = _r16(F.leaky_relu((x.float() * sc.float().view(1, -1, 1, 1) + sh.float().view(1, -1, 1, 1)).double(),
+                                SLOPE))
+        prot = tuple(t.float().to(DEV) for t in (mean, invstd, gamma, beta)) + (SLOPE,)
+    if upsample:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = torch.nn.grad.conv2d_weight(xin, (Co, Ci, ks, ks), dy, padding=ks // 2)
+    dw = ops16.conv2d_wgrad(to_blocked(x).to(DEV), to_blocked(dy).to(DEV), Ci, Co, ks, pro=prot, upsample=upsample)
+    return [("wgrad16%s%s%s" % (shape, "+pro" if pro else "", "+up" if upsample else ""), _err(dw, ref),
+             1e-3 if pro else TOL_F32)]
+
+
+def check_conv_fused(shape):
+    """prologue + upsample + stats + accumulate in one call"""
+    from sivae_hip import ops16
+    B, Ci, Co, H, W, ks = shape
+    res = []
+    x = _r16(_rand(B, Ci, H // 2, W // 2, seed=1))
+    w = _rand(Co, Ci, ks, ks, seed=2, scale=1.0 / (Ci * ks * ks) ** 0.5)
+    wp = ops16.PackedW16(w.float().to(DEV), 0)
+    # upsample addressing
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), _r16(w), padding=ks // 2)
+    y = ops16.conv2d(to_blocked(x).to(DEV), wp, Ci, Co, ks, upsample=True)
+    res.append(("conv16_up%s" % (shape,), _err16(from_blocked(y, Co), ref), TOL_BF16))
+    # accumulate
+    y0 = _r16(_rand(B, Co, H, W, seed=9))
+    yb = to_blocked(y0).to(DEV)
+    ops16.conv2d(to_blocked(x).to(DEV), wp, Ci, Co, ks, upsample=True, out=yb, accumulate=True)
+    res.append(("conv16_acc%s" % (shape,), _err16(from_blocked(yb, Co), ref + y0), TOL_BF16))
+    if ks == 3:
+        xf = _r16(_rand(B, Ci, H, W, seed=1))
+        mean, var = _rand(Ci, seed=5, scale=0.3), _rand(Ci, seed=6).abs() + 0.5
+        gamma, beta = _rand(Ci, seed=7, scale=0.5) + 1.0, _rand(Ci, seed=8, scale=0.2)
+        invstd = (var + 1e-5).rsqrt()
+        sc = (invstd.float() * gamma.float())
+        sh = (beta.float() - mean.float() * sc)
+        h = _r16(F.leaky_relu((xf.float() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).double(), SLOPE))
+        ref = F.conv2d(h, _r16(w), padding=1)
+        prot = tuple(t.float().to(DEV) for t in (mean, invstd, gamma, beta)) + (SLOPE,)
+        y, part = ops16.conv2d(to_blocked(xf).to(DEV), wp, Ci, Co, ks, pro=prot, want_stats=True)
+        # the prologue's own rounding of h to bf16 can differ by one ulp from the reference's (fma vs mul+add): allow
+        # a looser max-norm bound here
+        res.append(("conv16_pro%s" % (shape,), _err(from_blocked(y, Co), ref), 1.5e-2))
+        yr = from_blocked(y, Co)
+        s = part.double().cpu().sum(0)
+        res.append(("conv16_pro_stats%s" % (shape,), _err(s[:, 0], yr.sum((0, 2, 3))), 1e-4))
+    return res
+
+
+BN16_SHAPES = [(4, 64, 16, 16), (2, 24, 8, 12), (8, 512, 4, 4), (3, 128, 32, 32)]
+
+
+def _bn_params(C, x):
+    mean = x.mean((0, 2, 3))
+    var = x.var((0, 2, 3), unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    gamma, beta = _rand(C, seed=7, scale=0.5) + 1.0, _rand(C, seed=8, scale=0.2)
+    return [t.float().double() for t in (mean, invstd, gamma, beta)]
+
+
+def check_bn(shape, res_mode, pool):
+    """res_mode: 0 none, 1 same-resolution residual, 2 half-resolution residual (upsample addressing)"""
+    from sivae_hip import ops16
+    B, C, H, W = shape
+    x = _r16(_rand(B, C, H, W, seed=1))
+    mean, invstd, gamma, beta = _bn_params(C, x)
+    r = None
+    if res_mode == 1:
+        r = _r16(_rand(B, C, H, W, seed=2))
+    elif res_mode == 2:
+        r = _r16(_rand(B, C, H // 2, W // 2, seed=2))
+    rfull = None if r is None else (r if res_mode == 1 else F.interpolate(r, scale_factor=2, mode="nearest"))
+    sc = (invstd.float() * gamma.float())
+    sh = beta.float() - mean.float() * sc
+    z = (x.float() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).double()
+    if rfull is not None:
+        z = z + rfull
+    yref = F.leaky_relu(z, SLOPE)
+    dev = [t.float().to(DEV) for t in (mean, invstd, gamma, beta)]
+    y, yp = ops16.bn_apply_act(to_blocked(x).to(DEV), None if r is None else to_blocked(r).to(DEV), *dev, C,
+                               res_up=res_mode == 2, want_full=True, pool=pool)
+    tag = "bn16%s res%d%s" % (shape, res_mode, "+pool" if pool else "")
+    res = [(tag, _err(from_blocked(y, C), yref), TOL_BF16)]
+    if pool:
+        res.append((tag + " pooled", _err(from_blocked(yp, C), F.avg_pool2d(from_blocked(y, C), 2)), TOL_BF16))
+    # ---- backward
+    yr = from_blocked(y, C)  # the kernel takes the activation sign from ITS rounded output
+    for dy_pooled, dz_sum in ((False, False), (True, False), (False, True)):
+        dyf = _r16(_rand(B, C, H // 2, W // 2, seed=3) if dy_pooled else _rand(B, C, H, W, seed=3))
+        dy_full = F.interpolate(dyf, scale_factor=2, mode="nearest") * 0.25 if dy_pooled else dyf
+        g = dy_full * torch.where(yr > 0, 1.0, SLOPE)
+        xh = (x - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+        sg, sgx = g.sum((0, 2, 3)), (g * xh).sum((0, 2, 3))
+        n = B * H * W
+        dxr = (gamma * invstd).view(1, -1, 1, 1) * (g - (sg / n).view(1, -1, 1, 1) - xh * (sgx / n).view(1, -1, 1, 1))
+        dx, dz, dg, db = ops16.bn_bwd(to_blocked(dyf).to(DEV), y, to_blocked(x).to(DEV), *dev, C, dy_pooled=dy_pooled,
+                                      want_dz=True, dz_sum=dz_sum)
+        t2 = tag + (" bwd pooled-dy" if dy_pooled else (" bwd dzsum" if dz_sum else " bwd"))
+        res.append((t2 + " dx", _err(from_blocked(dx, C), dxr), 1.2e-2))
+        dzr = F.avg_pool2d(g, 2) * 4 if dz_sum else g
+        res.append((t2 + " dz", _err(from_blocked(dz, C), dzr), TOL_BF16))
+        res.append((t2 + " dgamma", _err(dg, sgx), 1e-4))
+        res.append((t2 + " dbeta", _err(db, sg), 1e-4))
+    if res_mode == 0:
+        # sign recomputed from x (no saved output): stem / BatchNorm-1 form
+        zz = (x - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+        # (drop elements within rounding of the kink: the recomputed sign may legitimately differ there)
+        dyf = _r16(_rand(B, C, H, W, seed=3))
+        g = dyf * torch.where(zz > 0, 1.0, SLOPE)
+        xh = (x - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+        sg, sgx = g.sum((0, 2, 3)), (g * xh).sum((0, 2, 3))
+        n = B * H * W
+        dxr = (gamma * invstd).view(1, -1, 1, 1) * (g - (sg / n).view(1, -1, 1, 1) - xh * (sgx / n).view(1, -1, 1, 1))
+        dx, _, dg, db = ops16.bn_bwd(to_blocked(dyf).to(DEV), None, to_blocked(x).to(DEV), *dev, C)
+        near = zz.abs() < 1e-4
+        d = (from_blocked(dx, C) - dxr).abs()
+        d[near] = 0
+        res.append((tag + " bwd recomputed-sign dx", float(d.max() / dxr.abs().max()), 1.2e-2))
+        res.append((tag + " bwd recomputed-sign dbeta", _err(db, sg), 2e-3))
+    return res
+
+
+def check_eltwise16():
+    from sivae_hip import ops16
+    res = []
+    x = _r16(_rand(3, 40, 6, 10, seed=1))
+    xb = to_blocked(x).to(DEV)
+    res.append(("upsample16_fwd", _err(from_blocked(ops16.upsample2_fwd(xb, 40), 40),
+                                       F.interpolate(x, scale_factor=2, mode="nearest")), 0.0))
+    dy = _r16(_rand(3, 40, 12, 20, seed=2))
+    res.append(("upsample16_bwd", _err(from_blocked(ops16.upsample2_bwd(to_blocked(dy).to(DEV), 40), 40),
+                                       F.avg_pool2d(dy, 2) * 4), TOL_BF16))
+    a, b = _r16(_rand(2, 64, 8, 8, seed=3)), _r16(_rand(2, 64, 8, 8, seed=4))
+    ab = to_blocked(a).to(DEV)
+    ops16.add_(ab, to_blocked(b).to(DEV))
+    res.append(("add16", _err(from_blocked(ab, 64), a + b), TOL_BF16))
+    return res
+
+
+def all_checks():
+    checks = [("convert16", check_convert)]
+    for s in CONV16_SHAPES:
+        checks.append(("conv16%s" % (s,), lambda s=s: check_conv(s)))
+        checks.append(("dgrad16%s" % (s,), lambda s=s: check_conv_dgrad(s)))
+        checks.append(("wgrad16%s" % (s,), lambda s=s: check_conv_wgrad(s)))
+    checks.append(("conv16_bias_f32out", lambda: check_conv((2, 64, 3, 32, 32, 5), bias=True, out_f32=True)
+                   + check_conv((2, 64, 3, 16, 16, 5), bias=True)))
+    checks.append(("conv16_stats", lambda: check_conv((3, 64, 128, 32, 32, 3), stats=True)
+                   + check_conv((3, 64, 64, 32, 32, 3), stats=True) + check_conv((3, 24, 40, 12, 12, 3), stats=True)
+                   + check_conv((5, 32, 96, 4, 4, 3), stats=True)))
+    for s in [(2, 64, 128, 32, 32, 3), (2, 128, 64, 16, 16, 1), (3, 64, 64, 8, 8, 3), (2, 24, 40, 12, 20, 3)]:
+        checks.append(("conv16_fused%s" % (s,), lambda s=s: check_conv_fused(s)))
+    for s in [(2, 64, 128, 32, 32, 3), (3, 24, 40, 12, 20, 3), (4, 64, 64, 8, 8, 3)]:
+        checks.append(("wgrad16_fused%s" % (s,), lambda s=s: check_conv_wgrad(s, pro=True)
+                       + check_conv_wgrad(s, upsample=True)))
+    for s in BN16_SHAPES:
+        for rm in (0, 1, 2):
+            checks.append(("bn16%s res%d" % (s, rm), lambda s=s, rm=rm: check_bn(s, rm, pool=rm != 2)))
+    checks.append(("eltwise16", check_eltwise16))
+    return checks
+
+
+def main():
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "soft-intro-vae-pytorch_amd"))
+    nfail = 0
+    rows = []
+    filt = sys.argv[1:]
+    for label, thunk in all_checks():
+        if filt and not any(f in label for f in filt):
+            continue
+        try:
+            for name, err, tol in thunk():
+                ok = err <= tol
+                nfail += (not ok)
+                rows.append("%-4s %-66s err=%.3e tol=%.1e" % ("ok" if ok else "FAIL", name, err, tol))
+        except Exception:  # noqa: BLE001
+            nfail += 1
+            rows.append("EXC  %s\n%s" % (label, traceback.format_exc(limit=4)))
+        torch.cuda.synchronize()
+    print("\n".join(rows))
+    print("kernel_checks16: %d failures of %d" % (nfail, len(rows)))
+    return nfail
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main() else 0)
