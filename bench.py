@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: config batch PER GPU (global = batch*N); strong: config batch is the global batch")
     ap.add_argument("--bootstrap", action="store_true", help="soft_intro_vae_bootstrap variant (config 5)")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32: the parity path (headline); bf16: config 3's build-defined mode (bf16 storage + bf16 MFMA "
+                         "convs, fp32 accumulation / statistics / master weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-iters", type=int, default=1)
@@ -158,7 +161,8 @@ def main():
     sync = dp.GradSync() if world > 1 else None
     sync_bn = dp.enable_sync_bn(args.sync_bn)
     eng = SoftIntroEngine(model, opt_e, opt_d, beta_kl=bk, beta_rec=br, beta_neg=bn, gamma_r=gr,
-                          bootstrap=args.bootstrap, grad_sync=sync, reuse_decoder_forward=not args.no_reuse)
+                          bootstrap=args.bootstrap, grad_sync=sync, reuse_decoder_forward=not args.no_reuse,
+                          compute_dtype=args.dtype)
     rng.manual_seed(0, rank)
     g = torch.Generator().manual_seed(1234 + rank)
     real = torch.rand(per, 3, image_size, image_size, generator=g).to(dev)
@@ -252,7 +256,7 @@ def main():
         else "training images/sec (whole node) at %dx%d bs%d" % (image_size, image_size, per),
         "value": round(value, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
         "config": {"workload": "soft_intro_vae%s %s %dx%d zdim=%d channels=%s, full E-step + D-step iteration"
                                % ("_bootstrap" if args.bootstrap else "", args.config, image_size, image_size, zdim,
                                   channels),

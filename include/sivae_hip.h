@@ -314,6 +314,19 @@ int sivae_u8_to_f32(const unsigned char* src, float* dst, const int* flip, int B
  * src and dst 16-byte aligned. */
 int sivae_f32_to_u8(const float* src, unsigned char* dst, size_t numel, float scale, sivae_stream_t stream);
 
+/* ---- nn.Linear (Encoder.fc :109,:121 / Decoder.fc :146,:166) as small-M GEMMs -------------------------------------
+ * x [B][K], W [N][K] (nn.Linear.weight), y [B][N], all fp32 row-major; B <= 256, K % 4 == 0, N % 4 == 0
+ * (sivae_linear_supported; other shapes run as 1x1 convolutions through sivae_conv2d_fwd / _wgrad).
+ * One wave per 32 output columns x a slice of the contraction (~1000 waves per call instead of cdiv(N,128) blocks),
+ * fixed-order reduction of the slices -> deterministic.  relu != 0 fuses the nn.ReLU after Decoder.fc (:147). */
+int sivae_linear_supported(int B, int K, int N);
+size_t sivae_linear_workspace_bytes(int B, int K, int N);
+int sivae_linear_fwd(const float* x, const float* w, const float* bias, float* y, int relu, int B, int K, int N,
+                     void* workspace, size_t workspace_bytes, sivae_stream_t stream);
+int sivae_linear_dgrad(const float* dy, const float* w, float* dx, int B, int K, int N, void* workspace,
+                       size_t workspace_bytes, sivae_stream_t stream);
+int sivae_linear_wgrad(const float* dy, const float* x, float* dw, int B, int K, int N, sivae_stream_t stream);
+
 /* ---- bf16 mode (config 3 of BASELINE.json: "CelebA 128x128 ... bf16") -----------------------------------------
  * The reference trains in fp32 only (soft_intro_vae/train_soft_intro_vae.py:376-440 has no autocast / GradScaler), so
  * this mode is build-defined: activations and activation gradients are stored in bf16, the convolutions run on

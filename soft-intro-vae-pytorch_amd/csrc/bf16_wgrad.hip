@@ -129,6 +129,55 @@ __global__ void __launch_bounds__(WVCO* WVCI* WVT * 64, MINW) bf16_wgrad_kernel(
   u32x4_t dr[MAXD], xr[MAXX];
   bool x_in[MAXX];
 
+  // ---- staging maps, tile-invariant part (done once): in-tile coordinates and the offset relative to the tile
+  // origin.  ((b*Cb + cb)*H + r)*W + c is linear in (b0, r0, c0), so a tile costs each vector one add and three
+  // range checks instead of a chain of integer divisions.
+  unsigned d_rel[MAXD];
+  int d_crd[MAXD];  // tb | rr << 8 | cc << 16, or -1: vector outside the tile image / channel range
+#pragma unroll
+  for (int p = 0; p < MAXD; ++p) {
+    const int v = tid + p * NT;
+    d_crd[p] = -1;
+    d_rel[p] = 0;
+    if (NDY % NT == 0 || v < NDY) {
+      const int cbl = v & 3;
+      const int slot = (v >> 2) % TPX;
+      const int sub = (v >> 2) / TPX;
+      const int cc = slot & (TW - 1);
+      const int rr = (slot >> a.tw_log2) & (TH - 1);
+      const int tb = slot >> (a.tw_log2 + a.th_log2);
+      const int cb = cob0 + sub * 4 + cbl;
+      if (cb < a.Cob) {
+        d_crd[p] = tb | (rr << 8) | (cc << 16);
+        d_rel[p] = ((((unsigned)tb * a.Cob + cb) * H + rr) * W + cc) * 16u;
+      }
+    }
+  }
+  int x_rel[MAXX];  // signed: the halo reaches above / left of the tile origin
+  int x_crd[MAXX];
+#pragma unroll
+  for (int p = 0; p < MAXX; ++p) {
+    const int v = tid + p * NT;
+    x_crd[p] = -1;
+    x_rel[p] = 0;
+    if (v < nxv) {
+      const int cbl = v & 3;
+      const int pos = (v >> 2) % plane;
+      const int sub = (v >> 2) / plane;
+      const int cc = pos % LW;
+      const int t3 = pos / LW;
+      const int rr = t3 % LH;
+      const int tb = t3 / LH;
+      const int cb = cib0 + sub * 4 + cbl;
+      if (cb < a.Cib) {
+        x_crd[p] = tb | (rr << 8) | (cc << 16);
+        // tile origins are even, so with upsample addressing (r0 + rr - P) >> 1 == (r0 >> 1) + ((rr - P) >> 1)
+        const int rs = a.upsample ? ((rr - P) >> 1) : (rr - P), cs = a.upsample ? ((cc - P) >> 1) : (cc - P);
+        x_rel[p] = (((tb * a.Cib + cb) * Hs + rs) * Ws + cs) * 16;
+      }
+    }
+  }
+
 #define SIVAE_WG_LOAD(T)                                                                                        \
   {                                                                                                             \
     const int tw_i = (T) % a.ntw;                                                                               \
@@ -136,43 +185,20 @@ __global__ void __launch_bounds__(WVCO* WVCI* WVT * 64, MINW) bf16_wgrad_kernel(
     const int th_i = t2 % a.nth;                                                                                \
     const int tb_i = t2 / a.nth;                                                                                \
     const int b0 = tb_i << a.tb_log2, r0 = th_i << a.th_log2, c0 = tw_i << a.tw_log2;                           \
+    const unsigned d_org = (((unsigned)b0 * a.Cob * H + r0) * W + c0) * 16u;                                    \
+    const int r0s = a.upsample ? (r0 >> 1) : r0, c0s = a.upsample ? (c0 >> 1) : c0;                             \
+    const unsigned x_org = (((unsigned)b0 * a.Cib * Hs + r0s) * Ws + c0s) * 16u;                                \
     _Pragma("unroll") for (int p = 0; p < MAXD; ++p) {                                                          \
-      const int v = tid + p * NT;                                                                               \
-      unsigned off = SIVAE_OOB;                                                                                 \
-      if (NDY % NT == 0 || v < NDY) {                                                                           \
-        const int cbl = v & 3;                                                                                  \
-        const int slot = (v >> 2) % TPX;                                                                        \
-        const int sub = (v >> 2) / TPX;                                                                         \
-        const int cc = slot & (TW - 1);                                                                         \
-        const int rr = (slot >> a.tw_log2) & (TH - 1);                                                          \
-        const int tb = slot >> (a.tw_log2 + a.th_log2);                                                         \
-        const int b = b0 + tb, r = r0 + rr, c = c0 + cc;                                                        \
-        const int cb = cob0 + sub * 4 + cbl;                                                                    \
-        if (b < a.B && r < H && c < W && cb < a.Cob)                                                            \
-          off = ((((unsigned)b * a.Cob + cb) * H + r) * W + c) * 16u;                                           \
-      }                                                                                                         \
-      dr[p] = buf_load_u32x4(dyrsrc, off, 0u);                                                                  \
+      const int crd = d_crd[p];                                                                                 \
+      const bool ok = crd >= 0 && b0 + (crd & 255) < a.B && r0 + ((crd >> 8) & 255) < H && c0 + (crd >> 16) < W; \
+      dr[p] = buf_load_u32x4(dyrsrc, ok ? d_org + d_rel[p] : SIVAE_OOB, 0u);                                    \
     }                                                                                                           \
     _Pragma("unroll") for (int p = 0; p < MAXX; ++p) {                                                          \
-      const int v = tid + p * NT;                                                                               \
-      unsigned off = SIVAE_OOB;                                                                                 \
-      if (v < nxv) {                                                                                            \
-        const int cbl = v & 3;                                                                                  \
-        const int pos = (v >> 2) % plane;                                                                       \
-        const int sub = (v >> 2) / plane;                                                                       \
-        const int cc = pos % LW;                                                                                \
-        const int t3 = pos / LW;                                                                                \
-        const int rr = t3 % LH;                                                                                 \
-        const int tb = t3 / LH;                                                                                 \
-        const int b = b0 + tb, r = r0 + rr - P, c = c0 + cc - P;                                                \
-        const int cb = cib0 + sub * 4 + cbl;                                                                    \
-        if (b < a.B && r >= 0 && r < H && c >= 0 && c < W && cb < a.Cib) {                                      \
-          const int rs = a.upsample ? (r >> 1) : r, cs = a.upsample ? (c >> 1) : c;                             \
-          off = ((((unsigned)b * a.Cib + cb) * Hs + rs) * Ws + cs) * 16u;                                       \
-        }                                                                                                       \
-      }                                                                                                         \
-      x_in[p] = off != SIVAE_OOB;                                                                               \
-      xr[p] = buf_load_u32x4(xrsrc, off, 0u);                                                                   \
+      const int crd = x_crd[p];                                                                                 \
+      const int r = r0 + ((crd >> 8) & 255) - P, c = c0 + (crd >> 16) - P;                                      \
+      const bool ok = crd >= 0 && b0 + (crd & 255) < a.B && r >= 0 && r < H && c >= 0 && c < W;                 \
+      x_in[p] = ok;                                                                                             \
+      xr[p] = buf_load_u32x4(xrsrc, ok ? (unsigned)((int)x_org + x_rel[p]) : SIVAE_OOB, 0u);                    \
     }                                                                                                           \
   }
 

@@ -62,7 +62,14 @@ class SoftIntroEngine:
     """Owns the two flat-buffer optimizers and runs iterations on a SoftIntroVAE model."""
 
     def __init__(self, model, opt_e, opt_d, beta_kl=1.0, beta_rec=1.0, beta_neg=1.0, gamma_r=1e-8,
-                 recon_loss_type="mse", bootstrap=False, grad_sync=None, reuse_decoder_forward=True):
+                 recon_loss_type="mse", bootstrap=False, grad_sync=None, reuse_decoder_forward=True,
+                 compute_dtype=None):
+        """compute_dtype: None (leave the model as it is), "fp32" (the parity path) or "bf16" (BASELINE.json config 3's
+        build-defined mode: bf16 activation storage and bf16 MFMA convs with fp32 accumulation — sivae_hip.nn
+        .set_compute_dtype; weights, BatchNorm statistics, losses, gradients buffers and Adam stay fp32)."""
+        if compute_dtype is not None:
+            from .nn import set_compute_dtype
+            set_compute_dtype(model, compute_dtype)
         self.model, self.opt_e, self.opt_d = model, opt_e, opt_d
         self.beta_kl, self.beta_rec, self.beta_neg, self.gamma_r = beta_kl, beta_rec, beta_neg, gamma_r
         self.loss_type = recon_loss_type

@@ -36,7 +36,11 @@ BN_MOMENTUM = 0.1
 # changes (torch's version counter for in-place updates, plus a generation counter bumped by the fused
 # optimizer which writes through raw pointers).
 # ---------------------------------------------------------------------------------------------------
-_pack_cache = {}
+_epoch = [0]  # bumped by clear_pack_cache(): every cached pack / replay cache built before it is stale
+
+
+def cache_epoch():
+    return _epoch[0]
 
 
 def bump_generation(params):
@@ -44,27 +48,29 @@ def bump_generation(params):
         p._sivae_gen = getattr(p, "_sivae_gen", 0) + 1
 
 
-def packed(w, mode):
-    key = (id(w), mode)
-    tag = (w._version, getattr(w, "_sivae_gen", 0), w.data_ptr())
-    hit = _pack_cache.get(key)
+def _wtag(w):
+    return (w._version, getattr(w, "_sivae_gen", 0), w.data_ptr(), _epoch[0])
+
+
+def _cached_pack(w, slot, build):
+    """packs live ON the parameter object (they die with it; no id() aliasing, nothing accumulates across models)"""
+    store = w.__dict__.setdefault("_sivae_pack", {})
+    tag = _wtag(w)
+    hit = store.get(slot)
     if hit is not None and hit[0] == tag:
         return hit[1]
-    wp = ops.PackedW(w.detach(), mode)
-    _pack_cache[key] = (tag, wp)
+    wp = build()
+    store[slot] = (tag, wp)
     return wp
+
+
+def packed(w, mode):
+    return _cached_pack(w, mode, lambda: ops.PackedW(w.detach(), mode))
 
 
 def packed5(w, mode):
     """pack for the small-channel 5x5 kernels (same invalidation rules as `packed`)"""
-    key = (id(w), 10 + mode)
-    tag = (w._version, getattr(w, "_sivae_gen", 0), w.data_ptr())
-    hit = _pack_cache.get(key)
-    if hit is not None and hit[0] == tag:
-        return hit[1]
-    wq = ops.pack5_smallco(w.detach(), mode)
-    _pack_cache[key] = (tag, wq)
-    return wq
+    return _cached_pack(w, 10 + mode, lambda: ops.pack5_smallco(w.detach(), mode))
 
 
 def _is_edge5(w):
@@ -72,7 +78,12 @@ def _is_edge5(w):
 
 
 def clear_pack_cache():
-    _pack_cache.clear()
+    _epoch[0] += 1
+
+
+def cache_tag(weights):
+    """validity tag of a replayable forward pass: (version, optimizer generation, storage) of every weight it used"""
+    return tuple(None if w is None else _wtag(w) for w in weights)
 
 
 class BNState:
@@ -127,7 +138,9 @@ class ResBlockFn(torch.autograd.Function):
     def forward(ctx, x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache=None, x_up=False):
         """cache: None, or a dict owned by the caller.  An empty dict is FILLED with this pass's activations;
         a filled one is REPLAYED: no kernels run except the BatchNorm running-stat updates, the outputs and the
-        tensors saved for backward are the cached ones (valid only while x and all weights are unchanged).
+        tensors saved for backward are the cached ones.  A replay is only valid while x and all weights are unchanged:
+        the weights are checked here (`cache_tag`: torch version counter, optimizer generation, storage) and a stale
+        entry is recomputed; the input is checked once per pass by Decoder.forward.
 
         x_up: x is stored at HALF resolution and stands for Upsample(2,'nearest')(x) (train_soft_intro_vae.py:155):
         every consumer (conv1, conv_expand or the identity add, both weight gradients) reads it through upsample
@@ -139,7 +152,8 @@ class ResBlockFn(torch.autograd.Function):
             H, W = 2 * H, 2 * W
         ctx.x_up = x_up
         Cm, Co = w1.shape[0], w2.shape[0]
-        if cache is not None and cache.get("y") is not None:
+        tag = cache_tag((w_exp, w1, g1, b1, w2, g2, b2))
+        if cache is not None and cache.get("y") is not None and cache.get("tag") == tag:
             a, h, c, out, mean1, invstd1, mean2, invstd2, y = (cache[k] for k in (
                 "a", "h", "c", "out", "mean1", "invstd1", "mean2", "invstd2", "y"))
             _replay_bn(st1, mean1, invstd1, B * H * W)
@@ -191,7 +205,8 @@ class ResBlockFn(torch.autograd.Function):
                 out = ops.bn_apply_act(c, idt, mean2, invstd2, g2.detach(), b2.detach(), SLOPE, res_up=x_up)
                 y = _post_fwd(out, post)
         if cache is not None:
-            cache.update(a=a, h=h, c=c, out=out, mean1=mean1, invstd1=invstd1, mean2=mean2, invstd2=invstd2, y=y)
+            cache.update(a=a, h=h, c=c, out=out, mean1=mean1, invstd1=invstd1, mean2=mean2, invstd2=invstd2, y=y,
+                         tag=tag)
         ctx.post = post
         ctx.has_exp = w_exp is not None
         ctx.training = st1.training and st2.training
@@ -348,7 +363,8 @@ class ConvBiasFn(torch.autograd.Function):
         ks = w.shape[2]
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
-        if cache is not None and cache.get("y") is not None:
+        tag = cache_tag((w, bias))
+        if cache is not None and cache.get("y") is not None and cache.get("tag") == tag:
             return cache["y"].view_as(cache["y"])
         b_ = None if bias is None else bias.detach()
         if _is_edge5(w) and w.shape[0] <= 3:
@@ -356,7 +372,7 @@ class ConvBiasFn(torch.autograd.Function):
         else:
             y = ops.conv2d_fwd(x, packed(w, 0), w.shape[0], ks, bias=b_)
         if cache is not None:
-            cache["y"] = y
+            cache["y"], cache["tag"] = y, tag
         return y
 
     @staticmethod
@@ -374,17 +390,22 @@ class ConvBiasFn(torch.autograd.Function):
 
 
 class LinearFn(torch.autograd.Function):
-    """y = x W^T + b (optionally followed by ReLU) on the ks=1 path of the conv kernels (H = W = 1)."""
+    """y = x W^T + b (optionally followed by ReLU): the small-batch GEMM kernels of linear.hip (split-contraction, ~1000
+    waves per call); shapes they do not take run on the ks=1 path of the conv kernels (H = W = 1)."""
 
     @staticmethod
     def forward(ctx, x, w, bias, relu):
         x = x.contiguous()
         B, K = x.shape
         N = w.shape[0]
-        y = ops.conv2d_fwd(x.view(B, K, 1, 1), packed(w, 0), N, 1, bias=None if bias is None else bias.detach())
-        y = y.view(B, N)
-        if relu:
-            ops.relu_fwd(y, inplace=True)
+        ctx.fast = ops.linear_supported(B, K, N)
+        b_ = None if bias is None else bias.detach()
+        if ctx.fast:
+            y = ops.linear_fwd(x, w.detach(), b_, relu)
+        else:
+            y = ops.conv2d_fwd(x.view(B, K, 1, 1), packed(w, 0), N, 1, bias=b_).view(B, N)
+            if relu:
+                ops.relu_fwd(y, inplace=True)
         ctx.relu = relu
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, w, y if relu else None)
@@ -400,9 +421,13 @@ class LinearFn(torch.autograd.Function):
         B, K = x.shape
         N = w.shape[0]
         dy4 = dy.view(B, N, 1, 1)
-        dw = ops.conv2d_wgrad(x.view(B, K, 1, 1), dy4, 1).view(N, K) if need[1] else None
         db = ops.channel_sum(dy4) if (ctx.has_bias and need[2]) else None
-        dx = ops.conv2d_fwd(dy4, packed(w, 1), K, 1).view(B, K) if need[0] else None
+        if ctx.fast:
+            dw = ops.linear_wgrad(dy, x) if need[1] else None
+            dx = ops.linear_dgrad(dy, w.detach()) if need[0] else None
+        else:
+            dw = ops.conv2d_wgrad(x.view(B, K, 1, 1), dy4, 1).view(N, K) if need[1] else None
+            dx = ops.conv2d_fwd(dy4, packed(w, 1), K, 1).view(B, K) if need[0] else None
         return dx, dw, db, None
 
 

@@ -1,0 +1,222 @@
+"""bf16-mode twins of the differentiable blocks in `functional.py` (config 3 of BASELINE.json, build-defined: the
+reference has no mixed precision).
+
+Same module granularity and the same saved-tensor policy as the fp32 blocks (one autograd node per ResidualBlock /
+stem / predict; BatchNorm-1's output is never written, its LeakyReLU sign is recomputed in the backward), but every
+activation and activation gradient between the blocks is a blocked bf16 tensor [B, C16/8, H, W, 8] (`ops16`), the convs
+run on the bf16 matrix pipe with fp32 accumulation, and BatchNorm statistics / all parameter gradients stay fp32 (they
+land in the same flat fp32 gradient buffers the fused Adam and the RCCL all-reduce use).  The two Linear layers, the
+sampler and the loss kernels keep their fp32 kernels: `to_blocked` / `from_blocked` are the differentiable layout
+changes at those seams (reference call sites: train_soft_intro_vae.py:116-122 encoder fc, :161-168 decoder fc/view).
+"""
+import torch
+
+from . import functional as SF
+from . import ops
+from . import ops16
+
+SLOPE = SF.SLOPE
+
+
+def packed16(w, mode):
+    """bf16 operand slabs of a master weight, cached ON the parameter (dies with it) and rebuilt when it changes"""
+    tag = (w._version, getattr(w, "_sivae_gen", 0), w.data_ptr(), SF.cache_epoch())
+    store = w.__dict__.setdefault("_sivae_pack16", {})
+    hit = store.get(mode)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    wp = ops16.PackedW16(w.detach(), mode)
+    store[mode] = (tag, wp)
+    return wp
+
+
+class ToBlockedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.C = x.shape[1]
+        return ops16.from_f32(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops16.to_f32(g.contiguous(), ctx.C)
+
+
+class FromBlockedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xb, C):
+        return ops16.to_f32(xb, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops16.from_f32(g.contiguous()), None
+
+
+def to_blocked(x):
+    return ToBlockedFn.apply(x)
+
+
+def from_blocked(xb, C):
+    return FromBlockedFn.apply(xb, C)
+
+
+class ResBlockFn16(torch.autograd.Function):
+    """ResidualBlock.forward (train_soft_intro_vae.py:65-75) on blocked bf16 activations; arguments as
+    functional.ResBlockFn (x_up: x is stored at half resolution and stands for Upsample(2)(x))"""
+
+    @staticmethod
+    def forward(ctx, x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache=None, x_up=False):
+        B, Cib, Hs, Ws, _ = x.shape
+        H, W = (2 * Hs, 2 * Ws) if x_up else (Hs, Ws)
+        Cm, Ci, Co = w1.shape[0], w1.shape[1], w2.shape[0]
+        ctx.x_up, ctx.post, ctx.has_exp = x_up, post, w_exp is not None
+        ctx.training = st1.training and st2.training
+        ctx.dims = (Ci, Cm, Co)
+        tag = SF.cache_tag((w_exp, w1, g1, b1, w2, g2, b2))
+        if cache is not None and cache.get("y") is not None and cache.get("tag") == tag:
+            a, c, out, mean1, invstd1, mean2, invstd2, y = (cache[k] for k in (
+                "a", "c", "out", "mean1", "invstd1", "mean2", "invstd2", "y"))
+            SF._replay_bn(st1, mean1, invstd1, B * H * W)
+            SF._replay_bn(st2, mean2, invstd2, B * H * W)
+            ctx.save_for_backward(x, a, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2, b2)
+            return y.view_as(y)
+        idt = x
+        if w_exp is not None:
+            idt = ops16.conv2d(x, packed16(w_exp, 0), Ci, Co, 1)  # (at half resolution with x_up: commutes with Upsample)
+        if st1.training:
+            a, p1 = ops16.conv2d(x, packed16(w1, 0), Ci, Cm, 3, want_stats=True, upsample=x_up)
+        else:
+            a, p1 = ops16.conv2d(x, packed16(w1, 0), Ci, Cm, 3, upsample=x_up), None
+        mean1, invstd1 = SF._stats(p1, B, Cm, H * W, st1)
+        pro1 = (mean1, invstd1, g1.detach(), b1.detach(), SLOPE)
+        if st2.training:
+            c, p2 = ops16.conv2d(a, packed16(w2, 0), Cm, Co, 3, pro=pro1, want_stats=True)
+        else:
+            c, p2 = ops16.conv2d(a, packed16(w2, 0), Cm, Co, 3, pro=pro1), None
+        mean2, invstd2 = SF._stats(p2, B, Co, H * W, st2)
+        pool = post == "pool"
+        out, yp = ops16.bn_apply_act(c, idt, mean2, invstd2, g2.detach(), b2.detach(), Co, SLOPE, res_up=x_up,
+                                     want_full=True, pool=pool)
+        if pool:
+            y = yp
+        elif post == "up":
+            y = ops16.upsample2_fwd(out, Co)
+        else:
+            y = out
+        if cache is not None:
+            cache.update(a=a, c=c, out=out, mean1=mean1, invstd1=invstd1, mean2=mean2, invstd2=invstd2, y=y, tag=tag)
+        ctx.save_for_backward(x, a, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2, b2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise RuntimeError("sivae_hip: backward through eval-mode BatchNorm is not supported")
+        x, a, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2, b2 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        need_x, need_we, need_w1, need_bn1, need_w2, need_bn2 = need[0], need[1], need[2], need[3] or need[4], \
+            need[5], need[6] or need[7]
+        Ci, Cm, Co = ctx.dims
+        x_up = ctx.x_up
+        dy = dy.contiguous()
+        pool = ctx.post == "pool"
+        d_out = ops16.upsample2_bwd(dy, Co) if ctx.post == "up" else dy
+        need_dz = need_x or (need_we and ctx.has_exp)
+        dc, dz, dg2, db2 = ops16.bn_bwd(d_out, out, c, mean2, invstd2, g2, b2, Co, SLOPE, dy_pooled=pool,
+                                        want_dz=need_dz and not x_up, dz_sum=need_dz and x_up,
+                                        want_param_grads=need_bn2)
+        del d_out
+        pro1 = (mean1, invstd1, g1, b1, SLOPE)
+        dw2 = ops16.conv2d_wgrad(a, dc, Cm, Co, 3, pro=pro1) if need_w2 else None
+        dh = ops16.conv2d(dc, packed16(w2, 1), Co, Cm, 3)
+        del dc
+        da, _, dg1, db1 = ops16.bn_bwd(dh, None, a, mean1, invstd1, g1, b1, Cm, SLOPE, want_param_grads=need_bn1)
+        del dh
+        dw1 = ops16.conv2d_wgrad(x, da, Ci, Cm, 3, upsample=x_up) if need_w1 else None
+        dwe = None
+        dx = None
+        if need_x:
+            dx = ops16.conv2d(da, packed16(w1, 1), Cm, Ci, 3)
+            if x_up:
+                dx = ops16.upsample2_bwd(dx, Ci)  # adjoint of the deferred nn.Upsample
+            if ctx.has_exp:
+                ops16.conv2d(dz, packed16(w_exp, 1), Co, Ci, 1, out=dx, accumulate=True)
+            else:
+                ops16.add_(dx, dz)
+        if need_we and ctx.has_exp:
+            dwe = ops16.conv2d_wgrad(x, dz, Ci, Co, 1)
+        return (dx, dwe, dw1, dg1 if need[3] else None, db1 if need[4] else None, dw2,
+                dg2 if need[6] else None, db2 if need[7] else None, None, None, None, None, None)
+
+
+class StemFn16(torch.autograd.Function):
+    """conv5x5 -> BatchNorm -> LeakyReLU -> AvgPool2d(2) (train_soft_intro_vae.py:88-93); x: blocked image batch"""
+
+    @staticmethod
+    def forward(ctx, x, w, g, b, st):
+        B, _, H, W, _ = x.shape
+        Co, Ci = w.shape[0], w.shape[1]
+        if st.training:
+            a, p = ops16.conv2d(x, packed16(w, 0), Ci, Co, 5, want_stats=True)
+        else:
+            a, p = ops16.conv2d(x, packed16(w, 0), Ci, Co, 5), None
+        mean, invstd = SF._stats(p, B, Co, H * W, st)
+        _, out = ops16.bn_apply_act(a, None, mean, invstd, g.detach(), b.detach(), Co, SLOPE, want_full=False,
+                                    pool=True)
+        ctx.training = st.training
+        ctx.save_for_backward(x, a, mean, invstd, w, g, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise RuntimeError("sivae_hip: backward through eval-mode BatchNorm is not supported")
+        x, a, mean, invstd, w, g, b = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        Co, Ci = w.shape[0], w.shape[1]
+        da, _, dg, db = ops16.bn_bwd(dy.contiguous(), None, a, mean, invstd, g, b, Co, SLOPE, dy_pooled=True,
+                                     want_param_grads=need[2] or need[3])
+        dw = ops16.conv2d_wgrad(x, da, Ci, Co, 5) if need[1] else None
+        dx = ops16.conv2d(da, packed16(w, 1), Co, Ci, 5) if need[0] else None
+        return dx, dw, dg if need[2] else None, db if need[3] else None, None
+
+
+class PredictFn16(torch.autograd.Function):
+    """Decoder.predict (conv5x5 + bias, train_soft_intro_vae.py:159): blocked bf16 in, fp32 NCHW out (the
+    reconstruction feeds the fp32 loss kernels directly)"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, cache=None):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        tag = SF.cache_tag((w, bias))
+        if cache is not None and cache.get("y") is not None and cache.get("tag") == tag:
+            return cache["y"].view_as(cache["y"])
+        Co, Ci, ks = w.shape[0], w.shape[1], w.shape[2]
+        y = ops16.conv2d(x, packed16(w, 0), Ci, Co, ks, bias=None if bias is None else bias.detach(), out_f32=True)
+        if cache is not None:
+            cache["y"], cache["tag"] = y, tag
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        Co, Ci, ks = w.shape[0], w.shape[1], w.shape[2]
+        dy = dy.contiguous()
+        dyb = ops16.from_f32(dy)
+        dw = ops16.conv2d_wgrad(x, dyb, Ci, Co, ks) if need[1] else None
+        db = ops.channel_sum(dy) if (ctx.has_bias and need[2]) else None
+        dx = ops16.conv2d(dyb, packed16(w, 1), Co, Ci, ks) if need[0] else None
+        return dx, dw, db, None
+
+
+def residual_block(x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post=None, cache=None, x_up=False):
+    return ResBlockFn16.apply(x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache, x_up)
+
+
+def stem(x, w, g, b, st):
+    return StemFn16.apply(x, w, g, b, st)
+
+
+def conv_bias(x, w, bias, cache=None):
+    return PredictFn16.apply(x, w, bias, cache)

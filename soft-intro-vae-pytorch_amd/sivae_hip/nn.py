@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as SF
+from . import functional16 as SF16
 
 
 # SIVAE_DEFER_UPSAMPLE=0 materialises every nn.Upsample output as the reference does (A/B measurements)
@@ -41,15 +42,32 @@ class ResidualBlock(nn.Module):
     def forward(self, x, post=None, cache=None, x_up=False):
         """post in {None, 'pool', 'up', 'up_deferred'} fuses the AvgPool2d / Upsample that follows the block in the
         nets ('up_deferred': the next block reads this block's output through upsample addressing, x_up=True there).
-        cache: see functional.ResBlockFn (activation cache for replaying an identical forward pass)."""
-        return SF.residual_block(x, None if self.conv_expand is None else self.conv_expand.weight,
+        cache: see functional.ResBlockFn (activation cache for replaying an identical forward pass).
+        A blocked bf16 input (bf16 mode, `set_compute_dtype`) runs the bf16 twin of the block."""
+        block = SF16.residual_block if x.dtype == torch.bfloat16 else SF.residual_block
+        return block(x, None if self.conv_expand is None else self.conv_expand.weight,
                                  self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight,
                                  self.bn2.weight, self.bn2.bias, SF.BNState(self.bn1), SF.BNState(self.bn2), post,
                                  cache, x_up)
 
 
+def set_compute_dtype(module, dtype):
+    """Select the arithmetic of every Encoder / Decoder under `module`: "fp32" (the parity path, default) or "bf16"
+    (build-defined mixed precision for BASELINE.json config 3: bf16 activation storage + bf16 MFMA convs with fp32
+    accumulation, fp32 BatchNorm statistics, master weights, losses and Adam — functional16.py)."""
+    if dtype not in ("fp32", "bf16"):
+        raise ValueError("compute dtype must be 'fp32' or 'bf16', got %r" % (dtype,))
+    for m in module.modules():
+        if isinstance(m, (Encoder, Decoder)):
+            m.compute_dtype = dtype
+    return module
+
+
 def _run_main(main, x, cache=None):
-    """Walk a reference-shaped nn.Sequential, dispatching each group of layers to its fused HIP block."""
+    """Walk a reference-shaped nn.Sequential, dispatching each group of layers to its fused HIP block.
+    x: fp32 NCHW, or a blocked bf16 activation (bf16 mode): the blocks dispatch on the input dtype."""
+    bf16 = x.dtype == torch.bfloat16
+    F_ = SF16 if bf16 else SF
     mods = list(main.children())
     i, n = 0, len(mods)
     x_up = False  # x currently stands for Upsample(2,'nearest')(x): the consumers read it through upsample addressing
@@ -65,7 +83,7 @@ def _run_main(main, x, cache=None):
             elif isinstance(nxt, nn.Upsample):
                 # leave the Upsample to the next block when that is a ResidualBlock (its kernels read through
                 # h>>1, w>>1; the residual add needs the upsampled width to be a multiple of 4)
-                w_here = x.shape[3] * (2 if x_up else 1)
+                w_here = x.shape[3] * (2 if x_up else 1)  # (dim 3 is W in both layouts)
                 defer = DEFER_UPSAMPLE and i + 2 < n and isinstance(mods[i + 2], ResidualBlock) and w_here % 2 == 0
                 x = m(x, post="up_deferred" if defer else "up", cache=sub, x_up=x_up)
                 x_up = defer
@@ -77,10 +95,10 @@ def _run_main(main, x, cache=None):
         elif isinstance(m, nn.Conv2d) and isinstance(nxt, nn.BatchNorm2d):
             # encoder stem: conv5x5 -> BN -> LeakyReLU -> AvgPool2d
             assert isinstance(mods[i + 2], nn.LeakyReLU) and isinstance(mods[i + 3], nn.AvgPool2d)
-            x = SF.stem(x, m.weight, nxt.weight, nxt.bias, SF.BNState(nxt))
+            x = F_.stem(x, m.weight, nxt.weight, nxt.bias, SF.BNState(nxt))
             i += 4
         elif isinstance(m, nn.Conv2d):
-            x = SF.conv_bias(x, m.weight, m.bias, sub)
+            x = F_.conv_bias(x, m.weight, m.bias, sub)
             i += 1
         else:
             raise RuntimeError("sivae_hip: unexpected layer %s in network" % type(m).__name__)
@@ -98,6 +116,7 @@ class Encoder(nn.Module):
         self.image_size = image_size
         self.conditional = conditional
         self.cond_dim = cond_dim
+        self.compute_dtype = "fp32"
         cc = channels[0]
         self.main = nn.Sequential(
             nn.Conv2d(cdim, cc, 5, 1, 2, bias=False),
@@ -139,7 +158,11 @@ class Encoder(nn.Module):
         return torch.Size([last.conv2.out_channels, s, s])
 
     def forward(self, x, o_cond=None):
-        y = _run_main(self.main, x).reshape(x.size(0), -1)
+        if self.compute_dtype == "bf16":
+            y = SF16.from_blocked(_run_main(self.main, SF16.to_blocked(x)), self.conv_output_size[0])
+            y = y.reshape(x.size(0), -1)
+        else:
+            y = _run_main(self.main, x).reshape(x.size(0), -1)
         if self.conditional and o_cond is not None:
             y = torch.cat([y, o_cond], dim=1)
         y = SF.linear(y, self.fc.weight, self.fc.bias)
@@ -156,6 +179,7 @@ class Decoder(nn.Module):
         self.cdim = cdim
         self.image_size = image_size
         self.conditional = conditional
+        self.compute_dtype = "fp32"
         cc = channels[-1]
         self.conv_input_size = conv_input_size
         if conv_input_size is None:
@@ -184,6 +208,15 @@ class Decoder(nn.Module):
         if self.conditional and y_cond is not None:
             y_cond = y_cond.reshape(y_cond.size(0), -1)
             z = torch.cat([z, y_cond], dim=1)
+        if cache is not None:
+            # a filled cache replays the pass only for the SAME input tensor (storage, version and shape); anything
+            # else starts a fresh fill.  (The weights are checked block by block: functional.cache_tag.)
+            key = (z.data_ptr(), z._version, tuple(z.shape), self.compute_dtype)
+            if cache.get("in_key") != key:
+                cache.clear()
+                cache["in_key"] = key
         y = SF.linear(z, self.fc[0].weight, self.fc[0].bias, relu=True)
         y = y.view(z.size(0), *self.conv_input_size)
+        if self.compute_dtype == "bf16":
+            y = SF16.to_blocked(y)
         return _run_main(self.main, y, cache)

@@ -373,6 +373,50 @@ def conv2d_wgrad(x, dy, ks, pro=None, upsample=False):
     return dw
 
 
+# ------------------------------------------------------------------------------------------------ linear
+def linear_supported(B, K, N):
+    return _lib.load().sivae_linear_supported(B, K, N) == 1
+
+
+def linear_fwd(x, w, bias=None, relu=False):
+    """y = x W^T + b (optionally ReLU) for a small batch: x [B, K], w [N, K] -> [B, N]"""
+    _require(x, w, bias)
+    B, K = x.shape
+    N = w.shape[0]
+    ws = workspace(_lib.load().sivae_linear_workspace_bytes(B, K, N), x.device)
+    y = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    t0 = TIMER.begin() if TIMER is not None else None
+    _lib.call("sivae_linear_fwd", _p(x), _p(w), _p(bias), _p(y), int(bool(relu)), B, K, N, _p(ws), ws.numel(), _s(x))
+    if t0 is not None:
+        TIMER.end("linear_fwd_kernel", 2.0 * B * K * N, t0)
+    return y
+
+
+def linear_dgrad(dy, w):
+    _require(dy, w)
+    B, N = dy.shape
+    K = w.shape[1]
+    ws = workspace(_lib.load().sivae_linear_workspace_bytes(B, K, N), dy.device)
+    dx = torch.empty((B, K), dtype=torch.float32, device=dy.device)
+    t0 = TIMER.begin() if TIMER is not None else None
+    _lib.call("sivae_linear_dgrad", _p(dy), _p(w), _p(dx), B, K, N, _p(ws), ws.numel(), _s(dy))
+    if t0 is not None:
+        TIMER.end("linear_dgrad_kernel", 2.0 * B * K * N, t0)
+    return dx
+
+
+def linear_wgrad(dy, x):
+    _require(dy, x)
+    B, N = dy.shape
+    K = x.shape[1]
+    dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    t0 = TIMER.begin() if TIMER is not None else None
+    _lib.call("sivae_linear_wgrad", _p(dy), _p(x), _p(dw), B, K, N, _s(dy))
+    if t0 is not None:
+        TIMER.end("linear_wgrad_kernel", 2.0 * B * K * N, t0)
+    return dw
+
+
 # ------------------------------------------------------------------------------------------------ 5x5 edges
 def pack5_smallco(w, mode):
     """mode 0: w [Cs<=3, Cb, 5, 5] (predict) ; mode 1: w [Cb, Cs<=3, 5, 5] (stem, data-gradient operand)"""

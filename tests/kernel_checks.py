@@ -231,6 +231,30 @@ def check_linear():
     return res
 
 
+def check_linear_fast():
+    """linear.hip (small-batch split-contraction GEMMs) incl. ragged batch / column / contraction sizes, bias + ReLU"""
+    from sivae_hip import ops
+    res = []
+    for (B, K, N) in [(128, 8192, 512), (16, 8192, 1024), (16, 512, 8192), (128, 256, 8192), (7, 100, 36), (33, 4100, 60),
+                      (1, 64, 128), (200, 72, 260)]:
+        assert ops.linear_supported(B, K, N)
+        x = _rand(B, K, seed=1).requires_grad_()
+        w = _rand(N, K, seed=2, scale=1.0 / math.sqrt(K)).requires_grad_()
+        b = _rand(N, seed=3)
+        dy = _rand(B, N, seed=4)
+        ref = F.linear(x, w, b)
+        ref.backward(dy)
+        tag = "(%d,%d,%d)" % (B, K, N)
+        y = ops.linear_fwd(_d(x.detach()), _d(w.detach()), _d(b))
+        res.append(("linear_fast_fwd" + tag, _err(y, ref), 1e-5))
+        yr = ops.linear_fwd(_d(x.detach()), _d(w.detach()), _d(b), relu=True)
+        res.append(("linear_fast_fwd_relu" + tag, _err(yr, ref.detach().clamp(min=0)), 1e-5))
+        res.append(("linear_fast_dgrad" + tag, _err(ops.linear_dgrad(_d(dy), _d(w.detach())), x.grad), 1e-5))
+        res.append(("linear_fast_wgrad" + tag, _err(ops.linear_wgrad(_d(dy), _d(x.detach())), w.grad), 1e-5))
+    res.append(("linear_fast_unsupported", float(ops.linear_supported(300, 64, 64) or ops.linear_supported(8, 66, 64)), 0.0))
+    return res
+
+
 # ------------------------------------------------------------------------------------------------ BN
 BN_SHAPES = [(4, 64, 32, 32), (8, 512, 4, 4), (3, 7, 7, 7), (2, 128, 64, 64), (16, 256, 1, 1)]
 
@@ -746,6 +770,7 @@ def all_checks():
                    + check_conv_up((2, 20, 33, 16, 32, 3), pro=True, stats=True)))
     checks.append(("conv5_edge", check_conv5_edge))
     checks.append(("linear", check_linear))
+    checks.append(("linear_fast", check_linear_fast))
     for s in BN_SHAPES:
         checks.append(("bn%s" % (s,), lambda s=s: check_bn(s, False)))
         checks.append(("bn+res%s" % (s,), lambda s=s: check_bn(s, True)))
