@@ -246,21 +246,25 @@ __global__ void __launch_bounds__(256) bf16_bn_bwd_partial_kernel(const void* __
   }
 }
 
-// sums[c] = {sg, sgx} (fp64 over the slices); dgamma = sgx, dbeta = sg
-__global__ void bf16_bn_bwd_finalize_kernel(const float* __restrict__ part, int nslices, int C,
-                                            float* __restrict__ sums, float* __restrict__ dgamma,
-                                            float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// sums[c] = {sg, sgx} (fp64 over the slices, one wave per channel, fixed order); dgamma = sgx, dbeta = sg
+__global__ void __launch_bounds__(64) bf16_bn_bwd_finalize_kernel(const float* __restrict__ part, int nslices, int C,
+                                                                  float* __restrict__ sums, float* __restrict__ dgamma,
+                                                                  float* __restrict__ dbeta) {
+  const int c = blockIdx.x;
   double a = 0.0, b = 0.0;
-  for (int s = 0; s < nslices; ++s) {
-    a += (double)part[((size_t)s * C + c) * 2 + 0];
-    b += (double)part[((size_t)s * C + c) * 2 + 1];
+  for (int s = threadIdx.x; s < nslices; s += 64) {
+    const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)s * C + c) * 2);
+    a += (double)v.x;
+    b += (double)v.y;
   }
-  sums[2 * c + 0] = (float)a;
-  sums[2 * c + 1] = (float)b;
-  if (dgamma) dgamma[c] = (float)b;
-  if (dbeta) dbeta[c] = (float)a;
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if (threadIdx.x == 0) {
+    sums[2 * c + 0] = (float)a;
+    sums[2 * c + 1] = (float)b;
+    if (dgamma) dgamma[c] = (float)b;
+    if (dbeta) dbeta[c] = (float)a;
+  }
 }
 
 template <int ACT, bool QUAD>
@@ -489,8 +493,7 @@ extern "C" int sivae_bf16_bn_bwd(const void* dy, int dy_pooled, const void* y, c
   else
     hipLaunchKernelGGL(bf16_bn_bwd_partial_kernel<2>, dim3(ns, Cb), dim3(256), 0, stream, dy, dy_pooled, y, x, mean,
                        invstd, gamma, beta, slope, part, B, C, Cb, H, W);
-  hipLaunchKernelGGL(bf16_bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, part, ns, C, sums,
-                     dgamma, dbeta);
+  hipLaunchKernelGGL(bf16_bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, stream, part, ns, C, sums, dgamma, dbeta);
   const float inv_n = 1.0f / ((float)B * H * W);
   const size_t lds = (size_t)Cb * 48 * sizeof(float);
   const size_t n = quad ? (size_t)B * Cb * (H / 2) * (W / 2) : (size_t)B * Cb * H * W;

@@ -303,23 +303,58 @@ __global__ void __launch_bounds__(WVCO* WVCI* WVT * 64, MINW) bf16_wgrad_kernel(
   }
 }
 
-// out[(co*Ci + ci)*TAPS + tap] = sum_slices part[slice][tap][co][ci]  (fixed order)
-__global__ void bf16_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nslices, int taps,
-                                         int coci) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= coci) return;
-  const size_t sstride = (size_t)taps * coci;
-  for (int t = 0; t < taps; ++t) {
-    const float* p = part + (size_t)t * coci + e;
-    float s0 = 0.f, s1 = 0.f;
-    int s = 0;
-    for (; s + 1 < nslices; s += 2) {
-      s0 += p[(size_t)s * sstride];
-      s1 += p[(size_t)(s + 1) * sstride];
+// dw[(co*Ci + ci)*TAPS + tap] = sum_slices part[slice][tap][co][ci]  (fixed order -> deterministic).
+// A block owns (co, 64 consecutive ci): NG groups of 64 lanes walk the slices (group g takes slices g, g + NG, ...) with
+// one accumulator per tap, loads coalesced along ci; the groups are folded through LDS in group order and the block
+// writes its 64 * TAPS results as ONE contiguous run of the [Co][Ci][TAPS] gradient (the tap index is the fastest one
+// there, so the transpose happens in LDS, not in strided global stores).
+template <int TAPS, int NG>
+__global__ void __launch_bounds__(64 * NG) bf16_wgrad_reduce_kernel(const float* __restrict__ part,
+                                                                    float* __restrict__ dw, int nslices, int Co,
+                                                                    int Ci) {
+  __shared__ float red[NG][TAPS][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int n_ci = (Ci + 63) / 64;
+  const int co = blockIdx.x / n_ci, ci0 = (blockIdx.x % n_ci) * 64;
+  const int ci = ci0 + lane;
+  float acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) acc[t] = 0.f;
+  if (ci < Ci) {
+    const size_t coci = (size_t)Co * Ci;
+    const float* p = part + (size_t)co * Ci + ci;
+    for (int s = g; s < nslices; s += NG) {
+      const float* ps = p + (size_t)s * TAPS * coci;
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) acc[t] += ps[(size_t)t * coci];
     }
-    if (s < nslices) s0 += p[(size_t)s * sstride];
-    dw[(size_t)e * taps + t] = s0 + s1;
   }
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) red[g][t][lane] = acc[t];
+  __syncthreads();
+  int n_here = Ci - ci0;
+  if (n_here > 64) n_here = 64;
+  float* dst = dw + ((size_t)co * Ci + ci0) * TAPS;
+  for (int j = threadIdx.x; j < n_here * TAPS; j += 64 * NG) {
+    const int c = j / TAPS, t = j - c * TAPS;
+    float v = 0.f;
+#pragma unroll
+    for (int gg = 0; gg < NG; ++gg) v += red[gg][t][c];
+    dst[j] = v;
+  }
+}
+
+template <int TAPS>
+static int launch_wg_reduce(const float* part, float* dw, int nslices, int Co, int Ci, hipStream_t stream) {
+  const unsigned nb = (unsigned)Co * (unsigned)((Ci + 63) / 64);
+  if (nslices >= 32 && TAPS * 16 * 64 * 4 <= 64 * 1024)
+    hipLaunchKernelGGL((bf16_wgrad_reduce_kernel<TAPS, (TAPS <= 9 ? 16 : 8)>), dim3(nb), dim3(64 * (TAPS <= 9 ? 16 : 8)), 0,
+                       stream, part, dw, nslices, Co, Ci);
+  else if (nslices >= 32)
+    hipLaunchKernelGGL((bf16_wgrad_reduce_kernel<TAPS, 8>), dim3(nb), dim3(512), 0, stream, part, dw, nslices, Co, Ci);
+  else
+    hipLaunchKernelGGL((bf16_wgrad_reduce_kernel<TAPS, 4>), dim3(nb), dim3(256), 0, stream, part, dw, nslices, Co, Ci);
+  return sivae_launch_status();
 }
 
 namespace {
@@ -347,7 +382,7 @@ int wg_slices(int B, int Ci, int Co, int H, int W, int ks, int* ntiles_out, Tile
   TileGeom g = make_tile_geom(B, H, W, 64);
   const int ntiles = g.ntb * g.nth * g.ntw;
   const long long out_tiles = (long long)cdiv(Co, c.TCO) * cdiv(Ci, c.TCI);
-  long long ns = (1024 + out_tiles - 1) / out_tiles;  // ~4 resident blocks per CU over the chip
+  long long ns = (512 + out_tiles - 1) / out_tiles;  // one resident wave of blocks (2 per CU at 2 waves per SIMD)
   if (ns > ntiles) ns = ntiles;
   const long long bytes_per = (long long)Co * Ci * ks * ks * 4;
   while (ns > 1 && ns * bytes_per > (96ll << 20)) --ns;
@@ -436,8 +471,7 @@ extern "C" int sivae_bf16_conv2d_wgrad(const void* x, const void* dy, float* dw,
     rc = launch_wg<5, 1, 1, 1, 1, 4, 4, false, 2>(a, g, stream);
   }
   if (rc != SIVAE_OK) return rc;
-  const int coci = Co * Ci;
-  hipLaunchKernelGGL(bf16_wgrad_reduce_kernel, dim3((unsigned)((coci + 255) / 256)), dim3(256), 0, stream, a.part, dw,
-                     a.nslices, ks * ks, coci);
-  return sivae_launch_status();
+  if (ks == 3) return launch_wg_reduce<9>(a.part, dw, a.nslices, Co, Ci, stream);
+  if (ks == 1) return launch_wg_reduce<1>(a.part, dw, a.nslices, Co, Ci, stream);
+  return launch_wg_reduce<25>(a.part, dw, a.nslices, Co, Ci, stream);
 }

@@ -9,6 +9,8 @@ land in the same flat fp32 gradient buffers the fused Adam and the RCCL all-redu
 sampler and the loss kernels keep their fp32 kernels: `to_blocked` / `from_blocked` are the differentiable layout
 changes at those seams (reference call sites: train_soft_intro_vae.py:116-122 encoder fc, :161-168 decoder fc/view).
 """
+import os
+
 import torch
 
 from . import functional as SF
@@ -16,6 +18,12 @@ from . import ops
 from . import ops16
 
 SLOPE = SF.SLOPE
+# h = LeakyReLU(BN1(conv1)) is WRITTEN (one bf16 pass) and kept for the backward in this mode: the producer-BatchNorm
+# prologue costs the bf16 conv / weight-gradient kernels more (unpack + affine + LeakyReLU + repack of every staged vector
+# between two short MFMA phases: conv2 137 vs 77 us, its weight gradient 190 vs 96 us per launch at 128x128 bs128) than
+# the extra half-width pass (~30 us).  In fp32 the same trade was a wash (functional.MATERIALIZE_H).
+# SIVAE_BF16_MATERIALIZE_H=0 keeps the fused prologue (A/B measurements).
+MATERIALIZE_H = os.environ.get("SIVAE_BF16_MATERIALIZE_H", "1") != "0"
 
 
 def packed16(w, mode):
@@ -73,11 +81,11 @@ class ResBlockFn16(torch.autograd.Function):
         ctx.dims = (Ci, Cm, Co)
         tag = SF.cache_tag((w_exp, w1, g1, b1, w2, g2, b2))
         if cache is not None and cache.get("y") is not None and cache.get("tag") == tag:
-            a, c, out, mean1, invstd1, mean2, invstd2, y = (cache[k] for k in (
-                "a", "c", "out", "mean1", "invstd1", "mean2", "invstd2", "y"))
+            a, h, c, out, mean1, invstd1, mean2, invstd2, y = (cache[k] for k in (
+                "a", "h", "c", "out", "mean1", "invstd1", "mean2", "invstd2", "y"))
             SF._replay_bn(st1, mean1, invstd1, B * H * W)
             SF._replay_bn(st2, mean2, invstd2, B * H * W)
-            ctx.save_for_backward(x, a, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2, b2)
+            ctx.save_for_backward(x, a, h, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2, b2)
             return y.view_as(y)
         idt = x
         if w_exp is not None:
@@ -87,11 +95,15 @@ class ResBlockFn16(torch.autograd.Function):
         else:
             a, p1 = ops16.conv2d(x, packed16(w1, 0), Ci, Cm, 3, upsample=x_up), None
         mean1, invstd1 = SF._stats(p1, B, Cm, H * W, st1)
-        pro1 = (mean1, invstd1, g1.detach(), b1.detach(), SLOPE)
-        if st2.training:
-            c, p2 = ops16.conv2d(a, packed16(w2, 0), Cm, Co, 3, pro=pro1, want_stats=True)
+        if MATERIALIZE_H:
+            h, _ = ops16.bn_apply_act(a, None, mean1, invstd1, g1.detach(), b1.detach(), Cm, SLOPE)
+            pro1 = None
         else:
-            c, p2 = ops16.conv2d(a, packed16(w2, 0), Cm, Co, 3, pro=pro1), None
+            h, pro1 = a, (mean1, invstd1, g1.detach(), b1.detach(), SLOPE)
+        if st2.training:
+            c, p2 = ops16.conv2d(h, packed16(w2, 0), Cm, Co, 3, pro=pro1, want_stats=True)
+        else:
+            c, p2 = ops16.conv2d(h, packed16(w2, 0), Cm, Co, 3, pro=pro1), None
         mean2, invstd2 = SF._stats(p2, B, Co, H * W, st2)
         pool = post == "pool"
         out, yp = ops16.bn_apply_act(c, idt, mean2, invstd2, g2.detach(), b2.detach(), Co, SLOPE, res_up=x_up,
@@ -103,15 +115,17 @@ class ResBlockFn16(torch.autograd.Function):
         else:
             y = out
         if cache is not None:
-            cache.update(a=a, c=c, out=out, mean1=mean1, invstd1=invstd1, mean2=mean2, invstd2=invstd2, y=y, tag=tag)
-        ctx.save_for_backward(x, a, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2, b2)
+            cache.update(a=a, h=h, c=c, out=out, mean1=mean1, invstd1=invstd1, mean2=mean2, invstd2=invstd2, y=y,
+                         tag=tag)
+        ctx.save_for_backward(x, a, h, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2, b2)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         if not ctx.training:
             raise RuntimeError("sivae_hip: backward through eval-mode BatchNorm is not supported")
-        x, a, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2, b2 = ctx.saved_tensors
+        x, a, h, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2, b2 = ctx.saved_tensors
+        h_saved = h.data_ptr() != a.data_ptr()
         need = ctx.needs_input_grad
         need_x, need_we, need_w1, need_bn1, need_w2, need_bn2 = need[0], need[1], need[2], need[3] or need[4], \
             need[5], need[6] or need[7]
@@ -125,11 +139,13 @@ class ResBlockFn16(torch.autograd.Function):
                                         want_dz=need_dz and not x_up, dz_sum=need_dz and x_up,
                                         want_param_grads=need_bn2)
         del d_out
-        pro1 = (mean1, invstd1, g1, b1, SLOPE)
-        dw2 = ops16.conv2d_wgrad(a, dc, Cm, Co, 3, pro=pro1) if need_w2 else None
+        pro1 = None if h_saved else (mean1, invstd1, g1, b1, SLOPE)
+        dw2 = ops16.conv2d_wgrad(h, dc, Cm, Co, 3, pro=pro1) if need_w2 else None
         dh = ops16.conv2d(dc, packed16(w2, 1), Co, Cm, 3)
         del dc
-        da, _, dg1, db1 = ops16.bn_bwd(dh, None, a, mean1, invstd1, g1, b1, Cm, SLOPE, want_param_grads=need_bn1)
+        # BatchNorm-1 + LeakyReLU: sign from the saved h, or recomputed from a when h was never stored
+        da, _, dg1, db1 = ops16.bn_bwd(dh, h if h_saved else None, a, mean1, invstd1, g1, b1, Cm, SLOPE,
+                                       want_param_grads=need_bn1)
         del dh
         dw1 = ops16.conv2d_wgrad(x, da, Ci, Cm, 3, upsample=x_up) if need_w1 else None
         dwe = None
