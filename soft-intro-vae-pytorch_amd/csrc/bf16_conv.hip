@@ -415,11 +415,42 @@ int launch_cfg(Bf16ConvArgs& a, hipStream_t stream) {
   return sivae_launch_status();
 }
 
+// SIVAE_BF16_CONV_TILE=0 forces the small pixel tiles (A/B switch for tools/bench_conv16.py)
+int big_tiles_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SIVAE_BF16_CONV_TILE");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
+// Pixel tile of the 3x3 kernels.  Per 16-channel chunk a block stages its whole weight slab (288 bytes per output
+// channel) through LDS, so with the small tile (128 co x 128 px: 1152 MFMA cycles per SIMD per chunk) the LDS pipe is as
+// busy as the matrix pipe (~535 cycles of ds_write_b128 + ~576 of operand reads).  Doubling the pixels per wave
+// (64 co x 128 px, 128 accumulators) halves the weight staging per MFMA -> LDS ~65 % of the MFMA time.  The big tile is
+// used where it still gives every CU two blocks; small maps / short grids keep the small one.
+int px_tile_3x3(int TCO, int B, int H, int W, int n_out) {
+  const int small = TCO == 128 ? 128 : 256;
+  if (!big_tiles_enabled() || TCO == 32) return small;
+  const int big = 2 * small;
+  TileGeom g = make_tile_geom(B, H, W, big);
+  const long long nblk = (long long)g.ntb * g.nth * g.ntw * cdiv(n_out, TCO);
+  const int plane = (1 << g.tb_log2) * ((1 << g.th_log2) + 2) * ((1 << g.tw_log2) + 2);
+  if (nblk < 512 || 2 * plane > 5 * 256) return small;
+  return big;
+}
+
 template <int KS, int CKS, int MAXV, bool PRO, bool OUTF32>
 int launch_by_co(Bf16ConvArgs& a, int TCO, hipStream_t stream) {
   if (TCO == 32) return launch_cfg<KS, 1, 2, 1, 4, CKS, MAXV, PRO, OUTF32, 2>(a, stream);
   if (OUTF32) return SIVAE_ERR_SHAPE;  // fp32 NCHW output exists for the RGB-side `predict` conv only
   if constexpr (!OUTF32) {
+    if constexpr (KS == 3) {
+      const int tpx = px_tile_3x3(TCO, a.B, a.H, a.W, a.Co);
+      if (TCO == 64 && tpx == 512) return launch_cfg<KS, 2, 4, 1, 4, CKS, MAXV, PRO, false, 2>(a, stream);
+      if (TCO == 128 && tpx == 256) return launch_cfg<KS, 2, 4, 2, 2, CKS, MAXV, PRO, false, 2>(a, stream);
+    }
     if (TCO == 64) return launch_cfg<KS, 2, 2, 1, 4, CKS, MAXV, PRO, false, 2>(a, stream);
     return launch_cfg<KS, 2, 2, 2, 2, CKS, MAXV, PRO, false, 2>(a, stream);
   }
@@ -455,7 +486,7 @@ extern "C" int sivae_bf16_pack_conv_weight(const float* w, void* wp, int Co, int
 extern "C" int sivae_bf16_conv2d_num_px_tiles(int B, int Co, int H, int W) {
   if (B <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
   const Bf16Cfg c = bf16_cfg(3, Co, 16);
-  TileGeom g = make_tile_geom(B, H, W, c.TPX);
+  TileGeom g = make_tile_geom(B, H, W, px_tile_3x3(c.TCO, B, H, W, Co));
   return g.ntb * g.nth * g.ntw;
 }
 
