@@ -8,15 +8,20 @@
 A "step" is one full Soft-IntroVAE iteration of soft_intro_vae/train_soft_intro_vae.py:547-624 (5 encoder +
 8 decoder forwards, both backwards, both Adam updates) on a synthetic U[0,1) NCHW batch already resident in
 HBM, fp32, random-init weights of the CelebA-HQ-256 network (channels [64,128,256,512,512,512], z 512).
-Data parallel runs keep the per-GPU work fixed at the N = 1 workload (128 images per GPU, global batch 128*N:
-"weak" scaling, the per-image shard rule of this path); `--scaling strong` instead fixes the global batch at 128
-(128/N images per GPU).  Gradients of the encoder and of the decoder are each all-reduced once per iteration
-over RCCL (two flat fp32 buffers, 109.5 MB + 83.8 MB).
+Data-parallel runs (N > 1) report the BASELINE configuration as it is stated — global batch 128 split per image over the
+N GPUs (128/N images per GPU, "scaling": "strong") — as the headline `value`, and ALSO time the fixed-per-GPU-work
+variant (128 images per GPU, global batch 128*N) in the same invocation, reported under "weak"; each names its
+per-GPU batch.  `--scaling strong|weak` runs just one of them.  Gradients of the encoder and of the decoder are each
+all-reduced once per iteration over RCCL (two flat fp32 buffers, 109.5 MB + 83.8 MB).
 
 Prints ONE JSON line (rank 0). Besides the contract keys it carries
-  roofline      the dominant MFMA kernel timed with HIP events around every launch in the timed region
-                (algorithmic conv FLOPs / measured time vs the 157.3 TFLOP/s fp32 matrix peak), plus the
-                whole-step algorithmic TFLOP/s (13 F_E + 19 F_D - 3 f_conv0 per image)
+  roofline      the dominant MFMA kernel timed with HIP events around every launch in the timed region.  `achieved` /
+                `frac` are PHYSICAL: FLOPs the kernel issued to the matrix pipe (Winograd F(2x2,3x3) issues 16/36 of a
+                3x3 conv's multiplies) / measured time, against the dense peak of the dtype (157.3 TFLOP/s fp32 MFMA,
+                2.5 PFLOP/s bf16) — always <= 1; `mfma_busy_pmc` is the same kernel's matrix-pipe busy fraction from
+                the committed rocprofv3 PMC pass (SQ_VALU_MFMA_BUSY_CYCLES); the reference op's ALGORITHMIC FLOPs per
+                second (what SURVEY 8d's formula counts, can exceed the peak for Winograd) are under `algorithmic_*`;
+                `step` carries the whole-iteration figures (13 F_E + 19 F_D - 3 f_conv0 per image)
   cpu_baseline  the CPU oracle (oracle/sivae_oracle.py, a torch-CPU restatement pinned to the reference by
                 golden vectors) timed on this host's cores on a bounded sample of the same workload.
 """
@@ -33,6 +38,9 @@ sys.path.insert(0, os.path.join(REPO, "soft-intro-vae-pytorch_amd"))
 sys.path.insert(0, REPO)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide; the 5 PF headline figure includes 2:1 sparsity)
+PEAK_HBM_TBS = 8.0
+PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
 
 CONFIGS = {
     # name: (image_size, channels, zdim, global_batch, betas(kl, rec, neg), gamma_r)
@@ -68,12 +76,22 @@ def forward_flops(channels, image_size, zdim, cdim=3):
     return fe, fd, f0
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(cfg, batch, iters, threads):
-    """time the CPU oracle on a bounded sample of the same workload (rank 0, N = 1 only)"""
+    """time the CPU oracle on a bounded sample of the same workload (rank 0, N = 1 only): >= 2 timed iterations after
+    one warm-up at the best thread count of a short sweep (oversubscribing a big host is SLOWER: 128 threads gave 0.235
+    img/s in round 1 where 8 gave 0.365)"""
     from oracle import sivae_oracle as O
     image_size, channels, zdim, _, (bk, br, bn), gr = cfg
-    if threads:
-        torch.set_num_threads(threads)
     hp = dict(beta_rec=br, beta_kl=bk, beta_neg=bn, gamma_r=gr)
     P = O.init_params(3, zdim, channels, image_size, seed=0)
     opt_e = O.Adam(P, O.trainable_keys(P, "encoder."), 2e-4)
@@ -86,72 +104,76 @@ def cpu_baseline(cfg, batch, iters, threads):
         eps = [torch.randn(batch, zdim, generator=g) for _ in range(5)]
         O.train_iteration(P, opt_e, opt_d, real, noise, eps, hp, channels, image_size)
 
-    one()  # warm-up
+    ncpu = os.cpu_count() or 1
+    physical = max(1, ncpu // 2)
+    sweep = {}
+    if threads:
+        cand = [threads]
+    else:
+        cand = sorted({t for t in (8, 16, 32, 64, physical) if t <= ncpu})
+    torch.set_num_threads(cand[0])
+    one()  # warm-up (allocator, oneDNN primitive caches)
+    for t in cand:
+        torch.set_num_threads(t)
+        t0 = time.time()
+        one()
+        sweep[t] = batch / (time.time() - t0)
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    iters = max(2, iters)
     t0 = time.time()
     for _ in range(iters):
         one()
     dt = time.time() - t0
-    return dict(value=batch * iters / dt, unit="img/s", cores=torch.get_num_threads(), kind="port",
-                sample="%d timed iterations at batch %d of the same %dx%d network after 1 warm-up (%.1f s); CPU "
-                       "throughput is batch-insensitive" % (iters, batch, image_size, image_size, dt))
+    return dict(value=batch * iters / dt, unit="img/s", cores=best, kind="port", cpu_model=_cpu_model(),
+                host_logical_cpus=ncpu, thread_sweep_img_per_s={str(k): round(v, 4) for k, v in sweep.items()},
+                sample="%d timed iterations at batch %d of the same %dx%d network after 1 warm-up + a %d-point thread "
+                       "sweep (%.1f s timed); CPU throughput is batch-insensitive" % (iters, batch, image_size,
+                                                                                    image_size, len(sweep), dt))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="celeb256", choices=sorted(CONFIGS))
-    ap.add_argument("--global-batch", type=int, default=None, help="override the global batch")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: config batch PER GPU (global = batch*N); strong: config batch is the global batch")
-    ap.add_argument("--bootstrap", action="store_true", help="soft_intro_vae_bootstrap variant (config 5)")
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
-                    help="fp32: the parity path (headline); bf16: config 3's build-defined mode (bf16 storage + bf16 MFMA "
-                         "convs, fp32 accumulation / statistics / master weights)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-iters", type=int, default=1)
-    ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
-    ap.add_argument("--same-device", action="store_true",
-                    help="testing only: every rank uses cuda:0 (with --backend gloo) to exercise the DP path on one GPU")
-    ap.add_argument("--sync-bn", action="store_true",
-                    help="synchronised BatchNorm across ranks (opt-in; default local BatchNorm as DDP would do)")
-    ap.add_argument("--hip-graph", action="store_true",
-                    help="capture the whole iteration into a HIP graph and time replays (single GPU; pays off where the "
-                         "host launch rate is the limit: 32x32 nets, small batches)")
-    ap.add_argument("--no-reuse", action="store_true",
-                    help="re-execute the two D-step decoder forwards whose inputs and weights are unchanged since the "
-                         "E-step (the reference does); default: replay them from the E-step's activations")
-    args = ap.parse_args()
+def _pmc_busy(kernel_key):
+    """matrix-pipe busy fraction of `kernel_key` from the committed rocprofv3 --pmc pass of the headline workload
+    (tools/pmc_mfma_busy.py over SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE; counters cannot be read from inside the
+    bench)"""
+    for name in ("r2_pmc_mfma_busy_bs128_final.json", "r2_pmc_mfma_busy_bs128.json"):
+        path = os.path.join(PROFILES, name)
+        if os.path.exists(path):
+            ks = json.load(open(path))["kernels"]
+            pref = kernel_key[:-1] + ","  # "conv_wino_kernel<1,4,false>" -> "conv_wino_kernel<1,4,false,"
+            hit = [v for k, v in ks.items() if k == kernel_key or k.startswith(pref)]
+            if hit:
+                return dict(value=hit[0]["mfma_busy_frac"], source="profiles/" + name)
+    return None
 
+
+def _pmc_traffic(kernel_key, config, dtype):
+    """HBM bytes per launch of `kernel_key` + whole-step bytes from the committed FETCH_SIZE / WRITE_SIZE passes"""
+    names = {("celeb256", "fp32"): ("r2_pmc_traffic_final.json", "r1_pmc_traffic.json"),
+             ("celeb128", "bf16"): ("r2_pmc_traffic_celeb128_bf16.json",)}.get((config, dtype), ())
+    for name in names:
+        path = os.path.join(PROFILES, name)
+        if os.path.exists(path):
+            d = json.load(open(path))
+            pref = kernel_key[:-1] + ","
+            hit = [v for k, v in d["kernels"].items() if k == kernel_key or k.startswith(pref)]
+            return dict(kernel_bytes=hit[0]["hbm_bytes"] if hit else None, step_bytes=d.get("step_total_hbm_bytes"),
+                        source="profiles/" + name)
+    return None
+
+
+def measure(args, cfg, gbatch, world, rank, dev, scaling):
+    """build a fresh model + engine for `gbatch` images over `world` ranks, run warm-up + timed steps
+    -> dict(dt, per, stats, timer_summary)"""
     from sivae_hip import dp, ops, rng
     from sivae_hip.engine import SoftIntroEngine
     from sivae_hip.optim import FlatAdam
     import train_soft_intro_vae as T
     import train_soft_intro_vae_bootstrap as TB
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm device (the Soft-IntroVAE HIP engine has no CPU path)")
-    world, rank, local = dp.init(backend=args.backend)
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
-    dev = torch.device("cuda", local if (world > 1 and not args.same_device) else 0)
-    torch.cuda.set_device(dev)
-
-    cfg = CONFIGS[args.config]
-    image_size, channels, zdim, gbatch, (bk, br, bn), gr = cfg
-    if args.global_batch:
-        gbatch = args.global_batch
-    elif args.scaling == "weak":
-        gbatch = gbatch * world
+    image_size, channels, zdim, _, (bk, br, bn), gr = cfg
     if args.bootstrap:
         gr = 1.0
     _, per = dp.shard_batch(gbatch, world, rank)
-
     torch.manual_seed(0)
     model = (TB if args.bootstrap else T).SoftIntroVAE(cdim=3, zdim=zdim, channels=channels, image_size=image_size)
     model = model.to(dev).train()
@@ -169,17 +191,18 @@ def main():
 
     for _ in range(args.warmup):
         eng.soft_intro_step(real)
+    no_timing = args.no_kernel_timing
     if args.hip_graph:
         if world > 1:
             raise SystemExit("--hip-graph is single-GPU")
         eng.capture(real, warmup=1)
         step_fn = eng.replay
-        args.no_kernel_timing = True  # (HIP events cannot be recorded per launch inside a graph)
+        no_timing = True  # (HIP events cannot be recorded per launch inside a graph)
     else:
         step_fn = eng.soft_intro_step
     torch.cuda.synchronize()
     dp.barrier()
-    if not args.no_kernel_timing:
+    if not no_timing:
         ops.TIMER = ops.KernelTimer()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -197,76 +220,150 @@ def main():
         dt = float(t.item())
     stats = dict(zip(("lossE", "lossD", "loss_rec", "kl_real", "kl_fake", "kl_rec", "expelbo_rec", "expelbo_fake"),
                      [float(v) for v in last["stats"].cpu()]))
+    summ = timer.summary() if timer is not None else None
+    del eng, model, opt_e, opt_d, real, last
+    torch.cuda.empty_cache()
+    return dict(dt=dt, per=per, gbatch=gbatch, stats=stats, summ=summ, sync_bn=sync_bn, scaling=scaling, gamma_r=gr)
 
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="celeb256", choices=sorted(CONFIGS))
+    ap.add_argument("--global-batch", type=int, default=None, help="override the global batch")
+    ap.add_argument("--scaling", default="both", choices=["both", "weak", "strong"],
+                    help="strong: the config's batch is the GLOBAL batch (BASELINE config 4: 128 over N GPUs); weak: "
+                         "the config's batch PER GPU; both (default): strong is the headline value, weak is reported "
+                         "beside it (identical runs for N = 1)")
+    ap.add_argument("--bootstrap", action="store_true", help="soft_intro_vae_bootstrap variant (config 5)")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32: the parity path (headline); bf16: config 3's build-defined mode (bf16 storage + bf16 MFMA "
+                         "convs, fp32 accumulation / statistics / master weights)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0: short thread sweep, the best count is used")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="testing only: every rank uses cuda:0 (with --backend gloo) to exercise the DP path on one GPU")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="synchronised BatchNorm across ranks (opt-in; default local BatchNorm as DDP would do)")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="capture the whole iteration into a HIP graph and time replays (single GPU; pays off where the "
+                         "host launch rate is the limit: 32x32 nets, small batches)")
+    ap.add_argument("--no-reuse", action="store_true",
+                    help="re-execute the two D-step decoder forwards whose inputs and weights are unchanged since the "
+                         "E-step (the reference does); default: replay them from the E-step's activations")
+    args = ap.parse_args()
+
+    from sivae_hip import dp
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (the Soft-IntroVAE HIP engine has no CPU path)")
+    world, rank, local = dp.init(backend=args.backend)
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    dev = torch.device("cuda", local if (world > 1 and not args.same_device) else 0)
+    torch.cuda.set_device(dev)
+
+    cfg = CONFIGS[args.config]
+    image_size, channels, zdim, cfg_batch, (bk, br, bn), gr = cfg
+    base = args.global_batch if args.global_batch else cfg_batch
+    runs = []
+    if world == 1 or args.global_batch:
+        runs.append(("strong" if args.scaling != "weak" else "weak", base))
+    else:
+        if args.scaling in ("both", "strong"):
+            runs.append(("strong", base))
+        if args.scaling in ("both", "weak"):
+            runs.append(("weak", base * world))
+    results = [measure(args, cfg, gb, world, rank, dev, sc) for sc, gb in runs]
     if rank != 0:
         return
+    head = results[0]
+    dt, per, gbatch, stats, summ = head["dt"], head["per"], head["gbatch"], head["stats"], head["summ"]
+
+    peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
     fe, fd, f0 = forward_flops(channels, image_size, zdim)
     flops_img = 13 * fe + (17 if args.bootstrap else 19) * fd - 3 * f0
     ms_per_step = 1e3 * dt / args.steps
     value = gbatch * args.steps / dt
-    step_tflops = flops_img * gbatch * args.steps / dt / 1e12 / world  # per GPU
-    roof = dict(bound="mfma", achieved=None, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=None, traffic=None)
-    if timer is not None:
-        summ = timer.summary()
+    step_tflops = flops_img * gbatch * args.steps / dt / 1e12 / world  # per GPU, algorithmic
+    roof = dict(bound="mfma", achieved=None, peak=peak, unit="TFLOP/s", frac=None, traffic=None)
+    if summ is not None:
         key = max(summ, key=lambda k: summ[k]["total_ms"])
         d = summ[key]
-        ach = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
-        ach_ex = d["executed_flops"] / (d["total_ms"] * 1e-3) / 1e12
+        alg = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
+        issued = d["executed_flops"] / (d["total_ms"] * 1e-3) / 1e12
         conv_ms = sum(v["total_ms"] for v in summ.values())
         conv_fl = sum(v["flops"] for v in summ.values())
-        roof.update(kernel=key, achieved=round(ach, 2), frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                    # `achieved` counts the reference op's ALGORITHMIC FLOPs (2*B*H*W*Co*Ci*k*k); the Winograd
-                    # F(2x2,3x3) kernels issue 16/36 of them to the matrix pipe, hence frac can exceed 1 —
-                    # executed_* is what the MFMA pipe actually ran (its utilisation)
-                    executed_tflops=round(ach_ex, 2), executed_frac=round(ach_ex / PEAK_FP32_MFMA_TFLOPS, 4),
+        conv_ex = sum(v["executed_flops"] for v in summ.values())
+        roof.update(kernel=key,
+                    # PHYSICAL: what the matrix pipe ran / time / dense peak of the dtype  (<= 1)
+                    achieved=round(issued, 2), frac=round(issued / peak, 4),
+                    basis="MFMA-issued FLOPs of the dominant kernel (Winograd F(2x2,3x3) issues 16/36, the upsample-phase "
+                          "kernels 9/36 of the reference conv's multiplies) / HIP-event time / dense %s MFMA peak"
+                          % ("fp32" if args.dtype == "fp32" else "bf16"),
+                    algorithmic_tflops=round(alg, 2), algorithmic_frac=round(alg / peak, 4),
                     launches=d["launches"], avg_launch_ms=round(d["avg_ms"], 4),
                     kernel_share_of_step=round(d["total_ms"] / (1e3 * dt), 4),
-                    all_mfma_kernels=dict(tflops=round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
+                    mfma_busy_pmc=_pmc_busy(key) if (args.config == "celeb256" and args.dtype == "fp32") else None,
+                    all_mfma_kernels=dict(issued_tflops=round(conv_ex / (conv_ms * 1e-3) / 1e12, 2),
+                                          issued_frac=round(conv_ex / (conv_ms * 1e-3) / 1e12 / peak, 4),
+                                          algorithmic_tflops=round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
                                           share_of_step=round(conv_ms / (1e3 * dt), 4)),
                     per_kernel={k: dict(launches=v["launches"], avg_ms=round(v["avg_ms"], 4),
-                                        tflops=round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2),
-                                        executed_tflops=round(v["executed_flops"] / (v["total_ms"] * 1e-3) / 1e12, 2))
+                                        issued_tflops=round(v["executed_flops"] / (v["total_ms"] * 1e-3) / 1e12, 2),
+                                        algorithmic_tflops=round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2))
                                 for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])})
-    if roof.get("kernel") and args.config == "celeb256" and per == 128 and not args.bootstrap:
-        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of THIS workload
-        # (tools/pmc_step.py + tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes, KiB units, read
-        # side x2.0 as calibrated on a 1 GiB copy in the same pass) — counters cannot be read from inside the bench
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
-        if os.path.exists(tpath):
-            tk = json.load(open(tpath))["kernels"]
-            hit = [v for k, v in tk.items() if k.startswith(roof["kernel"][:-1] + ",")]
-            if hit:
-                roof["traffic"] = hit[0]["hbm_bytes"]
-                roof["traffic_unit"] = "HBM bytes per launch (rocprofv3 PMC, profiles/r1_pmc_traffic.json)"
+        tr = _pmc_traffic(key, args.config, args.dtype) if per == cfg_batch and not args.bootstrap else None
+        if tr is not None:
+            roof["traffic"] = tr["kernel_bytes"]
+            roof["traffic_unit"] = "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, %s)" % tr["source"]
+            if tr["step_bytes"]:
+                # the whole iteration against the HBM roofline: fabric bytes per iteration / measured iteration time
+                roof["hbm"] = dict(step_bytes=tr["step_bytes"], achieved_tbs=round(tr["step_bytes"] / (dt / args.steps) / 1e12, 3),
+                                   peak_tbs=PEAK_HBM_TBS, frac=round(tr["step_bytes"] / (dt / args.steps) / 1e12 / PEAK_HBM_TBS, 4),
+                                   note="PMC bytes of one iteration (separate profiled run of this workload) over this "
+                                        "run's iteration time; bf16 mode is the HBM-borderline one (SURVEY 8d)")
     executed_img = flops_img - (0.0 if args.no_reuse else 2 * fd)  # two decoder forwards replayed, not re-executed
     roof["step"] = dict(algorithmic_gflop_per_image=round(flops_img / 1e9, 1),
-                        tflops_per_gpu=round(step_tflops, 2), frac=round(step_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
-                        executed_gflop_per_image=round(executed_img / 1e9, 1),
-                        executed_tflops_per_gpu=round(step_tflops * executed_img / flops_img, 2),
-                        executed_frac=round(step_tflops * executed_img / flops_img / PEAK_FP32_MFMA_TFLOPS, 4))
-    if timer is not None:
+                        algorithmic_tflops_per_gpu=round(step_tflops, 2),
+                        algorithmic_frac=round(step_tflops / peak, 4),
+                        executed_gflop_per_image=round(executed_img / 1e9, 1))
+    if summ is not None:
         # what the matrix pipe really ran per image (timer totals: direct kernels count 1:1, Winograd 16/36)
-        issued = sum(v["executed_flops"] for v in summ.values()) / (per * args.steps)
-        roof["step"].update(mfma_issued_gflop_per_image=round(issued / 1e9, 1),
-                            mfma_issued_tflops_per_gpu=round(issued * per * args.steps / dt / 1e12, 2),
-                            mfma_issued_frac=round(issued * per * args.steps / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4))
+        issued_img = sum(v["executed_flops"] for v in summ.values()) / (per * args.steps)
+        roof["step"].update(mfma_issued_gflop_per_image=round(issued_img / 1e9, 1),
+                            mfma_issued_tflops_per_gpu=round(issued_img * per * args.steps / dt / 1e12, 2),
+                            mfma_issued_frac=round(issued_img * per * args.steps / dt / 1e12 / peak, 4))
+    headline = args.config == "celeb256" and gbatch == 128 and not args.bootstrap
     out = {
-        # BASELINE.json's metric is quoted at 256x256 with 128 images per GPU; any other run says what it ran
-        "metric": "training images/sec (whole node) at 256x256 bs128" if (args.config == "celeb256" and per == 128)
-        else "training images/sec (whole node) at %dx%d bs%d" % (image_size, image_size, per),
+        # BASELINE.json's metric is quoted at 256x256 with a global batch of 128; any other run says what it ran
+        "metric": "training images/sec (whole node) at 256x256 bs128" if headline
+        else "training images/sec (whole node) at %dx%d global batch %d" % (image_size, image_size, gbatch),
         "value": round(value, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": head["scaling"], "vs_baseline": None,
         "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
         "config": {"workload": "soft_intro_vae%s %s %dx%d zdim=%d channels=%s, full E-step + D-step iteration"
                                % ("_bootstrap" if args.bootstrap else "", args.config, image_size, image_size, zdim,
                                   channels),
                    "global_batch": gbatch, "per_gpu_batch": per, "parallelism": "dp%d" % world,
-                   "betas": {"kl": bk, "rec": br, "neg": bn}, "gamma_r": gr, "lr": 2e-4,
+                   "betas": {"kl": bk, "rec": br, "neg": bn}, "gamma_r": head["gamma_r"], "lr": 2e-4,
                    "decoder_forward_reuse": not args.no_reuse, "hip_graph": bool(args.hip_graph),
-                   "batchnorm": "sync" if sync_bn else "local",
+                   "batchnorm": "sync" if head["sync_bn"] else "local",
                    "final_stats": stats},
         "roofline": roof,
     }
+    for r in results[1:]:
+        out[r["scaling"]] = {"value": round(r["gbatch"] * args.steps / r["dt"], 3), "unit": "img/s",
+                             "ms_per_step": round(1e3 * r["dt"] / args.steps, 3), "global_batch": r["gbatch"],
+                             "per_gpu_batch": r["per"], "scaling": r["scaling"],
+                             "algorithmic_tflops_per_gpu": round(flops_img * r["gbatch"] * args.steps / r["dt"] / 1e12 / world, 2)}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch, args.cpu_iters, args.cpu_threads)
         out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)

@@ -267,6 +267,15 @@ int sivae_kl_fwd(const float* logvar, const float* mu, int ld, float mu_o, float
 int sivae_kl_bwd(const float* g, int g_per_sample, float g_scale, const float* logvar, const float* mu, int ld,
                  float mu_o, float logvar_o, float* dlogvar, float* dmu, int ldg, int B, int Z,
                  sivae_stream_t stream);
+/* the same with TENSOR priors (calc_kl's mu_o / logvar_o may be tensors, :237-243): device pointers read through
+ * broadcast strides in elements (row stride, column stride; 0 = broadcast), i.e. 0-d, [Z], [1][Z], [B][1] or [B][Z]
+ * priors without a host round trip.  Gradients are those with respect to logvar / mu. */
+int sivae_kl_fwd_t(const float* logvar, const float* mu, int ld, const float* mu_o, int mu_o_rs, int mu_o_cs,
+                   const float* logvar_o, int lv_o_rs, int lv_o_cs, float* out /*[B]*/, int B, int Z,
+                   sivae_stream_t stream);
+int sivae_kl_bwd_t(const float* g, int g_per_sample, float g_scale, const float* logvar, const float* mu, int ld,
+                   const float* mu_o, int mu_o_rs, int mu_o_cs, const float* logvar_o, int lv_o_rs, int lv_o_cs,
+                   float* dlogvar, float* dmu, int ldg, int B, int Z, sivae_stream_t stream);
 /* loss_type: 0 mse, 1 l1, 2 bce.  rowsum: out[b] = sum_i term(x[b,i], recon[b,i]). */
 size_t sivae_recon_workspace_bytes(int B, int D);
 int sivae_recon_rowsum_fwd(const float* x, const float* recon, int loss_type, float* out, int B, int D,

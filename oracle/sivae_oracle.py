@@ -328,7 +328,8 @@ def vae_step(P, real, eps0, hp, channels, image_size, bootstrap=False):
 class Adam:
     def __init__(self, P, keys, lr, betas=(0.9, 0.999), eps=1e-8):
         self.P, self.keys, self.lr, self.betas, self.eps = P, list(keys), lr, betas, eps
-        self.t = 0
+        self.t = 0  # number of step() calls
+        self.steps = {k: 0 for k in self.keys}  # torch.optim.Adam keeps the step count PER PARAMETER ...
         self.m = {k: torch.zeros_like(P[k]) for k in self.keys}
         self.v = {k: torch.zeros_like(P[k]) for k in self.keys}
 
@@ -336,11 +337,12 @@ class Adam:
     def step(self):
         self.t += 1
         b1, b2 = self.betas
-        bc1, bc2 = 1 - b1 ** self.t, 1 - b2 ** self.t
         for k in self.keys:
             g = self.P[k].grad
             if g is None:
-                continue
+                continue  # ... and skips (state untouched, count not advanced) parameters without a gradient
+            self.steps[k] += 1
+            bc1, bc2 = 1 - b1 ** self.steps[k], 1 - b2 ** self.steps[k]
             self.m[k].lerp_(g, 1 - b1)
             self.v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
             denom = (self.v[k].sqrt() / math.sqrt(bc2)).add_(self.eps)

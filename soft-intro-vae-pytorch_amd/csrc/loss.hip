@@ -65,6 +65,44 @@ __global__ void __launch_bounds__(256) kl_bwd_kernel(const float* __restrict__ g
   }
 }
 
+// calc_kl with TENSOR priors (train_soft_intro_vae.py:231-251 accepts tensors for mu_o / logvar_o): the prior parameters
+// are read on the device through broadcast strides (row stride, column stride; 0 = broadcast), so a 0-d, [Z], [1, Z],
+// [B, 1] or [B, Z] prior needs no host round trip.
+__global__ void __launch_bounds__(64) kl_fwd_t_kernel(const float* __restrict__ lv, const float* __restrict__ mu, int ld,
+                                                      const float* __restrict__ mo, int mo_rs, int mo_cs,
+                                                      const float* __restrict__ lo, int lo_rs, int lo_cs,
+                                                      float* __restrict__ out, int Z) {
+  const int b = blockIdx.x;
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < Z; j += 64) {
+    const float l = lv[(size_t)b * ld + j], m = mu[(size_t)b * ld + j];
+    const float mu_o = mo[(size_t)b * mo_rs + (size_t)j * mo_cs], lv_o = lo[(size_t)b * lo_rs + (size_t)j * lo_cs];
+    const float elvo = expf(lv_o);
+    const float d = m - mu_o;
+    const float t = 1.f + l - lv_o - expf(l) / elvo - d * d / elvo;
+    acc += (double)t;
+  }
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) out[b] = (float)(-0.5 * acc);
+}
+__global__ void __launch_bounds__(256) kl_bwd_t_kernel(const float* __restrict__ g, int g_stride, float g_scale,
+                                                       const float* __restrict__ lv, const float* __restrict__ mu,
+                                                       int ld, const float* __restrict__ mo, int mo_rs, int mo_cs,
+                                                       const float* __restrict__ lo, int lo_rs, int lo_cs,
+                                                       float* __restrict__ dlv, float* __restrict__ dmu, int ldg, int B,
+                                                       int Z) {
+  const int n = B * Z;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int b = i / Z, j = i - b * Z;
+    const float gg = g[(size_t)b * g_stride] * g_scale;
+    const float l = lv[(size_t)b * ld + j], m = mu[(size_t)b * ld + j];
+    const float mu_o = mo[(size_t)b * mo_rs + (size_t)j * mo_cs];
+    const float elvo = expf(lo[(size_t)b * lo_rs + (size_t)j * lo_cs]);
+    dlv[(size_t)b * ldg + j] = gg * (-0.5f) * (1.f - expf(l) / elvo);
+    dmu[(size_t)b * ldg + j] = gg * (m - mu_o) / elvo;
+  }
+}
+
 // ---------------------------------------------------------------- reconstruction losses
 // TYPE 0 = mse (r-x)^2, 1 = l1 |r-x|, 2 = bce -(x log r + (1-x) log(1-r)) with logs clamped at -100
 template <int TYPE>
@@ -262,6 +300,27 @@ extern "C" int sivae_kl_bwd(const float* g, int g_per_sample, float g_scale, con
   if (B <= 0 || Z <= 0 || ld < Z || ldg < Z) return SIVAE_ERR_SHAPE;
   hipLaunchKernelGGL(kl_bwd_kernel, dim3(g1d((size_t)B * Z)), dim3(256), 0, stream, g, g_per_sample ? 1 : 0, g_scale,
                      logvar, mu, ld, mu_o, logvar_o, dlogvar, dmu, ldg, B, Z);
+  return sivae_launch_status();
+}
+
+extern "C" int sivae_kl_fwd_t(const float* logvar, const float* mu, int ld, const float* mu_o, int mu_o_rs, int mu_o_cs,
+                              const float* logvar_o, int lv_o_rs, int lv_o_cs, float* out, int B, int Z,
+                              hipStream_t stream) {
+  if (!logvar || !mu || !out || !mu_o || !logvar_o) return SIVAE_ERR_NULL;
+  if (B <= 0 || Z <= 0 || ld < Z) return SIVAE_ERR_SHAPE;
+  if (mu_o_rs < 0 || mu_o_cs < 0 || lv_o_rs < 0 || lv_o_cs < 0) return SIVAE_ERR_MODE;
+  hipLaunchKernelGGL(kl_fwd_t_kernel, dim3(B), dim3(64), 0, stream, logvar, mu, ld, mu_o, mu_o_rs, mu_o_cs, logvar_o,
+                     lv_o_rs, lv_o_cs, out, Z);
+  return sivae_launch_status();
+}
+extern "C" int sivae_kl_bwd_t(const float* g, int g_per_sample, float g_scale, const float* logvar, const float* mu,
+                              int ld, const float* mu_o, int mu_o_rs, int mu_o_cs, const float* logvar_o, int lv_o_rs,
+                              int lv_o_cs, float* dlogvar, float* dmu, int ldg, int B, int Z, hipStream_t stream) {
+  if (!g || !logvar || !mu || !dlogvar || !dmu || !mu_o || !logvar_o) return SIVAE_ERR_NULL;
+  if (B <= 0 || Z <= 0 || ld < Z || ldg < Z) return SIVAE_ERR_SHAPE;
+  if (mu_o_rs < 0 || mu_o_cs < 0 || lv_o_rs < 0 || lv_o_cs < 0) return SIVAE_ERR_MODE;
+  hipLaunchKernelGGL(kl_bwd_t_kernel, dim3(g1d((size_t)B * Z)), dim3(256), 0, stream, g, g_per_sample ? 1 : 0, g_scale,
+                     logvar, mu, ld, mu_o, mu_o_rs, mu_o_cs, logvar_o, lv_o_rs, lv_o_cs, dlogvar, dmu, ldg, B, Z);
   return sivae_launch_status();
 }
 

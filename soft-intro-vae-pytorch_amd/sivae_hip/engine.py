@@ -23,14 +23,12 @@ def reparameterize(mu, logvar, eps=None):
     return SF.reparameterize(mu, logvar, eps)
 
 
-def _as_float(v):
-    return float(v.item()) if isinstance(v, torch.Tensor) else float(v)
-
-
 def calc_kl(logvar, mu, mu_o=0.0, logvar_o=0.0, reduce="sum"):
-    """reduce in {'sum', 'mean'}; anything else returns the per-sample vector (reference :247-251)"""
+    """reduce in {'sum', 'mean'}; anything else returns the per-sample vector (reference :247-251).
+    mu_o / logvar_o: numbers, or tensors broadcastable to [B, Z] (the reference wraps numbers into tensors, :237-243);
+    tensors stay on the device — no .item() sync."""
     red = reduce if reduce in ("sum", "mean") else "none"
-    return SF.kl(logvar, mu, _as_float(mu_o), _as_float(logvar_o), red)
+    return SF.kl(logvar, mu, mu_o, logvar_o, red)
 
 
 def calc_reconstruction_loss(x, recon_x, loss_type="mse", reduction="sum"):
@@ -152,7 +150,7 @@ class SoftIntroEngine:
             self.grad_sync(opt.flat_grad)
 
     # -- vanilla VAE step (reference :516-533) ----------------------------------------------------------
-    def vae_step(self, real, eps=None):
+    def vae_step(self, real, eps=None, keep=False):
         m = self.model
         for p in m.encoder.parameters():
             p.requires_grad = True
@@ -168,10 +166,17 @@ class SoftIntroEngine:
         self.opt_e.zero_grad()
         loss.backward()
         self._sync(self.opt_e)
-        self._sync(self.opt_d)
         self.opt_e.step(self.grad_scale)
-        self.opt_d.step(self.grad_scale)
-        return {"loss": loss.detach(), "loss_rec": loss_rec.detach(), "loss_kl": loss_kl.detach(), "rec": rec.detach()}
+        if not self.bootstrap:
+            # (bootstrap: the reconstruction came from the frozen target decoder, :546 with target=True, so the decoder
+            # has no gradient; torch.optim.Adam skips parameters whose .grad is None — neither the weights nor the
+            # per-parameter step counts move — and so does this)
+            self._sync(self.opt_d)
+            self.opt_d.step(self.grad_scale)
+        res = {"loss": loss.detach(), "loss_rec": loss_rec.detach(), "loss_kl": loss_kl.detach(), "rec": rec.detach()}
+        if keep:
+            res.update(mu=mu.detach(), logvar=logvar.detach(), z=z.detach())
+        return res
 
     # -- Soft-Intro iteration (reference :547-624) --------------------------------------------------------
     def soft_intro_step(self, real, noise=None, eps=None, keep=False):

@@ -449,13 +449,20 @@ class ReparamFn(torch.autograd.Function):
 
 
 class KLFn(torch.autograd.Function):
-    """calc_kl: per-sample KL, optionally reduced ('sum' / 'mean') — train_soft_intro_vae.py:231-251"""
+    """calc_kl: per-sample KL, optionally reduced ('sum' / 'mean') — train_soft_intro_vae.py:231-251.
+    mu_o / logvar_o: python floats, or tensors broadcastable to [B, Z] (read on the device, no host sync)."""
 
     @staticmethod
     def forward(ctx, logvar, mu, mu_o, logvar_o, reduce):
-        per = ops.kl_fwd(logvar, mu, mu_o, logvar_o)
+        tensor_prior = isinstance(mu_o, torch.Tensor) or isinstance(logvar_o, torch.Tensor)
+        if tensor_prior:
+            mu_o = mu_o if isinstance(mu_o, torch.Tensor) else torch.tensor(float(mu_o))
+            logvar_o = logvar_o if isinstance(logvar_o, torch.Tensor) else torch.tensor(float(logvar_o))
+            per = ops.kl_fwd_t(logvar, mu, mu_o, logvar_o)
+        else:
+            per = ops.kl_fwd(logvar, mu, mu_o, logvar_o)
         ctx.save_for_backward(logvar, mu)
-        ctx.cfg = (mu_o, logvar_o, reduce, mu.shape[0])
+        ctx.cfg = (mu_o, logvar_o, reduce, mu.shape[0], tensor_prior)
         if reduce == "sum":
             return ops.vec_sum(per, 1.0)
         if reduce == "mean":
@@ -465,14 +472,15 @@ class KLFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         logvar, mu = ctx.saved_tensors
-        mu_o, logvar_o, reduce, B = ctx.cfg
+        mu_o, logvar_o, reduce, B, tensor_prior = ctx.cfg
         g = g.contiguous()
+        bwd = ops.kl_bwd_t if tensor_prior else ops.kl_bwd
         if reduce == "sum":
-            dlv, dmu = ops.kl_bwd(g, False, 1.0, logvar, mu, mu_o, logvar_o)
+            dlv, dmu = bwd(g, False, 1.0, logvar, mu, mu_o, logvar_o)
         elif reduce == "mean":
-            dlv, dmu = ops.kl_bwd(g, False, 1.0 / B, logvar, mu, mu_o, logvar_o)
+            dlv, dmu = bwd(g, False, 1.0 / B, logvar, mu, mu_o, logvar_o)
         else:
-            dlv, dmu = ops.kl_bwd(g, True, 1.0, logvar, mu, mu_o, logvar_o)
+            dlv, dmu = bwd(g, True, 1.0, logvar, mu, mu_o, logvar_o)
         return dlv, dmu, None, None, None
 
 
@@ -546,7 +554,13 @@ def reparameterize(mu, logvar, eps):
 
 
 def kl(logvar, mu, mu_o=0.0, logvar_o=0.0, reduce="none"):
-    return KLFn.apply(logvar, mu, float(mu_o), float(logvar_o), reduce)
+    for t in (mu_o, logvar_o):
+        if isinstance(t, torch.Tensor) and t.requires_grad:
+            raise NotImplementedError("sivae_hip: calc_kl does not propagate gradients into tensor priors "
+                                      "(mu_o / logvar_o); detach them")
+    mu_o = mu_o if isinstance(mu_o, torch.Tensor) else float(mu_o)
+    logvar_o = logvar_o if isinstance(logvar_o, torch.Tensor) else float(logvar_o)
+    return KLFn.apply(logvar, mu, mu_o, logvar_o, reduce)
 
 
 def expelbo(L, KL, scale, beta_rec, beta_neg):

@@ -743,6 +743,45 @@ def kl_bwd(g, per_sample, g_scale, logvar, mu, mu_o=0.0, logvar_o=0.0):
     return dlv, dmu
 
 
+def _prior(t, B, Z, like):
+    """calc_kl prior as (fp32 device tensor, row stride, column stride) broadcastable to [B, Z]"""
+    t = t.detach().to(device=like.device, dtype=torch.float32)
+    if t.dim() > 2:
+        raise ValueError("calc_kl: prior of shape %s does not broadcast to [B, Z]" % (tuple(t.shape),))
+    while t.dim() < 2:
+        t = t.unsqueeze(0)
+    r, c = t.shape
+    if r not in (1, B) or c not in (1, Z):
+        raise ValueError("calc_kl: prior of shape %s does not broadcast to [%d, %d]" % (tuple(t.shape), B, Z))
+    t = t.contiguous()
+    return t, (c if r == B else 0), (1 if c == Z else 0)
+
+
+def kl_fwd_t(logvar, mu, mu_o, logvar_o):
+    B, Z = mu.shape
+    ld = _ld(mu)
+    assert _ld(logvar) == ld
+    mo, mo_rs, mo_cs = _prior(mu_o, B, Z, mu)
+    lo, lo_rs, lo_cs = _prior(logvar_o, B, Z, mu)
+    out = torch.empty(B, dtype=torch.float32, device=mu.device)
+    _lib.call("sivae_kl_fwd_t", _p(logvar), _p(mu), ld, _p(mo), mo_rs, mo_cs, _p(lo), lo_rs, lo_cs, _p(out), B, Z,
+              _s(mu))
+    return out
+
+
+def kl_bwd_t(g, per_sample, g_scale, logvar, mu, mu_o, logvar_o):
+    _require(g)
+    B, Z = mu.shape
+    ld = _ld(mu)
+    mo, mo_rs, mo_cs = _prior(mu_o, B, Z, mu)
+    lo, lo_rs, lo_cs = _prior(logvar_o, B, Z, mu)
+    dlv = torch.empty((B, Z), dtype=torch.float32, device=mu.device)
+    dmu = torch.empty((B, Z), dtype=torch.float32, device=mu.device)
+    _lib.call("sivae_kl_bwd_t", _p(g), int(bool(per_sample)), float(g_scale), _p(logvar), _p(mu), ld, _p(mo), mo_rs,
+              mo_cs, _p(lo), lo_rs, lo_cs, _p(dlv), _p(dmu), Z, B, Z, _s(mu))
+    return dlv, dmu
+
+
 def recon_rowsum_fwd(x, recon, loss_type):
     _require(x, recon)
     B = x.shape[0]

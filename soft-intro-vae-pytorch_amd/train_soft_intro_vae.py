@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 
 from sivae_hip import data as _data
+from sivae_hip import dp as _dp
 from sivae_hip import engine as _engine
 from sivae_hip import rng as _rng
 from sivae_hip.engine import calc_kl, calc_reconstruction_loss, reparameterize  # noqa: F401  (reference API)
@@ -167,11 +168,21 @@ def _save_image(tensor, path, nrow):
         pass
 
 
-def _require_device(device):
+def _require_device(device, local_rank=None):
+    """-> the ROCm device this process trains on, made CURRENT (the kernels launch on the current stream of the
+    tensors' device; making it current keeps every helper that asks torch for "the" stream in agreement).
+    Under torchrun (WORLD_SIZE > 1) each rank takes the GPU of its LOCAL_RANK, the one-process-per-GPU convention of the
+    reference's only DP precedent (style_soft_intro_vae/launcher.py:126-129); SIVAE_DP_SAME_DEVICE=1 keeps the given
+    device on every rank (single-GPU testing of the DP path)."""
     device = torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("train_soft_intro_vae (MI355X build): device %s is not a ROCm device; this engine has no "
                            "CPU path" % device)
+    if local_rank is not None and os.environ.get("SIVAE_DP_SAME_DEVICE", "0") != "1":
+        device = torch.device("cuda", local_rank)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    torch.cuda.set_device(device)
     return device
 
 
@@ -190,46 +201,80 @@ def train_soft_intro_vae(dataset="cifar10", z_dim=128, lr_e=2e-4, lr_d=2e-4, bat
 def _train(dataset, z_dim, lr_e, lr_d, batch_size, num_workers, start_epoch, exit_on_negative_diff, num_epochs,
            num_vae, save_interval, recon_loss_type, beta_kl, beta_rec, beta_neg, test_iter, seed, pretrained, device,
            num_row, gamma_r, with_fid, bootstrap, copy_to_target_freq, model_factory, tag):
+    # ---- data parallelism: under torchrun (WORLD_SIZE > 1) this entry point is one of N processes, one per
+    # GPU; `batch_size` stays the GLOBAL batch of the reference's signature and is split per image over the ranks,
+    # weights / Adam state are replicated (rank 0's initial values), the two flat gradient buffers are all-reduced once
+    # per iteration each (RCCL; SIVAE_DP_BACKEND overrides the backend for tests), BatchNorm statistics stay per rank,
+    # rank 0 writes checkpoints / figures / logs (precedent: style_soft_intro_vae/train_style_soft_intro_vae.py:154-161,
+    # :231).  World size 1 is the reference's single-process run.
+    world, rank, local = _dp.init(backend=os.environ.get("SIVAE_DP_BACKEND") or None)
+    main_rank = rank == 0
     if seed != -1:
         random.seed(seed)
         np.random.seed(seed)
         torch.manual_seed(seed)
-        _rng.manual_seed(seed)
-        print("random seed: ", seed)
+        _rng.manual_seed(seed, rank)
+        if main_rank:
+            print("random seed: ", seed)
+        stream_seed = seed
+    else:
+        # unseeded (the reference's default): every run / every call draws fresh noise, like torch.randn does
+        stream_seed = int.from_bytes(os.urandom(7), "little")
+        _rng.manual_seed(stream_seed, rank)
     arch_key = dataset[len("synthetic-"):] if dataset.startswith("synthetic-") else dataset
     if arch_key not in _ARCH:
         raise NotImplementedError("dataset is not supported")
     image_size, channels, ch = _ARCH[arch_key]
-    device = _require_device(device)
+    device = _require_device(device, local if world > 1 else None)
     train_set = _build_dataset(dataset, image_size, ch)
+    shard_start, per_rank = _dp.shard_batch(batch_size, world, rank)
 
     model = model_factory(cdim=ch, zdim=z_dim, channels=channels, image_size=image_size).to(device)
     if pretrained is not None:
         load_model(model, pretrained, device)
-    print(model)
+    if main_rank:
+        print(model)
     fig_dir = "./figures_" + dataset
-    os.makedirs(fig_dir, exist_ok=True)
+    if main_rank:
+        os.makedirs(fig_dir, exist_ok=True)
 
     optimizer_e = FlatAdam(model.encoder.parameters(), lr=lr_e)
     optimizer_d = FlatAdam(model.decoder.parameters(), lr=lr_d)
     e_scheduler = MultiStepLR(optimizer_e, milestones=(350,), gamma=0.1)
     d_scheduler = MultiStepLR(optimizer_d, milestones=(350,), gamma=0.1)
+    grad_sync = None
+    if world > 1:
+        extra = [p.data for p in model.target_decoder.parameters()] if bootstrap else []
+        _dp.broadcast_([optimizer_e.flat, optimizer_d.flat] + extra + [b for b in model.buffers()])
+        grad_sync = _dp.GradSync()
+    # SIVAE_DTYPE=bf16 selects the build-defined mixed-precision mode (BASELINE.json config 3); the reference's
+    # signature has no such argument, hence the environment switch
     eng = _engine.SoftIntroEngine(model, optimizer_e, optimizer_d, beta_kl=beta_kl, beta_rec=beta_rec,
                                   beta_neg=beta_neg, gamma_r=gamma_r, recon_loss_type=recon_loss_type,
-                                  bootstrap=bootstrap)
+                                  bootstrap=bootstrap, grad_sync=grad_sync,
+                                  compute_dtype=os.environ.get("SIVAE_DTYPE") or None)
 
-    loader = torch.utils.data.DataLoader(train_set, batch_size=batch_size, shuffle=True, num_workers=num_workers,
-                                         pin_memory=True)
+    sampler = None
+    if world > 1:
+        sampler = torch.utils.data.distributed.DistributedSampler(train_set, num_replicas=world, rank=rank,
+                                                                  shuffle=True, seed=stream_seed % (2 ** 31))
+    loader = torch.utils.data.DataLoader(train_set, batch_size=per_rank, shuffle=sampler is None, sampler=sampler,
+                                         num_workers=num_workers, pin_memory=True)
     # torchvision datasets yield (img, label) (reference :510-511); 3-D batches are unsqueezed (:513-514)
     batches = _data.DevicePrefetcher(loader, device, take_first=arch_key in _TUPLE_DATASETS,
-                                     hflip=dataset.startswith("synthetic-"), seed=max(seed, 0))
+                                     hflip=dataset.startswith("synthetic-"), seed=(stream_seed + rank) % (2 ** 31))
+    # how many iterations' statistics may sit on the device before they are read back and checked for NaN (the
+    # reference checks every iteration, :625-626, at the price of a device sync per iteration; 1 reproduces that)
+    nan_every = max(1, int(os.environ.get("SIVAE_NAN_CHECK_EVERY", "64")))
     start_time = time.time()
     cur_iter = 0
     hist = {k: [] for k in ("kl_real", "kl_fake", "kl_rec", "rec_err", "exp_elbo_f", "exp_elbo_r")}
     best_fid = None
     real_batch = None
     for epoch in range(start_epoch, num_epochs):
-        if with_fid and ((epoch == 0) or (epoch >= 100 and epoch % 20 == 0) or epoch == num_epochs - 1):
+        if sampler is not None:
+            sampler.set_epoch(epoch)
+        if main_rank and with_fid and ((epoch == 0) or (epoch >= 100 and epoch % 20 == 0) or epoch == num_epochs - 1):
             from metrics.fid_score import calculate_fid_given_dataset  # the reference's metrics package
             with torch.no_grad():
                 print("calculating fid...")
@@ -243,7 +288,7 @@ def _train(dataset, z_dim, lr_e, lr_d, batch_size, num_workers, start_epoch, exi
                     best_fid = fid
                     prefix = "{}_{}_betas_{}_{}_{}_fid_{}_".format(dataset, tag, beta_kl, beta_neg, beta_rec, fid)
                     save_checkpoint(model, epoch, cur_iter, prefix)
-        if epoch % save_interval == 0 and epoch > 0:
+        if main_rank and epoch % save_interval == 0 and epoch > 0:
             prefix = "{}_{}_betas_{}_{}_{}_".format(dataset, tag, beta_kl, beta_neg, beta_rec)
             save_checkpoint(model, (epoch // save_interval) * save_interval, cur_iter, prefix)
         model.train()
@@ -271,7 +316,7 @@ def _train(dataset, z_dim, lr_e, lr_d, batch_size, num_workers, start_epoch, exi
         for real_batch in batches:  # device-resident fp32 NCHW, one batch prefetched (sivae_hip/data.py)
             if epoch < num_vae:
                 res = eng.vae_step(real_batch)
-                if cur_iter % test_iter == 0:
+                if main_rank and cur_iter % test_iter == 0:
                     _save_image(torch.cat([real_batch, res["rec"]], dim=0).cpu(),
                                 "{}/image_{}.jpg".format(fig_dir, cur_iter), num_row)
             else:
@@ -282,9 +327,10 @@ def _train(dataset, z_dim, lr_e, lr_d, batch_size, num_workers, start_epoch, exi
                     with torch.no_grad():
                         _, _, _, rec_det = model(real_batch, deterministic=True)
                     k = min(real_batch.size(0), 16)
-                    _save_image(torch.cat([real_batch[:k], rec_det[:k], res["fake"][:k]], dim=0).cpu(),
-                                "{}/image_{}.jpg".format(fig_dir, cur_iter), num_row)
-                elif len(pending) >= 64:
+                    if main_rank:
+                        _save_image(torch.cat([real_batch[:k], rec_det[:k], res["fake"][:k]], dim=0).cpu(),
+                                    "{}/image_{}.jpg".format(fig_dir, cur_iter), num_row)
+                elif len(pending) >= nan_every:
                     drain()
             cur_iter += 1
         drain()
@@ -301,6 +347,7 @@ def _train(dataset, z_dim, lr_e, lr_d, batch_size, num_workers, start_epoch, exi
         if epoch > num_vae - 1:
             for k in hist:
                 hist[k].append(np.mean(ep[k]))
+        if main_rank and epoch > num_vae - 1:
             print("#" * 50)
             print(f"Epoch {epoch} Summary:")
             print(f"beta_rec: {beta_rec}, beta_kl: {beta_kl}, beta_neg: {beta_neg}")
@@ -315,8 +362,12 @@ def _train(dataset, z_dim, lr_e, lr_d, batch_size, num_workers, start_epoch, exi
                 _, _, _, rec_det = model(real_batch, deterministic=True)
                 fake = model.sample(_rng.randn((real_batch.size(0), z_dim), device))
                 k = min(real_batch.size(0), 16)
-                _save_image(torch.cat([real_batch[:k], rec_det[:k], fake[:k]], dim=0).cpu(),
-                            "{}/image_{}.jpg".format(fig_dir, cur_iter), num_row)
+                if main_rank:
+                    _save_image(torch.cat([real_batch[:k], rec_det[:k], fake[:k]], dim=0).cpu(),
+                                "{}/image_{}.jpg".format(fig_dir, cur_iter), num_row)
+            if not main_rank:
+                model.train()
+                continue
             try:
                 import matplotlib
                 matplotlib.use("Agg")

@@ -315,10 +315,15 @@ def train_soft_intro_vae_toy(z_dim=2, lr_e=2e-4, lr_d=2e-4, batch_size=32, n_ite
         torch.manual_seed(seed)
         _rng.manual_seed(seed)
         print("random seed: ", seed)
+    else:
+        _rng.manual_seed(int.from_bytes(os.urandom(7), "little"))  # unseeded runs draw fresh noise, like torch.randn
     device = torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("train_soft_intro_vae_toy (MI355X build): device %s is not a ROCm device; this engine has "
                            "no CPU path" % device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    torch.cuda.set_device(device)  # kernels launch on the current stream of the tensors' device
     train_set = ToyDataset(distr=dataset)
     scale *= train_set.range
     model = SoftIntroVAESimple(x_dim=2, zdim=z_dim, n_layers=3, num_hidden=256).to(device)
@@ -332,9 +337,24 @@ def train_soft_intro_vae_toy(z_dim=2, lr_e=2e-4, lr_d=2e-4, batch_size=32, n_ite
     d_sched = MultiStepLR(opt_d, milestones=(10000, 15000), gamma=0.1)
     hp = dict(beta_rec=beta_rec, beta_kl=beta_kl, beta_neg=beta_neg, gamma_r=gamma_r, recon_loss_type=recon_loss_type)
     start = time.time()
+    # NaN guard (reference: `if torch.isnan(lossD) or torch.isnan(lossE): raise SystemError` every iteration, :644-645):
+    # a device-side flag accumulates isnan(lossE) | isnan(lossD) every iteration and is read back every
+    # SIVAE_NAN_CHECK_EVERY iterations (default 64; 1 = the reference's cadence), before EVERY checkpoint and before the
+    # final evaluation — a NaN model is never saved or scored.
+    nan_flag = torch.zeros((), dtype=torch.float32, device=device)
+    nan_every = max(1, int(os.environ.get("SIVAE_NAN_CHECK_EVERY", "64")))
+    unchecked = 0
+
+    def check_nan():
+        nonlocal unchecked
+        if unchecked and float(nan_flag.item()) != 0.0:
+            raise SystemError("loss is NaN.")
+        unchecked = 0
+
     for it in range(n_iter):
         batch = train_set.next_batch(batch_size=batch_size, device=device)
         if it % save_interval == 0 and it > 0:
+            check_nan()
             save_checkpoint(model, (it // save_interval) * save_interval, it, "")
         model.train()
         if it < num_vae:
@@ -346,16 +366,20 @@ def train_soft_intro_vae_toy(z_dim=2, lr_e=2e-4, lr_d=2e-4, batch_size=32, n_ite
             if batch.dim() == 3:
                 batch = batch.unsqueeze(0)
             res = soft_intro_iteration_2d(model, opt_e, opt_d, batch, hp)
+            nan_flag += torch.isnan(res["lossE"]).float() + torch.isnan(res["lossD"]).float()
+            unchecked += 1
+            if unchecked >= nan_every:
+                check_nan()
             if it % test_iter == 0:
+                check_nan()
                 s = {k: v.item() for k, v in res.items()}  # one sync per logging interval
-                if s["lossE"] != s["lossE"] or s["lossD"] != s["lossD"]:
-                    raise SystemError("loss is NaN.")
                 print("\nIter: {}/{} : time: {:4.4f}: Rec: {:.4f}, Kl_E: {:.4f}, expELBO_R: {:.4f}, expELBO_F: {:.4f}, "
                       "Kl_F: {:.4f}, KL_R: {:.4f}, DIFF_Kl_F: {:.4f}".format(
                           it, n_iter, time.time() - start, s["loss_rec"], s["kl_real"], s["expelbo_rec"],
                           s["expelbo_fake"], s["kl_fake"], s["kl_rec"], -s["kl_real"] + s["kl_fake"]))
         e_sched.step()
         d_sched.step()
+    check_nan()
     res = {}
     with torch.no_grad():
         res["sample_kl"] = calculate_sample_kl(model, train_set, num_samples=5000, device=device, hist_bins=100,

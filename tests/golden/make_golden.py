@@ -115,7 +115,59 @@ def make_helpers(T):
     print("helpers.npz", len(out))
 
 
-def make_step(T, name, cdim, zdim, channels, image_size, B, hp, bootstrap=False, seed=0):
+IMAGE_KEYS = ("fake", "rec", "rec_rec", "rec_fake")
+
+
+def _thin(out, key, t):
+    """large image tensors of the 128x128 / 256x256 fixtures: every 4th pixel in both directions + per-image,
+    per-channel sums and sums of squares (keeps a 256x256 fixture at a few MB; the input batch is stored in full)"""
+    a = _np(t)
+    out[key + "@thin"] = a[:, :, ::4, ::4].copy()
+    out[key + "@sum"] = a.astype(np.float64).sum((2, 3))
+    out[key + "@sumsq"] = (a.astype(np.float64) ** 2).sum((2, 3))
+
+
+def make_vae_step(T, name, cdim, zdim, channels, image_size, B, hp, bootstrap=False, seed=0):
+    """One vanilla-VAE iteration (the `epoch < num_vae` branch, train_soft_intro_vae.py:512-533; the bootstrap file's
+    branch decodes through the target decoder, train_soft_intro_vae_bootstrap.py:546 with target=True)."""
+    torch.manual_seed(seed)
+    model = T.SoftIntroVAE(cdim=cdim, zdim=zdim, channels=channels, image_size=image_size)
+    model.train()
+    out = {"meta_cdim": cdim, "meta_zdim": zdim, "meta_channels": np.array(channels), "meta_image_size": image_size,
+           "meta_bootstrap": int(bootstrap)}
+    for k, v in hp.items():
+        out["hp_" + k] = v
+    out.update(_sd(model, "init/"))
+    g = torch.Generator().manual_seed(1234)
+    real = torch.rand(B, cdim, image_size, image_size, generator=g)
+    out["real"] = _np(real)
+    opt_e = torch.optim.Adam(model.encoder.parameters(), lr=hp["lr"])
+    opt_d = torch.optim.Adam(model.decoder.parameters(), lr=hp["lr"])
+    with RandnRecorder() as rr:
+        real_mu, real_logvar, z, rec = model(real)
+        loss_rec = T.calc_reconstruction_loss(real, rec, loss_type="mse", reduction="mean")
+        loss_kl = T.calc_kl(real_logvar, real_mu, reduce="mean")
+        loss = hp["beta_rec"] * loss_rec + hp["beta_kl"] * loss_kl
+        opt_d.zero_grad()
+        opt_e.zero_grad()
+        loss.backward()
+        for k, v in dict(real_mu=real_mu, real_logvar=real_logvar, z=z, rec=rec, loss_rec=loss_rec, loss_kl=loss_kl,
+                         loss=loss).items():
+            out["V/" + k] = _np(v)
+        for net, pre in ((model.encoder, "encoder."), (model.decoder, "decoder.")):
+            for k, p in net.named_parameters():
+                if p.grad is not None:
+                    out["V/grad/" + pre + k] = _np(p.grad)
+        opt_e.step()
+        opt_d.step()
+    assert len(rr.draws) == 1
+    out["eps0"] = rr.draws[0]
+    out.update(_sd(model, "final/"))
+    np.savez_compressed(os.path.join(OUT, "step_%s.npz" % name), **out)
+    print("step_%s.npz" % name, "loss=%.6g" % float(loss))
+
+
+def make_step(T, name, cdim, zdim, channels, image_size, B, hp, bootstrap=False, seed=0, thin=False):
     """One iteration re-sequenced from the reference's modules (order of train_soft_intro_vae.py:547-624)."""
     torch.manual_seed(seed)
     model = T.SoftIntroVAE(cdim=cdim, zdim=zdim, channels=channels, image_size=image_size)
@@ -164,7 +216,10 @@ def make_step(T, name, cdim, zdim, channels, image_size, B, hp, bootstrap=False,
                          fake_logvar=fake_logvar, rec_fake=rec_fake, kl_rec=kl_rec, kl_fake=kl_fake,
                          expelbo_rec=expelbo_rec, expelbo_fake=expelbo_fake, lossE=lossE)
         for k, v in e_tensors.items():
-            out["E/" + k] = _np(v)
+            if thin and k in IMAGE_KEYS:
+                _thin(out, "E/" + k, v)
+            else:
+                out["E/" + k] = _np(v)
         for k, p in model.encoder.named_parameters():
             if _keep_grad(k):
                 out["E/grad/encoder." + k] = _np(p.grad)
@@ -200,7 +255,10 @@ def make_step(T, name, cdim, zdim, channels, image_size, B, hp, bootstrap=False,
                          fake_mu=fake_mu, fake_logvar=fake_logvar, rec_rec=rec_rec, rec_fake=rec_fake,
                          loss_rec_rec=l_rr, loss_fake_rec=l_fr, kl_rec=kl_rec, kl_fake=kl_fake, lossD=lossD)
         for k, v in d_tensors.items():
-            out["D/" + k] = _np(v)
+            if thin and k in IMAGE_KEYS:
+                _thin(out, "D/" + k, v)
+            else:
+                out["D/" + k] = _np(v)
         for k, p in model.decoder.named_parameters():
             if _keep_grad(k):
                 out["D/grad/decoder." + k] = _np(p.grad)
@@ -334,6 +392,24 @@ def make_loop_2d(T2):
     print("loop_2d.npz draws", len(rr.draws), "batches", len(batches))
 
 
+def main_round2():
+    """fixtures added in round 2 (the round-1 files are not regenerated): a vanilla-VAE iteration (plain and
+    bootstrap), and full iterations on the reduced-width 128x128 (5-level) and 256x256 (6-level) topologies incl. the
+    bootstrap variant on the 6-level one (SURVEY 8c list)"""
+    torch.set_num_threads(4)
+    _stub_torchvision()
+    T = _import_ref("soft_intro_vae", "train_soft_intro_vae")
+    hp = dict(beta_rec=1.0, beta_kl=1.0, beta_neg=256.0, gamma_r=1e-8, lr=2e-4)
+    hp2 = dict(beta_rec=0.5, beta_kl=1.0, beta_neg=1024.0, gamma_r=1e-8, lr=2e-4)
+    make_vae_step(T, "vae_narrow", 3, 16, [8, 16, 32], 32, 4, hp, seed=8)
+    make_step(T, "celeb128_narrow", 3, 32, [8, 16, 32, 64, 64], 128, 2, hp2, seed=4, thin=True)
+    make_step(T, "celeb256_narrow", 3, 32, [8, 16, 32, 64, 64, 64], 256, 2, hp2, seed=5, thin=True)
+    TB = _import_ref("soft_intro_vae_bootstrap", "train_soft_intro_vae_bootstrap")
+    hpb = dict(beta_rec=0.5, beta_kl=1.0, beta_neg=1024.0, gamma_r=1.0, lr=2e-4)
+    make_vae_step(TB, "vae_bootstrap_narrow", 3, 16, [8, 16, 32], 32, 4, dict(hp, gamma_r=1.0), bootstrap=True, seed=9)
+    make_step(TB, "bootstrap256_narrow", 3, 32, [8, 16, 32, 64, 64, 64], 256, 2, hpb, bootstrap=True, seed=6, thin=True)
+
+
 def main():
     torch.set_num_threads(4)
     _stub_torchvision()
@@ -364,4 +440,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--round2" in sys.argv:
+        main_round2()
+    else:
+        main()
+        main_round2()

@@ -429,6 +429,109 @@ def check_losses():
     return res
 
 
+def _allclose_err(a, ref, rtol, atol_scale=1e-6):
+    """element-wise criterion |a - ref| <= rtol*|ref| + atol (atol = atol_scale * max|ref|): returns the worst
+    violation ratio (<= 1 passes) — the strict reading of "1e-4 relative" for tensors with small entries"""
+    a = a.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    if a.shape != ref.shape or not torch.isfinite(a).all():
+        return float("inf")
+    atol = atol_scale * float(ref.abs().max())
+    return float(((a - ref).abs() / (rtol * ref.abs() + atol + 1e-300)).max())
+
+
+def check_kl_tensor_prior():
+    """calc_kl with TENSOR mu_o / logvar_o (reference :231-251 accepts tensors): broadcast shapes, no host sync"""
+    from sivae_hip import ops
+    res = []
+    B, Z = 6, 40
+    mu, lv = _rand(B, Z, seed=1).requires_grad_(), _rand(B, Z, seed=2).requires_grad_()
+    gk = _rand(B, seed=4)
+    for name, mo, lo in [("0d", _rand(1, seed=5)[0], _rand(1, seed=6)[0]), ("[Z]", _rand(Z, seed=5), _rand(Z, seed=6)),
+                         ("[B,Z]", _rand(B, Z, seed=5), _rand(B, Z, seed=6)), ("[B,1]", _rand(B, 1, seed=5), _rand(B, 1, seed=6)),
+                         ("[1,Z]/0d", _rand(1, Z, seed=5), torch.tensor(0.25, dtype=torch.float64))]:
+        mu.grad = lv.grad = None
+        kl = -0.5 * (1 + lv - lo - lv.exp() / torch.exp(lo) - (mu - mo).pow(2) / torch.exp(lo)).sum(1)
+        kl.backward(gk)
+        klh = ops.kl_fwd_t(_d(lv.detach()), _d(mu.detach()), mo.float().to(DEV), lo.float().to(DEV))
+        res.append(("kl_tensor_prior_fwd %s" % name, _err(klh, kl), 1e-6))
+        dlv, dmu = ops.kl_bwd_t(_d(gk), True, 1.0, _d(lv.detach()), _d(mu.detach()), mo.float().to(DEV), lo.float().to(DEV))
+        res.append(("kl_tensor_prior_dlv %s" % name, _err(dlv, lv.grad), 1e-6))
+        res.append(("kl_tensor_prior_dmu %s" % name, _err(dmu, mu.grad), 1e-6))
+    return res
+
+
+def check_adversarial():
+    """SURVEY T2 adversarial inputs: |logvar| up to 40 (exp range), a zero-variance BatchNorm channel, a constant
+    image, single-sample shards (B = 1)"""
+    from sivae_hip import ops
+    res = []
+    # ---- sampler / KL at the edge of the exp range: element-wise rtol 1e-5 (fp32 exp of +-40 is exact to ~1e-6 rel.)
+    B, Z = 4, 64
+    g = torch.Generator().manual_seed(11)
+    lv = (torch.rand(B, Z, generator=g, dtype=torch.float64) * 80.0 - 40.0)
+    lv[0, 0], lv[0, 1] = 40.0, -40.0
+    mu = _rand(B, Z, seed=12) * 3.0
+    eps = _rand(B, Z, seed=13)
+    lv32, mu32, eps32 = lv.float().double(), mu.float().double(), eps.float().double()
+    z = ops.reparam_fwd(_d(mu), _d(lv), _d(eps))
+    res.append(("adv reparam |logvar|<=40 (allclose 1e-5)", _allclose_err(z, mu32 + eps32 * torch.exp(0.5 * lv32), 1e-5), 1.0))
+    kl = ops.kl_fwd(_d(lv), _d(mu), 0.0, 0.0)
+    klref = -0.5 * (1 + lv32 - lv32.exp() - mu32.pow(2)).sum(1)
+    res.append(("adv kl |logvar|<=40 (allclose 1e-5)", _allclose_err(kl, klref, 1e-5), 1.0))
+    dlv, dmu = ops.kl_bwd(_d(torch.ones(B, dtype=torch.float64)), True, 1.0, _d(lv), _d(mu), 0.0, 0.0)
+    res.append(("adv kl_dlv |logvar|<=40 (allclose 1e-5)", _allclose_err(dlv, -0.5 * (1 - lv32.exp()), 1e-5), 1.0))
+    # exp-ELBO with a huge exponent must underflow to 0, not NaN
+    L = torch.tensor([0.0, 1e6, 3e7], dtype=torch.float64)
+    KLv = torch.tensor([0.0, 1e4, 1e9], dtype=torch.float64)
+    out, e = ops.expelbo_fwd(_d(L), _d(KLv), 1.0 / 3072, 1.0, 1024.0)
+    ref = (-2 / 3072 * (L + 1024.0 * KLv)).exp()
+    res.append(("adv expelbo underflow", _err(e, ref), 1e-6))
+    # ---- zero-variance channel: constant channel (2.5) inside a random tensor; invstd = 1/sqrt(eps), output = beta
+    Bc, C, H, W = 4, 8, 16, 16
+    x = _rand(Bc, C, H, W, seed=1)
+    x[:, 3] = 2.5
+    x[:, 5] = 0.0
+    gamma, beta = _rand(C, seed=3) * 0.5 + 1.0, _rand(C, seed=4)
+    xd = _d(x)
+    mean, invstd = ops.bn_stats(xd)
+    xv = x.float().double().var((0, 2, 3), unbiased=False)
+    res.append(("adv zero-variance bn mean", _err(mean, x.float().double().mean((0, 2, 3))), 1e-6))
+    res.append(("adv zero-variance bn invstd", _err(invstd, 1.0 / torch.sqrt(xv + 1e-5)), 1e-5))
+    y = ops.bn_apply_act(xd, None, mean, invstd, _d(gamma), _d(beta), 0.2)
+    yref = F.leaky_relu(F.batch_norm(x.float().double(), None, None, gamma.float().double(), beta.float().double(),
+                                     training=True, eps=1e-5), 0.2)
+    res.append(("adv zero-variance bn apply", _err(y, yref), 1e-5))
+    dy = _rand(Bc, C, H, W, seed=7)
+    dx, _, dg, db = ops.bn_bwd(_d(dy), y, xd, mean, invstd, _d(gamma), 0.2)
+    ok = bool(torch.isfinite(dx).all() and torch.isfinite(dg).all() and torch.isfinite(db).all())
+    res.append(("adv zero-variance bn bwd finite", 0.0 if ok else float("inf"), 0.5))
+    # conv epilogue statistics of an all-zero output channel (zero filter) and of a constant image
+    w = _rand(16, 3, 3, 3, seed=2)
+    w[7] = 0.0
+    img = torch.full((2, 3, 16, 16), 0.5, dtype=torch.float64)
+    yc, part = ops.conv2d_fwd(_d(img), ops.PackedW(_d(w), 0), 16, 3, want_stats=True)
+    m1, i1 = ops.bn_stats_from_conv(part, 2, 16, 256)
+    ref = _conv_ref(img, w.float().double())
+    res.append(("adv constant image conv", _err(yc, ref), 1e-5))
+    res.append(("adv constant image stats mean", _err(m1, ref.mean((0, 2, 3))), 1e-5))
+    res.append(("adv constant image stats invstd", _err(i1, 1.0 / torch.sqrt(ref.var((0, 2, 3), unbiased=False) + 1e-5)), 2e-4))
+    # constant image through the reconstruction losses: x == recon -> 0; bce at the clamp (r in {0, 1})
+    xi = torch.full((2, 300), 0.5, dtype=torch.float64)
+    res.append(("adv recon mse x==r", float(ops.recon_rowsum_fwd(_d(xi), _d(xi), "mse").abs().max()), 0.0))
+    r01 = torch.tensor([[0.0, 1.0, 0.0, 1.0]], dtype=torch.float64)
+    x01 = torch.tensor([[0.0, 1.0, 1.0, 0.0]], dtype=torch.float64)
+    bref = F.binary_cross_entropy(r01, x01, reduction="none").sum(1)
+    res.append(("adv bce clamp", _err(ops.recon_rowsum_fwd(_d(x01), _d(r01), "bce"), bref), 1e-6))
+    # ---- B = 1 shards
+    for shape in [(1, 64, 128, 16, 16, 3), (1, 512, 512, 4, 4, 3), (1, 3, 64, 32, 32, 5), (1, 64, 128, 8, 8, 1)]:
+        res += check_conv_fwd(shape, stats=shape[5] == 3, wino=shape[5] == 3)
+        res += check_conv_dgrad(shape, wino=shape[5] == 3)
+        res += check_conv_wgrad(shape)
+    res += check_bn((1, 32, 8, 8), True)
+    return res
+
+
 def check_randn():
     from sivae_hip import ops
     a = ops.randn((1 << 20,), 1234, 0, torch.device(DEV))
@@ -785,6 +888,8 @@ def all_checks():
     checks.append(("space_to_depth", check_space_to_depth))
     checks.append(("bn_apply_resup", check_bn_apply_resup))
     checks.append(("losses", check_losses))
+    checks.append(("kl_tensor_prior", check_kl_tensor_prior))
+    checks.append(("adversarial", check_adversarial))
     checks.append(("randn", check_randn))
     checks.append(("adam", check_adam))
     return checks

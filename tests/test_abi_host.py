@@ -68,6 +68,60 @@ def test_round1_late_entry_points_validate_arguments():
     assert L.sivae_conv2d_wino_up_supported(16, 32) == 1 and L.sivae_conv2d_wino_up_supported(8, 8) == 0
 
 
+def test_round2_entry_points_validate_arguments():
+    """bf16-mode kernels, the small-batch Linear kernels and the tensor-prior KL: host-side checks only (every call
+    returns before any kernel launch), plus the layout / tiling / workspace queries"""
+    L = lib.load()
+    null = None
+    one = ctypes.c_void_p(16)
+    # blocked bf16 layout: channel counts are padded to a multiple of 16 (two 8-channel blocks)
+    assert [L.sivae_bf16_cblocks(c) for c in (1, 3, 16, 17, 64, 512)] == [2, 2, 2, 4, 8, 64]
+    assert L.sivae_bf16_cblocks(0) == -2
+    # weight packs: [co_tile][chunk][tap][k-step][half][TCO][8] bf16
+    assert L.sivae_bf16_pack_conv_weight_bytes(128, 64, 3, 0) == 1 * 4 * 9 * 1 * 2 * 128 * 16
+    assert L.sivae_bf16_pack_conv_weight_bytes(64, 3, 5, 0) == 1 * 1 * 25 * 1 * 2 * 64 * 16
+    assert L.sivae_bf16_pack_conv_weight_bytes(64, 3, 5, 1) == 1 * 4 * 25 * 1 * 2 * 32 * 16   # dgrad: 3 outputs -> 32-row tile
+    assert L.sivae_bf16_pack_conv_weight_bytes(128, 64, 1, 0) == 1 * 1 * 1 * 4 * 2 * 128 * 16  # 1x1: 64-channel chunks
+    assert L.sivae_bf16_pack_conv_weight_bytes(64, 64, 2, 0) == 0
+    assert L.sivae_bf16_pack_conv_weight(one, one, 4, 4, 7, 0, null) == -3
+    assert L.sivae_bf16_pack_conv_weight(null, one, 4, 4, 3, 0, null) == -1
+    a = [null, null, null, null]
+    assert L.sivae_bf16_conv2d_fwd(null, one, one, null, *a, 0.2, null, 1, 16, 16, 4, 4, 3, 0, 0, 0, null) == -1
+    assert L.sivae_bf16_conv2d_fwd(one, one, one, null, *a, 0.2, null, 1, 16, 16, 4, 4, 2, 0, 0, 0, null) == -3
+    assert L.sivae_bf16_conv2d_fwd(one, one, one, null, *a, 0.2, null, 1, 16, 16, 5, 5, 3, 1, 0, 0, null) == -2
+    assert L.sivae_bf16_conv2d_fwd(one, one, one, null, one, one, one, one, 0.2, null, 1, 16, 16, 4, 4, 1, 0, 0, 0, null) == -6
+    assert L.sivae_bf16_conv2d_fwd(one, one, one, null, *a, 0.2, null, 1, 16, 64, 4, 4, 5, 0, 0, 1, null) == -6  # fp32 out: Co <= 32
+    assert L.sivae_bf16_conv2d_wgrad(one, one, one, *a, 0.2, 1, 16, 16, 4, 4, 3, 0, null, 0, null) == -1
+    assert L.sivae_bf16_conv2d_wgrad(one, one, one, *a, 0.2, 1, 16, 16, 4, 4, 3, 0, one, 8, null) == -4
+    assert L.sivae_bf16_conv2d_wgrad_workspace_bytes(128, 64, 64, 128, 128, 3) >= 64 * 64 * 9 * 4
+    assert L.sivae_bf16_conv2d_wgrad_workspace_bytes(128, 64, 64, 128, 128, 4) == 0
+    assert L.sivae_bf16_conv2d_num_px_tiles(128, 128, 64, 64) == 128 * 64 * 64 // 256   # big pixel tile (fills the chip)
+    assert L.sivae_bf16_conv2d_num_px_tiles(2, 128, 8, 8) == 1                           # small grid: 128-pixel tile
+    assert L.sivae_bf16_bn_apply_act(one, null, 0, one, one, one, one, 0.2, null, null, 1, 16, 4, 4, null) == -1
+    assert L.sivae_bf16_bn_apply_act(one, null, 0, one, one, one, one, 0.2, one, one, 1, 16, 3, 4, null) == -2  # pool: even H
+    assert L.sivae_bf16_bn_apply_act(one, null, 1, one, one, one, one, 0.2, one, null, 1, 16, 4, 4, null) == -1  # res_up w/o res
+    assert L.sivae_bf16_bn_bwd(one, 0, null, one, one, one, one, null, 0.2, one, null, 0, null, null, 1, 16, 4, 4, one, 1 << 20, null) == -1
+    assert L.sivae_bf16_bn_bwd(one, 0, one, one, one, one, one, null, 0.2, one, null, 1, null, null, 1, 16, 4, 4, one, 1 << 20, null) == -1
+    assert L.sivae_bf16_bn_bwd(one, 0, one, one, one, one, one, null, 0.2, one, null, 0, null, null, 1, 16, 4, 4, one, 8, null) == -4
+    assert L.sivae_bf16_bn_bwd_workspace_bytes(128, 64, 64, 64) > 0 and L.sivae_bf16_bn_bwd_workspace_bytes(0, 64, 8, 8) == 0
+    assert L.sivae_bf16_from_f32_nchw(null, one, 1, 3, 4, 4, 1.0, null) == -1
+    assert L.sivae_bf16_to_f32_nchw(one, one, 1, 0, 4, 4, null) == -2
+    assert L.sivae_bf16_add_inplace(one, null, 4, null) == -1 and L.sivae_bf16_add_inplace(one, one, 0, null) == 0
+    # small-batch Linear: B <= 256, K % 4 == 0, N % 4 == 0
+    assert L.sivae_linear_supported(128, 8192, 1024) == 1 and L.sivae_linear_supported(257, 64, 64) == 0
+    assert L.sivae_linear_supported(8, 66, 64) == 0 and L.sivae_linear_supported(8, 64, 30) == 0
+    assert L.sivae_linear_workspace_bytes(128, 8192, 512) >= 128 * 512 * 4
+    assert L.sivae_linear_fwd(null, one, null, one, 0, 8, 64, 64, one, 1 << 20, null) == -1
+    assert L.sivae_linear_fwd(one, one, null, one, 0, 300, 64, 64, one, 1 << 20, null) == -2
+    assert L.sivae_linear_fwd(one, one, null, one, 0, 128, 8192, 512, one, 16, null) == -4
+    assert L.sivae_linear_dgrad(one, one, one, 128, 256, 8192, one, 16, null) == -4
+    assert L.sivae_linear_wgrad(one, null, one, 8, 64, 64, null) == -1
+    # tensor-prior KL: null priors / negative strides
+    assert L.sivae_kl_fwd_t(one, one, 8, null, 0, 0, one, 0, 0, one, 2, 8, null) == -1
+    assert L.sivae_kl_fwd_t(one, one, 8, one, -1, 0, one, 0, 0, one, 2, 8, null) == -6
+    assert L.sivae_kl_bwd_t(one, 0, 1.0, one, one, 4, one, 0, 0, one, 0, 0, one, one, 8, 2, 8, null) == -2  # ld < Z
+
+
 def test_workspace_and_padding_queries():
     L = lib.load()
     assert L.sivae_conv_ck(3) == 8 and L.sivae_conv_ck(1) == 32 and L.sivae_conv_ck(5) == 4

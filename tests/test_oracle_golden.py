@@ -32,6 +32,17 @@ def _close(a, b, rtol, what):
     assert err <= rtol, "%s: rel err %.3e > %.1e" % (what, err, rtol)
 
 
+def _close_fx(v, fx, key, rtol, what):
+    """compare with a fixture entry stored in full, or thinned (every 4th pixel + per-image channel sums / sums of
+    squares: the 128x128 / 256x256 fixtures, tests/golden/make_golden.py::_thin)"""
+    if key in fx.files:
+        return _close(v, fx[key], rtol, what)
+    v = v.detach().double()
+    _close(v[:, :, ::4, ::4], fx[key + "@thin"], rtol, what + " (thin)")
+    _close(v.sum((2, 3)), fx[key + "@sum"], rtol, what + " (sum)")
+    _close((v * v).sum((2, 3)), fx[key + "@sumsq"], rtol, what + " (sumsq)")
+
+
 def _params_from(fx, prefix="init/"):
     P = {}
     for k in fx.files:
@@ -89,7 +100,8 @@ def test_init_params_structure(name):
 
 # ---------------------------------------------------------------------------------------------- one iteration
 @pytest.mark.parametrize("name", ["step_cifar_narrow", "step_deep64_narrow", "step_mnist_narrow",
-                                  "step_bootstrap_narrow"])
+                                  "step_bootstrap_narrow", "step_celeb128_narrow", "step_celeb256_narrow",
+                                  "step_bootstrap256_narrow"])
 def test_one_iteration_matches_reference(name):
     fx = _load(name + ".npz")
     cdim, zdim, channels, image_size, boot = _meta(fx)
@@ -103,7 +115,7 @@ def test_one_iteration_matches_reference(name):
     opt_d = O.Adam(P, O.trainable_keys(P, "decoder."), lr)
     e = O.e_step(P, real, noise, eps[:3], hp, channels, image_size, boot)
     for k, v in e.items():
-        _close(v, fx["E/" + k], 2e-5, "%s E/%s" % (name, k))
+        _close_fx(v, fx, "E/" + k, 2e-5, "%s E/%s" % (name, k))
     ng = 0
     for k in fx.files:
         if k.startswith("E/grad/"):
@@ -111,12 +123,55 @@ def test_one_iteration_matches_reference(name):
             ng += 1
     assert ng >= 4
     opt_e.step()
+    if "E/rec@thin" in fx.files:
+        # deep nets: start the D-step from the REFERENCE's post-E-step encoder (Adam's sign-like first step turns fp32
+        # summation-order noise in ~1e-8 gradients into O(lr) weight differences that depend on the thread count)
+        for k in O.trainable_keys(P, "encoder."):
+            P[k].data.copy_(_t(fx["final/" + k]))
     d = O.d_step(P, real, noise, e["z"], eps[3:], hp, channels, image_size, boot)
     for k, v in d.items():
-        _close(v, fx["D/" + k], 2e-5, "%s D/%s" % (name, k))
+        _close_fx(v, fx, "D/" + k, 2e-5, "%s D/%s" % (name, k))
     for k in fx.files:
         if k.startswith("D/grad/"):
             _close(P[k[len("D/grad/"):]].grad, fx[k], 2e-3, k)
+    opt_d.step()
+    thin = ("E/rec@thin" in fx.files)
+    for k in fx.files:
+        if k.startswith("final/") and (not thin or k.endswith(("running_mean", "running_var", "num_batches_tracked"))):
+            _close(P[k[len("final/"):]].double(), fx[k], 1e-4, k)
+    if thin:
+        # deep (5- / 6-level) nets: the first Adam step is sign-like on gradients of ~1e-8, so a few weights move by
+        # up to ~lr between any two fp32 evaluations -> post-step weights in units of lr (weight_drift below)
+        dmax, dmed, dfrac = weight_drift(P, fx, lr)
+        assert dmed <= 0.1 and dfrac <= 0.01, "weight drift in lr units: max %.3f median %.3e frac>lr %.4f" % (
+            dmax, dmed, dfrac)
+
+
+
+@pytest.mark.parametrize("name", ["step_vae_narrow", "step_vae_bootstrap_narrow"])
+def test_vanilla_vae_iteration_matches_reference(name):
+    """the `epoch < num_vae` branch (:512-533; bootstrap: decodes through the target decoder, so the decoder gets no
+    gradient and torch.optim.Adam leaves it alone): every output, every gradient, post-Adam weights"""
+    fx = _load(name + ".npz")
+    cdim, zdim, channels, image_size, boot = _meta(fx)
+    P = _params_from(fx)
+    hp = dict(beta_rec=float(fx["hp_beta_rec"]), beta_kl=float(fx["hp_beta_kl"]))
+    lr = float(fx["hp_lr"])
+    opt_e = O.Adam(P, O.trainable_keys(P, "encoder."), lr)
+    opt_d = O.Adam(P, O.trainable_keys(P, "decoder."), lr)
+    v = O.vae_step(P, _t(fx["real"]), _t(fx["eps0"]), hp, channels, image_size, boot)
+    for mine, theirs in (("mu", "real_mu"), ("logvar", "real_logvar"), ("z", "z"), ("rec", "rec"),
+                         ("loss_rec", "loss_rec"), ("loss_kl", "loss_kl"), ("loss", "loss")):
+        _close(v[mine], fx["V/" + theirs], 2e-5, "%s V/%s" % (name, theirs))
+    grads = [k for k in fx.files if k.startswith("V/grad/")]
+    assert any(k.startswith("V/grad/encoder.") for k in grads)
+    assert boot != any(k.startswith("V/grad/decoder.") for k in grads)  # bootstrap: no decoder gradients at all
+    for k in grads:
+        _close(P[k[len("V/grad/"):]].grad, fx[k], 2e-3, k)
+    if boot:
+        for k in O.trainable_keys(P, "decoder."):
+            assert P[k].grad is None, k
+    opt_e.step()
     opt_d.step()
     for k in fx.files:
         if k.startswith("final/"):
