@@ -354,9 +354,9 @@ size_t sivae_bf16_pack_conv_weight_bytes(int Co, int Ci, int ks, int mode);
 int sivae_bf16_pack_conv_weight(const float* w, void* wp, int Co, int Ci, int ks, int mode, sivae_stream_t stream);
 /* y (+)= conv(x', wp) + bias with the fusions of sivae_conv2d_fwd (producer BatchNorm+LeakyReLU prologue — 3x3 only —,
  * upsample addressing, {sum, sumsq} partials of the rounded output, accumulate).  out_f32_nchw != 0: y is float
- * [B][Co][H][W] (Co <= 32, no stats: Decoder.predict :159).  stats_partial has sivae_bf16_conv2d_num_px_tiles rows and
+ * [B][Co][H][W] (Co <= 32, no stats: Decoder.predict :159).  stats_partial has sivae_bf16_conv2d_num_px_tiles(B, Co, H, W, ks) rows and
  * feeds sivae_bn_stats_from_conv unchanged.  The data gradient is this function on dy with the mode-1 pack. */
-int sivae_bf16_conv2d_num_px_tiles(int B, int Co, int H, int W);
+int sivae_bf16_conv2d_num_px_tiles(int B, int Co, int H, int W, int ks);
 int sivae_bf16_conv2d_fwd(const void* x, const void* wp, void* y, const float* bias, const float* pro_mean,
                           const float* pro_invstd, const float* pro_gamma, const float* pro_beta, float pro_slope,
                           float* stats_partial, int B, int Ci, int Co, int H, int W, int ks, int upsample,

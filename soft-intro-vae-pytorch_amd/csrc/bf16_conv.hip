@@ -483,10 +483,12 @@ extern "C" int sivae_bf16_pack_conv_weight(const float* w, void* wp, int Co, int
   return sivae_launch_status();
 }
 
-extern "C" int sivae_bf16_conv2d_num_px_tiles(int B, int Co, int H, int W) {
+extern "C" int sivae_bf16_conv2d_num_px_tiles(int B, int Co, int H, int W, int ks) {
   if (B <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
-  const Bf16Cfg c = bf16_cfg(3, Co, 16);
-  TileGeom g = make_tile_geom(B, H, W, px_tile_3x3(c.TCO, B, H, W, Co));
+  if (ks != 1 && ks != 3 && ks != 5) return SIVAE_ERR_KSIZE;
+  const Bf16Cfg c = bf16_cfg(ks, Co, 16);
+  // (only the 3x3 kernels have the big pixel tiles; the launch below makes the same choice)
+  TileGeom g = make_tile_geom(B, H, W, ks == 3 ? px_tile_3x3(c.TCO, B, H, W, Co) : c.TPX);
   return g.ntb * g.nth * g.ntw;
 }
 

@@ -63,6 +63,16 @@ def set_compute_dtype(module, dtype):
     return module
 
 
+def _block_weights(m):
+    """the weight tuple a block's replay-cache tag is built from (same order as functional.ResBlockFn / ConvBiasFn)"""
+    if isinstance(m, ResidualBlock):
+        return (None if m.conv_expand is None else m.conv_expand.weight, m.conv1.weight, m.bn1.weight, m.bn1.bias,
+                m.conv2.weight, m.bn2.weight, m.bn2.bias)
+    if isinstance(m, nn.Conv2d):
+        return (m.weight, m.bias)
+    return ()
+
+
 def _run_main(main, x, cache=None):
     """Walk a reference-shaped nn.Sequential, dispatching each group of layers to its fused HIP block.
     x: fp32 NCHW, or a blocked bf16 activation (bf16 mode): the blocks dispatch on the input dtype."""
@@ -71,10 +81,17 @@ def _run_main(main, x, cache=None):
     mods = list(main.children())
     i, n = 0, len(mods)
     x_up = False  # x currently stands for Upsample(2,'nearest')(x): the consumers read it through upsample addressing
+    stale = False  # an earlier block of this pass missed its replay cache
     while i < n:
         m = mods[i]
         nxt = mods[i + 1] if i + 1 < n else None
         sub = None if cache is None else cache.setdefault(i, {})
+        if sub is not None and sub.get("y") is not None:
+            # a cached block is replayed only if its own weights are unchanged AND every block before it was replayed
+            # too (a recomputed block hands its successors a new input)
+            if stale or sub.get("tag") != SF.cache_tag(_block_weights(m)):
+                sub.clear()
+                stale = True
         if isinstance(m, ResidualBlock):
             if isinstance(nxt, nn.AvgPool2d):
                 x = m(x, post="pool", cache=sub, x_up=x_up)

@@ -92,7 +92,7 @@ def conv2d(x, wp, Ci, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
         y = empty_blocked(B, Co, H, W, x.device)
     stats = None
     if want_stats:
-        stats = torch.empty((L.sivae_bf16_conv2d_num_px_tiles(B, Co, H, W), Co, 2), dtype=torch.float32,
+        stats = torch.empty((L.sivae_bf16_conv2d_num_px_tiles(B, Co, H, W, ks), Co, 2), dtype=torch.float32,
                             device=x.device)
     pm = pi = pg = pb = None
     slope = 1.0

@@ -95,8 +95,12 @@ def test_round2_entry_points_validate_arguments():
     assert L.sivae_bf16_conv2d_wgrad(one, one, one, *a, 0.2, 1, 16, 16, 4, 4, 3, 0, one, 8, null) == -4
     assert L.sivae_bf16_conv2d_wgrad_workspace_bytes(128, 64, 64, 128, 128, 3) >= 64 * 64 * 9 * 4
     assert L.sivae_bf16_conv2d_wgrad_workspace_bytes(128, 64, 64, 128, 128, 4) == 0
-    assert L.sivae_bf16_conv2d_num_px_tiles(128, 128, 64, 64) == 128 * 64 * 64 // 256   # big pixel tile (fills the chip)
-    assert L.sivae_bf16_conv2d_num_px_tiles(2, 128, 8, 8) == 1                           # small grid: 128-pixel tile
+    assert L.sivae_bf16_conv2d_num_px_tiles(128, 128, 64, 64, 3) == 128 * 64 * 64 // 256   # big pixel tile (fills the chip)
+    assert L.sivae_bf16_conv2d_num_px_tiles(2, 128, 8, 8, 3) == 1                         # small grid: 128-pixel tile
+    # the 5x5 stem keeps its 256-pixel tile where the 3x3 kernel of the same width takes 512 (rows of the stats buffer!)
+    assert L.sivae_bf16_conv2d_num_px_tiles(128, 64, 128, 128, 5) == 128 * 128 * 128 // 256
+    assert L.sivae_bf16_conv2d_num_px_tiles(128, 64, 128, 128, 3) == 128 * 128 * 128 // 512
+    assert L.sivae_bf16_conv2d_num_px_tiles(128, 64, 128, 128, 4) == -3
     assert L.sivae_bf16_bn_apply_act(one, null, 0, one, one, one, one, 0.2, null, null, 1, 16, 4, 4, null) == -1
     assert L.sivae_bf16_bn_apply_act(one, null, 0, one, one, one, one, 0.2, one, one, 1, 16, 3, 4, null) == -2  # pool: even H
     assert L.sivae_bf16_bn_apply_act(one, null, 1, one, one, one, one, 0.2, one, null, 1, 16, 4, 4, null) == -1  # res_up w/o res
