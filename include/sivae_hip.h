@@ -78,6 +78,19 @@ int sivae_conv2d_wino_fwd(const float* x, const float* up, float* y, const float
                           float* stats_partial, int B, int Ci, int Co, int H, int W, int upsample, int accumulate,
                           sivae_stream_t stream);
 
+/* Split-K form of sivae_conv2d_wino_fwd for launches that would leave most of the chip idle (the deep 4x4 / 8x8 layers
+ * at small batch: the 16-image per-GPU shard of config 4): the input-channel range is cut into
+ * sivae_conv2d_wino_splitk(...) slices computed by separate work items into `workspace`, and a fixed-order reduce kernel
+ * sums them into y (+= with accumulate) and writes per-image {sum, sumsq} rows.  With 1 slice it IS
+ * sivae_conv2d_wino_fwd.  stats_partial has sivae_conv2d_wino_splitk_stats_rows(...) rows. */
+int sivae_conv2d_wino_splitk(int B, int Ci, int Co, int H, int W);
+size_t sivae_conv2d_wino_splitk_workspace_bytes(int B, int Ci, int Co, int H, int W);
+int sivae_conv2d_wino_splitk_stats_rows(int B, int Ci, int Co, int H, int W);
+int sivae_conv2d_wino_fwd_splitk(const float* x, const float* up, float* y, const float* pro_mean,
+                                 const float* pro_invstd, const float* pro_gamma, const float* pro_beta, float pro_slope,
+                                 float* stats_partial, int B, int Ci, int Co, int H, int W, int upsample, int accumulate,
+                                 void* workspace, size_t workspace_bytes, sivae_stream_t stream);
+
 /* 3x3 conv of a nearest-2x-upsampled input (nn.Upsample :155 -> ResidualBlock.conv1 :56), computed on the low-resolution
  * tensor: four output-parity phases, each a 2x2 conv run as Winograd F(2x2,2x2) — 36 multiplies per 4x4 output pixels
  * instead of 64 (sivae_conv2d_wino_fwd with upsample) or 144 (direct).  x_half is [B][Ci][H/2][W/2], y is

@@ -48,6 +48,12 @@ struct WinoArgs {
   int upsample;
   int n_items;
   int xcd_group;  // 1: start items grouped per XCD (see the kernel)
+  // split-K (small batches on the deep 4x4 / 8x8 maps: a handful of work items each walking 512 input channels):
+  // n_items = k_splits * n_items_base; item (slice s, base item) accumulates chunks [s*chunks_per_split, ...) and
+  // writes its partial output to y + s*y_split_stride (a workspace); a reduce kernel sums the slices
+  int n_items_base;
+  int chunks_per_split;
+  long long y_split_stride;
   // optional: the output y is the gradient flowing into LeakyReLU(BatchNorm(bnb_x)) (the data gradient of conv2 feeding
   // BatchNorm-1's backward): the `stats` partials then hold {sum g, sum g * xhat}, g = y * LeakyReLU'(z), instead of
   // {sum y, sum y^2} — the first reduction pass of the BatchNorm backward disappears
@@ -118,6 +124,7 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
   // transform of the current one, so launch latency, address set-up and the first HBM round trip are paid
   // once per block instead of once per 128 output pixels.
   const int n_items = a.n_items;
+  const int nchunks = a.Ci_pad / WINO_CK;
   // Consecutive blockIdx go round-robin to the 8 XCDs.  With xcd_group the block on XCD x, slot j starts at item
   // x * (grid / 8) + j: the co-tiles of one pixel tile (consecutive items) then run on ONE XCD and share the halo in its
   // L2.  Only for layers whose whole U (all co-tiles) fits an L2 next to the halos; with 8 co-tiles of 2 MB each the
@@ -125,6 +132,7 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
   int item = blockIdx.x;
   if (a.xcd_group) item = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
   int pt, b, r0, c0, co0;
+  int kc0, kc1, ysl;  // chunk range and output slice of the current item (split-K; the whole K range otherwise)
   __amdgpu_buffer_rsrc_t xrsrc;
   const __amdgpu_buffer_rsrc_t ursrc = make_rsrc(a.up, 16ull * a.Ci_pad * a.Co_pad * 4ull);
   unsigned xo, ua_base;
@@ -140,8 +148,12 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
   int nb_here;  // images of this item that exist (TB == 2 and odd batch: the last item has one)
 #define WINO_SETUP(ITEM)                                                 \
   {                                                                      \
-    const int co_tile = (ITEM) % a.n_co_tiles;                           \
-    pt = (ITEM) / a.n_co_tiles;                                          \
+    ysl = (ITEM) / a.n_items_base;                                       \
+    const int it_ = (ITEM) - ysl * a.n_items_base;                       \
+    kc0 = ysl * a.chunks_per_split;                                      \
+    kc1 = kc0 + a.chunks_per_split < nchunks ? kc0 + a.chunks_per_split : nchunks; \
+    const int co_tile = it_ % a.n_co_tiles;                              \
+    pt = it_ / a.n_co_tiles;                                             \
     const int tbx = pt % a.nbw;                                          \
     const int t2 = pt / a.nbw;                                           \
     const int tby = t2 % a.nbh;                                          \
@@ -179,7 +191,6 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
   float xr[CK];
   float4 AR[4][WM];  // ring of U operands: slot (k-step & 3); a slot is refilled with k-step + 4 right after the
                      // MFMAs that consumed it have been issued (prefetch distance = 4 k-steps, across chunks)
-  const int nksteps = a.Ci_pad / 2;
 
 #define WINO_LOAD_X(CH)                                                  \
   {                                                                      \
@@ -247,7 +258,7 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
     __builtin_amdgcn_sched_barrier(0);                                   \
     WINO_STEP((KK)&3, DA, DB)                                            \
     __builtin_amdgcn_sched_barrier(0);                                   \
-    if ((CH) * (CK / 2) + (KK) + 4 < nksteps) WINO_LOAD_A((CH) * (CK / 2) + (KK) + 4, (KK)&3) \
+    if ((CH) * (CK / 2) + (KK) + 4 < kc1 * (CK / 2)) WINO_LOAD_A((CH) * (CK / 2) + (KK) + 4, (KK)&3) \
   }
   // MFMA phase of chunk CH on halo buffer BUF.  The staged registers of chunk CH+1 (loaded at the top) are
   // written to the OTHER halo buffer late in the phase, so the only thing between two MFMA phases is the barrier.
@@ -279,7 +290,8 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
     float* ex = smem; /* [2 ar][4 j][2 cg][16 r][64 lanes] = 64 KB */    \
     constexpr int PPW = 32 / NW;                                         \
     const __amdgpu_buffer_rsrc_t yrsrc =                                 \
-        make_rsrc(a.y + (size_t)e_b * a.Co * H * W, (unsigned long long)e_nb * a.Co * H * W * 4ull); \
+        make_rsrc(a.y + (size_t)e_ysl * a.y_split_stride + (size_t)e_b * a.Co * H * W, \
+                  (unsigned long long)e_nb * a.Co * H * W * 4ull);       \
     const int row_base = e_r0 + 2 * ty, col = e_c0 + 2 * tx;             \
     _Pragma("unroll") for (int m = 0; m < WM; ++m)                       \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                     \
@@ -351,7 +363,6 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
   // One barrier per 16-channel chunk, at the end of its MFMA phase: it publishes the halo of chunk ch+1 (written
   // during the phase into the other buffer) and retires the readers of buffer (ch & 1) before chunk ch+1's
   // phase overwrites it with chunk ch+2.
-  const int nchunks = a.Ci_pad / CK;
   if (PRO) {
     // pro4[2p] = {mean, mean', scale, scale'}, pro4[2p + 1] = {beta, beta', 0, 0} of the channel pair (2p, 2p + 1)
     for (int c = tid; c < a.Ci_pad; c += NT) {
@@ -367,9 +378,9 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
     __syncthreads();
   }
   WINO_SETUP(item)
-  WINO_LOAD_X(0)
+  WINO_LOAD_X(kc0)
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) WINO_LOAD_A(kk, kk)
+  for (int kk = 0; kk < 4; ++kk) WINO_LOAD_A(kc0 * (CK / 2) + kk, kk)
   for (;;) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -377,35 +388,35 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
       for (int m = 0; m < WM; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][m][r] = 0.f;
-    WINO_STORE_X(0, 0)
+    WINO_STORE_X(kc0, 0)
     __syncthreads();
-    int ch = 0;
-    for (; ch + 1 < nchunks; ch += 2) {
+    int ch = kc0;
+    for (; ch + 1 < kc1; ch += 2) {
       WINO_MMA(ch, 0, true)
-      const bool more = ch + 2 < nchunks;
+      const bool more = ch + 2 < kc1;
       WINO_MMA(ch + 1, 1, more)
     }
-    if (ch < nchunks) WINO_MMA(ch, 0, false)
+    if (ch < kc1) WINO_MMA(ch, 0, false)
 
     WINO_EPI_PRIO_UP
     // coordinates of the item just accumulated; then put the next item's first loads in flight
-    const int e_pt = pt, e_b = b, e_nb = nb_here, e_r0 = r0, e_c0 = c0, e_co0 = co0;
+    const int e_pt = pt, e_b = b, e_nb = nb_here, e_r0 = r0, e_c0 = c0, e_co0 = co0, e_ysl = ysl;
     const int next = item + (int)gridDim.x;
     const bool has_next = next < n_items;
     // (with accumulate the epilogue loads y; vmcnt completes in order, so the prefetch goes after it)
     const bool early = has_next && !a.accumulate && a.bnb_x == nullptr;
     if (early) {
       WINO_SETUP(next)
-      WINO_LOAD_X(0)
+      WINO_LOAD_X(kc0)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) WINO_LOAD_A(kk, kk)
+      for (int kk = 0; kk < 4; ++kk) WINO_LOAD_A(kc0 * (CK / 2) + kk, kk)
     }
     WINO_EPILOGUE
     if (has_next && !early) {
       WINO_SETUP(next)
-      WINO_LOAD_X(0)
+      WINO_LOAD_X(kc0)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) WINO_LOAD_A(kk, kk)
+      for (int kk = 0; kk < 4; ++kk) WINO_LOAD_A(kc0 * (CK / 2) + kk, kk)
     }
     WINO_EPI_PRIO_DOWN
     if (!has_next) break;
@@ -541,9 +552,17 @@ static int wino_launch(WinoArgs& a, hipStream_t stream) {
     const int rc_lds = sivae_ensure_lds(reinterpret_cast<const void*>(kern), lds, &lds_hwm[a.pro_mean ? 1 : 0]);
     if (rc_lds != SIVAE_OK) return rc_lds;
   }
-  a.n_items = (int)nblk;
-  const int grid = nblk < wino_grid_blocks() ? (int)nblk : wino_grid_blocks();
-  a.xcd_group = (sivae_xcd_remap() && a.n_co_tiles > 1 && !(grid & 7) &&
+  a.n_items_base = (int)nblk;
+  if (a.chunks_per_split <= 0) {  // no split: one slice = the whole K range
+    a.chunks_per_split = a.Ci_pad / WINO_CK;
+    a.y_split_stride = 0;
+  }
+  const int k_splits = cdiv(a.Ci_pad / WINO_CK, a.chunks_per_split);
+  const long long nitems = nblk * k_splits;
+  if (nitems > 0x7fffffffLL) return SIVAE_ERR_RANGE;
+  a.n_items = (int)nitems;
+  const int grid = nitems < wino_grid_blocks() ? (int)nitems : wino_grid_blocks();
+  a.xcd_group = (sivae_xcd_remap() && k_splits == 1 && a.n_co_tiles > 1 && !(grid & 7) &&
                  (size_t)a.Ci_pad * a.Co_pad * 64 <= (size_t)2 << 20) ? 1 : 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NG * 256), lds, stream, a);
   return sivae_launch_status();
@@ -553,7 +572,8 @@ static int wino_fwd_impl(const float* x, const float* up, float* y, const float*
                          const float* pro_invstd, const float* pro_gamma, const float* pro_beta, float pro_slope,
                          float* stats_partial, const float* bnb_x, const float* bnb_mean, const float* bnb_invstd,
                          const float* bnb_gamma, const float* bnb_beta, float bnb_slope, int B, int Ci, int Co, int H,
-                         int W, int upsample, int accumulate, hipStream_t stream) {
+                         int W, int upsample, int accumulate, hipStream_t stream, int chunks_per_split = 0,
+                         long long y_split_stride = 0) {
   if (!x || !up || !y) return SIVAE_ERR_NULL;
   if (bias) return SIVAE_ERR_MODE;  // none of the 3x3 convs has a bias (:56-61); sivae_conv2d_fwd handles that case
   if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
@@ -585,6 +605,8 @@ static int wino_fwd_impl(const float* x, const float* up, float* y, const float*
   if (16ull * a.Ci_pad * a.Co_pad * 4ull >= 0xffffffffull) return SIVAE_ERR_RANGE;
   a.accumulate = accumulate;
   a.upsample = upsample;
+  a.chunks_per_split = chunks_per_split;
+  a.y_split_stride = y_split_stride;
   if (bnb_x && (!bnb_mean || !bnb_invstd || !bnb_gamma || !bnb_beta || !stats_partial)) return SIVAE_ERR_NULL;
   a.bnb_x = bnb_x;
   a.bnb_mean = bnb_mean;
@@ -617,4 +639,91 @@ extern "C" int sivae_conv2d_wino_dgrad_bnbwd(const float* dy, const float* up, f
   if (!bn_x) return SIVAE_ERR_NULL;
   return wino_fwd_impl(dy, up, y, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, bnbwd_partial, bn_x, bn_mean,
                        bn_invstd, bn_gamma, bn_beta, slope, B, Ci, Co, H, W, 0, 0, stream);
+}
+
+// ---- split-K variant for launches that would otherwise leave most of the chip idle (the 16-image shard of
+// config 4 runs the 512-channel 4x4 / 8x8 layers as 32..64 work items, each a serial walk over 512 input channels:
+// ~110 us per launch whatever the batch).  The K range is cut into S slices (S * items ~ one block per CU), every
+// (item, slice) writes its partial output tensor, and one small kernel sums the slices in a fixed order (deterministic),
+// adds the old y when accumulating, and leaves per-IMAGE {sum, sumsq} rows for the consumer BatchNorm.
+__global__ void __launch_bounds__(64) wino_splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ y,
+                                                                float* __restrict__ stats, int S, int C, int HW,
+                                                                size_t slice_stride, int accumulate) {
+  const int bc = blockIdx.x;  // b * C + c
+  const size_t base = (size_t)bc * HW;
+  float s = 0.f, q = 0.f;
+  for (int p = threadIdx.x; p < HW; p += 64) {
+    float v = accumulate ? y[base + p] : 0.f;
+    for (int k = 0; k < S; ++k) v += part[(size_t)k * slice_stride + base + p];
+    y[base + p] = v;
+    s += v;
+    q += v * v;
+  }
+  if (stats != nullptr) {
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (threadIdx.x == 0) {
+      stats[(size_t)bc * 2 + 0] = s;
+      stats[(size_t)bc * 2 + 1] = q;
+    }
+  }
+}
+
+// number of K slices sivae_conv2d_wino_fwd_splitk will use (1: it is the plain kernel)
+extern "C" int sivae_conv2d_wino_splitk(int B, int Ci, int Co, int H, int W) {
+  if (B <= 0 || Ci <= 0 || Co <= 0 || !sivae_conv2d_wino_supported(H, W)) return SIVAE_ERR_SHAPE;
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* e = getenv("SIVAE_WINO_SPLITK");
+    enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!enabled) return 1;
+  const long long items = (long long)sivae_conv2d_wino_num_px_tiles(B, H, W) * cdiv(Co, WINO_TCO);
+  const int nchunks = wino_kpad(Ci) / WINO_CK;
+  const int cus = wino_grid_blocks() / 2;
+  if (items * 2 > cus || nchunks < 8) return 1;  // at least half the CUs busy already, or a short K loop
+  int S = (int)(cus / items);
+  if (S > nchunks / 4) S = nchunks / 4;  // >= 4 chunks (64 input channels) per slice
+  if (S > 8) S = 8;
+  return S < 2 ? 1 : S;
+}
+
+extern "C" size_t sivae_conv2d_wino_splitk_workspace_bytes(int B, int Ci, int Co, int H, int W) {
+  const int S = sivae_conv2d_wino_splitk(B, Ci, Co, H, W);
+  if (S <= 1) return 0;
+  return (size_t)S * B * Co * H * W * sizeof(float);
+}
+
+// stats_partial: [B][Co][2] (one row per image) when the call splits, sivae_conv2d_wino_num_px_tiles rows otherwise —
+// sivae_conv2d_wino_splitk_stats_rows gives the count
+extern "C" int sivae_conv2d_wino_splitk_stats_rows(int B, int Ci, int Co, int H, int W) {
+  const int S = sivae_conv2d_wino_splitk(B, Ci, Co, H, W);
+  if (S < 0) return S;
+  return S > 1 ? B : sivae_conv2d_wino_num_px_tiles(B, H, W);
+}
+
+extern "C" int sivae_conv2d_wino_fwd_splitk(const float* x, const float* up, float* y, const float* pro_mean,
+                                            const float* pro_invstd, const float* pro_gamma, const float* pro_beta,
+                                            float pro_slope, float* stats_partial, int B, int Ci, int Co, int H, int W,
+                                            int upsample, int accumulate, void* workspace, size_t workspace_bytes,
+                                            hipStream_t stream) {
+  const int S = sivae_conv2d_wino_splitk(B, Ci, Co, H, W);
+  if (S < 0) return S;
+  if (S == 1)
+    return wino_fwd_impl(x, up, y, nullptr, pro_mean, pro_invstd, pro_gamma, pro_beta, pro_slope, stats_partial, nullptr,
+                         nullptr, nullptr, nullptr, nullptr, 1.f, B, Ci, Co, H, W, upsample, accumulate, stream);
+  if (!y || !workspace) return SIVAE_ERR_NULL;
+  if (workspace_bytes < sivae_conv2d_wino_splitk_workspace_bytes(B, Ci, Co, H, W)) return SIVAE_ERR_WORKSPACE;
+  if (((uintptr_t)workspace & 7u) != 0) return SIVAE_ERR_SHAPE;
+  const int nchunks = wino_kpad(Ci) / WINO_CK;
+  const int cps = cdiv(nchunks, S);
+  const long long stride = (long long)B * Co * H * W;
+  float* part = reinterpret_cast<float*>(workspace);
+  const int rc = wino_fwd_impl(x, up, part, nullptr, pro_mean, pro_invstd, pro_gamma, pro_beta, pro_slope, nullptr,
+                               nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, B, Ci, Co, H, W, upsample, 0, stream,
+                               cps, stride);
+  if (rc != SIVAE_OK) return rc;
+  hipLaunchKernelGGL(wino_splitk_reduce_kernel, dim3((unsigned)(B * Co)), dim3(64), 0, stream, part, y, stats_partial,
+                     cdiv(nchunks, cps), Co, H * W, (size_t)stride, accumulate);
+  return sivae_launch_status();
 }

@@ -294,10 +294,13 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
     _require(x, wp, bias, out)
     y = out if out is not None else torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
     assert y.shape == (B, Co, H, W)
+    # split-K for launches that would leave most of the chip idle (deep small maps at small batch)
+    splitk = wino and not wino_up and L.sivae_conv2d_wino_splitk(B, Ci, Co, H, W) > 1
     stats = None
     if want_stats:
         nt = (L.sivae_conv2d_wino_up_num_px_tiles(B, H, W) if wino_up else
-              (L.sivae_conv2d_wino_num_px_tiles(B, H, W) if wino else L.sivae_conv2d_fwd_num_px_tiles(B, Co, H, W)))
+              (L.sivae_conv2d_wino_splitk_stats_rows(B, Ci, Co, H, W) if splitk else
+               (L.sivae_conv2d_wino_num_px_tiles(B, H, W) if wino else L.sivae_conv2d_fwd_num_px_tiles(B, Co, H, W))))
         stats = torch.empty((nt, Co, 2), dtype=torch.float32, device=x.device)
     pm = pi = pg = pb = None
     slope = 1.0
@@ -308,6 +311,10 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
     if wino_up:
         _lib.call("sivae_conv2d_wino_up_fwd", _p(x), _p(wp), _p(y), _p(pm), _p(pi), _p(pg), _p(pb), float(slope),
                   _p(stats), B, Ci, Co, H, W, _s())
+    elif splitk:
+        ws = workspace(L.sivae_conv2d_wino_splitk_workspace_bytes(B, Ci, Co, H, W), x.device)
+        _lib.call("sivae_conv2d_wino_fwd_splitk", _p(x), _p(wp), _p(y), _p(pm), _p(pi), _p(pg), _p(pb), float(slope),
+                  _p(stats), B, Ci, Co, H, W, int(bool(upsample)), int(bool(accumulate)), _p(ws), ws.numel(), _s())
     elif wino:
         _lib.call("sivae_conv2d_wino_fwd", _p(x), _p(wp), _p(y), _p(bias), _p(pm), _p(pi), _p(pg), _p(pb),
                   float(slope), _p(stats), B, Ci, Co, H, W, int(bool(upsample)), int(bool(accumulate)), _s())

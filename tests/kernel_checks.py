@@ -532,6 +532,31 @@ def check_adversarial():
     return res
 
 
+def check_wino_splitk():
+    """split-K Winograd forward / data gradient (deep small maps at small batch): same numbers as the single-pass
+    kernel, incl. the fused prologue, accumulate and the per-image BatchNorm partial sums"""
+    from sivae_hip import lib, ops
+    L = lib.load()
+    res = []
+    for shape in [(16, 512, 512, 4, 4, 3), (16, 512, 512, 8, 8, 3), (8, 256, 384, 4, 4, 3), (3, 200, 72, 8, 8, 3),
+                  (2, 512, 512, 16, 16, 3)]:
+        B, Ci, Co, H, W, ks = shape
+        S = L.sivae_conv2d_wino_splitk(B, Ci, Co, H, W)
+        res.append(("splitk%s slices=%d" % (shape, S), 0.0 if S > 1 else float("inf"), 0.5))
+        res += check_conv_fwd(shape, stats=True, wino=True)
+        res += check_conv_dgrad(shape, wino=True)
+        res += check_conv_fused(shape, wino=True)
+    # accumulate through the split path
+    B, Ci, Co, H, W = 8, 256, 128, 8, 8
+    x, w, y0 = _rand(B, Ci, H, W, seed=1), _rand(Co, Ci, 3, 3, seed=2, scale=0.02), _rand(B, Co, H, W, seed=3)
+    y = _d(y0)
+    ops.conv2d_fwd(_d(x), ops.PackedW(_d(w), 0), Co, 3, out=y, accumulate=True)
+    res.append(("splitk accumulate", _err(y, y0 + _conv_ref(x, w)), WINO_TOL))
+    # and a large launch must NOT split
+    res.append(("splitk off at bs128", float(L.sivae_conv2d_wino_splitk(128, 512, 512, 4, 4) != 1), 0.0))
+    return res
+
+
 def check_randn():
     from sivae_hip import ops
     a = ops.randn((1 << 20,), 1234, 0, torch.device(DEV))
@@ -874,6 +899,7 @@ def all_checks():
     checks.append(("conv5_edge", check_conv5_edge))
     checks.append(("linear", check_linear))
     checks.append(("linear_fast", check_linear_fast))
+    checks.append(("wino_splitk", check_wino_splitk))
     for s in BN_SHAPES:
         checks.append(("bn%s" % (s,), lambda s=s: check_bn(s, False)))
         checks.append(("bn+res%s" % (s,), lambda s=s: check_bn(s, True)))
