@@ -681,8 +681,8 @@ extern "C" int sivae_conv2d_wino_splitk(int B, int Ci, int Co, int H, int W) {
   const long long items = (long long)sivae_conv2d_wino_num_px_tiles(B, H, W) * cdiv(Co, WINO_TCO);
   const int nchunks = wino_kpad(Ci) / WINO_CK;
   const int cus = wino_grid_blocks() / 2;
-  if (items * 2 > cus || nchunks < 8) return 1;  // at least half the CUs busy already, or a short K loop
-  int S = (int)(cus / items);
+  if (items > cus || nchunks < 8) return 1;  // every CU has a block already, or a short K loop
+  int S = (int)(2 * cus / items);             // aim at the persistent grid's two blocks per CU
   if (S > nchunks / 4) S = nchunks / 4;  // >= 4 chunks (64 input channels) per slice
   if (S > 8) S = 8;
   return S < 2 ? 1 : S;

@@ -552,8 +552,8 @@ def check_wino_splitk():
     y = _d(y0)
     ops.conv2d_fwd(_d(x), ops.PackedW(_d(w), 0), Co, 3, out=y, accumulate=True)
     res.append(("splitk accumulate", _err(y, y0 + _conv_ref(x, w)), WINO_TOL))
-    # and a large launch must NOT split
-    res.append(("splitk off at bs128", float(L.sivae_conv2d_wino_splitk(128, 512, 512, 4, 4) != 1), 0.0))
+    # a launch that already gives every CU more than one block must NOT split
+    res.append(("splitk off on large grids", float(L.sivae_conv2d_wino_splitk(128, 512, 512, 16, 16) != 1), 0.0))
     return res
 
 
