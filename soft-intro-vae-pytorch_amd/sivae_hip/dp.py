@@ -64,18 +64,91 @@ def shard_batch(global_batch, world, rank):
 
 
 class GradSync:
-    """callable handed to SoftIntroEngine: all-reduce(SUM) the flat gradient buffer; the mean's 1/world
-    factor is applied by FlatAdam.step(grad_scale)."""
+    """callable handed to SoftIntroEngine: all-reduce(SUM) the flat gradient buffer; the mean's 1/world factor is
+    applied by FlatAdam.step(grad_scale).
 
-    def __init__(self):
+    Overlap with the backward ("launch on a side stream once the flat buffer's last segment is written"):
+    the flat buffer is in module order (stem ... deepest block, fc) and a backward pass finalises gradients deepest
+    first, so the TAIL of the buffer — fc and the 512-channel blocks, most of the bytes — is final while the expensive
+    shallow layers of the last contributing pass are still running.  `arm(opt)` before `backward()` watches that tail
+    with post-accumulate hooks (autograd sums the contributions of all passes in the accumulator's input buffer and
+    runs it ONCE per backward, when the last one has arrived); when every tail parameter has been accumulated the tail
+    is all-reduced asynchronously (RCCL runs it on its own stream, ordered after the accumulations already enqueued);
+    the call after the backward reduces the head and waits for the tail.  Same values, same two buffers per iteration —
+    only the issue time moves.  overlap=False (or SIVAE_DP_OVERLAP=0) keeps the single post-backward all-reduce."""
+
+    TAIL_FRACTION = 0.6  # at least this share of the elements goes into the early (tail) bucket
+
+    def __init__(self, overlap=None):
         self.world = world_size()
         self.grad_scale = 1.0 / self.world
         self.calls = 0
         self.bytes = 0
+        if overlap is None:
+            overlap = os.environ.get("SIVAE_DP_OVERLAP", "1") != "0"
+        self.overlap = bool(overlap) and self.world > 1
+        self._plans = {}   # id(opt) -> (split element offset, tail params)
+        self._armed = None
+        self.overlapped = 0  # all-reduces whose tail bucket was issued during the backward
+
+    def _plan(self, opt):
+        plan = self._plans.get(id(opt))
+        if plan is None:
+            total = opt.flat_grad.numel()
+            acc, split, tail = 0, total, []
+            off = total
+            for p in reversed(opt.params):
+                off -= p.numel()
+                tail.append(p)
+                acc += p.numel()
+                split = off
+                if acc >= self.TAIL_FRACTION * total:
+                    break
+            if split == 0:  # (a single giant tensor: nothing left to overlap with)
+                tail, split = [], total
+            plan = (split, tail)
+            self._plans[id(opt)] = plan
+            self._hooks_for(opt, tail)
+        return plan
+
+    def _hooks_for(self, opt, tail):
+        def make(p):
+            def hook(_param):
+                st = self._armed
+                if st is None or st["opt"] is not opt:
+                    return
+                if id(p) in st["seen"]:
+                    return
+                st["seen"].add(id(p))
+                st["left"] -= 1
+                if st["left"] == 0 and st["handle"] is None:
+                    seg = opt.flat_grad[st["split"]:]
+                    st["handle"] = dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True)
+            return hook
+        for p in tail:
+            p.register_post_accumulate_grad_hook(make(p))
+
+    def arm(self, opt):
+        """call right before the backward() that fills `opt`'s gradient buffer"""
+        if not self.overlap:
+            self._armed = None
+            return
+        split, tail = self._plan(opt)
+        if not tail:
+            self._armed = None
+            return
+        self._armed = dict(opt=opt, seen=set(), left=len(tail), split=split, handle=None)
 
     def __call__(self, flat_grad):
         self.calls += 1
         self.bytes += flat_grad.numel() * 4
+        st, self._armed = self._armed, None
+        if st is not None and st["handle"] is not None and st["opt"].flat_grad.data_ptr() == flat_grad.data_ptr():
+            if st["split"] > 0:
+                allreduce_sum_(flat_grad[:st["split"]])
+            st["handle"].wait()  # (the current stream waits for the collective; the host does not block on NCCL)
+            self.overlapped += 1
+            return
         allreduce_sum_(flat_grad)
 
 

@@ -149,6 +149,12 @@ class SoftIntroEngine:
         if self.grad_sync is not None:
             self.grad_sync(opt.flat_grad)
 
+    def _arm(self, opt):
+        """let the gradient synchroniser start reducing the early-final tail of `opt`'s flat gradient buffer while the
+        coming backward is still running (dp.GradSync)"""
+        if self.grad_sync is not None and hasattr(self.grad_sync, "arm"):
+            self.grad_sync.arm(opt)
+
     # -- vanilla VAE step (reference :516-533) ----------------------------------------------------------
     def vae_step(self, real, eps=None, keep=False):
         m = self.model
@@ -228,6 +234,7 @@ class SoftIntroEngine:
         expelbo_fake = SF.expelbo(l_rec_fake, kl_fake, scale, br, bn)
         lossE = scale * (br * loss_rec + bk * kl_real) + 0.25 * (expelbo_rec + expelbo_fake)
         self.opt_e.zero_grad()
+        self._arm(self.opt_e)
         lossE.backward()
         self._sync(self.opt_e)
         self.opt_e.step(self.grad_scale)
@@ -274,6 +281,7 @@ class SoftIntroEngine:
         kl_fake = calc_kl(fake_logvar, fake_mu, reduce="mean")
         lossD = scale * (loss_rec * br + (kl_rec + kl_fake) * 0.5 * bk + gr * 0.5 * br * (l_rr + l_fr))
         self.opt_d.zero_grad()
+        self._arm(self.opt_d)
         lossD.backward()
         self._sync(self.opt_d)
         self.opt_d.step(self.grad_scale)

@@ -143,9 +143,9 @@ class ResBlockFn16(torch.autograd.Function):
         dw2 = ops16.conv2d_wgrad(h, dc, Cm, Co, 3, pro=pro1) if need_w2 else None
         dh = ops16.conv2d(dc, packed16(w2, 1), Co, Cm, 3)
         del dc
-        # BatchNorm-1 + LeakyReLU: sign from the saved h, or recomputed from a when h was never stored
-        da, _, dg1, db1 = ops16.bn_bwd(dh, h if h_saved else None, a, mean1, invstd1, g1, b1, Cm, SLOPE,
-                                       want_param_grads=need_bn1)
+        # BatchNorm-1 + LeakyReLU: the sign is recomputed from a (x-hat * gamma + beta) even when h was stored — both
+        # backward passes then read two tensors (dh, a) instead of three (2 of 7 tensor passes of this BatchNorm)
+        da, _, dg1, db1 = ops16.bn_bwd(dh, None, a, mean1, invstd1, g1, b1, Cm, SLOPE, want_param_grads=need_bn1)
         del dh
         dw1 = ops16.conv2d_wgrad(x, da, Ci, Cm, 3, upsample=x_up) if need_w1 else None
         dwe = None

@@ -86,7 +86,8 @@ def _engine_worker(rank, world, port, out_dir):
     order = [k for k, _ in model.encoder.named_parameters()]
     assert ["encoder." + k for k in order] == keys
     rel2 = float((hip.double() - gmean.double()).norm() / gmean.double().norm())
-    torch.save(dict(worst_fwd=worst, grad_rel2=rel2, flat=oe.flat.detach().cpu(), calls=sync.calls),
+    torch.save(dict(worst_fwd=worst, grad_rel2=rel2, flat=oe.flat.detach().cpu(), calls=sync.calls,
+                    overlapped=sync.overlapped),
                os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -100,6 +101,7 @@ def test_local_bn_two_ranks_match_per_shard_oracle(tmp_path):
         assert r["worst_fwd"] <= 1e-4, r["worst_fwd"]   # per-shard forward / loss parity vs the per-shard oracle
         assert r["grad_rel2"] <= 5e-3, r["grad_rel2"]   # all-reduced mean gradient == mean of the shard-oracle gradients
         assert r["calls"] == 1
+        assert r["overlapped"] == 1                     # the tail bucket was all-reduced DURING the backward
     assert torch.equal(r0["flat"], r1["flat"])          # replicas stay bit-identical after the Adam step
 
 
