@@ -374,6 +374,17 @@ int sivae_bf16_conv2d_fwd(const void* x, const void* wp, void* y, const float* b
                           const float* pro_invstd, const float* pro_gamma, const float* pro_beta, float pro_slope,
                           float* stats_partial, int B, int Ci, int Co, int H, int W, int ks, int upsample,
                           int accumulate, int out_f32_nchw, sivae_stream_t stream);
+/* split-K form for small grids (the 512-channel 8x8 / 4x4 layers: 64-256 blocks each walking 32 chunks): the
+ * input-channel range is cut into sivae_bf16_conv2d_splitk(...) slices (1: not split) written as fp32 partials into
+ * `workspace` and summed in a fixed order by a reduce kernel that rounds to bf16 and leaves per-image {sum, sumsq} rows
+ * (stats_partial has sivae_bf16_conv2d_splitk_stats_rows(...) rows).  3x3, no bias, bf16 output only. */
+int sivae_bf16_conv2d_splitk(int B, int Ci, int Co, int H, int W, int ks);
+size_t sivae_bf16_conv2d_splitk_workspace_bytes(int B, int Ci, int Co, int H, int W, int ks);
+int sivae_bf16_conv2d_splitk_stats_rows(int B, int Ci, int Co, int H, int W, int ks);
+int sivae_bf16_conv2d_fwd_splitk(const void* x, const void* wp, void* y, const float* pro_mean,
+                                 const float* pro_invstd, const float* pro_gamma, const float* pro_beta, float pro_slope,
+                                 float* stats_partial, int B, int Ci, int Co, int H, int W, int ks, int upsample,
+                                 int accumulate, void* workspace, size_t workspace_bytes, sivae_stream_t stream);
 /* dw [Co][Ci][ks][ks] fp32 = weight gradient (aten::convolution_backward, weight half); x' as above (prologue 3x3
  * only, upsample addressing); deterministic two-pass reduction over pixel slices */
 size_t sivae_bf16_conv2d_wgrad_workspace_bytes(int B, int Ci, int Co, int H, int W, int ks);

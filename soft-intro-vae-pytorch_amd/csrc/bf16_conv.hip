@@ -38,6 +38,11 @@ struct Bf16ConvArgs {
   int ntb, nth, ntw;
   int n_co_tiles, nchunks;
   int accumulate, upsample;
+  // split-K (small grids: the 512-channel 8x8 / 4x4 layers are 64-256 blocks each walking 32 chunks): block
+  // (slice s, base block) accumulates chunks [s*chunks_per_split, ...) and writes fp32 partials (NCHW, the OUTF32
+  // epilogue) to y + s*split_stride floats; bf16_splitk_reduce_kernel sums the slices
+  int nblk_base, chunks_per_split;
+  long long split_stride;
 };
 
 template <int KS, int WM, int WN, int WVM, int WVN, int CKS, int MAXV, bool PRO, bool OUTF32, int MINW>
@@ -67,7 +72,10 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
   const int HWs = Hs * Ws;
   float* ps = reinterpret_cast<float*>(xs + nvec);  // [Cib][16]: 8 scales, 8 shifts per channel block (PRO)
 
-  const int bid = blockIdx.x;
+  const int slice = (int)blockIdx.x / a.nblk_base;
+  const int bid = (int)blockIdx.x - slice * a.nblk_base;
+  const int kc0 = slice * a.chunks_per_split;
+  const int kc1 = kc0 + a.chunks_per_split < a.nchunks ? kc0 + a.chunks_per_split : a.nchunks;
   const int co_tile = bid % a.n_co_tiles;
   const int pt = bid / a.n_co_tiles;
   const int tw_i = pt % a.ntw;
@@ -160,9 +168,9 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
   }
   (void)wrsrc;
 
-  SIVAE_LOAD_CHUNK(0)
+  SIVAE_LOAD_CHUNK(kc0)
   if (PRO) __syncthreads();
-  for (int ch = 0; ch < a.nchunks; ++ch) {
+  for (int ch = kc0; ch < kc1; ++ch) {
 #pragma unroll
     for (int q = 0; q < NWQ; ++q) {
       const int idx = tid + q * NT;
@@ -184,7 +192,7 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
       if (v < nvec) xs[v] = q;
     }
     __syncthreads();
-    if (ch + 1 < a.nchunks) SIVAE_LOAD_CHUNK(ch + 1)
+    if (ch + 1 < kc1) SIVAE_LOAD_CHUNK(ch + 1)
 
 #pragma unroll
     for (int ks = 0; ks < CKS; ++ks) {
@@ -232,8 +240,9 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
   const bool want_stats = a.stats != nullptr;
 
   if (OUTF32) {
-    const __amdgpu_buffer_rsrc_t yrsrc = make_rsrc(reinterpret_cast<float*>(a.y) + (size_t)b0 * a.Co * HW,
-                                                   (unsigned long long)nb_here * a.Co * HW * 4ull);
+    const __amdgpu_buffer_rsrc_t yrsrc =
+        make_rsrc(reinterpret_cast<float*>(a.y) + (size_t)slice * a.split_stride + (size_t)b0 * a.Co * HW,
+                  (unsigned long long)nb_here * a.Co * HW * 4ull);
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
 #pragma unroll
@@ -405,8 +414,11 @@ int launch_cfg(Bf16ConvArgs& a, hipStream_t stream) {
   size_t lds = (size_t)(NW + 2 * CKS * plane) * 16 + (PRO ? (size_t)a.Cib * 64 : 0);
   const size_t red = (size_t)WVN * TCO * 2 * sizeof(float);
   if (lds < red) lds = red;
-  const long long nblk = (long long)a.n_co_tiles * g.ntb * g.nth * g.ntw;
+  const long long nbase = (long long)a.n_co_tiles * g.ntb * g.nth * g.ntw;
+  if (a.chunks_per_split <= 0) a.chunks_per_split = a.nchunks;
+  const long long nblk = nbase * cdiv(a.nchunks, a.chunks_per_split);
   if (nblk > 0x7fffffffLL) return SIVAE_ERR_RANGE;
+  a.nblk_base = (int)nbase;
   auto kern = bf16_conv_kernel<KS, WM, WN, WVM, WVN, CKS, MAXV, PRO, OUTF32, MINW>;
   static size_t lds_hwm = 0;
   const int rc_lds = sivae_ensure_lds(reinterpret_cast<const void*>(kern), lds, &lds_hwm);
@@ -444,7 +456,11 @@ int px_tile_3x3(int TCO, int B, int H, int W, int n_out) {
 template <int KS, int CKS, int MAXV, bool PRO, bool OUTF32>
 int launch_by_co(Bf16ConvArgs& a, int TCO, hipStream_t stream) {
   if (TCO == 32) return launch_cfg<KS, 1, 2, 1, 4, CKS, MAXV, PRO, OUTF32, 2>(a, stream);
-  if (OUTF32) return SIVAE_ERR_SHAPE;  // fp32 NCHW output exists for the RGB-side `predict` conv only
+  if constexpr (OUTF32 && KS == 3) {  // split-K partials of the 3x3 kernels (small pixel tiles)
+    if (TCO == 64) return launch_cfg<KS, 2, 2, 1, 4, CKS, MAXV, PRO, true, 2>(a, stream);
+    return launch_cfg<KS, 2, 2, 2, 2, CKS, MAXV, PRO, true, 2>(a, stream);
+  }
+  if (OUTF32) return SIVAE_ERR_SHAPE;  // fp32 NCHW output: the RGB-side `predict` conv and split-K partials
   if constexpr (!OUTF32) {
     if constexpr (KS == 3) {
       const int tpx = px_tile_3x3(TCO, a.B, a.H, a.W, a.Co);
@@ -526,6 +542,8 @@ extern "C" int sivae_bf16_conv2d_fwd(const void* x, const void* wp, void* y, con
   a.Cob = Cob;
   a.accumulate = accumulate;
   a.upsample = upsample;
+  a.chunks_per_split = 0;
+  a.split_stride = 0;
   const Bf16Cfg c = bf16_cfg(ks, Co, Ci);
   if (ks == 3) {
     if (pro_mean) return launch_by_co<3, 1, 5, true, false>(a, c.TCO, stream);
@@ -537,4 +555,133 @@ extern "C" int sivae_bf16_conv2d_fwd(const void* x, const void* wp, void* y, con
   }
   if (out_f32_nchw) return launch_by_co<5, 1, 4, false, true>(a, c.TCO, stream);
   return launch_by_co<5, 1, 4, false, false>(a, c.TCO, stream);
+}
+
+// ---- split-K form (3x3, small grids) ------------------------------------------------------------------------------
+// y[b][cb][p][8] = bf16( sum_s part[s][b][c][p] (+ y_old) );  stats[b][c] = {sum, sumsq} of the rounded values
+__global__ void __launch_bounds__(64) bf16_splitk_reduce_kernel(const float* __restrict__ part, void* __restrict__ y,
+                                                                float* __restrict__ stats, int S, int Co, int Cob,
+                                                                int HW, size_t slice_stride, int accumulate) {
+  const int b = blockIdx.x / Cob, cb = blockIdx.x % Cob;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  u32x4_t* yv = reinterpret_cast<u32x4_t*>(y) + ((size_t)b * Cob + cb) * HW;
+  for (int p = threadIdx.x; p < HW; p += 64) {
+    float f[8];
+    if (accumulate) {
+      unpack8(yv[p], f);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = cb * 8 + e;
+      if (c < Co) {
+        const float* src = part + ((size_t)b * Co + c) * HW + p;
+        for (int k = 0; k < S; ++k) f[e] += src[(size_t)k * slice_stride];
+      } else {
+        f[e] = 0.f;
+      }
+    }
+    const u32x4_t o = pack8(f);
+    yv[p] = o;
+    float r[8];
+    unpack8(o, r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s[e] += r[e];
+      q[e] += r[e] * r[e];
+    }
+  }
+  if (stats != nullptr) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float ss = wave_sum(s[e]), qq = wave_sum(q[e]);
+      const int c = cb * 8 + e;
+      if (threadIdx.x == 0 && c < Co) {
+        stats[((size_t)b * Co + c) * 2 + 0] = ss;
+        stats[((size_t)b * Co + c) * 2 + 1] = qq;
+      }
+    }
+  }
+}
+
+// number of K slices sivae_bf16_conv2d_fwd_splitk uses (1: it is the plain kernel)
+extern "C" int sivae_bf16_conv2d_splitk(int B, int Ci, int Co, int H, int W, int ks) {
+  if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* e = getenv("SIVAE_BF16_SPLITK");
+    enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!enabled || ks != 3 || Co <= 32) return 1;
+  const Bf16Cfg c = bf16_cfg(3, Co, Ci);
+  const int small = c.TCO == 128 ? 128 : 256;
+  if (px_tile_3x3(c.TCO, B, H, W, Co) != small) return 1;  // the grid already fills the chip
+  TileGeom g = make_tile_geom(B, H, W, small);
+  const long long blocks = (long long)g.ntb * g.nth * g.ntw * cdiv(Co, c.TCO);
+  const int nchunks = bf16_cblocks(Ci) / 2;
+  if (blocks > 256 || nchunks < 8) return 1;
+  int S = (int)(512 / blocks);
+  if (S > nchunks / 4) S = nchunks / 4;
+  if (S > 8) S = 8;
+  return S < 2 ? 1 : S;
+}
+
+extern "C" size_t sivae_bf16_conv2d_splitk_workspace_bytes(int B, int Ci, int Co, int H, int W, int ks) {
+  const int S = sivae_bf16_conv2d_splitk(B, Ci, Co, H, W, ks);
+  return S <= 1 ? 0 : (size_t)S * B * Co * H * W * sizeof(float);
+}
+
+extern "C" int sivae_bf16_conv2d_splitk_stats_rows(int B, int Ci, int Co, int H, int W, int ks) {
+  const int S = sivae_bf16_conv2d_splitk(B, Ci, Co, H, W, ks);
+  if (S < 0) return S;
+  return S > 1 ? B : sivae_bf16_conv2d_num_px_tiles(B, Co, H, W, ks);
+}
+
+extern "C" int sivae_bf16_conv2d_fwd_splitk(const void* x, const void* wp, void* y, const float* pro_mean,
+                                            const float* pro_invstd, const float* pro_gamma, const float* pro_beta,
+                                            float pro_slope, float* stats_partial, int B, int Ci, int Co, int H, int W,
+                                            int ks, int upsample, int accumulate, void* workspace,
+                                            size_t workspace_bytes, hipStream_t stream) {
+  const int S = sivae_bf16_conv2d_splitk(B, Ci, Co, H, W, ks);
+  if (S < 0) return S;
+  if (S == 1)
+    return sivae_bf16_conv2d_fwd(x, wp, y, nullptr, pro_mean, pro_invstd, pro_gamma, pro_beta, pro_slope, stats_partial,
+                                 B, Ci, Co, H, W, ks, upsample, accumulate, 0, stream);
+  if (!x || !wp || !y || !workspace) return SIVAE_ERR_NULL;
+  if (workspace_bytes < sivae_bf16_conv2d_splitk_workspace_bytes(B, Ci, Co, H, W, ks)) return SIVAE_ERR_WORKSPACE;
+  if (upsample && ((H & 1) || (W & 1))) return SIVAE_ERR_SHAPE;
+  if (pro_mean && (!pro_invstd || !pro_gamma || !pro_beta)) return SIVAE_ERR_NULL;
+  Bf16ConvArgs a;
+  a.x = x;
+  a.wp = wp;
+  a.y = workspace;
+  a.bias = nullptr;
+  a.pro_mean = pro_mean;
+  a.pro_invstd = pro_invstd;
+  a.pro_gamma = pro_gamma;
+  a.pro_beta = pro_beta;
+  a.pro_slope = pro_slope;
+  a.stats = nullptr;
+  a.B = B;
+  a.Ci = Ci;
+  a.Co = Co;
+  a.H = H;
+  a.W = W;
+  a.Cib = bf16_cblocks(Ci);
+  a.Cob = bf16_cblocks(Co);
+  a.accumulate = 0;
+  a.upsample = upsample;
+  const int nchunks = a.Cib / 2;
+  a.chunks_per_split = cdiv(nchunks, S);
+  a.split_stride = (long long)B * Co * H * W;
+  const Bf16Cfg c = bf16_cfg(3, Co, Ci);
+  const int rc = pro_mean ? launch_by_co<3, 1, 5, true, true>(a, c.TCO, stream)
+                          : launch_by_co<3, 1, 5, false, true>(a, c.TCO, stream);
+  if (rc != SIVAE_OK) return rc;
+  hipLaunchKernelGGL(bf16_splitk_reduce_kernel, dim3((unsigned)(B * a.Cob)), dim3(64), 0, stream,
+                     reinterpret_cast<const float*>(workspace), y, stats_partial, cdiv(nchunks, a.chunks_per_split), Co,
+                     a.Cob, H * W, (size_t)a.split_stride, accumulate);
+  return sivae_launch_status();
 }

@@ -90,10 +90,13 @@ def conv2d(x, wp, Ci, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
         y = torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
     else:
         y = empty_blocked(B, Co, H, W, x.device)
+    splitk = (ks == 3 and not out_f32 and bias is None
+              and L.sivae_bf16_conv2d_splitk(B, Ci, Co, H, W, ks) > 1)  # small grids: split the input-channel range
     stats = None
     if want_stats:
-        stats = torch.empty((L.sivae_bf16_conv2d_num_px_tiles(B, Co, H, W, ks), Co, 2), dtype=torch.float32,
-                            device=x.device)
+        rows = (L.sivae_bf16_conv2d_splitk_stats_rows(B, Ci, Co, H, W, ks) if splitk
+                else L.sivae_bf16_conv2d_num_px_tiles(B, Co, H, W, ks))
+        stats = torch.empty((rows, Co, 2), dtype=torch.float32, device=x.device)
     pm = pi = pg = pb = None
     slope = 1.0
     if pro is not None:
@@ -101,9 +104,15 @@ def conv2d(x, wp, Ci, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
         ops._require(pm, pi, pg, pb)
     ops._require(bias)
     t0 = ops.TIMER.begin() if ops.TIMER is not None else None
-    _lib.call("sivae_bf16_conv2d_fwd", _p(x), _p(wp.data), _p(y), _p(bias), _p(pm), _p(pi), _p(pg), _p(pb),
-              float(slope), _p(stats), B, Ci, Co, H, W, ks, int(bool(upsample)), int(bool(accumulate)),
-              int(bool(out_f32)), _s(x))
+    if splitk:
+        ws = ops.workspace(L.sivae_bf16_conv2d_splitk_workspace_bytes(B, Ci, Co, H, W, ks), x.device)
+        _lib.call("sivae_bf16_conv2d_fwd_splitk", _p(x), _p(wp.data), _p(y), _p(pm), _p(pi), _p(pg), _p(pb),
+                  float(slope), _p(stats), B, Ci, Co, H, W, ks, int(bool(upsample)), int(bool(accumulate)), _p(ws),
+                  ws.numel(), _s(x))
+    else:
+        _lib.call("sivae_bf16_conv2d_fwd", _p(x), _p(wp.data), _p(y), _p(bias), _p(pm), _p(pi), _p(pg), _p(pb),
+                  float(slope), _p(stats), B, Ci, Co, H, W, ks, int(bool(upsample)), int(bool(accumulate)),
+                  int(bool(out_f32)), _s(x))
     if t0 is not None:
         ops.TIMER.end("bf16_conv_kernel<%d,%s>" % (ks, "co32" if Co <= 32 else ("co64" if Co <= 64 else "co128")),
                       2.0 * B * H * W * Co * Ci * ks * ks, t0)

@@ -300,6 +300,22 @@ def check_eltwise16():
     return res
 
 
+def check_splitk16():
+    """split-K bf16 conv (small grids): same numbers as the single-pass kernel incl. per-image stats, accumulate"""
+    from sivae_hip import lib, ops16
+    L = lib.load()
+    res = []
+    for shape in [(16, 512, 512, 4, 4, 3), (32, 512, 512, 8, 8, 3), (8, 256, 384, 4, 4, 3), (3, 208, 72, 8, 8, 3)]:
+        B, Ci, Co, H, W, ks = shape
+        S = L.sivae_bf16_conv2d_splitk(B, Ci, Co, H, W, ks)
+        res.append(("splitk16%s slices=%d" % (shape, S), 0.0 if S > 1 else float("inf"), 0.5))
+        res += check_conv(shape, stats=True)
+        res += check_conv_dgrad(shape)
+    res += check_conv_fused((4, 256, 128, 8, 8, 3))
+    res.append(("splitk16 off on large grids", float(L.sivae_bf16_conv2d_splitk(128, 128, 128, 64, 64, 3) != 1), 0.0))
+    return res
+
+
 def all_checks():
     checks = [("convert16", check_convert)]
     for s in CONV16_SHAPES:
@@ -320,6 +336,7 @@ def all_checks():
         for rm in (0, 1, 2):
             checks.append(("bn16%s res%d" % (s, rm), lambda s=s, rm=rm: check_bn(s, rm, pool=rm != 2)))
     checks.append(("eltwise16", check_eltwise16))
+    checks.append(("splitk16", check_splitk16))
     return checks
 
 
