@@ -174,3 +174,68 @@ def test_bf16_training_tracks_fp32_training():
         rel = ((a[:, col] - b[:, col]).abs() / a[:, col].abs()).max()
         print("bf16 vs fp32 training, %s: max relative deviation over 20 iterations %.3e" % (name, float(rel)))
         assert rel < 0.05, (name, float(rel))
+
+
+def test_bf16_bootstrap_iteration_vs_fp32_oracle():
+    """config 5's variant (frozen target decoder, gamma_r = 1, un-detached D-step targets) in the bf16 mode: one full
+    iteration on the 32x32 net, same tolerances as the plain variant"""
+    from oracle import sivae_oracle as O
+    import train_soft_intro_vae_bootstrap as TB
+    from sivae_hip.engine import SoftIntroEngine
+    from sivae_hip.optim import FlatAdam
+    dev = torch.device("cuda:0")
+    cdim, zdim, channels, image_size, B = 3, 64, [32, 64, 128], 32, 16
+    hp = dict(beta_rec=1.0, beta_kl=1.0, beta_neg=256.0, gamma_r=1.0)
+    P = O.init_params(cdim, zdim, channels, image_size, seed=3, bootstrap=True)
+    model = TB.SoftIntroVAE(cdim=cdim, zdim=zdim, channels=channels, image_size=image_size)
+    model.load_state_dict({k: v.clone() for k, v in P.items()}, strict=True)
+    model = model.to(dev).train()
+    eng = SoftIntroEngine(model, FlatAdam(model.encoder.parameters(), lr=2e-4),
+                          FlatAdam(model.decoder.parameters(), lr=2e-4), beta_kl=1.0, beta_rec=1.0, beta_neg=256.0,
+                          gamma_r=1.0, bootstrap=True, compute_dtype="bf16")
+    g = torch.Generator().manual_seed(1234)
+    real = torch.rand(B, cdim, image_size, image_size, generator=g)
+    noise = torch.randn(B, zdim, generator=g)
+    eps = [torch.randn(B, zdim, generator=g) for _ in range(5)]
+    e = O.e_step(P, real, noise, eps[:3], hp, channels, image_size, True)
+    es = eng.e_step(real.to(dev), noise.to(dev), [t.to(dev) for t in eps[:3]], keep=True)
+    bad = [(k, _rel(es["kept"][k], v)) for k, v in e.items() if _rel(es["kept"][k], v) > _tol(k)]
+    assert not bad, bad
+    target_before = {k: v.clone() for k, v in model.target_decoder.state_dict().items() if "running" not in k and "num_b" not in k}
+    ds = eng.d_step(real.to(dev), noise.to(dev), es["z"], [t.to(dev) for t in eps[3:]])
+    torch.cuda.synchronize()
+    assert torch.isfinite(ds["lossD"]).all()
+    for k, v in target_before.items():  # the target decoder is frozen in both steps
+        assert torch.equal(model.target_decoder.state_dict()[k], v), k
+
+
+def test_bf16_eval_mode_inference_vs_fp32_oracle():
+    """eval-mode BatchNorm (running statistics) through the bf16 kernels: deterministic encode / decode / sample vs the
+    fp32 oracle with training=False at the bf16 tolerances; no buffer moves"""
+    import train_soft_intro_vae as T
+    from oracle import sivae_oracle as O
+    from sivae_hip.nn import set_compute_dtype
+    dev = torch.device("cuda:0")
+    channels, image_size, zdim, B = [32, 64, 128], 32, 24, 6
+    torch.manual_seed(3)
+    model = set_compute_dtype(T.SoftIntroVAE(cdim=3, zdim=zdim, channels=channels, image_size=image_size), "bf16")
+    model = model.to(dev).train()
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for _ in range(3):  # move the running statistics away from their initial values
+            model(torch.rand(B, 3, image_size, image_size, generator=g).to(dev))
+    model.eval()
+    P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    x = torch.rand(B, 3, image_size, image_size, generator=g)
+    z = torch.randn(B, zdim, generator=g)
+    with torch.no_grad():
+        mu, logvar, zz, rec = model(x.to(dev), deterministic=True)
+        smp = model.sample(z.to(dev))
+        mu_o, logvar_o = O.encode(P, x, channels, image_size, training=False)
+        rec_o = O.decode(P, mu_o, channels, image_size, training=False)
+        smp_o = O.decode(P, z, channels, image_size, training=False)
+    assert _rel(mu, mu_o) <= BF16_TOL and _rel(logvar, logvar_o) <= BF16_TOL, (_rel(mu, mu_o), _rel(logvar, logvar_o))
+    assert _rel(rec, rec_o) <= BF16_IMG_TOL and _rel(smp, smp_o) <= BF16_IMG_TOL, (_rel(rec, rec_o), _rel(smp, smp_o))
+    for k, v in model.state_dict().items():
+        if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            assert torch.equal(v.cpu(), P[k]), k
