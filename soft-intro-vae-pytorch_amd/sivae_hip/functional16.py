@@ -151,13 +151,19 @@ class ResBlockFn16(torch.autograd.Function):
         dwe = None
         dx = None
         if need_x:
-            dx = ops16.conv2d(da, packed16(w1, 1), Cm, Ci, 3)
-            if x_up:
-                dx = ops16.upsample2_bwd(dx, Ci)  # adjoint of the deferred nn.Upsample
-            if ctx.has_exp:
-                ops16.conv2d(dz, packed16(w_exp, 1), Co, Ci, 1, out=dx, accumulate=True)
+            if not x_up and not ctx.has_exp:
+                # identity skip at the block's own resolution: conv1's data gradient is accumulated straight into the
+                # skip gradient (one read-modify-write in the conv epilogue instead of a separate 3-pass add)
+                dx = dz
+                ops16.conv2d(da, packed16(w1, 1), Cm, Ci, 3, out=dx, accumulate=True)
             else:
-                ops16.add_(dx, dz)
+                dx = ops16.conv2d(da, packed16(w1, 1), Cm, Ci, 3)
+                if x_up:
+                    dx = ops16.upsample2_bwd(dx, Ci)  # adjoint of the deferred nn.Upsample
+                if ctx.has_exp:
+                    ops16.conv2d(dz, packed16(w_exp, 1), Co, Ci, 1, out=dx, accumulate=True)
+                else:
+                    ops16.add_(dx, dz)
         if need_we and ctx.has_exp:
             dwe = ops16.conv2d_wgrad(x, dz, Ci, Co, 1)
         return (dx, dwe, dw1, dg1 if need[3] else None, db1 if need[4] else None, dw2,
