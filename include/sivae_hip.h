@@ -393,18 +393,21 @@ int sivae_bf16_conv2d_wgrad(const void* x, const void* dy, float* dw, const floa
                             int H, int W, int ks, int upsample, void* workspace, size_t workspace_bytes,
                             sivae_stream_t stream);
 /* y = LeakyReLU((x-mean)*invstd*gamma+beta + res): res NULL, same shape, or (res_up) [B][C][H/2][W/2] read through
- * nearest-2x addressing; y and/or y_pool = AvgPool2d(2)(y) are written (either may be NULL, not both) */
+ * nearest-2x addressing; y and/or y_pool = AvgPool2d(2)(y) are written (either may be NULL, not both).  sign_mask (may be
+ * NULL): sivae_bf16_bn_signmask_bytes(...) bytes, one per 8-channel pixel vector, bit e = (output e > 0) — the backward
+ * reads it (1/16 of the tensor) instead of the saved output, and a pooled block need not write its full-resolution y. */
+size_t sivae_bf16_bn_signmask_bytes(int B, int C, int H, int W);
 int sivae_bf16_bn_apply_act(const void* x, const void* res, int res_up, const float* mean, const float* invstd,
-                            const float* gamma, const float* beta, float slope, void* y, void* y_pool, int B, int C,
-                            int H, int W, sivae_stream_t stream);
-/* backward of the above: dy (or, dy_pooled, the gradient of y_pool), activation sign from y or — y NULL — recomputed
- * from x (no residual; needs beta); dx, dz = gradient of the residual branch (NULL to skip; dz_sum: its 2x2 block
- * sums [B][C][H/2][W/2]), dgamma / dbeta (NULL to skip) */
+                            const float* gamma, const float* beta, float slope, void* y, void* y_pool,
+                            unsigned char* sign_mask, int B, int C, int H, int W, sivae_stream_t stream);
+/* backward of the above: dy (or, dy_pooled, the gradient of y_pool); activation sign from sign_mask, else from y, else —
+ * both NULL — recomputed from x (no residual; needs beta); dx, dz = gradient of the residual branch (NULL to skip;
+ * dz_sum: its 2x2 block sums [B][C][H/2][W/2]), dgamma / dbeta (NULL to skip) */
 size_t sivae_bf16_bn_bwd_workspace_bytes(int B, int C, int H, int W);
-int sivae_bf16_bn_bwd(const void* dy, int dy_pooled, const void* y, const void* x, const float* mean,
-                      const float* invstd, const float* gamma, const float* beta, float slope, void* dx, void* dz,
-                      int dz_sum, float* dgamma, float* dbeta, int B, int C, int H, int W, void* workspace,
-                      size_t workspace_bytes, sivae_stream_t stream);
+int sivae_bf16_bn_bwd(const void* dy, int dy_pooled, const void* y, const unsigned char* sign_mask, const void* x,
+                      const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                      void* dx, void* dz, int dz_sum, float* dgamma, float* dbeta, int B, int C, int H, int W,
+                      void* workspace, size_t workspace_bytes, sivae_stream_t stream);
 int sivae_bf16_upsample2_fwd(const void* x, void* y, int B, int C, int Hs, int Ws, sivae_stream_t stream);
 int sivae_bf16_upsample2_bwd(const void* dy, void* dx, int B, int C, int Hs, int Ws, sivae_stream_t stream);
 int sivae_bf16_add_inplace(void* y, const void* x, size_t nvec, sivae_stream_t stream);

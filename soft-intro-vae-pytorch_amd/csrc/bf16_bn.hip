@@ -21,6 +21,19 @@ __device__ __forceinline__ u32x4_t ldv(const void* base, size_t vec) {
 }
 __device__ __forceinline__ void stv(void* base, size_t vec, u32x4_t v) { reinterpret_cast<u32x4_t*>(base)[vec] = v; }
 
+// LeakyReLU sign of a vector's 8 (rounded) outputs as one byte: bit e set <=> output e > 0.  The backward reads this
+// byte (1/16 of the tensor) instead of the saved output; "> 0" on the rounded value is exactly what the output-based
+// path tests, so both give the same gradients bit for bit.
+__device__ __forceinline__ unsigned char sign_byte(const u32x4_t o) {
+  unsigned m = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    m |= (bf16_lo(o[i]) > 0.f ? 1u : 0u) << (2 * i);
+    m |= (bf16_hi(o[i]) > 0.f ? 1u : 0u) << (2 * i + 1);
+  }
+  return (unsigned char)m;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -73,8 +86,9 @@ __global__ void __launch_bounds__(256) bf16_bn_apply_kernel(const void* __restri
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float slope,
-                                                            void* __restrict__ y, void* __restrict__ yp, int B, int C,
-                                                            int Cb, int H, int W) {
+                                                            void* __restrict__ y, void* __restrict__ yp,
+                                                            unsigned char* __restrict__ mask, int B, int C, int Cb,
+                                                            int H, int W) {
   extern __shared__ __attribute__((aligned(16))) float tab[];  // [Cb][2][8]
   for (int c = threadIdx.x; c < Cb * 8; c += blockDim.x) {
     float sc = 0.f, sh = 0.f;
@@ -103,7 +117,9 @@ __global__ void __launch_bounds__(256) bf16_bn_apply_kernel(const void* __restri
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = lrelu01(f[e] * p[0][e] + p[1][e], slope);
       }
-      stv(y, v, pack8(f));
+      const u32x4_t o = pack8(f);
+      if (y != nullptr) stv(y, v, o);
+      if (mask != nullptr) mask[v] = sign_byte(o);
     }
   } else {
     const int Hh = H >> 1, Wh = W >> 1, HWh = Hh * Wh;
@@ -142,6 +158,7 @@ __global__ void __launch_bounds__(256) bf16_bn_apply_kernel(const void* __restri
           for (int e = 0; e < 8; ++e) f[e] = lrelu01(f[e], slope);
           const u32x4_t o = pack8(f);
           if (y != nullptr) stv(y, v, o);
+          if (mask != nullptr) mask[v] = sign_byte(o);
           // the pooled value averages the ROUNDED outputs (what a separate AvgPool2d pass over y would read)
           float fr[8];
           unpack8(o, fr);
@@ -165,23 +182,27 @@ __global__ void __launch_bounds__(256) bf16_bn_apply_kernel(const void* __restri
 //   pass 2: dx = gamma*invstd * (g - sg/N - xhat * sgx/N);  dz = g  (gradient of the residual branch), optionally as
 //           its 2x2 block sums (all a block behind an nn.Upsample needs of it)
 // ---------------------------------------------------------------------------------------------------------------
+// ACT 1: sign from the saved output yv; ACT 2: recomputed from xhat * gamma + beta; ACT 3: from the sign byte `m`
 template <int ACT>
 __device__ __forceinline__ void bwd_g(const float* dy, const float* yv, const float* xhat, const float* gam,
-                                      const float* bet, float slope, float* g) {
+                                      const float* bet, float slope, float* g, unsigned m = 0) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    float s;
+    bool pos;
     if (ACT == 1)
-      s = yv[e];
+      pos = yv[e] > 0.f;
+    else if (ACT == 2)
+      pos = xhat[e] * gam[e] + bet[e] > 0.f;
     else
-      s = xhat[e] * gam[e] + bet[e];
-    g[e] = dy[e] * (s > 0.f ? 1.f : slope);
+      pos = (m >> e) & 1u;
+    g[e] = dy[e] * (pos ? 1.f : slope);
   }
 }
 
 template <int ACT>
 __global__ void __launch_bounds__(256) bf16_bn_bwd_partial_kernel(const void* __restrict__ dy, int dy_pooled,
                                                                   const void* __restrict__ y,
+                                                                  const unsigned char* __restrict__ mask,
                                                                   const void* __restrict__ x,
                                                                   const float* __restrict__ mean,
                                                                   const float* __restrict__ invstd,
@@ -219,9 +240,10 @@ __global__ void __launch_bounds__(256) bf16_bn_bwd_partial_kernel(const void* __
     }
     unpack8(ldv(x, v), xv);
     if (ACT == 1) unpack8(ldv(y, v), yv);
+    const unsigned mb = ACT == 3 ? mask[v] : 0u;
 #pragma unroll
     for (int e = 0; e < 8; ++e) xh[e] = (xv[e] - mu[e]) * is[e];
-    bwd_g<ACT>(d, yv, xh, gm, bt, slope, g);
+    bwd_g<ACT>(d, yv, xh, gm, bt, slope, g, mb);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       sg[e] += g[e];
@@ -270,6 +292,7 @@ __global__ void __launch_bounds__(64) bf16_bn_bwd_finalize_kernel(const float* _
 template <int ACT, bool QUAD>
 __global__ void __launch_bounds__(256) bf16_bn_bwd_apply_kernel(const void* __restrict__ dy, int dy_pooled,
                                                                 const void* __restrict__ y,
+                                                                const unsigned char* __restrict__ mask,
                                                                 const void* __restrict__ x,
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd,
@@ -300,9 +323,10 @@ __global__ void __launch_bounds__(256) bf16_bn_bwd_apply_kernel(const void* __re
       unpack8(ldv(dy, v), d);
       unpack8(ldv(x, v), xv);
       if (ACT == 1) unpack8(ldv(y, v), yv);
+      const unsigned mb = ACT == 3 ? mask[v] : 0u;
 #pragma unroll
       for (int e = 0; e < 8; ++e) xh[e] = (xv[e] - p[0][e]) * p[1][e];
-      bwd_g<ACT>(d, yv, xh, p[2], p[3], slope, g);
+      bwd_g<ACT>(d, yv, xh, p[2], p[3], slope, g, mb);
       if (dz != nullptr) stv(dz, v, pack8(g));
 #pragma unroll
       for (int e = 0; e < 8; ++e) g[e] = p[2][e] * p[1][e] * (g[e] - p[4][e] - xh[e] * p[5][e]);
@@ -339,9 +363,10 @@ __global__ void __launch_bounds__(256) bf16_bn_bwd_apply_kernel(const void* __re
           }
           unpack8(ldv(x, v), xv);
           if (ACT == 1) unpack8(ldv(y, v), yv);
+          const unsigned mb = ACT == 3 ? mask[v] : 0u;
 #pragma unroll
           for (int e = 0; e < 8; ++e) xh[e] = (xv[e] - p[0][e]) * p[1][e];
-          bwd_g<ACT>(d, yv, xh, p[2], p[3], slope, g);
+          bwd_g<ACT>(d, yv, xh, p[2], p[3], slope, g, mb);
           if (dz != nullptr && !dz_sum) stv(dz, v, pack8(g));
 #pragma unroll
           for (int e = 0; e < 8; ++e) zs[e] += g[e];
@@ -435,9 +460,15 @@ extern "C" int sivae_bf16_to_f32_nchw(const void* src, float* dst, int B, int C,
   return sivae_launch_status();
 }
 
+extern "C" size_t sivae_bf16_bn_signmask_bytes(int B, int C, int H, int W) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+  return (size_t)B * bf16_cblocks(C) * H * W;  // one byte per 8-channel pixel vector
+}
+
 extern "C" int sivae_bf16_bn_apply_act(const void* x, const void* res, int res_up, const float* mean,
                                        const float* invstd, const float* gamma, const float* beta, float slope,
-                                       void* y, void* y_pool, int B, int C, int H, int W, hipStream_t stream) {
+                                       void* y, void* y_pool, unsigned char* sign_mask, int B, int C, int H, int W,
+                                       hipStream_t stream) {
   if (!x || !mean || !invstd || !gamma || !beta || (!y && !y_pool)) return SIVAE_ERR_NULL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
   if (res_up && !res) return SIVAE_ERR_NULL;
@@ -448,11 +479,12 @@ extern "C" int sivae_bf16_bn_apply_act(const void* x, const void* res, int res_u
   if (quad) {
     const size_t n = (size_t)B * Cb * (H / 2) * (W / 2);
     hipLaunchKernelGGL(bf16_bn_apply_kernel<true>, dim3(grid_for(n)), dim3(256), lds, stream, x, res, res_up, mean,
-                       invstd, gamma, beta, slope, y, y_pool, B, C, Cb, H, W);
+                       invstd, gamma, beta, slope, y, y_pool, sign_mask, B, C, Cb, H, W);
   } else {
+    if (!y) return SIVAE_ERR_NULL;
     const size_t n = (size_t)B * Cb * H * W;
     hipLaunchKernelGGL(bf16_bn_apply_kernel<false>, dim3(grid_for(n)), dim3(256), lds, stream, x, res, res_up, mean,
-                       invstd, gamma, beta, slope, y, y_pool, B, C, Cb, H, W);
+                       invstd, gamma, beta, slope, y, y_pool, sign_mask, B, C, Cb, H, W);
   }
   return sivae_launch_status();
 }
@@ -472,12 +504,14 @@ extern "C" size_t sivae_bf16_bn_bwd_workspace_bytes(int B, int C, int H, int W) 
   return ((size_t)bn_bwd_slices(B, C, H, W) * C * 2 + (size_t)C * 2) * sizeof(float);
 }
 
-extern "C" int sivae_bf16_bn_bwd(const void* dy, int dy_pooled, const void* y, const void* x, const float* mean,
-                                 const float* invstd, const float* gamma, const float* beta, float slope, void* dx,
-                                 void* dz, int dz_sum, float* dgamma, float* dbeta, int B, int C, int H, int W,
-                                 void* workspace, size_t workspace_bytes, hipStream_t stream) {
+extern "C" int sivae_bf16_bn_bwd(const void* dy, int dy_pooled, const void* y, const unsigned char* sign_mask,
+                                 const void* x, const float* mean, const float* invstd, const float* gamma,
+                                 const float* beta, float slope, void* dx, void* dz, int dz_sum, float* dgamma,
+                                 float* dbeta, int B, int C, int H, int W, void* workspace, size_t workspace_bytes,
+                                 hipStream_t stream) {
   if (!dy || !x || !mean || !invstd || !gamma || !dx || !workspace) return SIVAE_ERR_NULL;
-  if (!y && !beta) return SIVAE_ERR_NULL;  // the activation sign comes from y, or is recomputed (needs beta)
+  // the activation sign comes from the sign mask, from the saved output y, or is recomputed (needs beta)
+  if (!y && !sign_mask && !beta) return SIVAE_ERR_NULL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
   if (dz_sum && !dz) return SIVAE_ERR_NULL;
   const bool quad = dy_pooled || dz_sum;
@@ -487,20 +521,29 @@ extern "C" int sivae_bf16_bn_bwd(const void* dy, int dy_pooled, const void* y, c
   const int ns = bn_bwd_slices(B, C, H, W);
   float* part = reinterpret_cast<float*>(workspace);
   float* sums = part + (size_t)ns * C * 2;
-  if (y)
-    hipLaunchKernelGGL(bf16_bn_bwd_partial_kernel<1>, dim3(ns, Cb), dim3(256), 0, stream, dy, dy_pooled, y, x, mean,
-                       invstd, gamma, beta, slope, part, B, C, Cb, H, W);
+  const int act = sign_mask ? 3 : (y ? 1 : 2);
+  if (act == 3)
+    hipLaunchKernelGGL(bf16_bn_bwd_partial_kernel<3>, dim3(ns, Cb), dim3(256), 0, stream, dy, dy_pooled, y, sign_mask, x,
+                       mean, invstd, gamma, beta, slope, part, B, C, Cb, H, W);
+  else if (act == 1)
+    hipLaunchKernelGGL(bf16_bn_bwd_partial_kernel<1>, dim3(ns, Cb), dim3(256), 0, stream, dy, dy_pooled, y, sign_mask, x,
+                       mean, invstd, gamma, beta, slope, part, B, C, Cb, H, W);
   else
-    hipLaunchKernelGGL(bf16_bn_bwd_partial_kernel<2>, dim3(ns, Cb), dim3(256), 0, stream, dy, dy_pooled, y, x, mean,
-                       invstd, gamma, beta, slope, part, B, C, Cb, H, W);
+    hipLaunchKernelGGL(bf16_bn_bwd_partial_kernel<2>, dim3(ns, Cb), dim3(256), 0, stream, dy, dy_pooled, y, sign_mask, x,
+                       mean, invstd, gamma, beta, slope, part, B, C, Cb, H, W);
   hipLaunchKernelGGL(bf16_bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, stream, part, ns, C, sums, dgamma, dbeta);
   const float inv_n = 1.0f / ((float)B * H * W);
   const size_t lds = (size_t)Cb * 48 * sizeof(float);
   const size_t n = quad ? (size_t)B * Cb * (H / 2) * (W / 2) : (size_t)B * Cb * H * W;
 #define SIVAE_BWD_APPLY(ACT, Q)                                                                                      \
   hipLaunchKernelGGL((bf16_bn_bwd_apply_kernel<ACT, Q>), dim3(grid_for(n)), dim3(256), lds, stream, dy, dy_pooled, y, \
-                     x, mean, invstd, gamma, beta, slope, sums, inv_n, dx, dz, dz_sum, B, C, Cb, H, W)
-  if (y) {
+                     sign_mask, x, mean, invstd, gamma, beta, slope, sums, inv_n, dx, dz, dz_sum, B, C, Cb, H, W)
+  if (act == 3) {
+    if (quad)
+      SIVAE_BWD_APPLY(3, true);
+    else
+      SIVAE_BWD_APPLY(3, false);
+  } else if (act == 1) {
     if (quad)
       SIVAE_BWD_APPLY(1, true);
     else

@@ -24,6 +24,8 @@ SLOPE = SF.SLOPE
 # the extra half-width pass (~30 us).  In fp32 the same trade was a wash (functional.MATERIALIZE_H).
 # SIVAE_BF16_MATERIALIZE_H=0 keeps the fused prologue (A/B measurements).
 MATERIALIZE_H = os.environ.get("SIVAE_BF16_MATERIALIZE_H", "1") != "0"
+# 1-bit LeakyReLU sign mask for the block-output BatchNorm (SIVAE_BF16_SIGNMASK=0: the backward re-reads the output)
+SIGNMASK = os.environ.get("SIVAE_BF16_SIGNMASK", "1") != "0"
 
 
 def packed16(w, mode):
@@ -106,14 +108,21 @@ class ResBlockFn16(torch.autograd.Function):
             c, p2 = ops16.conv2d(h, packed16(w2, 0), Cm, Co, 3, pro=pro1), None
         mean2, invstd2 = SF._stats(p2, B, Co, H * W, st2)
         pool = post == "pool"
-        out, yp = ops16.bn_apply_act(c, idt, mean2, invstd2, g2.detach(), b2.detach(), Co, SLOPE, res_up=x_up,
-                                     want_full=True, pool=pool)
+        if ctx.training and SIGNMASK:
+            # the backward takes the LeakyReLU sign from a 1-bit-per-element mask written here (`out` below IS that mask),
+            # and a pooled block never writes its full-resolution output
+            full, yp, out = ops16.bn_apply_act(c, idt, mean2, invstd2, g2.detach(), b2.detach(), Co, SLOPE,
+                                               res_up=x_up, want_full=not pool, pool=pool, want_mask=True)
+        else:
+            full, yp = ops16.bn_apply_act(c, idt, mean2, invstd2, g2.detach(), b2.detach(), Co, SLOPE, res_up=x_up,
+                                          want_full=True, pool=pool)
+            out = full
         if pool:
             y = yp
         elif post == "up":
-            y = ops16.upsample2_fwd(out, Co)
+            y = ops16.upsample2_fwd(full, Co)
         else:
-            y = out
+            y = full
         if cache is not None:
             cache.update(a=a, h=h, c=c, out=out, mean1=mean1, invstd1=invstd1, mean2=mean2, invstd2=invstd2, y=y,
                          tag=tag)

@@ -140,23 +140,32 @@ def conv2d_wgrad(x, dy, Ci, Co, ks, pro=None, upsample=False):
     return dw
 
 
-def bn_apply_act(x, res, mean, invstd, gamma, beta, C, slope=LRELU_SLOPE, res_up=False, want_full=True, pool=False):
-    """LeakyReLU(BN(x) + res) -> (y or None, AvgPool2d(2)(y) or None)"""
+def bn_apply_act(x, res, mean, invstd, gamma, beta, C, slope=LRELU_SLOPE, res_up=False, want_full=True, pool=False,
+                 want_mask=False):
+    """LeakyReLU(BN(x) + res) -> (y or None, AvgPool2d(2)(y) or None[, sign mask])
+    want_mask: also return the activation's sign bits (uint8, one byte per 8-channel pixel vector) for bn_bwd"""
     _req16(x, res)
     ops._require(mean, invstd, gamma, beta)
     B, Cb, H, W, _ = x.shape
     assert want_full or pool
     y = torch.empty_like(x) if want_full else None
     yp = torch.empty((B, Cb, H // 2, W // 2, 8), dtype=torch.bfloat16, device=x.device) if pool else None
+    mask = torch.empty((B, Cb, H, W), dtype=torch.uint8, device=x.device) if want_mask else None
     _lib.call("sivae_bf16_bn_apply_act", _p(x), _p(res), int(bool(res_up)), _p(mean), _p(invstd), _p(gamma), _p(beta),
-              float(slope), _p(y), _p(yp), B, C, H, W, _s(x))
-    return y, yp
+              float(slope), _p(y), _p(yp), _p(mask), B, C, H, W, _s(x))
+    return (y, yp, mask) if want_mask else (y, yp)
 
 
 def bn_bwd(dy, y, x, mean, invstd, gamma, beta, C, slope=LRELU_SLOPE, dy_pooled=False, want_dz=False, dz_sum=False,
            want_param_grads=True):
     """-> dx, dz (full resolution, its 2x2 block sums with dz_sum, or None), dgamma, dbeta.
-    y: the saved block output (sign of the activation), or None to recompute the sign from x (needs beta)."""
+    y: the saved block output (bf16) or its sign mask (uint8 from bn_apply_act(want_mask=True)) — the sign of the
+    activation —, or None to recompute the sign from x (needs beta)."""
+    mask = None
+    if y is not None and y.dtype == torch.uint8:
+        mask, y = y, None
+        if not mask.is_cuda or mask.numel() != x.numel() // 8:
+            raise TypeError("sivae_hip: bn_bwd needs the uint8 device mask bn_apply_act(want_mask=True) returned")
     _req16(dy, y, x)
     ops._require(mean, invstd, gamma, beta)
     B, Cb, H, W, _ = x.shape
@@ -169,7 +178,7 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, beta, C, slope=LRELU_SLOPE, dy_pooled=
         dz = torch.empty_like(x)
     dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
     dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
-    _lib.call("sivae_bf16_bn_bwd", _p(dy), int(bool(dy_pooled)), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma),
+    _lib.call("sivae_bf16_bn_bwd", _p(dy), int(bool(dy_pooled)), _p(y), _p(mask), _p(x), _p(mean), _p(invstd), _p(gamma),
               _p(beta), float(slope), _p(dx), _p(dz), int(bool(dz_sum)), _p(dgamma), _p(dbeta), B, C, H, W, _p(ws),
               ws.numel(), _s(x))
     return dx, dz, dgamma, dbeta

@@ -240,10 +240,14 @@ def check_bn(shape, res_mode, pool):
         z = z + rfull
     yref = F.leaky_relu(z, SLOPE)
     dev = [t.float().to(DEV) for t in (mean, invstd, gamma, beta)]
-    y, yp = ops16.bn_apply_act(to_blocked(x).to(DEV), None if r is None else to_blocked(r).to(DEV), *dev, C,
-                               res_up=res_mode == 2, want_full=True, pool=pool)
+    y, yp, mask = ops16.bn_apply_act(to_blocked(x).to(DEV), None if r is None else to_blocked(r).to(DEV), *dev, C,
+                                     res_up=res_mode == 2, want_full=True, pool=pool, want_mask=True)
     tag = "bn16%s res%d%s" % (shape, res_mode, "+pool" if pool else "")
     res = [(tag, _err(from_blocked(y, C), yref), TOL_BF16)]
+    # the sign mask: bit e of byte (b, cb, h, w) <=> output channel 8*cb + e > 0; padded channels 0
+    yb = y.detach().cpu().float()
+    bits = ((yb > 0).to(torch.int32) << torch.arange(8, dtype=torch.int32)).sum(-1)
+    res.append((tag + " signmask", float((bits - mask.cpu().to(torch.int32)).abs().max()), 0.0))
     if pool:
         res.append((tag + " pooled", _err(from_blocked(yp, C), F.avg_pool2d(from_blocked(y, C), 2)), TOL_BF16))
     # ---- backward
@@ -258,6 +262,12 @@ def check_bn(shape, res_mode, pool):
         dxr = (gamma * invstd).view(1, -1, 1, 1) * (g - (sg / n).view(1, -1, 1, 1) - xh * (sgx / n).view(1, -1, 1, 1))
         dx, dz, dg, db = ops16.bn_bwd(to_blocked(dyf).to(DEV), y, to_blocked(x).to(DEV), *dev, C, dy_pooled=dy_pooled,
                                       want_dz=True, dz_sum=dz_sum)
+        # the mask-based backward must reproduce the output-based one bit for bit
+        dxm, dzm, dgm, dbm = ops16.bn_bwd(to_blocked(dyf).to(DEV), mask, to_blocked(x).to(DEV), *dev, C,
+                                          dy_pooled=dy_pooled, want_dz=True, dz_sum=dz_sum)
+        same = torch.equal(dx, dxm) and torch.equal(dz, dzm) and torch.equal(dg, dgm) and torch.equal(db, dbm)
+        res.append((tag + (" pooled-dy" if dy_pooled else (" dzsum" if dz_sum else "")) + " bwd mask == bwd output",
+                    0.0 if same else float("inf"), 0.0))
         t2 = tag + (" bwd pooled-dy" if dy_pooled else (" bwd dzsum" if dz_sum else " bwd"))
         res.append((t2 + " dx", _err(from_blocked(dx, C), dxr), 1.2e-2))
         dzr = F.avg_pool2d(g, 2) * 4 if dz_sum else g

@@ -101,12 +101,14 @@ def test_round2_entry_points_validate_arguments():
     assert L.sivae_bf16_conv2d_num_px_tiles(128, 64, 128, 128, 5) == 128 * 128 * 128 // 256
     assert L.sivae_bf16_conv2d_num_px_tiles(128, 64, 128, 128, 3) == 128 * 128 * 128 // 512
     assert L.sivae_bf16_conv2d_num_px_tiles(128, 64, 128, 128, 4) == -3
-    assert L.sivae_bf16_bn_apply_act(one, null, 0, one, one, one, one, 0.2, null, null, 1, 16, 4, 4, null) == -1
-    assert L.sivae_bf16_bn_apply_act(one, null, 0, one, one, one, one, 0.2, one, one, 1, 16, 3, 4, null) == -2  # pool: even H
-    assert L.sivae_bf16_bn_apply_act(one, null, 1, one, one, one, one, 0.2, one, null, 1, 16, 4, 4, null) == -1  # res_up w/o res
-    assert L.sivae_bf16_bn_bwd(one, 0, null, one, one, one, one, null, 0.2, one, null, 0, null, null, 1, 16, 4, 4, one, 1 << 20, null) == -1
-    assert L.sivae_bf16_bn_bwd(one, 0, one, one, one, one, one, null, 0.2, one, null, 1, null, null, 1, 16, 4, 4, one, 1 << 20, null) == -1
-    assert L.sivae_bf16_bn_bwd(one, 0, one, one, one, one, one, null, 0.2, one, null, 0, null, null, 1, 16, 4, 4, one, 8, null) == -4
+    assert L.sivae_bf16_bn_apply_act(one, null, 0, one, one, one, one, 0.2, null, null, null, 1, 16, 4, 4, null) == -1
+    assert L.sivae_bf16_bn_apply_act(one, null, 0, one, one, one, one, 0.2, one, one, null, 1, 16, 3, 4, null) == -2  # pool: even H
+    assert L.sivae_bf16_bn_apply_act(one, null, 1, one, one, one, one, 0.2, one, null, null, 1, 16, 4, 4, null) == -1  # res_up w/o res
+    assert L.sivae_bf16_bn_signmask_bytes(2, 24, 4, 4) == 2 * 4 * 16 and L.sivae_bf16_bn_signmask_bytes(0, 8, 4, 4) == 0
+    # no sign source at all (y, mask and beta NULL) / dz_sum without dz / workspace too small
+    assert L.sivae_bf16_bn_bwd(one, 0, null, null, one, one, one, one, null, 0.2, one, null, 0, null, null, 1, 16, 4, 4, one, 1 << 20, null) == -1
+    assert L.sivae_bf16_bn_bwd(one, 0, one, null, one, one, one, one, null, 0.2, one, null, 1, null, null, 1, 16, 4, 4, one, 1 << 20, null) == -1
+    assert L.sivae_bf16_bn_bwd(one, 0, null, one, one, one, one, one, null, 0.2, one, null, 0, null, null, 1, 16, 4, 4, one, 8, null) == -4
     assert L.sivae_bf16_bn_bwd_workspace_bytes(128, 64, 64, 64) > 0 and L.sivae_bf16_bn_bwd_workspace_bytes(0, 64, 8, 8) == 0
     assert L.sivae_bf16_from_f32_nchw(null, one, 1, 3, 4, 4, 1.0, null) == -1
     assert L.sivae_bf16_to_f32_nchw(one, one, 1, 0, 4, 4, null) == -2
