@@ -362,7 +362,18 @@ int sivae_bf16_cblocks(int C);
 int sivae_bf16_from_f32_nchw(const float* src, void* dst, int B, int C, int H, int W, float scale,
                              sivae_stream_t stream);
 int sivae_bf16_to_f32_nchw(const void* src, float* dst, int B, int C, int H, int W, sivae_stream_t stream);
-/* fp32 master weight [Co][Ci][ks][ks] -> bf16 MFMA-operand slabs; mode 0 forward, mode 1 data gradient */
+/* kw-packed form of the RGB-side 5x5 layers (Encoder stem train_soft_intro_vae.py:88, Decoder.predict :159; C <= 3):
+ * the 5 kernel columns move into the channel dimension, so the 5x5 conv over / into C channels runs as a 5-tap conv
+ * (ks code 51 of the conv / weight-gradient entry points: 5 rows x 1 column) over / into 5C <= 15 channels.
+ *   im2col: dst (blocked bf16, 16 channels) [kw*C + c][h][w] = src (fp32 NCHW) [c][h][w + sgn*(kw-2)], 0 outside
+ *   fold:   dst (fp32 NCHW, C channels) [c][h][w] = bias[c] + sum_kw g (fp32 NCHW, 5C channels) [kw*C + c][h][w + sgn*(kw-2)]
+ * sgn = +1 / -1.  (stem: im2col +1 of the image, fold -1 for its input gradient; predict: fold +1 for its output,
+ * im2col -1 of its output gradient.) */
+int sivae_bf16_im2col_kw5(const float* src, void* dst, int B, int C, int H, int W, int sgn, sivae_stream_t stream);
+int sivae_bf16_fold_kw5(const float* g, const float* bias, float* dst, int B, int C, int H, int W, int sgn,
+                        sivae_stream_t stream);
+/* fp32 master weight [Co][Ci][ks][ks] -> bf16 MFMA-operand slabs; mode 0 forward, mode 1 data gradient.
+ * ks is 1, 3, 5 or the code 51 = 5 rows x 1 column (weight [Co][Ci][5][1]) in all bf16 conv entry points */
 size_t sivae_bf16_pack_conv_weight_bytes(int Co, int Ci, int ks, int mode);
 int sivae_bf16_pack_conv_weight(const float* w, void* wp, int Co, int Ci, int ks, int mode, sivae_stream_t stream);
 /* y (+)= conv(x', wp) + bias with the fusions of sivae_conv2d_fwd (producer BatchNorm+LeakyReLU prologue — 3x3 only —,

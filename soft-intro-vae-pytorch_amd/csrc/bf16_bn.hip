@@ -75,6 +75,65 @@ __global__ void bf16_to_f32_nchw_kernel(const void* __restrict__ src, float* __r
   }
 }
 
+// kw-packed form of the RGB-side 5x5 layers (the stem conv reads 3 image channels, the decoder's predict conv writes 3:
+// padded to a 16-channel k-step / a 32-channel MFMA tile they waste 13/16 of the matrix work over 25 taps).  The 5
+// kernel COLUMNS are moved into the channel dimension instead: with X'[kw*C + c][h][w] = x[c][h][w + sgn*(kw-2)] a 5x5
+// conv over C <= 3 channels is a 5x1 conv over 5C <= 15 channels (ks code 51 of bf16_conv.hip / bf16_wgrad.hip: 5 taps
+// instead of 25), and a 5x5 conv INTO C channels is a 5x1 conv into 5C channels followed by the column fold below.
+//   sgn = +1: the stem's image (forward + weight gradient);  sgn = -1: the predict conv's output gradient
+// (a thread owns one pixel: 5C loads that neighbouring lanes share through the cache, two 16-byte stores; C is a
+// template parameter and the batch index a grid dimension, which leaves one integer division per pixel)
+template <int C>
+__global__ void __launch_bounds__(256) bf16_im2col_kw5_kernel(const float* __restrict__ src, void* __restrict__ dst,
+                                                              int H, int W, int sgn) {
+  const int HW = H * W, b = blockIdx.y;
+  const float* sb = src + (size_t)b * C * HW;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+    const int w = p % W;
+    float f[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) f[j] = 0.f;
+#pragma unroll
+    for (int kw = 0; kw < 5; ++kw) {
+      const int ws = w + sgn * (kw - 2);
+      const bool ok = ws >= 0 && ws < W;
+#pragma unroll
+      for (int c = 0; c < C; ++c) f[kw * C + c] = ok ? sb[(size_t)c * HW + (p - w + ws)] : 0.f;
+    }
+    stv(dst, ((size_t)b * 2 + 0) * HW + p, pack8(f));
+    stv(dst, ((size_t)b * 2 + 1) * HW + p, pack8(f + 8));
+  }
+}
+
+// dst[b][c][h][w] = bias[c] + sum_kw g[b][kw*C + c][h][w + sgn*(kw-2)]   (g: fp32 NCHW with 5C channels)
+//   sgn = +1: the predict conv's output;  sgn = -1: the stem's input gradient
+template <int C>
+__global__ void __launch_bounds__(256) bf16_fold_kw5_kernel(const float* __restrict__ g, const float* __restrict__ bias,
+                                                            float* __restrict__ dst, int H, int W, int sgn) {
+  const int HW = H * W, b = blockIdx.y;
+  const float* gb = g + (size_t)b * 5 * C * HW;
+  float* db = dst + (size_t)b * C * HW;
+  float bv[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) bv[c] = bias ? bias[c] : 0.f;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+    const int w = p % W;
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = bv[c];
+#pragma unroll
+    for (int kw = 0; kw < 5; ++kw) {
+      const int ws = w + sgn * (kw - 2);
+      if (ws >= 0 && ws < W) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] += gb[(size_t)(kw * C + c) * HW + (p - w + ws)];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) db[(size_t)c * HW + p] = acc[c];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // y = LeakyReLU(x * scale[c] + shift[c] + res)        (BatchNorm apply + residual + activation)
 // QUAD: a thread owns a 2x2 pixel quad (needed for the fused AvgPool2d output and for a half-resolution residual
@@ -457,6 +516,36 @@ extern "C" int sivae_bf16_to_f32_nchw(const void* src, float* dst, int B, int C,
   const int Cb = bf16_cblocks(C);
   const size_t n = (size_t)B * Cb * H * W;
   hipLaunchKernelGGL(bf16_to_f32_nchw_kernel, dim3(grid_for(n)), dim3(256), 0, stream, src, dst, B, C, Cb, H * W);
+  return sivae_launch_status();
+}
+
+extern "C" int sivae_bf16_im2col_kw5(const float* src, void* dst, int B, int C, int H, int W, int sgn,
+                                     hipStream_t stream) {
+  if (!src || !dst) return SIVAE_ERR_NULL;
+  if (B <= 0 || C <= 0 || 5 * C > 16 || H <= 0 || W <= 0 || B > 65535) return SIVAE_ERR_SHAPE;
+  if (sgn != 1 && sgn != -1) return SIVAE_ERR_MODE;
+  const dim3 grid((unsigned)((H * W + 255) / 256 < 64 ? (H * W + 255) / 256 : 64), (unsigned)B);
+  if (C == 1)
+    hipLaunchKernelGGL(bf16_im2col_kw5_kernel<1>, grid, dim3(256), 0, stream, src, dst, H, W, sgn);
+  else if (C == 2)
+    hipLaunchKernelGGL(bf16_im2col_kw5_kernel<2>, grid, dim3(256), 0, stream, src, dst, H, W, sgn);
+  else
+    hipLaunchKernelGGL(bf16_im2col_kw5_kernel<3>, grid, dim3(256), 0, stream, src, dst, H, W, sgn);
+  return sivae_launch_status();
+}
+
+extern "C" int sivae_bf16_fold_kw5(const float* g, const float* bias, float* dst, int B, int C, int H, int W, int sgn,
+                                   hipStream_t stream) {
+  if (!g || !dst) return SIVAE_ERR_NULL;
+  if (B <= 0 || C <= 0 || 5 * C > 16 || H <= 0 || W <= 0 || B > 65535) return SIVAE_ERR_SHAPE;
+  if (sgn != 1 && sgn != -1) return SIVAE_ERR_MODE;
+  const dim3 grid((unsigned)((H * W + 255) / 256 < 64 ? (H * W + 255) / 256 : 64), (unsigned)B);
+  if (C == 1)
+    hipLaunchKernelGGL(bf16_fold_kw5_kernel<1>, grid, dim3(256), 0, stream, g, bias, dst, H, W, sgn);
+  else if (C == 2)
+    hipLaunchKernelGGL(bf16_fold_kw5_kernel<2>, grid, dim3(256), 0, stream, g, bias, dst, H, W, sgn);
+  else
+    hipLaunchKernelGGL(bf16_fold_kw5_kernel<3>, grid, dim3(256), 0, stream, g, bias, dst, H, W, sgn);
   return sivae_launch_status();
 }
 

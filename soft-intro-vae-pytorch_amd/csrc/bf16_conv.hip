@@ -45,12 +45,13 @@ struct Bf16ConvArgs {
   long long split_stride;
 };
 
-template <int KS, int WM, int WN, int WVM, int WVN, int CKS, int MAXV, bool PRO, bool OUTF32, int MINW>
+// KS x KW taps (KW = KS except for the kw-packed 5x1 form of the RGB-side layers, ks code 51)
+template <int KS, int WM, int WN, int WVM, int WVN, int CKS, int MAXV, bool PRO, bool OUTF32, int MINW, int KW = KS>
 __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16ConvArgs a) {
-  constexpr int P = KS / 2;
+  constexpr int P = KS / 2, PW = KW / 2;
   constexpr int NT = WVM * WVN * 64;
   constexpr int TCO = WVM * WM * 32;
-  constexpr int TAPS = KS * KS;
+  constexpr int TAPS = KS * KW;
   constexpr int NCB = 2 * CKS;
   constexpr int NW = TAPS * CKS * 2 * TCO;  // 16-byte weight vectors per chunk
   constexpr int NWQ = (NW + NT - 1) / NT;
@@ -64,7 +65,7 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
   const int wvm = wave / WVN, wvn = wave % WVN;
 
   const int TW = 1 << a.tw_log2, TH = 1 << a.th_log2, TB = 1 << a.tb_log2;
-  const int LW = TW + 2 * P, LH = TH + 2 * P;
+  const int LW = TW + 2 * PW, LH = TH + 2 * P;
   const int plane = TB * LH * LW;
   const int nvec = NCB * plane;
   const int H = a.H, W = a.W, HW = H * W;
@@ -120,7 +121,7 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
       const int t = pos / LW;
       const int rr = t % LH;
       const int tb = t / LH;
-      const int r = r0 + rr - P, c = c0 + cc - P;
+      const int r = r0 + rr - P, c = c0 + cc - PW;
       if (tb < nb_here && r >= 0 && r < H && c >= 0 && c < W) {
         const int rs = a.upsample ? (r >> 1) : r, cs = a.upsample ? (c >> 1) : c;
         off = ((((unsigned)tb * a.Cib + cbl) * Hs + rs) * Ws + cs) * 16u;
@@ -199,8 +200,8 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
 #pragma unroll
       for (int kh = 0; kh < KS; ++kh) {
 #pragma unroll
-        for (int kw = 0; kw < KS; ++kw) {
-          const int tap = kh * KS + kw;
+        for (int kw = 0; kw < KW; ++kw) {
+          const int tap = kh * KW + kw;
           bf16x8_t av[WM], bv[WN];
 #pragma unroll
           for (int m = 0; m < WM; ++m)
@@ -345,13 +346,13 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
 // mode 0: forward operand; mode 1: data-gradient operand (output channels = the conv's input channels, taps flipped)
 // ------------------------------------------------------------------------------------------------
 __global__ void bf16_pack_conv_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Co,
-                                             int Ci, int KS, int mode, int TCO, int CKS, int nchunks,
+                                             int Ci, int KS, int KW, int mode, int TCO, int CKS, int nchunks,
                                              size_t total) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   // outputs / inputs of the GEMM this pack feeds
   const int N_out = mode == 0 ? Co : Ci, N_in = mode == 0 ? Ci : Co;
-  const int TAPS = KS * KS;
+  const int TAPS = KS * KW;
   size_t t = i;
   const int e = (int)(t % 8);
   t /= 8;
@@ -369,11 +370,11 @@ __global__ void bf16_pack_conv_weight_kernel(const float* __restrict__ w, unsign
   const int ic = (chunk * CKS + ks) * 16 + hh * 8 + e;
   float v = 0.f;
   if (oc < N_out && ic < N_in) {
-    const int kh = tap / KS, kw = tap % KS;
+    const int kh = tap / KW, kw = tap % KW;
     if (mode == 0)
-      v = w[(((size_t)oc * Ci + ic) * KS + kh) * KS + kw];
+      v = w[(((size_t)oc * Ci + ic) * KS + kh) * KW + kw];
     else
-      v = w[(((size_t)ic * Ci + oc) * KS + (KS - 1 - kh)) * KS + (KS - 1 - kw)];
+      v = w[(((size_t)ic * Ci + oc) * KS + (KS - 1 - kh)) * KW + (KW - 1 - kw)];
   }
   const unsigned u = pack_bf16(v, 0.f);
   wp[i] = (unsigned short)(u & 0xffffu);
@@ -384,6 +385,11 @@ namespace {
 struct Bf16Cfg {
   int TCO, TPX, CKS;
 };
+// ks codes: 1, 3, 5 = square kernels; 51 = 5 rows x 1 column (the kw-packed form of the RGB-side 5x5 layers: the 3
+// image channels and the 5 kernel columns share the 16-channel k-step, bf16_bn.hip::bf16_im2col_kw5_kernel)
+bool ks_ok(int ks) { return ks == 1 || ks == 3 || ks == 5 || ks == 51; }
+int ks_h(int ks) { return ks == 51 ? 5 : ks; }
+int ks_w(int ks) { return ks == 51 ? 1 : ks; }
 // tile configuration by (ks, output channels, input channels) — shared by the pack and the launch
 Bf16Cfg bf16_cfg(int ks, int n_out, int n_in) {
   Bf16Cfg c;
@@ -393,13 +399,13 @@ Bf16Cfg bf16_cfg(int ks, int n_out, int n_in) {
   return c;
 }
 
-template <int KS, int WM, int WN, int WVM, int WVN, int CKS, int MAXV, bool PRO, bool OUTF32, int MINW>
+template <int KS, int WM, int WN, int WVM, int WVN, int CKS, int MAXV, bool PRO, bool OUTF32, int MINW, int KW = KS>
 int launch_cfg(Bf16ConvArgs& a, hipStream_t stream) {
   constexpr int TCO = WVM * WM * 32;
   constexpr int TPX = WVN * WN * 32;
   constexpr int NT = WVM * WVN * 64;
-  constexpr int P = KS / 2;
-  constexpr int NW = KS * KS * CKS * 2 * TCO;
+  constexpr int P = KS / 2, PW = KW / 2;
+  constexpr int NW = KS * KW * CKS * 2 * TCO;
   TileGeom g = make_tile_geom(a.B, a.H, a.W, TPX);
   a.tb_log2 = g.tb_log2;
   a.th_log2 = g.th_log2;
@@ -409,7 +415,7 @@ int launch_cfg(Bf16ConvArgs& a, hipStream_t stream) {
   a.ntw = g.ntw;
   a.n_co_tiles = cdiv(a.Co, TCO);
   a.nchunks = a.Cib / (2 * CKS);
-  const int plane = (1 << g.tb_log2) * ((1 << g.th_log2) + 2 * P) * ((1 << g.tw_log2) + 2 * P);
+  const int plane = (1 << g.tb_log2) * ((1 << g.th_log2) + 2 * P) * ((1 << g.tw_log2) + 2 * PW);
   if (2 * CKS * plane > MAXV * NT) return SIVAE_ERR_SHAPE;
   size_t lds = (size_t)(NW + 2 * CKS * plane) * 16 + (PRO ? (size_t)a.Cib * 64 : 0);
   const size_t red = (size_t)WVN * TCO * 2 * sizeof(float);
@@ -419,7 +425,7 @@ int launch_cfg(Bf16ConvArgs& a, hipStream_t stream) {
   const long long nblk = nbase * cdiv(a.nchunks, a.chunks_per_split);
   if (nblk > 0x7fffffffLL) return SIVAE_ERR_RANGE;
   a.nblk_base = (int)nbase;
-  auto kern = bf16_conv_kernel<KS, WM, WN, WVM, WVN, CKS, MAXV, PRO, OUTF32, MINW>;
+  auto kern = bf16_conv_kernel<KS, WM, WN, WVM, WVN, CKS, MAXV, PRO, OUTF32, MINW, KW>;
   static size_t lds_hwm = 0;
   const int rc_lds = sivae_ensure_lds(reinterpret_cast<const void*>(kern), lds, &lds_hwm);
   if (rc_lds != SIVAE_OK) return rc_lds;
@@ -453,9 +459,9 @@ int px_tile_3x3(int TCO, int B, int H, int W, int n_out) {
   return big;
 }
 
-template <int KS, int CKS, int MAXV, bool PRO, bool OUTF32>
+template <int KS, int CKS, int MAXV, bool PRO, bool OUTF32, int KW = KS>
 int launch_by_co(Bf16ConvArgs& a, int TCO, hipStream_t stream) {
-  if (TCO == 32) return launch_cfg<KS, 1, 2, 1, 4, CKS, MAXV, PRO, OUTF32, 2>(a, stream);
+  if (TCO == 32) return launch_cfg<KS, 1, 2, 1, 4, CKS, MAXV, PRO, OUTF32, 2, KW>(a, stream);
   if constexpr (OUTF32 && KS == 3) {  // split-K partials of the 3x3 kernels (small pixel tiles)
     if (TCO == 64) return launch_cfg<KS, 2, 2, 1, 4, CKS, MAXV, PRO, true, 2>(a, stream);
     return launch_cfg<KS, 2, 2, 2, 2, CKS, MAXV, PRO, true, 2>(a, stream);
@@ -467,8 +473,8 @@ int launch_by_co(Bf16ConvArgs& a, int TCO, hipStream_t stream) {
       if (TCO == 64 && tpx == 512) return launch_cfg<KS, 2, 4, 1, 4, CKS, MAXV, PRO, false, 2>(a, stream);
       if (TCO == 128 && tpx == 256) return launch_cfg<KS, 2, 4, 2, 2, CKS, MAXV, PRO, false, 2>(a, stream);
     }
-    if (TCO == 64) return launch_cfg<KS, 2, 2, 1, 4, CKS, MAXV, PRO, false, 2>(a, stream);
-    return launch_cfg<KS, 2, 2, 2, 2, CKS, MAXV, PRO, false, 2>(a, stream);
+    if (TCO == 64) return launch_cfg<KS, 2, 2, 1, 4, CKS, MAXV, PRO, false, 2, KW>(a, stream);
+    return launch_cfg<KS, 2, 2, 2, 2, CKS, MAXV, PRO, false, 2, KW>(a, stream);
   }
   return SIVAE_ERR_SHAPE;
 }
@@ -478,30 +484,31 @@ int launch_by_co(Bf16ConvArgs& a, int TCO, hipStream_t stream) {
 extern "C" int sivae_bf16_cblocks(int C) { return C <= 0 ? SIVAE_ERR_SHAPE : bf16_cblocks(C); }
 
 extern "C" size_t sivae_bf16_pack_conv_weight_bytes(int Co, int Ci, int ks, int mode) {
-  if (Co <= 0 || Ci <= 0 || (ks != 1 && ks != 3 && ks != 5) || (mode != 0 && mode != 1)) return 0;
+  if (Co <= 0 || Ci <= 0 || !ks_ok(ks) || (mode != 0 && mode != 1)) return 0;
   const int n_out = mode == 0 ? Co : Ci, n_in = mode == 0 ? Ci : Co;
   const Bf16Cfg c = bf16_cfg(ks, n_out, n_in);
   const int nchunks = bf16_cblocks(n_in) / (2 * c.CKS);
-  return (size_t)cdiv(n_out, c.TCO) * nchunks * ks * ks * c.CKS * 2 * c.TCO * 16;
+  return (size_t)cdiv(n_out, c.TCO) * nchunks * ks_h(ks) * ks_w(ks) * c.CKS * 2 * c.TCO * 16;
 }
 
 extern "C" int sivae_bf16_pack_conv_weight(const float* w, void* wp, int Co, int Ci, int ks, int mode,
                                            hipStream_t stream) {
   if (!w || !wp) return SIVAE_ERR_NULL;
   const size_t bytes = sivae_bf16_pack_conv_weight_bytes(Co, Ci, ks, mode);
-  if (bytes == 0) return (ks != 1 && ks != 3 && ks != 5) ? SIVAE_ERR_KSIZE : SIVAE_ERR_SHAPE;
+  if (bytes == 0) return !ks_ok(ks) ? SIVAE_ERR_KSIZE : SIVAE_ERR_SHAPE;
   const int n_out = mode == 0 ? Co : Ci, n_in = mode == 0 ? Ci : Co;
   const Bf16Cfg c = bf16_cfg(ks, n_out, n_in);
   const int nchunks = bf16_cblocks(n_in) / (2 * c.CKS);
   const size_t total = bytes / 2;
   hipLaunchKernelGGL(bf16_pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w,
-                     reinterpret_cast<unsigned short*>(wp), Co, Ci, ks, mode, c.TCO, c.CKS, nchunks, total);
+                     reinterpret_cast<unsigned short*>(wp), Co, Ci, ks_h(ks), ks_w(ks), mode, c.TCO, c.CKS, nchunks,
+                     total);
   return sivae_launch_status();
 }
 
 extern "C" int sivae_bf16_conv2d_num_px_tiles(int B, int Co, int H, int W, int ks) {
   if (B <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
-  if (ks != 1 && ks != 3 && ks != 5) return SIVAE_ERR_KSIZE;
+  if (!ks_ok(ks)) return SIVAE_ERR_KSIZE;
   const Bf16Cfg c = bf16_cfg(ks, Co, 16);
   // (only the 3x3 kernels have the big pixel tiles; the launch below makes the same choice)
   TileGeom g = make_tile_geom(B, H, W, ks == 3 ? px_tile_3x3(c.TCO, B, H, W, Co) : c.TPX);
@@ -514,7 +521,7 @@ extern "C" int sivae_bf16_conv2d_fwd(const void* x, const void* wp, void* y, con
                                      int upsample, int accumulate, int out_f32_nchw, hipStream_t stream) {
   if (!x || !wp || !y) return SIVAE_ERR_NULL;
   if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
-  if (ks != 1 && ks != 3 && ks != 5) return SIVAE_ERR_KSIZE;
+  if (!ks_ok(ks)) return SIVAE_ERR_KSIZE;
   if (upsample && ((H & 1) || (W & 1))) return SIVAE_ERR_SHAPE;
   if (pro_mean && (!pro_invstd || !pro_gamma || !pro_beta)) return SIVAE_ERR_NULL;
   if (pro_mean && ks != 3) return SIVAE_ERR_MODE;  // the producer-BatchNorm prologue exists on the 3x3 kernel (conv2)
@@ -552,6 +559,10 @@ extern "C" int sivae_bf16_conv2d_fwd(const void* x, const void* wp, void* y, con
   if (ks == 1) {
     if (c.CKS == 4) return launch_by_co<1, 4, 8, false, false>(a, c.TCO, stream);
     return launch_by_co<1, 1, 2, false, false>(a, c.TCO, stream);
+  }
+  if (ks == 51) {
+    if (out_f32_nchw) return launch_by_co<5, 1, 4, false, true, 1>(a, c.TCO, stream);
+    return launch_by_co<5, 1, 4, false, false, 1>(a, c.TCO, stream);
   }
   if (out_f32_nchw) return launch_by_co<5, 1, 4, false, true>(a, c.TCO, stream);
   return launch_by_co<5, 1, 4, false, false>(a, c.TCO, stream);

@@ -40,11 +40,12 @@ struct Bf16WgArgs {
 };
 
 // WCO x WCI 32x32 MFMA tiles per wave, WVCO x WVCI waves over (co, ci), WVT waves splitting the taps
-template <int KS, int WCO, int WCI, int WVCO, int WVCI, int WVT, int MAXX, bool PRO, int MINW>
+// KS x KW taps (KW = KS except for ks code 51 = 5 rows x 1 column, see bf16_conv.hip)
+template <int KS, int WCO, int WCI, int WVCO, int WVCI, int WVT, int MAXX, bool PRO, int MINW, int KW = KS>
 __global__ void __launch_bounds__(WVCO* WVCI* WVT * 64, MINW) bf16_wgrad_kernel(Bf16WgArgs a) {
-  constexpr int P = KS / 2;
+  constexpr int P = KS / 2, PW = KW / 2;
   constexpr int NT = WVCO * WVCI * WVT * 64;
-  constexpr int TAPS = KS * KS;
+  constexpr int TAPS = KS * KW;
   constexpr int TPW = (TAPS + WVT - 1) / WVT;  // taps per wave
   constexpr int TCO = WVCO * WCO * 32, TCI = WVCI * WCI * 32;
   constexpr int NSUB_CO = TCO / 32, NSUB_CI = TCI / 32;
@@ -64,7 +65,7 @@ __global__ void __launch_bounds__(WVCO* WVCI* WVT * 64, MINW) bf16_wgrad_kernel(
   const int wco = wave / (WVT * WVCI);
 
   const int TW = 1 << a.tw_log2, TH = 1 << a.th_log2, TB = 1 << a.tb_log2;
-  const int LW = TW + 2 * P, LH = TH + 2 * P;
+  const int LW = TW + 2 * PW, LH = TH + 2 * P;
   const int plane = TB * LH * LW;
   const int nxv = NSUB_CI * plane * 4;
   const int H = a.H, W = a.W, HW = H * W;
@@ -172,7 +173,7 @@ __global__ void __launch_bounds__(WVCO* WVCI* WVT * 64, MINW) bf16_wgrad_kernel(
       if (cb < a.Cib) {
         x_crd[p] = tb | (rr << 8) | (cc << 16);
         // tile origins are even, so with upsample addressing (r0 + rr - P) >> 1 == (r0 >> 1) + ((rr - P) >> 1)
-        const int rs = a.upsample ? ((rr - P) >> 1) : (rr - P), cs = a.upsample ? ((cc - P) >> 1) : (cc - P);
+        const int rs = a.upsample ? ((rr - P) >> 1) : (rr - P), cs = a.upsample ? ((cc - PW) >> 1) : (cc - PW);
         x_rel[p] = (((tb * a.Cib + cb) * Hs + rs) * Ws + cs) * 16;
       }
     }
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(WVCO* WVCI* WVT * 64, MINW) bf16_wgrad_kernel(
     }                                                                                                           \
     _Pragma("unroll") for (int p = 0; p < MAXX; ++p) {                                                          \
       const int crd = x_crd[p];                                                                                 \
-      const int r = r0 + ((crd >> 8) & 255) - P, c = c0 + (crd >> 16) - P;                                      \
+      const int r = r0 + ((crd >> 8) & 255) - P, c = c0 + (crd >> 16) - PW;                                     \
       const bool ok = crd >= 0 && b0 + (crd & 255) < a.B && r >= 0 && r < H && c >= 0 && c < W;                 \
       x_in[p] = ok;                                                                                             \
       xr[p] = buf_load_u32x4(xrsrc, ok ? (unsigned)((int)x_org + x_rel[p]) : SIVAE_OOB, 0u);                    \
@@ -253,7 +254,7 @@ __global__ void __launch_bounds__(WVCO* WVCI* WVT * 64, MINW) bf16_wgrad_kernel(
       for (int tt = 0; tt < TPW; ++tt) {
         const int tap = wt + tt * WVT;  // (wave-uniform)
         if (tap < TAPS) {
-          const int kh = tap / KS, kw = tap % KS;
+          const int kh = tap / KW, kw = tap % KW;
           const int toff = (kh * LW + kw) * 64;
 #pragma unroll
           for (int n = 0; n < WCI; ++n) {
@@ -362,7 +363,9 @@ namespace {
 struct WgCfg {
   int TCO, TCI;
 };
-WgCfg wg_cfg(int ks) {
+bool ks_ok(int ks) { return ks == 1 || ks == 3 || ks == 5 || ks == 51; }
+int ks_taps(int ks) { return ks == 51 ? 5 : ks * ks; }
+WgCfg wg_cfg(int ks, int Co) {
   WgCfg c;
   if (ks == 1) {
     c.TCO = 128;
@@ -370,6 +373,9 @@ WgCfg wg_cfg(int ks) {
   } else if (ks == 3) {
     c.TCO = 64;
     c.TCI = 64;
+  } else if (ks == 51) {  // kw-packed RGB-side layers: one side has <= 16 channels
+    c.TCO = Co <= 32 ? 32 : 64;
+    c.TCI = Co <= 32 ? 64 : 32;
   } else {
     c.TCO = 32;
     c.TCI = 32;
@@ -378,13 +384,28 @@ WgCfg wg_cfg(int ks) {
 }
 
 int wg_slices(int B, int Ci, int Co, int H, int W, int ks, int* ntiles_out, TileGeom* g_out) {
-  const WgCfg c = wg_cfg(ks);
+  const WgCfg c = wg_cfg(ks, Co);
   TileGeom g = make_tile_geom(B, H, W, 64);
+  if (ks == 51) {
+    // 5 rows x 1 column: the halo is vertical only, so a tall narrow tile (8 wide x 8 high: 12 staged rows for 8)
+    // instead of the default 32 x 2 (6 staged rows for 2)
+    int tw = next_pow2(W);
+    if (tw > 8) tw = 8;
+    int th = next_pow2(H);
+    if (th > 64 / tw) th = 64 / tw;
+    const int tb = 64 / (tw * th);
+    g.tw_log2 = ilog2_exact(tw);
+    g.th_log2 = ilog2_exact(th);
+    g.tb_log2 = ilog2_exact(tb);
+    g.ntw = cdiv(W, tw);
+    g.nth = cdiv(H, th);
+    g.ntb = cdiv(B, tb);
+  }
   const int ntiles = g.ntb * g.nth * g.ntw;
   const long long out_tiles = (long long)cdiv(Co, c.TCO) * cdiv(Ci, c.TCI);
   long long ns = (512 + out_tiles - 1) / out_tiles;  // one resident wave of blocks (2 per CU at 2 waves per SIMD)
   if (ns > ntiles) ns = ntiles;
-  const long long bytes_per = (long long)Co * Ci * ks * ks * 4;
+  const long long bytes_per = (long long)Co * Ci * ks_taps(ks) * 4;
   while (ns > 1 && ns * bytes_per > (96ll << 20)) --ns;
   if (ns < 1) ns = 1;
   if (ntiles_out) *ntiles_out = ntiles;
@@ -392,18 +413,18 @@ int wg_slices(int B, int Ci, int Co, int H, int W, int ks, int* ntiles_out, Tile
   return (int)ns;
 }
 
-template <int KS, int WCO, int WCI, int WVCO, int WVCI, int WVT, int MAXX, bool PRO, int MINW>
+template <int KS, int WCO, int WCI, int WVCO, int WVCI, int WVT, int MAXX, bool PRO, int MINW, int KW = KS>
 int launch_wg(Bf16WgArgs& a, const TileGeom& g, hipStream_t stream) {
   constexpr int NT = WVCO * WVCI * WVT * 64;
-  constexpr int P = KS / 2;
+  constexpr int P = KS / 2, PW = KW / 2;
   constexpr int TCO = WVCO * WCO * 32, TCI = WVCI * WCI * 32;
-  const int plane = (1 << g.tb_log2) * ((1 << g.th_log2) + 2 * P) * ((1 << g.tw_log2) + 2 * P);
+  const int plane = (1 << g.tb_log2) * ((1 << g.th_log2) + 2 * P) * ((1 << g.tw_log2) + 2 * PW);
   const int nxv = (TCI / 32) * plane * 4;
   if (nxv > MAXX * NT) return SIVAE_ERR_SHAPE;
   const size_t lds = (size_t)((TCO / 32) * 64 * 4 + nxv) * 16 + (PRO ? (size_t)(TCI / 8) * 64 : 0);
   const long long nblk = (long long)a.n_co_tiles * a.n_ci_tiles * a.nslices;
   if (nblk > 0x7fffffffLL) return SIVAE_ERR_RANGE;
-  auto kern = bf16_wgrad_kernel<KS, WCO, WCI, WVCO, WVCI, WVT, MAXX, PRO, MINW>;
+  auto kern = bf16_wgrad_kernel<KS, WCO, WCI, WVCO, WVCI, WVT, MAXX, PRO, MINW, KW>;
   static size_t lds_hwm = 0;
   const int rc_lds = sivae_ensure_lds(reinterpret_cast<const void*>(kern), lds, &lds_hwm);
   if (rc_lds != SIVAE_OK) return rc_lds;
@@ -414,9 +435,9 @@ int launch_wg(Bf16WgArgs& a, const TileGeom& g, hipStream_t stream) {
 }  // namespace
 
 extern "C" size_t sivae_bf16_conv2d_wgrad_workspace_bytes(int B, int Ci, int Co, int H, int W, int ks) {
-  if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0 || (ks != 1 && ks != 3 && ks != 5)) return 0;
+  if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0 || !ks_ok(ks)) return 0;
   const int ns = wg_slices(B, Ci, Co, H, W, ks, nullptr, nullptr);
-  return (size_t)ns * Co * Ci * ks * ks * sizeof(float);
+  return (size_t)ns * Co * Ci * ks_taps(ks) * sizeof(float);
 }
 
 extern "C" int sivae_bf16_conv2d_wgrad(const void* x, const void* dy, float* dw, const float* pro_mean,
@@ -425,7 +446,7 @@ extern "C" int sivae_bf16_conv2d_wgrad(const void* x, const void* dy, float* dw,
                                        void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!x || !dy || !dw || !workspace) return SIVAE_ERR_NULL;
   if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
-  if (ks != 1 && ks != 3 && ks != 5) return SIVAE_ERR_KSIZE;
+  if (!ks_ok(ks)) return SIVAE_ERR_KSIZE;
   if (upsample && ((H & 1) || (W & 1))) return SIVAE_ERR_SHAPE;
   if (pro_mean && (!pro_invstd || !pro_gamma || !pro_beta)) return SIVAE_ERR_NULL;
   if (pro_mean && ks != 3) return SIVAE_ERR_MODE;
@@ -458,7 +479,7 @@ extern "C" int sivae_bf16_conv2d_wgrad(const void* x, const void* dy, float* dw,
   a.ntb = g.ntb;
   a.nth = g.nth;
   a.ntw = g.ntw;
-  const WgCfg c = wg_cfg(ks);
+  const WgCfg c = wg_cfg(ks, Co);
   a.n_co_tiles = cdiv(Co, c.TCO);
   a.n_ci_tiles = cdiv(Ci, c.TCI);
   int rc;
@@ -467,10 +488,14 @@ extern "C" int sivae_bf16_conv2d_wgrad(const void* x, const void* dy, float* dw,
                   : launch_wg<3, 1, 1, 2, 2, 1, 5, false, 2>(a, g, stream);
   } else if (ks == 1) {
     rc = launch_wg<1, 2, 2, 2, 2, 1, 4, false, 2>(a, g, stream);
+  } else if (ks == 51) {
+    rc = Co <= 32 ? launch_wg<5, 1, 1, 1, 2, 2, 6, false, 2, 1>(a, g, stream)
+                  : launch_wg<5, 1, 1, 2, 1, 2, 4, false, 2, 1>(a, g, stream);
   } else {
     rc = launch_wg<5, 1, 1, 1, 1, 4, 4, false, 2>(a, g, stream);
   }
   if (rc != SIVAE_OK) return rc;
+  if (ks == 51) return launch_wg_reduce<5>(a.part, dw, a.nslices, Co, Ci, stream);
   if (ks == 3) return launch_wg_reduce<9>(a.part, dw, a.nslices, Co, Ci, stream);
   if (ks == 1) return launch_wg_reduce<1>(a.part, dw, a.nslices, Co, Ci, stream);
   return launch_wg_reduce<25>(a.part, dw, a.nslices, Co, Ci, stream);

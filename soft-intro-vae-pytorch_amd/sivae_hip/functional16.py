@@ -28,16 +28,48 @@ MATERIALIZE_H = os.environ.get("SIVAE_BF16_MATERIALIZE_H", "1") != "0"
 SIGNMASK = os.environ.get("SIVAE_BF16_SIGNMASK", "1") != "0"
 
 
-def packed16(w, mode):
+# kw-packed form of the RGB-side 5x5 layers (ops16.im2col_kw5 / fold_kw5, ks code 51): SIVAE_BF16_KWPACK=0 runs them
+# as padded 25-tap convs (A/B measurements)
+KWPACK = os.environ.get("SIVAE_BF16_KWPACK", "1") != "0"
+
+
+def _virtual(w, virt):
+    """the [*, *, 5, 1] weight of the 5-tap conv that stands for a 5x5 layer with <= 3 channels on one side
+    (W = w[co][ci][kh][kw];  j = kw*C + c with c the index of the narrow side)"""
+    if virt == "in":        # narrow input, forward:        V[co][j][kh]  = W[co][ci][kh][kw]
+        v = w.permute(0, 3, 1, 2).reshape(w.shape[0], 5 * w.shape[1], 5, 1)
+    elif virt == "in_d":    # narrow input, data gradient:  V[j][co][kh'] = W[co][ci][4-kh'][kw]
+        v = w.flip(2).permute(3, 1, 0, 2).reshape(5 * w.shape[1], w.shape[0], 5, 1)
+    elif virt == "out":     # narrow output, forward:       V[j][ci][kh]  = W[co][ci][kh][kw]
+        v = w.permute(3, 0, 1, 2).reshape(5 * w.shape[0], w.shape[1], 5, 1)
+    elif virt == "out_d":   # narrow output, data gradient: V[ci][j][kh'] = W[co][ci][4-kh'][kw]
+        v = w.flip(2).permute(1, 3, 0, 2).reshape(w.shape[1], 5 * w.shape[0], 5, 1)
+    else:
+        raise ValueError(virt)
+    return v.contiguous()
+
+
+def _unpack_dw(dwv, Co, Ci, virt):
+    """gradient of the virtual weight ([.., .., 5, 1] from the ks-51 weight-gradient kernel) -> [Co][Ci][kh][kw]"""
+    if virt == "in":    # [Co][kw*Ci + ci][kh]
+        return dwv.view(Co, 5, Ci, 5).permute(0, 2, 3, 1).contiguous()
+    return dwv.view(5, Co, Ci, 5).permute(1, 2, 3, 0).contiguous()  # "out": [kw*Co + co][Ci][kh]
+
+
+def packed16(w, mode, virt=None):
     """bf16 operand slabs of a master weight, cached ON the parameter (dies with it) and rebuilt when it changes"""
     tag = (w._version, getattr(w, "_sivae_gen", 0), w.data_ptr(), SF.cache_epoch())
     store = w.__dict__.setdefault("_sivae_pack16", {})
-    hit = store.get(mode)
+    hit = store.get((mode, virt))
     if hit is not None and hit[0] == tag:
         return hit[1]
-    wp = ops16.PackedW16(w.detach(), mode)
-    store[mode] = (tag, wp)
+    wp = ops16.PackedW16(w.detach() if virt is None else _virtual(w.detach(), virt), mode)
+    store[(mode, virt)] = (tag, wp)
     return wp
+
+
+def _kwpack_ok(w, narrow):
+    return KWPACK and w.dim() == 4 and tuple(w.shape[2:]) == (5, 5) and 5 * narrow <= 16
 
 
 class ToBlockedFn(torch.autograd.Function):
@@ -180,40 +212,58 @@ class ResBlockFn16(torch.autograd.Function):
 
 
 class StemFn16(torch.autograd.Function):
-    """conv5x5 -> BatchNorm -> LeakyReLU -> AvgPool2d(2) (train_soft_intro_vae.py:88-93); x: blocked image batch"""
+    """conv5x5 -> BatchNorm -> LeakyReLU -> AvgPool2d(2) (train_soft_intro_vae.py:88-93).  x: the fp32 NCHW image batch;
+    out: blocked bf16.  With <= 3 image channels the conv runs kw-packed (5 taps over 5C channels)."""
 
     @staticmethod
     def forward(ctx, x, w, g, b, st):
-        B, _, H, W, _ = x.shape
-        Co, Ci = w.shape[0], w.shape[1]
-        if st.training:
-            a, p = ops16.conv2d(x, packed16(w, 0), Ci, Co, 5, want_stats=True)
+        B, Ci, H, W = x.shape
+        Co = w.shape[0]
+        ctx.kw = _kwpack_ok(w, Ci)
+        if ctx.kw:
+            xb, wp, ci_eff, ks = ops16.im2col_kw5(x.contiguous(), +1), packed16(w, 0, "in"), 5 * Ci, ops16.KS51
         else:
-            a, p = ops16.conv2d(x, packed16(w, 0), Ci, Co, 5), None
+            xb, wp, ci_eff, ks = ops16.from_f32(x.contiguous()), packed16(w, 0), Ci, w.shape[2]
+        if st.training:
+            a, p = ops16.conv2d(xb, wp, ci_eff, Co, ks, want_stats=True)
+        else:
+            a, p = ops16.conv2d(xb, wp, ci_eff, Co, ks), None
         mean, invstd = SF._stats(p, B, Co, H * W, st)
         _, out = ops16.bn_apply_act(a, None, mean, invstd, g.detach(), b.detach(), Co, SLOPE, want_full=False,
                                     pool=True)
         ctx.training = st.training
-        ctx.save_for_backward(x, a, mean, invstd, w, g, b)
+        ctx.Ci = Ci
+        ctx.save_for_backward(xb, a, mean, invstd, w, g, b)
         return out
 
     @staticmethod
     def backward(ctx, dy):
         if not ctx.training:
             raise RuntimeError("sivae_hip: backward through eval-mode BatchNorm is not supported")
-        x, a, mean, invstd, w, g, b = ctx.saved_tensors
+        xb, a, mean, invstd, w, g, b = ctx.saved_tensors
         need = ctx.needs_input_grad
-        Co, Ci = w.shape[0], w.shape[1]
+        Co, Ci, ks = w.shape[0], ctx.Ci, w.shape[2]
         da, _, dg, db = ops16.bn_bwd(dy.contiguous(), None, a, mean, invstd, g, b, Co, SLOPE, dy_pooled=True,
                                      want_param_grads=need[2] or need[3])
-        dw = ops16.conv2d_wgrad(x, da, Ci, Co, 5) if need[1] else None
-        dx = ops16.conv2d(da, packed16(w, 1), Co, Ci, 5) if need[0] else None
+        dw = dx = None
+        if ctx.kw:
+            if need[1]:
+                dw = _unpack_dw(ops16.conv2d_wgrad(xb, da, 5 * Ci, Co, ops16.KS51), Co, Ci, "in")
+            if need[0]:
+                gk = ops16.conv2d(da, packed16(w, 0, "in_d"), Co, 5 * Ci, ops16.KS51, out_f32=True)
+                dx = ops16.fold_kw5(gk, None, Ci, -1)
+        else:
+            if need[1]:
+                dw = ops16.conv2d_wgrad(xb, da, Ci, Co, ks)
+            if need[0]:
+                dx = ops16.to_f32(ops16.conv2d(da, packed16(w, 1), Co, Ci, ks), Ci)
         return dx, dw, dg if need[2] else None, db if need[3] else None, None
 
 
 class PredictFn16(torch.autograd.Function):
     """Decoder.predict (conv5x5 + bias, train_soft_intro_vae.py:159): blocked bf16 in, fp32 NCHW out (the
-    reconstruction feeds the fp32 loss kernels directly)"""
+    reconstruction feeds the fp32 loss kernels directly).  With <= 3 image channels the conv runs kw-packed (5 taps into
+    5C fp32 channels, then the column fold adds the bias)."""
 
     @staticmethod
     def forward(ctx, x, w, bias, cache=None):
@@ -223,7 +273,12 @@ class PredictFn16(torch.autograd.Function):
         if cache is not None and cache.get("y") is not None and cache.get("tag") == tag:
             return cache["y"].view_as(cache["y"])
         Co, Ci, ks = w.shape[0], w.shape[1], w.shape[2]
-        y = ops16.conv2d(x, packed16(w, 0), Ci, Co, ks, bias=None if bias is None else bias.detach(), out_f32=True)
+        bv = None if bias is None else bias.detach()
+        if _kwpack_ok(w, Co):
+            yk = ops16.conv2d(x, packed16(w, 0, "out"), Ci, 5 * Co, ops16.KS51, out_f32=True)
+            y = ops16.fold_kw5(yk, bv, Co, +1)
+        else:
+            y = ops16.conv2d(x, packed16(w, 0), Ci, Co, ks, bias=bv, out_f32=True)
         if cache is not None:
             cache["y"], cache["tag"] = y, tag
         return y
@@ -234,10 +289,18 @@ class PredictFn16(torch.autograd.Function):
         need = ctx.needs_input_grad
         Co, Ci, ks = w.shape[0], w.shape[1], w.shape[2]
         dy = dy.contiguous()
-        dyb = ops16.from_f32(dy)
-        dw = ops16.conv2d_wgrad(x, dyb, Ci, Co, ks) if need[1] else None
         db = ops.channel_sum(dy) if (ctx.has_bias and need[2]) else None
-        dx = ops16.conv2d(dyb, packed16(w, 1), Co, Ci, ks) if need[0] else None
+        dw = dx = None
+        if _kwpack_ok(w, Co):
+            dyk = ops16.im2col_kw5(dy, -1)                                       # [kw*Co + co][h][w] = dy[co][h][w-kw+2]
+            if need[1]:
+                dw = _unpack_dw(ops16.conv2d_wgrad(x, dyk, Ci, 5 * Co, ops16.KS51), Co, Ci, "out")
+            if need[0]:
+                dx = ops16.conv2d(dyk, packed16(w, 0, "out_d"), 5 * Co, Ci, ops16.KS51)
+        else:
+            dyb = ops16.from_f32(dy)
+            dw = ops16.conv2d_wgrad(x, dyb, Ci, Co, ks) if need[1] else None
+            dx = ops16.conv2d(dyb, packed16(w, 1), Co, Ci, ks) if need[0] else None
         return dx, dw, db, None
 
 

@@ -73,10 +73,12 @@ def _block_weights(m):
     return ()
 
 
-def _run_main(main, x, cache=None):
+def _run_main(main, x, cache=None, bf16=None):
     """Walk a reference-shaped nn.Sequential, dispatching each group of layers to its fused HIP block.
-    x: fp32 NCHW, or a blocked bf16 activation (bf16 mode): the blocks dispatch on the input dtype."""
-    bf16 = x.dtype == torch.bfloat16
+    x: fp32 NCHW, or a blocked bf16 activation (bf16 mode): the blocks dispatch on the input dtype unless `bf16` says
+    otherwise (the bf16 encoder hands its stem the fp32 image)."""
+    if bf16 is None:
+        bf16 = x.dtype == torch.bfloat16
     F_ = SF16 if bf16 else SF
     mods = list(main.children())
     i, n = 0, len(mods)
@@ -176,7 +178,8 @@ class Encoder(nn.Module):
 
     def forward(self, x, o_cond=None):
         if self.compute_dtype == "bf16":
-            y = SF16.from_blocked(_run_main(self.main, SF16.to_blocked(x)), self.conv_output_size[0])
+            # (the stem takes the fp32 image itself: it chooses the operand layout of the 5x5 conv)
+            y = SF16.from_blocked(_run_main(self.main, x, bf16=True), self.conv_output_size[0])
             y = y.reshape(x.size(0), -1)
         else:
             y = _run_main(self.main, x).reshape(x.size(0), -1)

@@ -16,6 +16,13 @@ LRELU_SLOPE = ops.LRELU_SLOPE
 TIMER_KEYS = True
 
 
+KS51 = 51  # ks code of the 5-row x 1-column conv (kw-packed RGB-side layers, include/sivae_hip.h)
+
+
+def _taps(ks):
+    return 5 if ks == KS51 else ks * ks
+
+
 def cblocks(C):
     return ((C + 15) // 16) * 2
 
@@ -57,6 +64,25 @@ def to_f32(xb, C):
     return y
 
 
+def im2col_kw5(x, sgn):
+    """fp32 NCHW [B, C<=3, H, W] -> blocked bf16 16 channels: [kw*C + c][h][w] = x[c][h][w + sgn*(kw-2)]"""
+    ops._require(x)
+    B, C, H, W = x.shape
+    y = empty_blocked(B, 16, H, W, x.device)
+    _lib.call("sivae_bf16_im2col_kw5", _p(x), _p(y), B, C, H, W, int(sgn), _s(x))
+    return y
+
+
+def fold_kw5(g, bias, C, sgn):
+    """fp32 NCHW [B, 5C, H, W] -> fp32 NCHW [B, C, H, W]: bias[c] + sum_kw g[kw*C + c][h][w + sgn*(kw-2)]"""
+    ops._require(g, bias)
+    B, C5, H, W = g.shape
+    assert C5 == 5 * C
+    y = torch.empty((B, C, H, W), dtype=torch.float32, device=g.device)
+    _lib.call("sivae_bf16_fold_kw5", _p(g), _p(bias), _p(y), B, C, H, W, int(sgn), _s(g))
+    return y
+
+
 class PackedW16:
     """bf16 MFMA-operand slabs of one fp32 master weight (mode 0 forward, 1 data gradient)"""
 
@@ -66,6 +92,10 @@ class PackedW16:
             Co, Ci, ks = w.shape[0], w.shape[1], 1
         else:
             Co, Ci, ks = w.shape[0], w.shape[1], w.shape[2]
+            if w.shape[3] != w.shape[2]:
+                if tuple(w.shape[2:]) != (5, 1):
+                    raise _lib.SivaeError("sivae_bf16_pack_conv_weight", -4)
+                ks = KS51
         self.Co, self.Ci, self.ks, self.mode = Co, Ci, ks, mode
         nbytes = _lib.load().sivae_bf16_pack_conv_weight_bytes(Co, Ci, ks, mode)
         if nbytes == 0:
@@ -115,18 +145,18 @@ def conv2d(x, wp, Ci, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
                   int(bool(out_f32)), _s(x))
     if t0 is not None:
         ops.TIMER.end("bf16_conv_kernel<%d,%s>" % (ks, "co32" if Co <= 32 else ("co64" if Co <= 64 else "co128")),
-                      2.0 * B * H * W * Co * Ci * ks * ks, t0)
+                      2.0 * B * H * W * Co * Ci * _taps(ks), t0)
     return (y, stats) if want_stats else y
 
 
 def conv2d_wgrad(x, dy, Ci, Co, ks, pro=None, upsample=False):
-    """-> dW fp32 [Co, Ci, ks, ks]"""
+    """-> dW fp32 [Co, Ci, ks, ks]  ([Co, Ci, 5, 1] for ks = KS51)"""
     _req16(x, dy)
     B, Cob, H, W, _ = dy.shape
     assert Cob == cblocks(Co) and x.shape[1] == cblocks(Ci)
     L = _lib.load()
     ws = ops.workspace(L.sivae_bf16_conv2d_wgrad_workspace_bytes(B, Ci, Co, H, W, ks), x.device)
-    dw = torch.empty((Co, Ci, ks, ks), dtype=torch.float32, device=x.device)
+    dw = torch.empty((Co, Ci, 5, 1) if ks == KS51 else (Co, Ci, ks, ks), dtype=torch.float32, device=x.device)
     pm = pi = pg = pb = None
     slope = 1.0
     if pro is not None:
@@ -136,7 +166,7 @@ def conv2d_wgrad(x, dy, Ci, Co, ks, pro=None, upsample=False):
     _lib.call("sivae_bf16_conv2d_wgrad", _p(x), _p(dy), _p(dw), _p(pm), _p(pi), _p(pg), _p(pb), float(slope), B, Ci,
               Co, H, W, ks, int(bool(upsample)), _p(ws), ws.numel(), _s(x))
     if t0 is not None:
-        ops.TIMER.end("bf16_wgrad_kernel<%d>" % ks, 2.0 * B * H * W * Co * Ci * ks * ks, t0)
+        ops.TIMER.end("bf16_wgrad_kernel<%d>" % ks, 2.0 * B * H * W * Co * Ci * _taps(ks), t0)
     return dw
 
 

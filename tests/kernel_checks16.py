@@ -94,7 +94,16 @@ CONV16_SHAPES = [
     (3, 3, 64, 32, 32, 5),    # encoder stem
     (2, 64, 3, 32, 32, 5),    # decoder predict
     (2, 1, 64, 28, 28, 5),
+    (3, 15, 64, 32, 32, 51),  # kw-packed stem (5 taps over 5*3 channels)
+    (2, 64, 15, 32, 32, 51),  # kw-packed predict
+    (2, 15, 32, 24, 40, 51),
+    (2, 32, 5, 28, 28, 51),
 ]
+
+
+def _khw(ks):
+    """ks code 51 = 5 rows x 1 column (kw-packed RGB-side layers)"""
+    return (5, 1) if ks == 51 else (ks, ks)
 
 
 def check_convert():
@@ -112,10 +121,11 @@ def check_convert():
 def check_conv(shape, bias=False, stats=False, out_f32=False):
     from sivae_hip import ops16
     B, Ci, Co, H, W, ks = shape
+    kh, kw = _khw(ks)
     x = _r16(_rand(B, Ci, H, W, seed=1))
-    w = _rand(Co, Ci, ks, ks, seed=2, scale=1.0 / (Ci * ks * ks) ** 0.5)
+    w = _rand(Co, Ci, kh, kw, seed=2, scale=1.0 / (Ci * kh * kw) ** 0.5)
     b = _rand(Co, seed=3) if bias else None
-    ref = F.conv2d(x, _r16(w), b.float().double() if bias else None, padding=ks // 2)
+    ref = F.conv2d(x, _r16(w), b.float().double() if bias else None, padding=(kh // 2, kw // 2))
     wp = ops16.PackedW16(w.float().to(DEV), 0)
     out = ops16.conv2d(to_blocked(x).to(DEV), wp, Ci, Co, ks, bias=None if b is None else b.float().to(DEV),
                        want_stats=stats, out_f32=out_f32)
@@ -140,9 +150,10 @@ def check_conv(shape, bias=False, stats=False, out_f32=False):
 def check_conv_dgrad(shape):
     from sivae_hip import ops16
     B, Ci, Co, H, W, ks = shape
+    kh, kw = _khw(ks)
     dy = _r16(_rand(B, Co, H, W, seed=4))
-    w = _rand(Co, Ci, ks, ks, seed=2, scale=1.0 / (Ci * ks * ks) ** 0.5)
-    ref = F.conv_transpose2d(dy, _r16(w), padding=ks // 2)
+    w = _rand(Co, Ci, kh, kw, seed=2, scale=1.0 / (Ci * kh * kw) ** 0.5)
+    ref = F.conv_transpose2d(dy, _r16(w), padding=(kh // 2, kw // 2))
     wp = ops16.PackedW16(w.float().to(DEV), 1)
     dx = ops16.conv2d(to_blocked(dy).to(DEV), wp, Co, Ci, ks)
     return [("dgrad16%s" % (shape,), _err16(from_blocked(dx, Ci), ref), TOL_BF16)]
@@ -167,7 +178,8 @@ def check_conv_wgrad(shape, pro=False, upsample=False):
         prot = tuple(t.float().to(DEV) for t in (mean, invstd, gamma, beta)) + (SLOPE,)
     if upsample:
         xin = F.interpolate(xin, scale_factor=2, mode="nearest")
-    ref = torch.nn.grad.conv2d_weight(xin, (Co, Ci, ks, ks), dy, padding=ks // 2)
+    kh, kw = _khw(ks)
+    ref = torch.nn.grad.conv2d_weight(xin, (Co, Ci, kh, kw), dy, padding=(kh // 2, kw // 2))
     dw = ops16.conv2d_wgrad(to_blocked(x).to(DEV), to_blocked(dy).to(DEV), Ci, Co, ks, pro=prot, upsample=upsample)
     return [("wgrad16%s%s%s" % (shape, "+pro" if pro else "", "+up" if upsample else ""), _err(dw, ref),
              1e-3 if pro else TOL_F32)]
@@ -326,13 +338,80 @@ def check_splitk16():
     return res
 
 
+def check_kwpack(C, Cw, H, W, B=2):
+    """kw-packed form of the RGB-side 5x5 layers (C <= 3 image channels, Cw feature channels), each piece against the
+    plain 5x5 op of torch on the same bf16-rounded operands: im2col / fold kernels, stem forward / weight gradient /
+    input gradient, predict forward / weight gradient / input gradient — through the SAME virtual-weight and
+    gradient-unpacking helpers the autograd blocks use (functional16._virtual / _unpack_dw)."""
+    from sivae_hip import functional16 as SF16
+    from sivae_hip import ops16
+    res = []
+    tag = "kwpack(C=%d,Cw=%d,%dx%d) " % (C, Cw, H, W)
+    img = _rand(B, C, H, W, seed=1)
+    # ---- layout kernels against their definition
+    for sgn in (+1, -1):
+        ref = torch.zeros(B, 16, H, W, dtype=torch.float64)
+        for kw in range(5):
+            for w_ in range(W):
+                ws = w_ + sgn * (kw - 2)
+                if 0 <= ws < W:
+                    ref[:, kw * C:(kw + 1) * C, :, w_] = img[:, :, :, ws]
+        got = ops16.im2col_kw5(img.float().to(DEV), sgn)
+        res.append((tag + "im2col sgn%+d" % sgn, _err(from_blocked(got, 16), _r16(ref)), 0.0))
+        g = _rand(B, 5 * C, H, W, seed=2).float()
+        bias = _rand(C, seed=3).float()
+        reff = bias.double().view(1, C, 1, 1).expand(B, C, H, W).clone()
+        for kw in range(5):
+            for w_ in range(W):
+                ws = w_ + sgn * (kw - 2)
+                if 0 <= ws < W:
+                    reff[:, :, :, w_] += g.double()[:, kw * C:(kw + 1) * C, :, ws]
+        got = ops16.fold_kw5(g.to(DEV), bias.to(DEV), C, sgn)
+        res.append((tag + "fold sgn%+d" % sgn, _err(got, reff), 1e-6))
+    # ---- stem (C -> Cw): forward, weight gradient, input gradient
+    w = _rand(Cw, C, 5, 5, seed=4, scale=1.0 / (C * 25) ** 0.5)
+    wd = w.float().to(DEV)
+    x16 = _r16(img)
+    xk = ops16.im2col_kw5(img.float().to(DEV), +1)
+    y = ops16.conv2d(xk, ops16.PackedW16(SF16._virtual(wd, "in"), 0), 5 * C, Cw, ops16.KS51)
+    res.append((tag + "stem fwd", _err16(from_blocked(y, Cw), F.conv2d(x16, _r16(w), padding=2)), TOL_BF16))
+    da = _r16(_rand(B, Cw, H, W, seed=5))
+    dab = to_blocked(da).to(DEV)
+    dw = SF16._unpack_dw(ops16.conv2d_wgrad(xk, dab, 5 * C, Cw, ops16.KS51), Cw, C, "in")
+    res.append((tag + "stem wgrad", _err(dw, torch.nn.grad.conv2d_weight(x16, (Cw, C, 5, 5), da, padding=2)), TOL_F32))
+    gk = ops16.conv2d(dab, ops16.PackedW16(SF16._virtual(wd, "in_d"), 0), Cw, 5 * C, ops16.KS51, out_f32=True)
+    dx = ops16.fold_kw5(gk, None, C, -1)
+    res.append((tag + "stem dgrad", _err(dx, F.conv_transpose2d(da, _r16(w), padding=2)), TOL_F32))
+    # ---- predict (Cw -> C): forward (+ bias, fp32 out), weight gradient, input gradient
+    wp = _rand(C, Cw, 5, 5, seed=6, scale=1.0 / (Cw * 25) ** 0.5)
+    wpd = wp.float().to(DEV)
+    bias = _rand(C, seed=7).float()
+    xf = _r16(_rand(B, Cw, H, W, seed=8))
+    xfb = to_blocked(xf).to(DEV)
+    yk = ops16.conv2d(xfb, ops16.PackedW16(SF16._virtual(wpd, "out"), 0), Cw, 5 * C, ops16.KS51, out_f32=True)
+    yp = ops16.fold_kw5(yk, bias.to(DEV), C, +1)
+    res.append((tag + "predict fwd", _err(yp, F.conv2d(xf, _r16(wp), bias.double(), padding=2)), TOL_F32))
+    dy = _rand(B, C, H, W, seed=9)
+    dyk = ops16.im2col_kw5(dy.float().to(DEV), -1)
+    dwp = SF16._unpack_dw(ops16.conv2d_wgrad(xfb, dyk, Cw, 5 * C, ops16.KS51), C, Cw, "out")
+    res.append((tag + "predict wgrad",
+                _err(dwp, torch.nn.grad.conv2d_weight(xf, (C, Cw, 5, 5), _r16(dy), padding=2)), TOL_F32))
+    dxp = ops16.conv2d(dyk, ops16.PackedW16(SF16._virtual(wpd, "out_d"), 0), 5 * C, Cw, ops16.KS51)
+    res.append((tag + "predict dgrad",
+                _err16(from_blocked(dxp, Cw), F.conv_transpose2d(_r16(dy), _r16(wp), padding=2)), TOL_BF16))
+    return res
+
+
 def all_checks():
     checks = [("convert16", check_convert)]
+    for cfg in [(3, 64, 32, 32), (3, 32, 24, 40), (1, 64, 28, 28), (2, 48, 9, 7)]:
+        checks.append(("kwpack%s" % (cfg,), lambda cfg=cfg: check_kwpack(*cfg)))
     for s in CONV16_SHAPES:
         checks.append(("conv16%s" % (s,), lambda s=s: check_conv(s)))
         checks.append(("dgrad16%s" % (s,), lambda s=s: check_conv_dgrad(s)))
         checks.append(("wgrad16%s" % (s,), lambda s=s: check_conv_wgrad(s)))
     checks.append(("conv16_bias_f32out", lambda: check_conv((2, 64, 3, 32, 32, 5), bias=True, out_f32=True)
+                   + check_conv((2, 64, 15, 32, 32, 51), out_f32=True)
                    + check_conv((2, 64, 3, 16, 16, 5), bias=True)))
     checks.append(("conv16_stats", lambda: check_conv((3, 64, 128, 32, 32, 3), stats=True)
                    + check_conv((3, 64, 64, 32, 32, 3), stats=True) + check_conv((3, 24, 40, 12, 12, 3), stats=True)
