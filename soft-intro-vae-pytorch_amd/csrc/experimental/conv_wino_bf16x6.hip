@@ -62,16 +62,24 @@ struct B6Args {
 #else
 #define B6_FREQ_FENCE
 #endif
-#define B6_EX_FLOATS (2 * 4 * 2 * 16 * 64)
+#ifndef B6_WM
+#define B6_WM 2  // 32-channel output subtiles per wave
+#endif
+#define B6_EX_FLOATS (2 * 4 * B6_WM * 16 * 64)
 
 template <int TTH_L2, int TTW_L2>
 __global__ void __launch_bounds__(256, B6_OCC) conv_wino_b6_kernel(B6Args a) {
   constexpr int TTH = 1 << TTH_L2, TTW = 1 << TTW_L2;
   static_assert(TTH * TTW == 32, "one image per 32-tile block in this experiment");
-  constexpr int WM = 2, NW = 4;
+  constexpr int WM = B6_WM, NW = 4;
   constexpr int PXH = 2 * TTH, PXW = 2 * TTW;
   constexpr int LH = PXH + 2, LWU = PXW + 2;
+#ifdef B6_LDSDIRECT
+  constexpr int PH = TTW + TTW / 4, RS = 2 * PH, PLANE = 256;  // plane slot == staging thread (LDS-direct loads)
+  static_assert(LH * RS <= 256, "halo plane fits one slot per thread");
+#else
   constexpr int PH = TTW + TTW / 4, RS = 2 * PH, PLANE = LH * RS;
+#endif
   constexpr int NPOS = LH * LWU;
   static_assert(NPOS <= 256, "one halo position per thread");
   constexpr int CK = B6_CK, XBUF = CK * PLANE;
@@ -91,9 +99,16 @@ __global__ void __launch_bounds__(256, B6_OCC) conv_wino_b6_kernel(B6Args a) {
   __amdgpu_buffer_rsrc_t xrsrc;
   const __amdgpu_buffer_rsrc_t ursrc = make_rsrc(a.up, 96ull * a.Ci_pad * a.Co_pad);
   unsigned xo, ua_base;
+#ifdef B6_LDSDIRECT
+  // thread t stages plane slot t = xrr*RS + parity*PH + col/2 (slots outside the halo load nothing: OOB -> 0)
+  const int xrr = tid / RS, xcc = 2 * ((tid % RS) % PH) + (tid % RS) / PH;
+  const bool xslot = xrr < LH && xcc < LWU;
+#else
   const int teff = tid % NPOS;
   const int xrr = teff / LWU, xcc = teff % LWU;
   const int xl = xrr * RS + (xcc & 1) * PH + (xcc >> 1);
+  const bool xslot = true;
+#endif
 #define B6_SETUP(ITEM)                                                   \
   {                                                                      \
     const int co_tile = (ITEM) % a.n_co_tiles;                           \
@@ -104,11 +119,11 @@ __global__ void __launch_bounds__(256, B6_OCC) conv_wino_b6_kernel(B6Args a) {
     b = t2 / a.nbh;                                                      \
     r0 = tby * PXH;                                                      \
     c0 = tbx * PXW;                                                      \
-    co0 = co_tile * 64;                                                  \
+    co0 = co_tile * 32 * WM;                                                 \
     xrsrc = make_rsrc(a.x + (size_t)b * a.Ci * HW, (unsigned long long)a.Ci * HW * 4ull); \
     const int r = r0 + xrr - 1, c = c0 + xcc - 1;                        \
     xo = OOB;                                                            \
-    if (r >= 0 && r < H && c >= 0 && c < W) xo = (unsigned)(r * W + c) * 4u; \
+    if (xslot && r >= 0 && r < H && c >= 0 && c < W) xo = (unsigned)(r * W + c) * 4u; \
     ua_base = (unsigned)(wj * nch * 24) * (unsigned)a.Co_pad * 16u + (unsigned)co0 * 16u; \
   }
 
@@ -126,8 +141,17 @@ __global__ void __launch_bounds__(256, B6_OCC) conv_wino_b6_kernel(B6Args a) {
   const int base_b = bb + (cb & 1) * PH + (cb >> 1);
 
   f32x16 acc[4][WM];
+#ifndef B6_LDSDIRECT
   float xr0[CK], xr1[CK];  // halo staging registers of chunk c: set c & 1, requested TWO chunks ahead
-  u32x4 AR[2][WM][3];  // ring over frequency steps f = chunk * 4 + i: slot f & 1
+#else
+  const int xr0 = 0, xr1 = 0;
+  (void)xr0;
+  (void)xr1;
+#endif
+#ifndef B6_RING
+#define B6_RING 2
+#endif
+  u32x4 AR[B6_RING][WM][3];  // ring over frequency steps f = chunk * 4 + i: slot f % B6_RING
   const int nfsteps = nch * 4;
 
 #define B6_LOAD_X(CH, XR)                                                \
@@ -167,7 +191,7 @@ __global__ void __launch_bounds__(256, B6_OCC) conv_wino_b6_kernel(B6Args a) {
       bp[1][e] = p1;                                                     \
       bp[2][e] = p2;                                                     \
     }                                                                    \
-    constexpr int slot = (I)&1;                                          \
+    constexpr int slot = (I) % B6_RING;                                  \
     _Pragma("unroll") for (int m = 0; m < WM; ++m) {                     \
       const bf16x8 a0 = __builtin_bit_cast(bf16x8, AR[slot][m][0]);      \
       const bf16x8 a1 = __builtin_bit_cast(bf16x8, AR[slot][m][1]);      \
@@ -180,11 +204,28 @@ __global__ void __launch_bounds__(256, B6_OCC) conv_wino_b6_kernel(B6Args a) {
       acc[I][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bp[0], acc[I][m], 0, 0, 0); \
     }                                                                    \
     B6_FREQ_FENCE                                                        \
-    if ((CH)*4 + (I) + 2 < nfsteps) B6_LOAD_A((CH)*4 + (I) + 2, slot)    \
+    { /* unconditional refill (clamped past the end): a conditional one makes every wait assume NO younger loads */ \
+      const int fnext = (CH)*4 + (I) + B6_RING;                          \
+      B6_LOAD_A(fnext < nfsteps ? fnext : nfsteps - 1, slot)             \
+    }                                                                    \
   }
+#ifdef B6_LDSDIRECT
+#define B6_LOAD_LDS(CH, BUF)                                             \
+  {                                                                      \
+    _Pragma("unroll") for (int ck = 0; ck < CK; ++ck)                    \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(                          \
+          xrsrc, (float __attribute__((address_space(3)))*)(xs + (BUF)*XBUF + ck * PLANE + wave * 64), 4, xo, \
+          (unsigned)((CH)*CK + ck) * (unsigned)HW * 4u, 0, 0);           \
+  }
+#define B6_TOP(CH, BUF, NEXT, XCUR) if (NEXT) B6_LOAD_LDS((CH) + 1, (BUF) ^ 1)
+#define B6_BOTTOM(CH, BUF, NEXT, XNXT) __builtin_amdgcn_s_waitcnt(0x0F70);
+#else
+#define B6_TOP(CH, BUF, NEXT, XCUR) if ((CH) + 2 < nch) B6_LOAD_X((CH) + 2, XCUR)
+#define B6_BOTTOM(CH, BUF, NEXT, XNXT) if (NEXT) B6_STORE_X((CH) + 1, (BUF) ^ 1, XNXT)
+#endif
 #define B6_MMA(CH, BUF, NEXT, XCUR, XNXT)                                \
   {                                                                      \
-    if ((CH) + 2 < nch) B6_LOAD_X((CH) + 2, XCUR)                        \
+    B6_TOP(CH, BUF, NEXT, XCUR)                                          \
     float v[8][4];                                                       \
     _Pragma("unroll") for (int e = 0; e < 8; ++e) {                      \
       const float* pa = xs + (BUF)*XBUF + 2 * e * PLANE + base_a;        \
@@ -199,17 +240,25 @@ __global__ void __launch_bounds__(256, B6_OCC) conv_wino_b6_kernel(B6Args a) {
     B6_FREQ(CH, 0)                                                       \
     B6_FREQ(CH, 1)                                                       \
     B6_FREQ(CH, 2)                                                       \
-    if (NEXT) B6_STORE_X((CH) + 1, (BUF) ^ 1, XNXT)                      \
+    B6_BOTTOM(CH, BUF, NEXT, XNXT)                                       \
     __builtin_amdgcn_sched_barrier(0);                                   \
     B6_FREQ(CH, 3)                                                       \
     __syncthreads();                                                     \
   }
 
   B6_SETUP(item)
+#ifdef B6_LDSDIRECT
+  B6_LOAD_LDS(0, 0)
+#else
   B6_LOAD_X(0, xr0)
   if (nch > 1) B6_LOAD_X(1, xr1)
+#endif
   B6_LOAD_A(0, 0)
   B6_LOAD_A(1, 1)
+  if (B6_RING == 4) {
+    B6_LOAD_A(2, 2 % B6_RING)
+    B6_LOAD_A(3, 3 % B6_RING)
+  }
   for (;;) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -217,7 +266,11 @@ __global__ void __launch_bounds__(256, B6_OCC) conv_wino_b6_kernel(B6Args a) {
       for (int m = 0; m < WM; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][m][r] = 0.f;
+#ifdef B6_LDSDIRECT
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#else
     B6_STORE_X(0, 0, xr0)
+#endif
     __syncthreads();
     int ch = 0;
     for (; ch + 1 < nch; ch += 2) {
@@ -232,15 +285,21 @@ __global__ void __launch_bounds__(256, B6_OCC) conv_wino_b6_kernel(B6Args a) {
     const bool has_next = next < a.n_items;
     if (has_next) {
       B6_SETUP(next)
+#ifndef B6_LDSDIRECT
       B6_LOAD_X(0, xr0)
       if (nch > 1) B6_LOAD_X(1, xr1)
+#endif
       B6_LOAD_A(0, 0)
       B6_LOAD_A(1, 1)
+      if (B6_RING == 4) {
+        B6_LOAD_A(2, 2 % B6_RING)
+        B6_LOAD_A(3, 3 % B6_RING)
+      }
     }
     // ---- output transform (as conv_wino.hip): rows in registers, columns across the four waves through LDS
     {
       float* ex = smem;  // [2 ar][4 j][2 cg][16 r][64 lanes]
-      constexpr int PPW = 32 / NW;
+      constexpr int PPW = 16 * WM / NW;
       const __amdgpu_buffer_rsrc_t yrsrc =
           make_rsrc(a.y + (size_t)e_b * a.Co * HW, (unsigned long long)a.Co * HW * 4ull);
       const int row_base = e_r0 + 2 * ty, col = e_c0 + 2 * tx;
@@ -248,8 +307,8 @@ __global__ void __launch_bounds__(256, B6_OCC) conv_wino_b6_kernel(B6Args a) {
       for (int m = 0; m < WM; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          ex[((wj * 2 + m) * 16 + r) * 64 + lane] = acc[0][m][r] + acc[1][m][r] + acc[2][m][r];
-          ex[(((4 + wj) * 2 + m) * 16 + r) * 64 + lane] = acc[1][m][r] - acc[2][m][r] - acc[3][m][r];
+          ex[((wj * WM + m) * 16 + r) * 64 + lane] = acc[0][m][r] + acc[1][m][r] + acc[2][m][r];
+          ex[(((4 + wj) * WM + m) * 16 + r) * 64 + lane] = acc[1][m][r] - acc[2][m][r] - acc[3][m][r];
         }
       __syncthreads();
 #pragma unroll
@@ -261,7 +320,7 @@ __global__ void __launch_bounds__(256, B6_OCC) conv_wino_b6_kernel(B6Args a) {
         for (int ar = 0; ar < 2; ++ar) {
           float e[4];
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) e[jj] = ex[(((ar * 4 + jj) * 2 + (p >> 4)) * 16 + (p & 15)) * 64 + lane];
+          for (int jj = 0; jj < 4; ++jj) e[jj] = ex[(((ar * 4 + jj) * WM + (p >> 4)) * 16 + (p & 15)) * 64 + lane];
           const bool ok = yo != OOB && row_base + ar < H;
           buf_store_f32x2(yrsrc, e[0] + e[1] + e[2], e[1] - e[2] - e[3], ok ? yo + (unsigned)(ar * W) * 4u : OOB);
         }
@@ -269,6 +328,9 @@ __global__ void __launch_bounds__(256, B6_OCC) conv_wino_b6_kernel(B6Args a) {
       __syncthreads();
     }
     if (!has_next) break;
+#ifdef B6_LDSDIRECT
+    B6_LOAD_LDS(0, 0)
+#endif
     item = next;
   }
 }
@@ -331,9 +393,10 @@ static int run(int B, int Ci, int Co, int H, int W, bool check, int reps) {
   B6Args a;
   a.x = dx; a.up = dup; a.y = dy;
   a.B = B; a.Ci = Ci; a.Co = Co; a.H = H; a.W = W; a.Ci_pad = kpad; a.Co_pad = npad;
-  a.nbh = cdiv(H, 4); a.nbw = cdiv(W, 32); a.n_co_tiles = cdiv(Co, 64);
+  a.nbh = cdiv(H, 4); a.nbw = cdiv(W, 32); a.n_co_tiles = cdiv(Co, 32 * B6_WM);
   a.n_items = B * a.nbh * a.nbw * a.n_co_tiles;
-  const size_t lds = (size_t)B6_EX_FLOATS * 4;
+  const size_t lds_x = (size_t)2 * 16 * 256 * 4;  // two halo buffers (TTH = 2, TTW = 16)
+  const size_t lds = (size_t)B6_EX_FLOATS * 4 > lds_x ? (size_t)B6_EX_FLOATS * 4 : lds_x;
   auto kern = conv_wino_b6_kernel<1, 4>;
   CK_(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = a.n_items < 256 * B6_OCC ? a.n_items : 256 * B6_OCC;
@@ -379,7 +442,7 @@ static int run(int B, int Ci, int Co, int H, int W, bool check, int reps) {
 }
 
 int main(int argc, char** argv) {
-  if (run(2, 40, 72, 8, 32, true, 0)) return 1;   // ragged channels, two chunks + padding
+  if (run(2, 48, 72, 8, 32, true, 0)) return 1;   // ragged output channels, three chunks
   if (run(1, 64, 64, 12, 64, true, 0)) return 1;
   if (argc > 1) return 0;
   if (run(128, 256, 256, 64, 64, false, 5)) return 1;
