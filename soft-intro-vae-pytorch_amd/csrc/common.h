@@ -56,6 +56,19 @@ static inline TileGeom make_tile_geom(int B, int H, int W, int tpx /* pixels per
   return g;
 }
 
+// compute units of the current device (cached; 256 on an MI355X) — the persistent kernels size their grids by it
+static inline int sivae_num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  }
+  return cus;
+}
+
 #ifdef __HIPCC__
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E) — the index is usable in
 // `constexpr` / `if constexpr`, which keeps register arrays statically indexed in unrolled pipelines
