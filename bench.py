@@ -26,6 +26,7 @@ Prints ONE JSON line (rank 0). Besides the contract keys it carries
                 golden vectors) timed on this host's cores on a bounded sample of the same workload.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -132,18 +133,44 @@ def cpu_baseline(cfg, batch, iters, threads):
                                                                                     image_size, len(sweep), dt))
 
 
-def _pmc_busy(kernel_key):
-    """matrix-pipe busy fraction of `kernel_key` from the committed rocprofv3 --pmc pass of the headline workload
+def _pmc_match(kernel_key, kernels):
+    """the entry of a PMC summary (keys = demangled kernel names without spaces) that a KernelTimer key stands for:
+    exact / template-prefix match (fp32 kernels), or — bf16 timer keys name the tile class, e.g.
+    "bf16_conv_kernel<3,co128>" — the heaviest instantiation <KS, WM, WN, WVM, WVN, ...> with WVM*WM*32 == 128"""
+    pref = kernel_key[:-1] + ","  # "conv_wino_kernel<1,4,false>" -> "conv_wino_kernel<1,4,false,"
+    hit = [v for k, v in kernels.items() if k == kernel_key or k.startswith(pref)]
+    if hit:
+        return hit[0]
+    if kernel_key.startswith("bf16_") and "<" in kernel_key:
+        base, targs = kernel_key[:-1].split("<")
+        targs = targs.split(",")
+        cand = []
+        for k, v in kernels.items():
+            if not k.startswith(base + "<" + targs[0] + ","):
+                continue
+            a = k[k.index("<") + 1:-1].split(",")
+            if len(targs) > 1 and targs[1].startswith("co"):
+                if int(a[1]) * int(a[3]) * 32 != int(targs[1][2:]):
+                    continue
+            cand.append(v)
+        if cand:
+            # several instantiations share a timer key (small / big pixel tile): the one with the largest share of the step
+            return max(cand, key=lambda v: (v.get("share_of_gpu_active", 0.0), v.get("launches", 0) * v.get("hbm_bytes", 0)))
+    return None
+
+
+def _pmc_busy(kernel_key, config="celeb256", dtype="fp32"):
+    """matrix-pipe busy fraction of `kernel_key` from the committed rocprofv3 --pmc pass of the workload
     (tools/pmc_mfma_busy.py over SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE; counters cannot be read from inside the
     bench)"""
-    for name in ("r2_pmc_mfma_busy_bs128_final.json", "r2_pmc_mfma_busy_bs128.json"):
+    names = {("celeb256", "fp32"): ("r2_pmc_mfma_busy_bs128_final.json", "r2_pmc_mfma_busy_bs128.json"),
+             ("celeb128", "bf16"): ("r2_pmc_mfma_busy_celeb128_bf16.json",)}.get((config, dtype), ())
+    for name in names:
         path = os.path.join(PROFILES, name)
         if os.path.exists(path):
-            ks = json.load(open(path))["kernels"]
-            pref = kernel_key[:-1] + ","  # "conv_wino_kernel<1,4,false>" -> "conv_wino_kernel<1,4,false,"
-            hit = [v for k, v in ks.items() if k == kernel_key or k.startswith(pref)]
+            hit = _pmc_match(kernel_key, json.load(open(path))["kernels"])
             if hit:
-                return dict(value=hit[0]["mfma_busy_frac"], source="profiles/" + name)
+                return dict(value=hit["mfma_busy_frac"], source="profiles/" + name)
     return None
 
 
@@ -155,9 +182,8 @@ def _pmc_traffic(kernel_key, config, dtype):
         path = os.path.join(PROFILES, name)
         if os.path.exists(path):
             d = json.load(open(path))
-            pref = kernel_key[:-1] + ","
-            hit = [v for k, v in d["kernels"].items() if k == kernel_key or k.startswith(pref)]
-            return dict(kernel_bytes=hit[0]["hbm_bytes"] if hit else None, step_bytes=d.get("step_total_hbm_bytes"),
+            hit = _pmc_match(kernel_key, d["kernels"])
+            return dict(kernel_bytes=hit["hbm_bytes"] if hit else None, step_bytes=d.get("step_total_hbm_bytes"),
                         source="profiles/" + name)
     return None
 
@@ -175,7 +201,8 @@ def measure(args, cfg, gbatch, world, rank, dev, scaling):
         gr = 1.0
     _, per = dp.shard_batch(gbatch, world, rank)
     torch.manual_seed(0)
-    model = (TB if args.bootstrap else T).SoftIntroVAE(cdim=3, zdim=zdim, channels=channels, image_size=image_size)
+    with contextlib.redirect_stdout(sys.stderr):  # the constructor prints like the reference's: stdout carries ONE JSON line
+        model = (TB if args.bootstrap else T).SoftIntroVAE(cdim=3, zdim=zdim, channels=channels, image_size=image_size)
     model = model.to(dev).train()
     opt_e = FlatAdam(model.encoder.parameters(), lr=2e-4)
     opt_d = FlatAdam(model.decoder.parameters(), lr=2e-4)
@@ -311,7 +338,7 @@ def main():
                     algorithmic_tflops=round(alg, 2), algorithmic_frac=round(alg / peak, 4),
                     launches=d["launches"], avg_launch_ms=round(d["avg_ms"], 4),
                     kernel_share_of_step=round(d["total_ms"] / (1e3 * dt), 4),
-                    mfma_busy_pmc=_pmc_busy(key) if (args.config == "celeb256" and args.dtype == "fp32") else None,
+                    mfma_busy_pmc=_pmc_busy(key, args.config, args.dtype),
                     all_mfma_kernels=dict(issued_tflops=round(conv_ex / (conv_ms * 1e-3) / 1e12, 2),
                                           issued_frac=round(conv_ex / (conv_ms * 1e-3) / 1e12 / peak, 4),
                                           algorithmic_tflops=round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
