@@ -67,6 +67,10 @@ struct B6Args {
 #endif
 #define B6_CK 16
 #define B6_EX_FLOATS (2 * 4 * B6_WM * 16 * 64)
+// VALU per MFMA inside a region: split slice = 11 VALU, transform slice = 8 VALU, over WM MFMAs
+#define B6_NVS ((11 + B6_WM - 1) / B6_WM)
+#define B6_NVT ((8 + B6_WM - 1) / B6_WM)
+#define B6_NDR ((8 + B6_WM - 1) / B6_WM)
 #ifndef B6_NDS
 #define B6_NDS 8  // ds_read2st64_b32 instructions of one channel pair's 16 halo values
 #endif
@@ -199,28 +203,40 @@ __global__ void __launch_bounds__(256, 1) conv_wino_b6_kernel(B6Args a) {
     _Pragma("unroll") for (int m = 0; m < WM; ++m) AR[SLOT][m][P] = buf_load_b128(ursrc, va0 + m * 512u, so); \
   }
 #define B6_FENCE __builtin_amdgcn_sched_barrier(0);
+  // interleave inside a region: WM x { 1 MFMA, NV VALU, NL buffer loads, ND LDS reads }
+#ifdef B6_NOPAT
+#define B6_PAT(NV, NL, ND)
+#else
+#define B6_PAT(NV, NL, ND)                                               \
+  _Pragma("unroll") for (int g_ = 0; g_ < WM; ++g_) {                    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
+    if (NV) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);          \
+    if (NL) __builtin_amdgcn_sched_group_barrier(0x020, NL, 0);          \
+    if (ND) __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);          \
+  }
+#endif
   // frequency step I (0..2) of a chunk: MFMAs of frequency I from pieces BPC; under them the split of frequency I + 1 into
   // BPN and the transform of channels 2I, 2I + 1 of the next chunk (raw values read one step earlier into DA*/DB*).
   // The piece-pair order (smallest products first) frees U piece 2 after the third group, piece 1 after the fifth.
 #define B6_STEP(F, I, SLOT, CUR, NXT, XN, BPC, BPN)                      \
   {                                                                      \
-    B6_MF(I, SLOT, 0, 2, BPC) B6_SPLIT1(CUR, (I) + 1, BPN, 0) B6_FENCE   \
-    B6_MF(I, SLOT, 1, 1, BPC) B6_SPLIT1(CUR, (I) + 1, BPN, 1) B6_FENCE   \
-    B6_MF(I, SLOT, 2, 0, BPC) B6_SPLIT1(CUR, (I) + 1, BPN, 2) B6_LOAD_A1((F) + 2, SLOT, 2) B6_FENCE \
-    B6_MF(I, SLOT, 0, 1, BPC) B6_SPLIT1(CUR, (I) + 1, BPN, 3) B6_FENCE   \
-    B6_MF(I, SLOT, 1, 0, BPC) B6_TRANS1(NXT, 2 * (I), da0, db0) B6_LOAD_A1((F) + 2, SLOT, 1) B6_FENCE \
+    B6_MF(I, SLOT, 0, 2, BPC) B6_SPLIT1(CUR, (I) + 1, BPN, 0) B6_PAT(B6_NVS, 0, 0) B6_FENCE \
+    B6_MF(I, SLOT, 1, 1, BPC) B6_SPLIT1(CUR, (I) + 1, BPN, 1) B6_PAT(B6_NVS, 0, 0) B6_FENCE \
+    B6_MF(I, SLOT, 2, 0, BPC) B6_SPLIT1(CUR, (I) + 1, BPN, 2) B6_LOAD_A1((F) + 2, SLOT, 2) B6_PAT(B6_NVS, 1, 0) B6_FENCE \
+    B6_MF(I, SLOT, 0, 1, BPC) B6_SPLIT1(CUR, (I) + 1, BPN, 3) B6_PAT(B6_NVS, 0, 0) B6_FENCE \
+    B6_MF(I, SLOT, 1, 0, BPC) B6_TRANS1(NXT, 2 * (I), da0, db0) B6_LOAD_A1((F) + 2, SLOT, 1) B6_PAT(B6_NVT, 1, 0) B6_FENCE \
     B6_MF(I, SLOT, 0, 0, BPC) B6_TRANS1(NXT, 2 * (I) + 1, da1, db1) B6_LOAD_A1((F) + 2, SLOT, 0) \
-    B6_READ1(XN, 2 * (I) + 2, da0, db0) B6_READ1(XN, 2 * (I) + 3, da1, db1) B6_FENCE \
+    B6_READ1(XN, 2 * (I) + 2, da0, db0) B6_READ1(XN, 2 * (I) + 3, da1, db1) B6_PAT(B6_NVT, 1, B6_NDR) B6_FENCE \
   }
   // last step of the chunk: the transform of the next chunk's channels 6, 7 first, then the split of ITS frequency 0
 #define B6_STEP3(F, SLOT, NXT, BPC, BPN)                                 \
   {                                                                      \
-    B6_MF(3, SLOT, 0, 2, BPC) B6_TRANS1(NXT, 6, da0, db0) B6_FENCE       \
-    B6_MF(3, SLOT, 1, 1, BPC) B6_TRANS1(NXT, 7, da1, db1) B6_FENCE       \
-    B6_MF(3, SLOT, 2, 0, BPC) B6_SPLIT1(NXT, 0, BPN, 0) B6_LOAD_A1((F) + 2, SLOT, 2) B6_FENCE \
-    B6_MF(3, SLOT, 0, 1, BPC) B6_SPLIT1(NXT, 0, BPN, 1) B6_FENCE         \
-    B6_MF(3, SLOT, 1, 0, BPC) B6_SPLIT1(NXT, 0, BPN, 2) B6_LOAD_A1((F) + 2, SLOT, 1) B6_FENCE \
-    B6_MF(3, SLOT, 0, 0, BPC) B6_SPLIT1(NXT, 0, BPN, 3) B6_LOAD_A1((F) + 2, SLOT, 0) B6_FENCE \
+    B6_MF(3, SLOT, 0, 2, BPC) B6_TRANS1(NXT, 6, da0, db0) B6_PAT(B6_NVT, 0, 0) B6_FENCE \
+    B6_MF(3, SLOT, 1, 1, BPC) B6_TRANS1(NXT, 7, da1, db1) B6_PAT(B6_NVT, 0, 0) B6_FENCE \
+    B6_MF(3, SLOT, 2, 0, BPC) B6_SPLIT1(NXT, 0, BPN, 0) B6_LOAD_A1((F) + 2, SLOT, 2) B6_PAT(B6_NVS, 1, 0) B6_FENCE \
+    B6_MF(3, SLOT, 0, 1, BPC) B6_SPLIT1(NXT, 0, BPN, 1) B6_PAT(B6_NVS, 0, 0) B6_FENCE \
+    B6_MF(3, SLOT, 1, 0, BPC) B6_SPLIT1(NXT, 0, BPN, 2) B6_LOAD_A1((F) + 2, SLOT, 1) B6_PAT(B6_NVS, 1, 0) B6_FENCE \
+    B6_MF(3, SLOT, 0, 0, BPC) B6_SPLIT1(NXT, 0, BPN, 3) B6_LOAD_A1((F) + 2, SLOT, 0) B6_PAT(B6_NVS, 1, 0) B6_FENCE \
   }
   // one chunk.  The barrier at the top publishes the halo of chunk CH + 1 (requested a whole chunk ago: more than 63
   // loads back) and retires the readers of the buffer that chunk CH + 2's halo is about to overwrite.
