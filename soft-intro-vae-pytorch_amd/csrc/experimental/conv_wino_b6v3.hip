@@ -66,7 +66,7 @@ struct B6Args {
 #define B6_WM 4
 #endif
 #define B6_CK 16
-#define B6_EX_FLOATS (2 * 4 * B6_WM * 16 * 64)
+#define B6_EX_FLOATS (2 * 4 * 2 * 16 * 64)  // output-transform exchange area: two co-subtiles at a time (64 KB)
 // VALU per MFMA inside a region: split slice = 11 VALU, transform slice = 8 VALU, over WM MFMAs
 #define B6_NVS ((11 + B6_WM - 1) / B6_WM)
 #define B6_NVT ((8 + B6_WM - 1) / B6_WM)
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_b6_kernel(B6Args a) {
   // ---- the K loop is written as small scheduling regions (sched_barrier between them): one group of WM MFMAs (one
   // piece pair of one frequency, all co-subtiles), one slice of VALU work that the NEXT regions need, two U loads.
   // halo reads of channel E (of the lane's 8: channel 2E + hh) of the chunk at float offset XOFF -> raw values DA, DB
-#define B6_READ1(XOFF, E, DA, DB)                                        \
+#define B6_READ1_(XOFF, E, DA, DB)                                       \
   {                                                                      \
     const float* pa = xs + (XOFF) + 2 * (E)*PLANE + base_a;              \
     const float* pb_ = xs + (XOFF) + 2 * (E)*PLANE + base_b;             \
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_b6_kernel(B6Args a) {
     }                                                                    \
   }
   // input transform of channel E from its raw values -> V[E][0..3]   (8 VALU)
-#define B6_TRANS1(V, E, DA, DB)                                          \
+#define B6_TRANS1_(V, E, DA, DB)                                         \
   {                                                                      \
     float t[4];                                                          \
     _Pragma("unroll") for (int r = 0; r < 4; ++r) t[r] = DA[r] + sgn * DB[r]; \
@@ -180,7 +180,16 @@ __global__ void __launch_bounds__(256, 1) conv_wino_b6_kernel(B6Args a) {
     V[E][3] = t[1] - t[3];                                               \
   }
   // three exact bf16 pieces (truncation: 8 + 8 + 8 significant bits) of values 2D, 2D + 1 of frequency I, packed (11 VALU)
-#define B6_SPLIT1(V, I, BP, D)                                           \
+#ifdef B6_NO_VALU
+#define B6_SPLIT1(V, I, BP, D)
+#define B6_TRANS1(V, E, DA, DB)
+#define B6_READ1(XOFF, E, DA, DB)
+#else
+#define B6_SPLIT1(V, I, BP, D) B6_SPLIT1_(V, I, BP, D)
+#define B6_TRANS1(V, E, DA, DB) B6_TRANS1_(V, E, DA, DB)
+#define B6_READ1(XOFF, E, DA, DB) B6_READ1_(XOFF, E, DA, DB)
+#endif
+#define B6_SPLIT1_(V, I, BP, D)                                          \
   {                                                                      \
     const float x0 = V[2 * (D)][I], x1 = V[2 * (D) + 1][I];              \
     const unsigned h0 = __builtin_bit_cast(unsigned, x0) & 0xffff0000u, h1 = __builtin_bit_cast(unsigned, x1) & 0xffff0000u; \
@@ -196,12 +205,24 @@ __global__ void __launch_bounds__(256, 1) conv_wino_b6_kernel(B6Args a) {
     acc[I][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, AR[SLOT][m][P]), \
                                                         __builtin_bit_cast(bf16x8, BP[Q]), acc[I][m], 0, 0, 0);
   // U piece P of frequency step F (clamped past the end: the refill is unconditional so that waits know what is in flight)
-#define B6_LOAD_A1(F, SLOT, P)                                           \
+#ifdef B6_NO_U
+#define B6_LOAD_A1(F, SLOT, P)
+#else
+#define B6_LOAD_A1(F, SLOT, P) B6_LOAD_A1_(F, SLOT, P)
+#endif
+#define B6_LOAD_A1_(F, SLOT, P)                                          \
   {                                                                      \
     const int fc = (F) < nfsteps ? (F) : nfsteps - 1;                    \
     const unsigned so = ua_base + (unsigned)(fc * 3 + (P)) * ua_step;    \
     _Pragma("unroll") for (int m = 0; m < WM; ++m) AR[SLOT][m][P] = buf_load_b128(ursrc, va0 + m * 512u, so); \
   }
+// ablation switches for timing experiments (the results are wrong with any of them): -DB6_NO_DMA drops the halo loads of
+// the K loop, -DB6_NO_U the U refills, -DB6_NO_VALU the splits / transforms (pieces and values keep their first contents)
+#ifdef B6_NO_DMA
+#define B6_ABL_DMA(X)
+#else
+#define B6_ABL_DMA(X) X
+#endif
 #define B6_FENCE __builtin_amdgcn_sched_barrier(0);
   // interleave inside a region: WM x { 1 MFMA, NV VALU, NL buffer loads, ND LDS reads }
 #ifdef B6_NOPAT
@@ -245,7 +266,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_b6_kernel(B6Args a) {
     __builtin_amdgcn_s_waitcnt(0xCF7F); /* vmcnt(63) */                  \
     __syncthreads();                                                     \
     const int xn = (((CH) + 1) % 3) * XBUF;                              \
-    B6_LOAD_LDS((CH) + 2, ((CH) + 2) % 3)                                \
+    B6_ABL_DMA(B6_LOAD_LDS((CH) + 2, ((CH) + 2) % 3))                    \
     B6_READ1(xn, 0, da0, db0)                                            \
     B6_READ1(xn, 1, da1, db1)                                            \
     B6_FENCE                                                             \
@@ -272,11 +293,14 @@ __global__ void __launch_bounds__(256, 1) conv_wino_b6_kernel(B6Args a) {
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      B6_READ1(0, e, da0, db0)
-      B6_TRANS1(v0, e, da0, db0)
+      B6_READ1_(0, e, da0, db0)
+      B6_TRANS1_(v0, e, da0, db0)
     }
 #pragma unroll
-    for (int d = 0; d < 4; ++d) B6_SPLIT1(v0, 0, bpA, d)
+    for (int d = 0; d < 4; ++d) {
+      B6_SPLIT1_(v0, 0, bpA, d)
+      B6_SPLIT1_(v0, 1, bpB, d)
+    }
     {
       int ch = 0;
       for (; ch + 1 < nch; ch += 2) {
@@ -290,43 +314,59 @@ __global__ void __launch_bounds__(256, 1) conv_wino_b6_kernel(B6Args a) {
     const int e_b = b, e_r0 = r0, e_c0 = c0, e_co0 = co0;
     const int next = item + (int)gridDim.x;
     const bool has_next = next < a.n_items;
-    // ---- output transform (as conv_wino.hip): rows in registers, columns across the four waves through LDS
+    // the next item's first two halo chunks and U steps go in flight before the output transform (the exchange area
+    // below does not alias the halo ring, and the U ring is dead here)
+    if (has_next) {
+      B6_SETUP(next)
+      B6_LOAD_LDS(0, 0)
+      B6_LOAD_LDS(1, 1)
+      B6_LOAD_A(0, 0)
+      B6_LOAD_A(1, 1)
+    }
+    // ---- output transform (as conv_wino.hip): rows in registers, columns across the four waves through LDS, two
+    // co-subtiles (64 KB) at a time.  The lane index is laundered so that the address arithmetic stays inside the item
+    // loop as base + immediate instead of being hoisted into ~250 loop-invariant registers (which spilled).
     {
-      float* ex = smem;  // [2 ar][4 j][WM cg][16 r][64 lanes]
-      constexpr int PPW = 16 * WM / NW;
+      int lane_l = lane;
+      asm volatile("" : "+v"(lane_l));
+      float* ex = smem + 3 * XBUF;  // [2 ar][4 j][2 cg][16 r][64 lanes]
+      constexpr int PPW = 32 / NW;  // rows (cg, r) of a half per wave
       const __amdgpu_buffer_rsrc_t yrsrc =
           make_rsrc(a.y + (size_t)e_b * a.Co * HW, (unsigned long long)a.Co * HW * 4ull);
       const int row_base = e_r0 + 2 * ty, col = e_c0 + 2 * tx;
+      float* exw0 = ex + (wj * 2 * 16) * 64 + lane_l;
+      float* exw1 = ex + ((4 + wj) * 2 * 16) * 64 + lane_l;
+      const float* exr = ex + lane_l;
 #pragma unroll
-      for (int m = 0; m < WM; ++m)
+      for (int h = 0; h < WM / 2; ++h) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          ex[((wj * WM + m) * 16 + r) * 64 + lane] = acc[0][m][r] + acc[1][m][r] + acc[2][m][r];
-          ex[(((4 + wj) * WM + m) * 16 + r) * 64 + lane] = acc[1][m][r] - acc[2][m][r] - acc[3][m][r];
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = 2 * h + mm;
+            exw0[(mm * 16 + r) * 64] = acc[0][m][r] + acc[1][m][r] + acc[2][m][r];
+            exw1[(mm * 16 + r) * 64] = acc[1][m][r] - acc[2][m][r] - acc[3][m][r];
+            if ((r & 3) == 3) B6_FENCE  // keep the accumulator reads in small batches (all 256 at once spill)
+          }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < PPW; ++rr) {
+          const int p = wave * PPW + rr;  // (cg = p >> 4, r = p & 15) of this half
+          const int chn = e_co0 + (2 * h + (p >> 4)) * 32 + (p & 3) + 8 * ((p & 15) >> 2) + 4 * hh;
+          const unsigned yo = (chn < a.Co && col < W) ? (unsigned)((chn * H + row_base) * W + col) * 4u : OOB;
+#pragma unroll
+          for (int ar = 0; ar < 2; ++ar) {
+            float e[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) e[jj] = exr[(((ar * 4 + jj) * 2) * 16 + p) * 64];
+            const bool ok = yo != OOB && row_base + ar < H;
+            buf_store_f32x2(yrsrc, e[0] + e[1] + e[2], e[1] - e[2] - e[3], ok ? yo + (unsigned)(ar * W) * 4u : OOB);
+          }
         }
-      __syncthreads();
-#pragma unroll
-      for (int rr = 0; rr < PPW; ++rr) {
-        const int p = wave * PPW + rr;
-        const int chn = e_co0 + (p >> 4) * 32 + (p & 3) + 8 * ((p & 15) >> 2) + 4 * hh;
-        const unsigned yo = (chn < a.Co && col < W) ? (unsigned)((chn * H + row_base) * W + col) * 4u : OOB;
-#pragma unroll
-        for (int ar = 0; ar < 2; ++ar) {
-          float e[4];
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) e[jj] = ex[(((ar * 4 + jj) * WM + (p >> 4)) * 16 + (p & 15)) * 64 + lane];
-          const bool ok = yo != OOB && row_base + ar < H;
-          buf_store_f32x2(yrsrc, e[0] + e[1] + e[2], e[1] - e[2] - e[3], ok ? yo + (unsigned)(ar * W) * 4u : OOB);
-        }
+        __syncthreads();
       }
-      __syncthreads();
     }
     if (!has_next) break;
-    B6_SETUP(next)
-    B6_LOAD_LDS(0, 0)
-    B6_LOAD_LDS(1, 1)
-    B6_LOAD_A(0, 0)
-    B6_LOAD_A(1, 1)
     item = next;
   }
 }
@@ -392,7 +432,7 @@ static int run(int B, int Ci, int Co, int H, int W, bool check, int reps) {
   a.nbh = cdiv(H, 4); a.nbw = cdiv(W, 32); a.n_co_tiles = cdiv(Co, 32 * B6_WM);
   a.n_items = B * a.nbh * a.nbw * a.n_co_tiles;
   const size_t lds_x = (size_t)3 * 16 * 256 * 4;  // three halo buffers
-  const size_t lds = (size_t)B6_EX_FLOATS * 4 > lds_x ? (size_t)B6_EX_FLOATS * 4 : lds_x;
+  const size_t lds = (size_t)B6_EX_FLOATS * 4 + lds_x;  // the exchange area sits behind the halo ring (no aliasing)
   auto kern = conv_wino_b6_kernel<1, 4>;
   CK_(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = a.n_items < 256 ? a.n_items : 256;
