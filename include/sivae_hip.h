@@ -117,6 +117,15 @@ int sivae_pack_wino_up_dgrad_weight(const float* w /*[Co][Ci][3][3]*/, float* ud
 int sivae_conv2d_wino_up_dgrad_supported(int Hs, int Ws);
 int sivae_conv2d_wino_up_dgrad(const float* dy, const float* ud, float* dx, int B, int C, int N, int Hs, int Ws,
                                int accumulate, sivae_stream_t stream);
+/* Split-K form for small shards (16 images per GPU: 512 -> 512 @16x16 is 128 work items each walking 4 x 512 planes):
+ * _splitk = number of K slices the run would use (1: the plain kernel), _splitk_workspace_bytes = size of the partial
+ * outputs (0 when 1 slice), _splitk_run = sliced kernel + fixed-order reduce (same numbers as the plain entry up to the
+ * fp32 summation order of the slices). */
+int sivae_conv2d_wino_up_dgrad_splitk(int B, int C, int N, int Hs, int Ws);
+size_t sivae_conv2d_wino_up_dgrad_splitk_workspace_bytes(int B, int C, int N, int Hs, int Ws);
+int sivae_conv2d_wino_up_dgrad_splitk_run(const float* dy, const float* ud, float* dx, int B, int C, int N, int Hs,
+                                          int Ws, int accumulate, void* workspace, size_t workspace_bytes,
+                                          sivae_stream_t stream);
 
 /* Weight gradient of the same op in the phase form (dU_pq = sum_tiles (A dY_pq A^T).(B^T d_pq B), F(2x2,2x2);
  * dW folded back from the four 2x2 phase filters): 36 multiplies per 4x4 dy pixels instead of 64.  x_half is

@@ -26,6 +26,12 @@ struct WinoUpDgArgs {
   int n_n_tiles;
   int n_items;
   int accumulate;
+  // split-K (small shards: 512 -> 512 @16x16 with 16 images is 128 work items each walking 4 x 512 planes): item =
+  // (slice, base item); slice s accumulates the chunk sequence [s * q_per_split, ...) and writes its partial dx to
+  // dx + s * dx_split_stride (a workspace); wud_splitk_reduce_kernel sums the slices in a fixed order
+  int n_items_base;
+  int q_per_split;
+  long long dx_split_stride;
 };
 
 #define WUD_CK 16
@@ -65,6 +71,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_dgrad_kernel(WinoUpDgArgs
   const int n_items = a.n_items;
   int item = blockIdx.x;
   int b, r0, c0, n0;
+  int q0, q1, sl;  // chunk-sequence range and output slice of the current item
   __amdgpu_buffer_rsrc_t xrsrc;
   const __amdgpu_buffer_rsrc_t ursrc = make_rsrc(a.ud, 4ull * a.Cpad * a.Npad * 48ull);
   unsigned xo, ua_base;
@@ -74,8 +81,12 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_dgrad_kernel(WinoUpDgArgs
   const int xl = xrr * RS + (xcc & 1) * PH + (xcc >> 1);
 #define WUD_SETUP(ITEM)                                                  \
   {                                                                      \
-    const int n_tile = (ITEM) % a.n_n_tiles;                             \
-    const int pt = (ITEM) / a.n_n_tiles;                                 \
+    sl = (ITEM) / a.n_items_base;                                        \
+    const int it_ = (ITEM)-sl * a.n_items_base;                          \
+    q0 = sl * a.q_per_split;                                             \
+    q1 = q0 + a.q_per_split < nchunks ? q0 + a.q_per_split : nchunks;    \
+    const int n_tile = it_ % a.n_n_tiles;                                \
+    const int pt = it_ / a.n_n_tiles;                                    \
     const int tbx = pt % a.nbw;                                          \
     const int t2 = pt / a.nbw;                                           \
     const int tby = t2 % a.nbh;                                          \
@@ -176,7 +187,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_dgrad_kernel(WinoUpDgArgs
     __builtin_amdgcn_sched_barrier(0);                                   \
     WUD_STEP((KK)&3, D)                                                  \
     __builtin_amdgcn_sched_barrier(0);                                   \
-    if ((Q) * KPC + (KK) + 4 < nksteps) WUD_LOAD_A((Q) * KPC + (KK) + 4, (KK)&3) \
+    if ((Q) * KPC + (KK) + 4 < q1 * KPC) WUD_LOAD_A((Q) * KPC + (KK) + 4, (KK)&3) \
   }
 #define WUD_MMA(Q, BUF, NEXT)                                            \
   {                                                                      \
@@ -201,8 +212,8 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_dgrad_kernel(WinoUpDgArgs
 #define WUD_PREFETCH(ITEM)                                               \
   {                                                                      \
     WUD_SETUP(ITEM)                                                      \
-    WUD_LOAD_X(0)                                                        \
-    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) WUD_LOAD_A(kk, kk)  \
+    WUD_LOAD_X(q0)                                                       \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) WUD_LOAD_A(q0 * KPC + kk, kk) \
   }
 
   WUD_PREFETCH(item)
@@ -211,25 +222,25 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_dgrad_kernel(WinoUpDgArgs
     for (int f = 0; f < 9; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
-    WUD_STORE_X(0, 0)
+    WUD_STORE_X(q0, 0)
     __syncthreads();
-    int q = 0;
-    for (; q + 1 < nchunks; q += 2) {
+    int q = q0;
+    for (; q + 1 < q1; q += 2) {
       WUD_MMA(q, 0, true)
-      const bool more = q + 2 < nchunks;
+      const bool more = q + 2 < q1;
       WUD_MMA(q + 1, 1, more)
     }
-    if (q < nchunks) WUD_MMA(q, 0, false)
+    if (q < q1) WUD_MMA(q, 0, false)
 
     __builtin_amdgcn_s_setprio(1);  // serial tail at raised priority (see conv_wino.hip)
-    const int e_b = b, e_r0 = r0, e_c0 = c0, e_n0 = n0;
+    const int e_b = b, e_r0 = r0, e_c0 = c0, e_n0 = n0, e_sl = sl;
     const int next = item + (int)gridDim.x;
     const bool has_next = next < n_items;
     const bool early = has_next && !a.accumulate;  // (accumulate loads dx: keep the prefetch behind those loads)
     if (early) WUD_PREFETCH(next)
     {
       const __amdgpu_buffer_rsrc_t yrsrc =
-          make_rsrc(a.dx + (size_t)e_b * a.N * HWs, (unsigned long long)a.N * HWs * 4ull);
+          make_rsrc(a.dx + (size_t)e_sl * a.dx_split_stride + (size_t)e_b * a.N * HWs, (unsigned long long)a.N * HWs * 4ull);
       const int li = e_r0 + 2 * ty, lj = e_c0 + 2 * tx;
       const bool okc = lj < Ws;  // Ws even: lj + 1 < Ws too
       const unsigned base = (unsigned)(li * Ws + lj) * 4u;
@@ -434,15 +445,20 @@ static int wud_launch(WinoUpDgArgs& a, hipStream_t stream) {
   if (nblk > 0x7fffffffLL) return SIVAE_ERR_RANGE;
   size_t lds = (size_t)2 * WUD_CK * PLANE * sizeof(float);
   if (KS2 && lds < 2 * 64 * 64 * sizeof(float)) lds = 2 * 64 * 64 * sizeof(float);
-  a.n_items = (int)nblk;
-  const int grid = nblk < wud_grid_blocks() ? (int)nblk : wud_grid_blocks();
+  a.n_items_base = (int)nblk;
+  const int nchunks = 4 * (a.Cpad / WUD_CK);
+  if (a.q_per_split <= 0) a.q_per_split = nchunks;
+  const long long nitems = nblk * cdiv(nchunks, a.q_per_split);
+  if (nitems > 0x7fffffffLL) return SIVAE_ERR_RANGE;
+  a.n_items = (int)nitems;
+  const int grid = nitems < wud_grid_blocks() ? (int)nitems : wud_grid_blocks();
   hipLaunchKernelGGL((conv_wino_up_dgrad_kernel<TTH_L2, TTW_L2, KS2>), dim3((unsigned)grid), dim3(256), lds, stream,
                      a);
   return sivae_launch_status();
 }
 
-extern "C" int sivae_conv2d_wino_up_dgrad(const float* dy, const float* ud, float* dx, int B, int C, int N, int Hs,
-                                          int Ws, int accumulate, hipStream_t stream) {
+static int wud_run(const float* dy, const float* ud, float* dx, int B, int C, int N, int Hs, int Ws, int accumulate,
+                   hipStream_t stream, int q_per_split, long long dx_split_stride) {
   const float* dyp = dy;  // [B][C][2Hs][2Ws]
   if (!dyp || !ud || !dx) return SIVAE_ERR_NULL;
   if (B <= 0 || C <= 0 || N <= 0 || Hs <= 0 || Ws <= 0) return SIVAE_ERR_SHAPE;
@@ -463,6 +479,79 @@ extern "C" int sivae_conv2d_wino_up_dgrad(const float* dy, const float* ud, floa
   a.Npad = wud_npad(N);
   a.accumulate = accumulate;
   if (4ull * a.Cpad * a.Npad * 48ull >= 0xffffffffull) return SIVAE_ERR_RANGE;
+  a.q_per_split = q_per_split;
+  a.dx_split_stride = dx_split_stride;
   if (N <= 64) return (Ws >= 32) ? wud_launch<1, 4, true>(a, stream) : wud_launch<2, 3, true>(a, stream);
   return (Ws >= 32) ? wud_launch<1, 4, false>(a, stream) : wud_launch<2, 3, false>(a, stream);
+}
+
+extern "C" int sivae_conv2d_wino_up_dgrad(const float* dy, const float* ud, float* dx, int B, int C, int N, int Hs,
+                                          int Ws, int accumulate, hipStream_t stream) {
+  return wud_run(dy, ud, dx, B, C, N, Hs, Ws, accumulate, stream, 0, 0);
+}
+
+// ---- split-K form (small shards) -----------------------------------------------------------------------------------
+// dx[i] (+)= sum_s part[s][i], slices in a fixed order (deterministic)
+__global__ void __launch_bounds__(256) wud_splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ dx,
+                                                                int S, size_t n, size_t slice_stride, int accumulate) {
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+    float4 v = accumulate ? *reinterpret_cast<const float4*>(dx + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < S; ++k) {
+      const float4 p = *reinterpret_cast<const float4*>(part + (size_t)k * slice_stride + i);
+      v.x += p.x;
+      v.y += p.y;
+      v.z += p.z;
+      v.w += p.w;
+    }
+    *reinterpret_cast<float4*>(dx + i) = v;
+  }
+}
+
+// number of K slices sivae_conv2d_wino_up_dgrad_splitk_run will use (1: it is the plain kernel)
+extern "C" int sivae_conv2d_wino_up_dgrad_splitk(int B, int C, int N, int Hs, int Ws) {
+  if (B <= 0 || C <= 0 || N <= 0 || !sivae_conv2d_wino_up_dgrad_supported(Hs, Ws)) return SIVAE_ERR_SHAPE;
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* e = getenv("SIVAE_WUD_SPLITK");
+    enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!enabled || N <= 64 || ((Hs * Ws) & 3)) return 1;
+  const int pxh = Ws >= 32 ? 4 : 8, pxw = Ws >= 32 ? 32 : 16;
+  const long long items = (long long)B * cdiv(Hs, pxh) * cdiv(Ws, pxw) * cdiv(N, WUD_TN);
+  const int nch = wud_cpad(C) / WUD_CK;  // 16-channel chunks per phase
+  const int cus = wud_grid_blocks() / 2;
+  if (items > cus || nch < 8) return 1;
+  int S = (int)(2 * cus / items);
+  if (S > nch / 4) S = nch / 4;  // >= 4 channel chunks (x 4 phases) per slice
+  if (S > 8) S = 8;
+  return S < 2 ? 1 : S;
+}
+
+extern "C" size_t sivae_conv2d_wino_up_dgrad_splitk_workspace_bytes(int B, int C, int N, int Hs, int Ws) {
+  const int S = sivae_conv2d_wino_up_dgrad_splitk(B, C, N, Hs, Ws);
+  if (S <= 1) return 0;
+  return (size_t)S * B * N * Hs * Ws * sizeof(float);
+}
+
+extern "C" int sivae_conv2d_wino_up_dgrad_splitk_run(const float* dy, const float* ud, float* dx, int B, int C, int N,
+                                                     int Hs, int Ws, int accumulate, void* workspace,
+                                                     size_t workspace_bytes, hipStream_t stream) {
+  const int S = sivae_conv2d_wino_up_dgrad_splitk(B, C, N, Hs, Ws);
+  if (S < 0) return S;
+  if (S <= 1 || ((uintptr_t)dx & 15u) != 0)  // (the reduce kernel moves 16-byte vectors)
+    return wud_run(dy, ud, dx, B, C, N, Hs, Ws, accumulate, stream, 0, 0);
+  if (!workspace) return SIVAE_ERR_NULL;
+  if (((uintptr_t)workspace & 15u) != 0) return SIVAE_ERR_SHAPE;
+  if (workspace_bytes < sivae_conv2d_wino_up_dgrad_splitk_workspace_bytes(B, C, N, Hs, Ws)) return SIVAE_ERR_WORKSPACE;
+  const int nch = wud_cpad(C) / WUD_CK;
+  const int qps = 4 * cdiv(nch, S);  // whole channel chunks: the four parity planes of a chunk stay in one slice
+  const size_t n = (size_t)B * N * Hs * Ws;
+  float* part = reinterpret_cast<float*>(workspace);
+  const int rc = wud_run(dy, ud, part, B, C, N, Hs, Ws, 0, stream, qps, (long long)n);
+  if (rc != SIVAE_OK) return rc;
+  const int nsl = cdiv(4 * nch, qps);
+  size_t nb = (n / 4 + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(wud_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, part, dx, nsl, n, n, accumulate);
+  return sivae_launch_status();
 }

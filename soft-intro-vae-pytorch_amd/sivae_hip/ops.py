@@ -267,8 +267,14 @@ def conv2d_up_dgrad(dy, wp, N, out=None, accumulate=False):
     dx = out if out is not None else torch.empty((B, N, Hs, Ws), dtype=torch.float32, device=dy.device)
     assert dx.shape == (B, N, Hs, Ws)
     t0 = TIMER.begin() if TIMER is not None else None
-    _lib.call("sivae_conv2d_wino_up_dgrad", _p(dy), _p(wp.wino_up_dgrad()), _p(dx), B, C, N, Hs, Ws,
-              int(bool(accumulate)), _s())
+    L = _lib.load()
+    if L.sivae_conv2d_wino_up_dgrad_splitk(B, C, N, Hs, Ws) > 1:  # small shards: split the 4C input planes
+        ws = workspace(L.sivae_conv2d_wino_up_dgrad_splitk_workspace_bytes(B, C, N, Hs, Ws), dy.device)
+        _lib.call("sivae_conv2d_wino_up_dgrad_splitk_run", _p(dy), _p(wp.wino_up_dgrad()), _p(dx), B, C, N, Hs, Ws,
+                  int(bool(accumulate)), _p(ws), ws.numel(), _s(dy))
+    else:
+        _lib.call("sivae_conv2d_wino_up_dgrad", _p(dy), _p(wp.wino_up_dgrad()), _p(dx), B, C, N, Hs, Ws,
+                  int(bool(accumulate)), _s(dy))
     if t0 is not None:
         flops = 2.0 * B * H * W * C * N * 9
         TIMER.end("conv_wino_up_dgrad_kernel<%s>" % ("1,4" if Ws >= 32 else "2,3"), flops, t0, executed=flops * 9.0 / 36.0)

@@ -47,6 +47,7 @@ CONV_SHAPES = [
     (2, 64, 128, 32, 32, 1),
     (2, 128, 64, 16, 16, 1),
     (3, 100, 40, 8, 8, 1),
+    (3, 72, 200, 12, 20, 1),   # ragged output channels, two output-channel tiles
     (9, 40, 72, 64, 64, 1),    # 144 split-K slices -> 16-row slice reduce with a ragged tail
     (5, 64, 96, 48, 48, 1),    # 45 slices -> 4-row slice reduce with a ragged tail
     (3, 3, 64, 32, 32, 5),     # encoder stem
@@ -557,6 +558,23 @@ def check_wino_splitk():
     return res
 
 
+def check_up_dgrad_splitk():
+    """split-K form of the upsample-conv data gradient (small shards): same numbers as the single-pass kernel, plain
+    and accumulating; shape order as check_conv_up_dgrad: (B, Ci = low-res channels, Co = dy channels, H, W = dy size)"""
+    from sivae_hip import lib
+    L = lib.load()
+    res = []
+    for shape in [(4, 512, 512, 32, 32, 3), (2, 256, 512, 16, 32, 3), (16, 512, 512, 32, 32, 3), (3, 200, 136, 16, 32, 3)]:
+        B, Ci, Co, H, W, ks = shape
+        S = L.sivae_conv2d_wino_up_dgrad_splitk(B, Co, Ci, H // 2, W // 2)
+        res.append(("up_dgrad_splitk%s slices=%d" % (shape, S), 0.0 if S > 1 else float("inf"), 0.5))
+        res += check_conv_up_dgrad(shape) + check_conv_up_dgrad(shape, True)
+    res.append(("up_dgrad_splitk off on large grids",
+                float(L.sivae_conv2d_wino_up_dgrad_splitk(128, 512, 512, 16, 32) != 1), 0.0))
+    res.append(("up_dgrad_splitk off for N <= 64", float(L.sivae_conv2d_wino_up_dgrad_splitk(2, 512, 64, 16, 32) != 1), 0.0))
+    return res
+
+
 def check_randn():
     from sivae_hip import ops
     a = ops.randn((1 << 20,), 1234, 0, torch.device(DEV))
@@ -896,6 +914,7 @@ def all_checks():
         checks.append(("dgrad_bnbwd%s" % (s,), lambda s=s: check_dgrad_bnbwd(s)))
     checks.append(("wino_up_stats", lambda: check_conv_up((3, 32, 72, 32, 64, 3), stats=True)
                    + check_conv_up((2, 20, 33, 16, 32, 3), pro=True, stats=True)))
+    checks.append(("up_dgrad_splitk", check_up_dgrad_splitk))
     checks.append(("conv5_edge", check_conv5_edge))
     checks.append(("linear", check_linear))
     checks.append(("linear_fast", check_linear_fast))
