@@ -72,6 +72,7 @@ struct Conv5FwdArgs {
   float* y;
   const float* bias;
   int B, Ci, Co, H, W;
+  int xcd_remap;  // 1: blocks of one XCD take a contiguous item range (row groups sharing halo rows meet in one L2)
   int sw;      // output columns per block (<= 128)
   int ntile;   // 16-wide position tiles per wave (odd, <= NWT): 16*ntile >= sw + 4
   int nseg;    // column segments per row
@@ -91,7 +92,11 @@ __global__ void __launch_bounds__(256, 2) conv5_smallco_fwd_kernel(Conv5FwdArgs 
   float* ws = smem;                   // [CK*5][16]
   float* xs = smem + CK * 5 * 16;     // [CK][XPL]
 
+  // Consecutive blockIdx go round-robin to the 8 XCDs, and vertically adjacent row groups share 4 of their 8 input rows:
+  // with the remap XCD x takes the contiguous items [x * grid/8, ...), so the two readers of a halo row are co-resident
+  // and the second one hits in L2 (FETCH_SIZE 5.4 GB per launch on 64 -> 3 @256x256 against 2.25 GB of tensors before)
   int bid = blockIdx.x;
+  if (a.xcd_remap) bid = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
   const int seg = bid % a.nseg; bid /= a.nseg;
   const int rg = bid % a.nrow4;
   const int b = bid / a.nrow4;
@@ -216,6 +221,7 @@ extern "C" int sivae_conv5_smallco_fwd(const float* x, const float* wq, float* y
   const size_t lds = (size_t)(8 * 5 * 16 + 8 * XPL) * sizeof(float);
   const long long nblk = (long long)B * a.nrow4 * a.nseg;
   if (nblk > 0x7fffffffLL) return SIVAE_ERR_RANGE;
+  a.xcd_remap = (sivae_xcd_remap() && (nblk & 7) == 0) ? 1 : 0;
   hipLaunchKernelGGL((conv5_smallco_fwd_kernel<9>), dim3((unsigned)nblk), dim3(256), lds, stream, a);
   return sivae_launch_status();
 }
@@ -268,10 +274,12 @@ __global__ void __launch_bounds__(256, 2) conv5_edge_wgrad_kernel(Conv5WgradArgs
   const int big_row = (wave * 16 + li) * BLD;
 
   for (int tile = tile_begin; tile < tile_end; ++tile) {
+    // row group fastest: consecutive tiles of a block are vertically adjacent, so the 4 halo rows of the large-side
+    // slab that they share (SMALL_CO: 8 staged rows per 4 output rows) were fetched a moment ago and hit in cache
     int t = tile;
-    const int cseg = t % a.ncol32; t /= a.ncol32;
-    const int rg = t % a.nrow4;
-    const int b = t / a.nrow4;
+    const int rg = t % a.nrow4; t /= a.nrow4;
+    const int cseg = t % a.ncol32;
+    const int b = t / a.ncol32;
     const int r0 = rg * 4, c0 = cseg * 32;
     const __amdgpu_buffer_rsrc_t brs = make_rsrc(pbig + (size_t)b * Cbig * HW, (unsigned long long)Cbig * HW * 4ull);
     const __amdgpu_buffer_rsrc_t srs = make_rsrc(psml + (size_t)b * Csml * HW, (unsigned long long)Csml * HW * 4ull);

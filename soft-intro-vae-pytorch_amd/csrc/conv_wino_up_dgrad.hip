@@ -32,6 +32,7 @@ struct WinoUpDgArgs {
   int n_items_base;
   int q_per_split;
   long long dx_split_stride;
+  int xcd_group;
 };
 
 #define WUD_CK 16
@@ -69,7 +70,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_dgrad_kernel(WinoUpDgArgs
   const int koff = kh * (CK / 2);             // first channel of this wave inside a chunk
 
   const int n_items = a.n_items;
+  // XCD-aware start items (as conv_wino.hip): the blocks of XCD x walk the contiguous items x * grid/8 + slot (+ k * grid),
+  // so vertically / horizontally adjacent tile blocks — which share halo rows of dy — meet in one L2
   int item = blockIdx.x;
+  if (a.xcd_group) item = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
   int b, r0, c0, n0;
   int q0, q1, sl;  // chunk-sequence range and output slice of the current item
   __amdgpu_buffer_rsrc_t xrsrc;
@@ -452,6 +456,7 @@ static int wud_launch(WinoUpDgArgs& a, hipStream_t stream) {
   if (nitems > 0x7fffffffLL) return SIVAE_ERR_RANGE;
   a.n_items = (int)nitems;
   const int grid = nitems < wud_grid_blocks() ? (int)nitems : wud_grid_blocks();
+  a.xcd_group = (sivae_xcd_remap() && !(grid & 7) && nitems > grid) ? 1 : 0;
   hipLaunchKernelGGL((conv_wino_up_dgrad_kernel<TTH_L2, TTW_L2, KS2>), dim3((unsigned)grid), dim3(256), lds, stream,
                      a);
   return sivae_launch_status();
