@@ -130,6 +130,13 @@ def test_bf16_cifar_net_vs_fp32_oracle():
     assert not _bf16_vs_oracle(3, 128, [64, 128, 256], 32, 16, hp)
 
 
+def test_bf16_mnist_net_vs_fp32_oracle():
+    """the single-channel 28x28 network (reference :376-379: channels [64, 128], z 32): odd 7x7 maps, and the kw-packed
+    5x5 layers with ONE image channel (5 of the 16 k-step channels used)"""
+    hp = dict(beta_rec=1.0, beta_kl=1.0, beta_neg=256.0, gamma_r=1e-8)
+    assert not _bf16_vs_oracle(1, 32, [64, 128], 28, 16, hp, seed=2)
+
+
 def test_bf16_celeb128_config_vs_fp32_oracle():
     """config 3's network exactly: 128x128, channels [64,128,256,512,512], z 256 (reference :381-386), at B = 8"""
     hp = dict(beta_rec=0.5, beta_kl=1.0, beta_neg=1024.0, gamma_r=1e-8)
