@@ -332,6 +332,12 @@ int sivae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
 int sivae_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double* state,
                         double beta1, double beta2, float eps, float grad_scale, sivae_stream_t stream);
 
+/* grad[i] += s0[i] + s1[i] + s2[i] + s3[i] (s1 .. s3 may be NULL): folds the per-use parameter-gradient slabs of one backward pass
+ * into the flat gradient buffer — the reference's `loss.backward()` accumulation `p.grad += g` (:571, :619) for
+ * parameters used by several passes, as ONE launch per network instead of one torch add per tensor and use. */
+int sivae_sum_slabs(float* grad, const float* s0, const float* s1, const float* s2, const float* s3, size_t n,
+                    sivae_stream_t stream);
+
 /* ---- input side ------------------------------------------------------------------------------
  * uint8 image batch [B][C][H][W] (nhwc == 0) or [B][H][W][C] (nhwc != 0) -> fp32 NCHW * scale, sample b mirrored
  * horizontally when flip[b] != 0 (flip may be NULL): the reference's random mirror + transforms.ToTensor()

@@ -78,3 +78,46 @@ extern "C" int sivae_adam_step_dev(float* param, const float* grad, float* exp_a
                      (const double*)state, (float)beta1, (float)beta2, eps, grad_scale);
   return sivae_launch_status();
 }
+
+// flat_grad[i] += s0[i] + s1[i] + s2[i] + s3[i]  (s1 .. s3 may be NULL).  A parameter used by several passes of one backward gets
+// one gradient per use; each use writes its own slab (no read-modify-write, no per-tensor add launches) and this single
+// launch folds the slabs into the buffer the all-reduce and the fused Adam read (sivae_hip/optim.py).
+__global__ void __launch_bounds__(256) sum_slabs_kernel(float* __restrict__ g, const float* __restrict__ s0,
+                                                        const float* __restrict__ s1, const float* __restrict__ s2,
+                                                        const float* __restrict__ s3, size_t n4, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 v = reinterpret_cast<float4*>(g)[i];
+    const float4 a = reinterpret_cast<const float4*>(s0)[i];
+    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    if (s1) {
+      const float4 b = reinterpret_cast<const float4*>(s1)[i];
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (s2) {
+      const float4 c = reinterpret_cast<const float4*>(s2)[i];
+      v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
+    }
+    if (s3) {
+      const float4 d = reinterpret_cast<const float4*>(s3)[i];
+      v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+    }
+    reinterpret_cast<float4*>(g)[i] = v;
+  }
+  // ragged tail (n not a multiple of 4)
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    g[i] = (((g[i] + s0[i]) + (s1 ? s1[i] : 0.f)) + (s2 ? s2[i] : 0.f)) + (s3 ? s3[i] : 0.f);
+}
+
+extern "C" int sivae_sum_slabs(float* grad, const float* s0, const float* s1, const float* s2, const float* s3,
+                               size_t n, hipStream_t stream) {
+  if (!grad || !s0) return SIVAE_ERR_NULL;
+  if (n == 0) return SIVAE_OK;
+  const bool al = (((uintptr_t)grad | (uintptr_t)s0 | (uintptr_t)s1 | (uintptr_t)s2 | (uintptr_t)s3) & 15u) == 0;
+  const size_t n4 = al ? n / 4 : 0;
+  size_t nb = ((al ? n4 : n) + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  if (nb == 0) nb = 1;
+  hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)nb), dim3(256), 0, stream, grad, s0, s1, s2, s3, n4, n);
+  return sivae_launch_status();
+}

@@ -112,21 +112,39 @@ class GradSync:
         return plan
 
     def _hooks_for(self, opt, tail):
+        def final(p, st):
+            """parameter p's gradient is complete for this backward"""
+            if id(p) in st["seen"]:
+                return
+            st["seen"].add(id(p))
+            st["left"] -= 1
+            if st["left"] == 0 and st["handle"] is None:
+                if getattr(opt, "slabs", None):
+                    opt.fold_slabs(st["split"], None)  # the tail's per-use slabs -> flat buffer, then reduce it
+                    st["folded"] = True
+                seg = opt.flat_grad[st["split"]:]
+                st["handle"] = dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True)
+
         def make(p):
-            def hook(_param):
+            def hook(_param):  # autograd accumulated p's gradient (runs once per backward per parameter)
                 st = self._armed
                 if st is None or st["opt"] is not opt:
                     return
-                if id(p) in st["seen"]:
+                final(p, st)
+
+            def wrote(_param):  # one USE of p wrote its gradient slab (functional._done): final after the last use
+                st = self._armed
+                if st is None or st["opt"] is not opt:
                     return
-                st["seen"].add(id(p))
-                st["left"] -= 1
-                if st["left"] == 0 and st["handle"] is None:
-                    seg = opt.flat_grad[st["split"]:]
-                    st["handle"] = dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True)
-            return hook
+                c = st["writes"].get(id(p), 0) + 1
+                st["writes"][id(p)] = c
+                if c >= p.__dict__.get("_sivae_use", 0):
+                    final(p, st)
+            return hook, wrote
         for p in tail:
-            p.register_post_accumulate_grad_hook(make(p))
+            hook, wrote = make(p)
+            p.register_post_accumulate_grad_hook(hook)
+            p.__dict__["_sivae_on_grad"] = wrote
 
     def arm(self, opt):
         """call right before the backward() that fills `opt`'s gradient buffer"""
@@ -137,18 +155,27 @@ class GradSync:
         if not tail:
             self._armed = None
             return
-        self._armed = dict(opt=opt, seen=set(), left=len(tail), split=split, handle=None)
+        self._armed = dict(opt=opt, seen=set(), left=len(tail), split=split, handle=None, writes={}, folded=False)
 
-    def __call__(self, flat_grad):
+    def __call__(self, opt_or_flat):
+        """after backward(): `opt_or_flat` is the FlatAdam whose gradient buffer was just filled (its per-use slabs are
+        folded here) or a bare flat gradient tensor"""
+        opt = opt_or_flat if hasattr(opt_or_flat, "flat_grad") else None
+        flat_grad = opt.flat_grad if opt is not None else opt_or_flat
+        slabs = opt is not None and bool(getattr(opt, "slabs", None))
         self.calls += 1
         self.bytes += flat_grad.numel() * 4
         st, self._armed = self._armed, None
         if st is not None and st["handle"] is not None and st["opt"].flat_grad.data_ptr() == flat_grad.data_ptr():
             if st["split"] > 0:
+                if slabs:
+                    opt.fold_slabs(0, st["split"])
                 allreduce_sum_(flat_grad[:st["split"]])
             st["handle"].wait()  # (the current stream waits for the collective; the host does not block on NCCL)
             self.overlapped += 1
             return
+        if slabs:
+            opt.fold_slabs()
         allreduce_sum_(flat_grad)
 
 

@@ -82,6 +82,14 @@ class SoftIntroEngine:
         # pass, 2 of 8 decoder forwards (50.3 of 818.7 GFLOP per image at 256x256) not re-executed.
         self.reuse_decoder_forward = reuse_decoder_forward
         self._cache_fake, self._cache_rec = None, None
+        # parameter gradients of every pass go straight into per-use slabs of the flat optimizers and are folded with
+        # one launch per network after each backward (functional._claim / FlatAdam.fold_slabs; SIVAE_DIRECT_GRADS=0:
+        # autograd's per-tensor accumulation)
+        from . import functional as _SF
+        if _SF.DIRECT_GRADS:
+            for opt in (opt_e, opt_d):
+                if hasattr(opt, "enable_slabs"):
+                    opt.enable_slabs(4)  # the decoder runs four times inside lossD (fake, rec, rec_rec, rec_fake)
 
     # -- whole-iteration HIP graph -------------------------------------------------------
     def capture(self, real_example, warmup=2):
@@ -146,8 +154,11 @@ class SoftIntroEngine:
         return self.model.target_decoder if self.bootstrap else self.model.decoder
 
     def _sync(self, opt):
+        """after backward(): fold the per-use gradient slabs into the flat buffer, all-reduce it (data parallel)"""
         if self.grad_sync is not None:
-            self.grad_sync(opt.flat_grad)
+            self.grad_sync(opt)
+        else:
+            opt.fold_slabs()
 
     def _arm(self, opt):
         """let the gradient synchroniser start reducing the early-final tail of `opt`'s flat gradient buffer while the

@@ -133,6 +133,54 @@ def _replay_bn(st, mean, invstd, count):
                               st.momentum)
 
 
+# ---- parameter gradients written straight into the optimizer's slabs ------------------------------------------------
+# A parameter used by several passes of one backward (the encoder runs three times inside lossE, the decoder four times
+# inside lossD: train_soft_intro_vae.py:566-571, :601-619) gets one gradient per use, and autograd folds them with one
+# elementwise add per tensor and use: 343 tiny launches per iteration.  With optim.FlatAdam.enable_slabs() every USE
+# owns a slab (a second / third flat buffer laid out like flat_grad): the forward reserves the slab index, the backward
+# hands the slab view to the kernel that produces the gradient as its destination and returns None to autograd, and one
+# launch per network (`FlatAdam.fold_slabs`) sums the slabs into flat_grad before the all-reduce and the Adam step.
+# SIVAE_DIRECT_GRADS=0 (or a parameter without slabs: plain autograd use of the modules) keeps autograd's accumulation.
+DIRECT_GRADS = os.environ.get("SIVAE_DIRECT_GRADS", "1") != "0"
+
+
+def _claim(ctx, indexed_params):
+    """forward: reserve a slab index for each (input position, parameter) that will receive a gradient from this node"""
+    use = []
+    for i, p in indexed_params:
+        k = -1
+        if DIRECT_GRADS and p is not None and ctx.needs_input_grad[i]:
+            slabs = p.__dict__.get("_sivae_slabs")
+            if slabs is not None:
+                u = p.__dict__.get("_sivae_use", 0)
+                if u < len(slabs):
+                    k = u
+                    p.__dict__["_sivae_use"] = u + 1
+        use.append(k)
+    ctx.use = tuple(use)
+
+
+def _dst(p, k):
+    """the slab view reserved for this use of parameter p (None: return the gradient to autograd)"""
+    return p.__dict__["_sivae_slabs"][k] if k >= 0 else None
+
+
+def _pg_dst(g, kg, b, kb):
+    """(dgamma, dbeta) destinations of a BatchNorm backward, or None (both or neither go direct)"""
+    if kg < 0 or kb < 0:
+        return None
+    return (_dst(g, kg), _dst(b, kb))
+
+
+def _done(*params):
+    """after the kernel that wrote a use's gradient into its slab has been enqueued: tell the gradient synchroniser
+    (dp.GradSync watches the tail of the flat buffer to start its all-reduce during the backward)"""
+    for p in params:
+        cb = None if p is None else p.__dict__.get("_sivae_on_grad")
+        if cb is not None:
+            cb(p)
+
+
 class ResBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache=None, x_up=False):
@@ -147,6 +195,7 @@ class ResBlockFn(torch.autograd.Function):
         addressing, so the 4x tensor is never written.  post == "up_deferred": the Upsample after this block is
         left to the next block's x_up (the output is returned at this block's resolution)."""
         x = x.contiguous()
+        _claim(ctx, ((1, w_exp), (2, w1), (3, g1), (4, b1), (5, w2), (6, g2), (7, b2)))
         B, Ci, H, W = x.shape
         if x_up:
             H, W = 2 * H, 2 * W
@@ -161,7 +210,7 @@ class ResBlockFn(torch.autograd.Function):
             ctx.post = post
             ctx.has_exp = w_exp is not None
             ctx.training = st1.training and st2.training
-            ctx.save_for_backward(x, a, h, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2)
+            ctx.save_for_backward(x, a, h, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2, b2)
             return y.view_as(y)
         idt = x
         if w_exp is not None:
@@ -210,14 +259,15 @@ class ResBlockFn(torch.autograd.Function):
         ctx.post = post
         ctx.has_exp = w_exp is not None
         ctx.training = st1.training and st2.training
-        ctx.save_for_backward(x, a, h, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2)
+        ctx.save_for_backward(x, a, h, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2, b2)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         if not ctx.training:
             raise RuntimeError("sivae_hip: backward through eval-mode BatchNorm is not supported")
-        x, a, h, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2 = ctx.saved_tensors
+        x, a, h, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2, b2 = ctx.saved_tensors
+        k_we, k_w1, k_g1, k_b1, k_w2, k_g2, k_b2 = ctx.use
         h_saved = h.data_ptr() != a.data_ptr()
         need = ctx.needs_input_grad
         need_x, need_we, need_w1, need_bn1, need_w2, need_bn2 = need[0], need[1], need[2], need[3] or need[4], \
@@ -225,34 +275,41 @@ class ResBlockFn(torch.autograd.Function):
         Cm = w1.shape[0]
         # BN2 + residual + LeakyReLU; the AvgPool2d that follows an encoder block is undone while reading dy
         x_up = ctx.x_up
+        pg2 = _pg_dst(g2, k_g2, b2, k_b2) if need_bn2 else None
+        pg1 = _pg_dst(g1, k_g1, b1, k_b1) if need_bn1 else None
         dzh = None  # 2x2 block sums of dz: all a block behind an Upsample ever needs of it
         if out.dtype == torch.uint8:  # `out` is the LeakyReLU sign mask (1 bit per element)
             if ctx.post == "pool" and not (x_up and not ctx.has_exp):
                 dc, dz, dg2, db2 = ops.bn_bwd_signmask(dy.contiguous(), out, c, mean2, invstd2, g2, SLOPE,
-                                                       dy_pooled=True, want_param_grads=need_bn2)
+                                                       dy_pooled=True, want_param_grads=need_bn2, pg_out=pg2)
             else:
                 d_out = _post_bwd(dy.contiguous(), ctx.post, c.shape)
                 want_sum = x_up and ctx.post != "pool"
                 dc, dz, dg2, db2 = ops.bn_bwd_signmask(d_out, out, c, mean2, invstd2, g2, SLOPE, dz_sum=want_sum,
-                                                       want_param_grads=need_bn2)
+                                                       want_param_grads=need_bn2, pg_out=pg2)
                 if want_sum:
                     dzh, dz = dz, None
                 del d_out
         elif x_up and ctx.post != "pool" and ops.bn_bwd_dzsum_supported(c):
             d_out = _post_bwd(dy.contiguous(), ctx.post, out.shape)
-            dc, dzh, dg2, db2 = ops.bn_bwd_dzsum(d_out, out, c, mean2, invstd2, g2, SLOPE, want_param_grads=need_bn2)
+            dc, dzh, dg2, db2 = ops.bn_bwd_dzsum(d_out, out, c, mean2, invstd2, g2, SLOPE, want_param_grads=need_bn2,
+                                                 pg_out=pg2)
             dz = None
             del d_out
         elif ctx.post == "pool":
             dc, dz, dg2, db2 = ops.bn_bwd(dy.contiguous(), out, c, mean2, invstd2, g2, SLOPE, want_dz=True,
-                                          want_param_grads=need_bn2, act_mode=1, dy_pooled=True)
+                                          want_param_grads=need_bn2, act_mode=1, dy_pooled=True, pg_out=pg2)
         else:
             d_out = _post_bwd(dy.contiguous(), ctx.post, out.shape)
             dc, dz, dg2, db2 = ops.bn_bwd(d_out, out, c, mean2, invstd2, g2, SLOPE, want_dz=True,
-                                          want_param_grads=need_bn2, act_mode=1)
+                                          want_param_grads=need_bn2, act_mode=1, pg_out=pg2)
             del d_out
         pro1 = None if h_saved else (mean1, invstd1, g1, b1, SLOPE)
-        dw2 = ops.conv2d_wgrad(h, dc, 3, pro=pro1) if need_w2 else None
+        if pg2 is not None:
+            _done(g2, b2)
+        dw2 = ops.conv2d_wgrad(h, dc, 3, pro=pro1, out=_dst(w2, k_w2)) if need_w2 else None
+        if need_w2 and k_w2 >= 0:
+            _done(w2)
         fuse_bn1 = (not h_saved) and ops.conv2d_dgrad_bnbwd_supported(dc.shape[2], dc.shape[3])
         if fuse_bn1:
             # conv2's data gradient also reduces BatchNorm-1's backward sums in its epilogue (one pass fewer over dh, a)
@@ -263,15 +320,19 @@ class ResBlockFn(torch.autograd.Function):
         # BN1 + LeakyReLU (sign from the saved h, or recomputed from a when h was never stored)
         if fuse_bn1:
             da, dg1, db1 = ops.bn_bwd_from_partials(dh, a, mean1, invstd1, g1, b1, part1, SLOPE,
-                                                    want_param_grads=need_bn1)
+                                                    want_param_grads=need_bn1, pg_out=pg1)
         elif h_saved:
             da, _, dg1, db1 = ops.bn_bwd(dh, h, a, mean1, invstd1, g1, SLOPE, want_dz=False,
-                                         want_param_grads=need_bn1, act_mode=1)
+                                         want_param_grads=need_bn1, act_mode=1, pg_out=pg1)
         else:
             da, _, dg1, db1 = ops.bn_bwd(dh, None, a, mean1, invstd1, g1, SLOPE, want_dz=False,
-                                         want_param_grads=need_bn1, beta=b1, act_mode=2)
+                                         want_param_grads=need_bn1, beta=b1, act_mode=2, pg_out=pg1)
         del dh
-        dw1 = ops.conv2d_wgrad(x, da, 3, upsample=x_up) if need_w1 else None
+        if pg1 is not None:
+            _done(g1, b1)
+        dw1 = ops.conv2d_wgrad(x, da, 3, upsample=x_up, out=_dst(w1, k_w1)) if need_w1 else None
+        if need_w1 and k_w1 >= 0:
+            _done(w1)
         dwe = None
         dx = None
         # conv1's data gradient straight to the low-resolution x (phase-folded F(2x2,2x2) kernel)
@@ -281,7 +342,7 @@ class ResBlockFn(torch.autograd.Function):
             if dzh is None:
                 dzh = ops.upsample2_bwd(dz) if (need_we or need_x) else None
             if need_we:
-                dwe = ops.conv2d_wgrad(x, dzh, 1)
+                dwe = ops.conv2d_wgrad(x, dzh, 1, out=_dst(w_exp, k_we))
             if need_x:
                 if up_dg:
                     dx = ops.conv2d_up_dgrad(da, packed(w1, 0), x.shape[1])
@@ -300,7 +361,7 @@ class ResBlockFn(torch.autograd.Function):
         else:
             if ctx.has_exp:
                 if need_we:
-                    dwe = ops.conv2d_wgrad(x, dz, 1)
+                    dwe = ops.conv2d_wgrad(x, dz, 1, out=_dst(w_exp, k_we))
                 if need_x:
                     dx = ops.conv2d_fwd(da, packed(w1, 1), x.shape[1], 3)
                     ops.conv2d_fwd(dz, packed(w_exp, 1), x.shape[1], 1, out=dx, accumulate=True)
@@ -309,8 +370,14 @@ class ResBlockFn(torch.autograd.Function):
                 ops.conv2d_fwd(da, packed(w1, 1), x.shape[1], 3, out=dx, accumulate=True)
             if x_up and dx is not None:
                 dx = ops.upsample2_bwd(dx)  # adjoint of the deferred Upsample: sum each 2x2 block
-        return (dx, dwe, dw1, dg1 if need[3] else None, db1 if need[4] else None, dw2,
-                dg2 if need[6] else None, db2 if need[7] else None, None, None, None, None, None)
+        if need_we and ctx.has_exp and k_we >= 0:
+            _done(w_exp)
+        # (gradients that went into a slab are not handed to autograd)
+        return (dx, dwe if k_we < 0 else None, dw1 if k_w1 < 0 else None,
+                dg1 if (need[3] and pg1 is None) else None, db1 if (need[4] and pg1 is None) else None,
+                dw2 if k_w2 < 0 else None,
+                dg2 if (need[6] and pg2 is None) else None, db2 if (need[7] and pg2 is None) else None,
+                None, None, None, None, None)
 
 
 class StemFn(torch.autograd.Function):
@@ -319,6 +386,7 @@ class StemFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, g, b, st):
         x = x.contiguous()
+        _claim(ctx, ((1, w), (2, g), (3, b)))
         B, Ci, H, W = x.shape
         Co = w.shape[0]
         if st.training:
@@ -341,17 +409,26 @@ class StemFn(torch.autograd.Function):
             raise RuntimeError("sivae_hip: backward through eval-mode BatchNorm is not supported")
         x, a, mean, invstd, w, g, b = ctx.saved_tensors
         need = ctx.needs_input_grad
+        k_w, k_g, k_b = ctx.use
+        pg = _pg_dst(g, k_g, b, k_b) if (need[2] or need[3]) else None
         da, _, dg, db = ops.bn_bwd(dy.contiguous(), None, a, mean, invstd, g, SLOPE, want_dz=False,
-                                   want_param_grads=need[2] or need[3], beta=b, act_mode=2, dy_pooled=True)
+                                   want_param_grads=need[2] or need[3], beta=b, act_mode=2, dy_pooled=True,
+                                   pg_out=pg)
         edge = _is_edge5(w) and w.shape[1] <= 3
         dw = None
         if need[1]:
-            dw = ops.conv5_edge_wgrad(x, da) if edge else ops.conv2d_wgrad(x, da, 5)
+            dst = _dst(w, k_w)
+            dw = ops.conv5_edge_wgrad(x, da, out=dst) if edge else ops.conv2d_wgrad(x, da, 5, out=dst)
+            if dst is not None:
+                _done(w)
+        if pg is not None:
+            _done(g, b)
         dx = None
         if need[0]:
             dx = (ops.conv5_smallco_fwd(da, packed5(w, 1), x.shape[1]) if edge
                   else ops.conv2d_fwd(da, packed(w, 1), x.shape[1], 5))
-        return dx, dw, dg if need[2] else None, db if need[3] else None, None
+        return (dx, dw if k_w < 0 else None, dg if (need[2] and pg is None) else None,
+                db if (need[3] and pg is None) else None, None)
 
 
 class ConvBiasFn(torch.autograd.Function):
@@ -360,8 +437,9 @@ class ConvBiasFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, cache=None):
         x = x.contiguous()
+        _claim(ctx, ((1, w), (2, bias)))
         ks = w.shape[2]
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x, w, bias)
         ctx.has_bias = bias is not None
         tag = cache_tag((w, bias))
         if cache is not None and cache.get("y") is not None and cache.get("tag") == tag:
@@ -377,16 +455,19 @@ class ConvBiasFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, w, bias = ctx.saved_tensors
         need = ctx.needs_input_grad
+        k_w, k_b = ctx.use
         dy = dy.contiguous()
         ks = w.shape[2]
         dw = None
         if need[1]:
-            dw = ops.conv5_edge_wgrad(x, dy) if _is_edge5(w) else ops.conv2d_wgrad(x, dy, ks)
-        db = ops.channel_sum(dy) if (ctx.has_bias and need[2]) else None
+            dst = _dst(w, k_w)
+            dw = ops.conv5_edge_wgrad(x, dy, out=dst) if _is_edge5(w) else ops.conv2d_wgrad(x, dy, ks, out=dst)
+        db = ops.channel_sum(dy, out=_dst(bias, k_b)) if (ctx.has_bias and need[2]) else None
+        _done(w if (need[1] and k_w >= 0) else None, bias if (db is not None and k_b >= 0) else None)
         dx = ops.conv2d_fwd(dy, packed(w, 1), x.shape[1], ks) if need[0] else None
-        return dx, dw, db, None
+        return dx, dw if k_w < 0 else None, db if k_b < 0 else None, None
 
 
 class LinearFn(torch.autograd.Function):
@@ -396,6 +477,7 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, relu):
         x = x.contiguous()
+        _claim(ctx, ((1, w), (2, bias)))
         B, K = x.shape
         N = w.shape[0]
         ctx.fast = ops.linear_supported(B, K, N)
@@ -408,27 +490,33 @@ class LinearFn(torch.autograd.Function):
                 ops.relu_fwd(y, inplace=True)
         ctx.relu = relu
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.save_for_backward(x, w, y if relu else None, bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y = ctx.saved_tensors
+        x, w, y, bias = ctx.saved_tensors
         need = ctx.needs_input_grad
+        k_w, k_b = ctx.use
         dy = dy.contiguous()
         if ctx.relu:
             dy = ops.relu_bwd(dy, y)
         B, K = x.shape
         N = w.shape[0]
         dy4 = dy.view(B, N, 1, 1)
-        db = ops.channel_sum(dy4) if (ctx.has_bias and need[2]) else None
+        db = ops.channel_sum(dy4, out=_dst(bias, k_b)) if (ctx.has_bias and need[2]) else None
+        dst = _dst(w, k_w) if need[1] else None
         if ctx.fast:
-            dw = ops.linear_wgrad(dy, x) if need[1] else None
+            dw = ops.linear_wgrad(dy, x, out=dst) if need[1] else None
             dx = ops.linear_dgrad(dy, w.detach()) if need[0] else None
         else:
-            dw = ops.conv2d_wgrad(x.view(B, K, 1, 1), dy4, 1).view(N, K) if need[1] else None
+            dw = None
+            if need[1]:
+                dw = ops.conv2d_wgrad(x.view(B, K, 1, 1), dy4, 1, out=None if dst is None else dst.view(N, K, 1, 1))
+                dw = dw.view(N, K)
             dx = ops.conv2d_fwd(dy4, packed(w, 1), K, 1).view(B, K) if need[0] else None
-        return dx, dw, db, None
+        _done(w if (need[1] and k_w >= 0) else None, bias if (db is not None and k_b >= 0) else None)
+        return dx, dw if k_w < 0 else None, db if k_b < 0 else None, None
 
 
 # ---------------------------------------------------------------------------------------------------

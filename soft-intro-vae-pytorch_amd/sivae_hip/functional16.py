@@ -49,11 +49,17 @@ def _virtual(w, virt):
     return v.contiguous()
 
 
-def _unpack_dw(dwv, Co, Ci, virt):
-    """gradient of the virtual weight ([.., .., 5, 1] from the ks-51 weight-gradient kernel) -> [Co][Ci][kh][kw]"""
+def _unpack_dw(dwv, Co, Ci, virt, out=None):
+    """gradient of the virtual weight ([.., .., 5, 1] from the ks-51 weight-gradient kernel) -> [Co][Ci][kh][kw]
+    (a fresh tensor, or copied into `out`: the parameter's gradient slab)"""
     if virt == "in":    # [Co][kw*Ci + ci][kh]
-        return dwv.view(Co, 5, Ci, 5).permute(0, 2, 3, 1).contiguous()
-    return dwv.view(5, Co, Ci, 5).permute(1, 2, 3, 0).contiguous()  # "out": [kw*Co + co][Ci][kh]
+        v = dwv.view(Co, 5, Ci, 5).permute(0, 2, 3, 1)
+    else:               # "out": [kw*Co + co][Ci][kh]
+        v = dwv.view(5, Co, Ci, 5).permute(1, 2, 3, 0)
+    if out is None:
+        return v.contiguous()
+    out.copy_(v)
+    return out
 
 
 def packed16(w, mode, virt=None):
@@ -107,6 +113,7 @@ class ResBlockFn16(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache=None, x_up=False):
+        SF._claim(ctx, ((1, w_exp), (2, w1), (3, g1), (4, b1), (5, w2), (6, g2), (7, b2)))
         B, Cib, Hs, Ws, _ = x.shape
         H, W = (2 * Hs, 2 * Ws) if x_up else (Hs, Ws)
         Cm, Ci, Co = w1.shape[0], w1.shape[1], w2.shape[0]
@@ -166,6 +173,7 @@ class ResBlockFn16(torch.autograd.Function):
         if not ctx.training:
             raise RuntimeError("sivae_hip: backward through eval-mode BatchNorm is not supported")
         x, a, h, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2, b2 = ctx.saved_tensors
+        k_we, k_w1, k_g1, k_b1, k_w2, k_g2, k_b2 = ctx.use
         h_saved = h.data_ptr() != a.data_ptr()
         need = ctx.needs_input_grad
         need_x, need_we, need_w1, need_bn1, need_w2, need_bn2 = need[0], need[1], need[2], need[3] or need[4], \
@@ -176,19 +184,30 @@ class ResBlockFn16(torch.autograd.Function):
         pool = ctx.post == "pool"
         d_out = ops16.upsample2_bwd(dy, Co) if ctx.post == "up" else dy
         need_dz = need_x or (need_we and ctx.has_exp)
+        pg2 = SF._pg_dst(g2, k_g2, b2, k_b2) if need_bn2 else None
+        pg1 = SF._pg_dst(g1, k_g1, b1, k_b1) if need_bn1 else None
         dc, dz, dg2, db2 = ops16.bn_bwd(d_out, out, c, mean2, invstd2, g2, b2, Co, SLOPE, dy_pooled=pool,
                                         want_dz=need_dz and not x_up, dz_sum=need_dz and x_up,
-                                        want_param_grads=need_bn2)
+                                        want_param_grads=need_bn2, pg_out=pg2)
+        if pg2 is not None:
+            SF._done(g2, b2)
         del d_out
         pro1 = None if h_saved else (mean1, invstd1, g1, b1, SLOPE)
-        dw2 = ops16.conv2d_wgrad(h, dc, Cm, Co, 3, pro=pro1) if need_w2 else None
+        dw2 = ops16.conv2d_wgrad(h, dc, Cm, Co, 3, pro=pro1, out=SF._dst(w2, k_w2)) if need_w2 else None
+        if need_w2 and k_w2 >= 0:
+            SF._done(w2)
         dh = ops16.conv2d(dc, packed16(w2, 1), Co, Cm, 3)
         del dc
         # BatchNorm-1 + LeakyReLU: the sign is recomputed from a (x-hat * gamma + beta) even when h was stored — both
         # backward passes then read two tensors (dh, a) instead of three (2 of 7 tensor passes of this BatchNorm)
-        da, _, dg1, db1 = ops16.bn_bwd(dh, None, a, mean1, invstd1, g1, b1, Cm, SLOPE, want_param_grads=need_bn1)
+        da, _, dg1, db1 = ops16.bn_bwd(dh, None, a, mean1, invstd1, g1, b1, Cm, SLOPE, want_param_grads=need_bn1,
+                                       pg_out=pg1)
+        if pg1 is not None:
+            SF._done(g1, b1)
         del dh
-        dw1 = ops16.conv2d_wgrad(x, da, Ci, Cm, 3, upsample=x_up) if need_w1 else None
+        dw1 = ops16.conv2d_wgrad(x, da, Ci, Cm, 3, upsample=x_up, out=SF._dst(w1, k_w1)) if need_w1 else None
+        if need_w1 and k_w1 >= 0:
+            SF._done(w1)
         dwe = None
         dx = None
         if need_x:
@@ -206,9 +225,14 @@ class ResBlockFn16(torch.autograd.Function):
                 else:
                     ops16.add_(dx, dz)
         if need_we and ctx.has_exp:
-            dwe = ops16.conv2d_wgrad(x, dz, Ci, Co, 1)
-        return (dx, dwe, dw1, dg1 if need[3] else None, db1 if need[4] else None, dw2,
-                dg2 if need[6] else None, db2 if need[7] else None, None, None, None, None, None)
+            dwe = ops16.conv2d_wgrad(x, dz, Ci, Co, 1, out=SF._dst(w_exp, k_we))
+            if k_we >= 0:
+                SF._done(w_exp)
+        return (dx, dwe if k_we < 0 else None, dw1 if k_w1 < 0 else None,
+                dg1 if (need[3] and pg1 is None) else None, db1 if (need[4] and pg1 is None) else None,
+                dw2 if k_w2 < 0 else None,
+                dg2 if (need[6] and pg2 is None) else None, db2 if (need[7] and pg2 is None) else None,
+                None, None, None, None, None)
 
 
 class StemFn16(torch.autograd.Function):
@@ -217,6 +241,7 @@ class StemFn16(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, g, b, st):
+        SF._claim(ctx, ((1, w), (2, g), (3, b)))
         B, Ci, H, W = x.shape
         Co = w.shape[0]
         ctx.kw = _kwpack_ok(w, Ci)
@@ -242,22 +267,30 @@ class StemFn16(torch.autograd.Function):
             raise RuntimeError("sivae_hip: backward through eval-mode BatchNorm is not supported")
         xb, a, mean, invstd, w, g, b = ctx.saved_tensors
         need = ctx.needs_input_grad
+        k_w, k_g, k_b = ctx.use
         Co, Ci, ks = w.shape[0], ctx.Ci, w.shape[2]
+        pg = SF._pg_dst(g, k_g, b, k_b) if (need[2] or need[3]) else None
         da, _, dg, db = ops16.bn_bwd(dy.contiguous(), None, a, mean, invstd, g, b, Co, SLOPE, dy_pooled=True,
-                                     want_param_grads=need[2] or need[3])
+                                     want_param_grads=need[2] or need[3], pg_out=pg)
+        if pg is not None:
+            SF._done(g, b)
         dw = dx = None
+        dst = SF._dst(w, k_w) if need[1] else None
         if ctx.kw:
             if need[1]:
-                dw = _unpack_dw(ops16.conv2d_wgrad(xb, da, 5 * Ci, Co, ops16.KS51), Co, Ci, "in")
+                dw = _unpack_dw(ops16.conv2d_wgrad(xb, da, 5 * Ci, Co, ops16.KS51), Co, Ci, "in", out=dst)
             if need[0]:
                 gk = ops16.conv2d(da, packed16(w, 0, "in_d"), Co, 5 * Ci, ops16.KS51, out_f32=True)
                 dx = ops16.fold_kw5(gk, None, Ci, -1)
         else:
             if need[1]:
-                dw = ops16.conv2d_wgrad(xb, da, Ci, Co, ks)
+                dw = ops16.conv2d_wgrad(xb, da, Ci, Co, ks, out=dst)
             if need[0]:
                 dx = ops16.to_f32(ops16.conv2d(da, packed16(w, 1), Co, Ci, ks), Ci)
-        return dx, dw, dg if need[2] else None, db if need[3] else None, None
+        if dst is not None:
+            SF._done(w)
+        return (dx, dw if k_w < 0 else None, dg if (need[2] and pg is None) else None,
+                db if (need[3] and pg is None) else None, None)
 
 
 class PredictFn16(torch.autograd.Function):
@@ -267,7 +300,8 @@ class PredictFn16(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, cache=None):
-        ctx.save_for_backward(x, w)
+        SF._claim(ctx, ((1, w), (2, bias)))
+        ctx.save_for_backward(x, w, bias)
         ctx.has_bias = bias is not None
         tag = SF.cache_tag((w, bias))
         if cache is not None and cache.get("y") is not None and cache.get("tag") == tag:
@@ -285,23 +319,26 @@ class PredictFn16(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, w, bias = ctx.saved_tensors
         need = ctx.needs_input_grad
+        k_w, k_b = ctx.use
         Co, Ci, ks = w.shape[0], w.shape[1], w.shape[2]
         dy = dy.contiguous()
-        db = ops.channel_sum(dy) if (ctx.has_bias and need[2]) else None
+        db = ops.channel_sum(dy, out=SF._dst(bias, k_b)) if (ctx.has_bias and need[2]) else None
         dw = dx = None
+        dst = SF._dst(w, k_w) if need[1] else None
         if _kwpack_ok(w, Co):
             dyk = ops16.im2col_kw5(dy, -1)                                       # [kw*Co + co][h][w] = dy[co][h][w-kw+2]
             if need[1]:
-                dw = _unpack_dw(ops16.conv2d_wgrad(x, dyk, Ci, 5 * Co, ops16.KS51), Co, Ci, "out")
+                dw = _unpack_dw(ops16.conv2d_wgrad(x, dyk, Ci, 5 * Co, ops16.KS51), Co, Ci, "out", out=dst)
             if need[0]:
                 dx = ops16.conv2d(dyk, packed16(w, 0, "out_d"), 5 * Co, Ci, ops16.KS51)
         else:
             dyb = ops16.from_f32(dy)
-            dw = ops16.conv2d_wgrad(x, dyb, Ci, Co, ks) if need[1] else None
+            dw = ops16.conv2d_wgrad(x, dyb, Ci, Co, ks, out=dst) if need[1] else None
             dx = ops16.conv2d(dyb, packed16(w, 1), Co, Ci, ks) if need[0] else None
-        return dx, dw, db, None
+        SF._done(w if dst is not None else None, bias if (db is not None and k_b >= 0) else None)
+        return dx, dw if k_w < 0 else None, db if k_b < 0 else None, None
 
 
 def residual_block(x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post=None, cache=None, x_up=False):

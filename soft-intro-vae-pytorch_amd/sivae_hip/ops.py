@@ -124,6 +124,26 @@ def workspace(nbytes, device):
     return buf
 
 
+def _out(out, shape, device):
+    """a caller-provided destination (a contiguous fp32 device tensor of exactly `shape`: the parameter-gradient slab
+    views of optim.FlatAdam) or a fresh tensor"""
+    if out is None:
+        return torch.empty(shape, dtype=torch.float32, device=device)
+    if (tuple(out.shape) != tuple(shape) or out.dtype != torch.float32 or not out.is_contiguous()
+            or out.device != device):
+        raise ValueError("sivae_hip: out must be a contiguous float32 tensor of shape %s on %s" % (tuple(shape), device))
+    return out
+
+
+def _pg(pg_out, C, device, want):
+    """(dgamma, dbeta) destinations of a BatchNorm backward"""
+    if not want:
+        return None, None
+    if pg_out is not None:
+        return _out(pg_out[0], (C,), device), _out(pg_out[1], (C,), device)
+    return (torch.empty(C, dtype=torch.float32, device=device), torch.empty(C, dtype=torch.float32, device=device))
+
+
 # ------------------------------------------------------------------------------------------------ conv
 def pack_weight(w, mode):
     """w [Co, Ci, k, k] (or [out, in] for Linear) -> packed GEMM operand. mode 0 fwd, 1 dgrad."""
@@ -240,15 +260,15 @@ def conv2d_dgrad_bnbwd(dy, wp, Cm, bn_x, mean, invstd, gamma, beta, slope=LRELU_
     return dh, part
 
 
-def bn_bwd_from_partials(dy, x, mean, invstd, gamma, beta, partials, slope=LRELU_SLOPE, want_param_grads=True):
+def bn_bwd_from_partials(dy, x, mean, invstd, gamma, beta, partials, slope=LRELU_SLOPE, want_param_grads=True,
+                         pg_out=None):
     """BatchNorm(+LeakyReLU, sign recomputed from x) backward whose reduction pass was done by the producer of dy"""
     _require(dy, x, mean, invstd, gamma, beta, partials)
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
     ws = workspace(_lib.load().sivae_bn_workspace_bytes(B, C, HW), x.device)
     dx = torch.empty_like(x)
-    dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
-    dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
+    dgamma, dbeta = _pg(pg_out, C, x.device, want_param_grads)
     _lib.call("sivae_bn_bwd_from_partials", _p(dy), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), float(slope),
               _p(partials), partials.shape[0], _p(dx), _p(dgamma), _p(dbeta), B, C, HW, _p(ws), ws.numel(), _s())
     return dx, dgamma, dbeta
@@ -341,8 +361,8 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
     return (y, stats) if want_stats else y
 
 
-def conv2d_wgrad(x, dy, ks, pro=None, upsample=False):
-    """-> dW [Co, Ci, ks, ks]"""
+def conv2d_wgrad(x, dy, ks, pro=None, upsample=False, out=None):
+    """-> dW [Co, Ci, ks, ks]  (written into `out` when given)"""
     _require(x, dy)
     B, Ci = x.shape[0], x.shape[1]
     _, Co, H, W = dy.shape
@@ -351,7 +371,7 @@ def conv2d_wgrad(x, dy, ks, pro=None, upsample=False):
             and L.sivae_conv2d_wino_up_wgrad_supported(H // 2, W // 2) == 1):
         # conv after nearest-2x upsample: phase-form F(2x2,2x2) weight gradient on the low-resolution x
         ws = workspace(L.sivae_conv2d_wino_up_wgrad_workspace_bytes(B, Ci, Co, H // 2, W // 2), x.device)
-        dw = torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=x.device)
+        dw = _out(out, (Co, Ci, 3, 3), x.device)
         t0 = TIMER.begin() if TIMER is not None else None
         _lib.call("sivae_conv2d_wino_up_wgrad", _p(x), _p(dy), _p(dw), B, Ci, Co, H // 2, W // 2, _p(ws), ws.numel(),
                   _s())
@@ -363,7 +383,7 @@ def conv2d_wgrad(x, dy, ks, pro=None, upsample=False):
     nbytes = (L.sivae_conv2d_wino_wgrad_workspace_bytes(B, Ci, Co, H, W) if wino
               else L.sivae_conv2d_wgrad_workspace_bytes(B, Ci, Co, H, W, ks))
     ws = workspace(nbytes, x.device)
-    dw = torch.empty((Co, Ci, ks, ks), dtype=torch.float32, device=x.device)
+    dw = _out(out, (Co, Ci, ks, ks), x.device)
     pm = pi = pg = pb = None
     slope = 1.0
     if pro is not None:
@@ -418,11 +438,11 @@ def linear_dgrad(dy, w):
     return dx
 
 
-def linear_wgrad(dy, x):
+def linear_wgrad(dy, x, out=None):
     _require(dy, x)
     B, N = dy.shape
     K = x.shape[1]
-    dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    dw = _out(out, (N, K), dy.device)
     t0 = TIMER.begin() if TIMER is not None else None
     _lib.call("sivae_linear_wgrad", _p(dy), _p(x), _p(dw), B, K, N, _s(dy))
     if t0 is not None:
@@ -454,12 +474,12 @@ def conv5_smallco_fwd(x, wq, Co, bias=None):
     return y
 
 
-def conv5_edge_wgrad(x, dy):
+def conv5_edge_wgrad(x, dy, out=None):
     _require(x, dy)
     B, Ci, H, W = x.shape
     Co = dy.shape[1]
     ws = workspace(_lib.load().sivae_conv5_edge_wgrad_workspace_bytes(B, Ci, Co, H, W), x.device)
-    dw = torch.empty((Co, Ci, 5, 5), dtype=torch.float32, device=x.device)
+    dw = _out(out, (Co, Ci, 5, 5), x.device)
     t0 = TIMER.begin() if TIMER is not None else None
     _lib.call("sivae_conv5_edge_wgrad", _p(x), _p(dy), _p(dw), B, Ci, Co, H, W, _p(ws), ws.numel(), _s())
     if t0 is not None:
@@ -563,7 +583,7 @@ def bn_apply_act_signmask(x, res, mean, invstd, gamma, beta, slope=LRELU_SLOPE, 
 
 
 def bn_bwd_signmask(dy, mask, x, mean, invstd, gamma, slope=LRELU_SLOPE, dy_pooled=False, dz_sum=False,
-                    want_dz=True, want_param_grads=True):
+                    want_dz=True, want_param_grads=True, pg_out=None):
     """backward of bn_apply_act_signmask -> dx, dz (full resolution, or its 2x2 block sums with dz_sum), dgamma,
     dbeta.  dy_pooled: dy is the gradient of the pooled output."""
     _require(dy, x, mean, invstd, gamma)
@@ -577,8 +597,7 @@ def bn_bwd_signmask(dy, mask, x, mean, invstd, gamma, slope=LRELU_SLOPE, dy_pool
         dz = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
     elif want_dz:
         dz = torch.empty_like(x)
-    dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
-    dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
+    dgamma, dbeta = _pg(pg_out, C, x.device, want_param_grads)
     _lib.call("sivae_bn_bwd_signmask", _p(dy), _p(mask), _p(x), _p(mean), _p(invstd), _p(gamma), float(slope), _p(dx),
               _p(dz), _p(dgamma), _p(dbeta), B, C, H, W, int(bool(dy_pooled)), int(bool(dz_sum)), _p(ws), ws.numel(),
               _s())
@@ -589,7 +608,7 @@ def bn_bwd_dzsum_supported(x):
     return SYNC_BN is None and not (x.shape[2] & 1) and not (x.shape[3] & 3)
 
 
-def bn_bwd_dzsum(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_param_grads=True):
+def bn_bwd_dzsum(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_param_grads=True, pg_out=None):
     """act_mode-1 BatchNorm(+residual+LeakyReLU) backward -> dx, dz_half (2x2 block sums of the residual-branch
     gradient, [B, C, H/2, W/2]), dgamma, dbeta"""
     _require(dy, y, x, mean, invstd, gamma)
@@ -597,15 +616,14 @@ def bn_bwd_dzsum(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_param_gr
     ws = workspace(_lib.load().sivae_bn_workspace_bytes(B, C, H * W), x.device)
     dx = torch.empty_like(x)
     dzh = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
-    dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
-    dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
+    dgamma, dbeta = _pg(pg_out, C, x.device, want_param_grads)
     _lib.call("sivae_bn_bwd_dzsum", _p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), float(slope), _p(dx), _p(dzh),
               _p(dgamma), _p(dbeta), B, C, H, W, _p(ws), ws.numel(), _s())
     return dx, dzh, dgamma, dbeta
 
 
 def bn_bwd(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_dz=False, want_param_grads=True, beta=None,
-           act_mode=None, dy_pooled=False):
+           act_mode=None, dy_pooled=False, pg_out=None):
     """-> dx, dz (or None), dgamma, dbeta (or None, None).
     act_mode: 0 none, 1 LeakyReLU sign from the saved output y, 2 sign recomputed from x (needs beta).
     dy_pooled: dy is the gradient of AvgPool2d(2)(output) at half resolution; the pool's adjoint is applied on load."""
@@ -621,8 +639,7 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_dz=False, want
     ws = workspace(L.sivae_bn_workspace_bytes(B, C, HW), x.device)
     dx = torch.empty_like(x)
     dz = torch.empty_like(x) if want_dz else None
-    dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
-    dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
+    dgamma, dbeta = _pg(pg_out, C, x.device, want_param_grads)
     if SYNC_BN is not None:
         local = torch.empty((C, 2), dtype=torch.float64, device=x.device)
         _lib.call("sivae_bn_bwd_reduce", _p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta),
@@ -643,13 +660,13 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_dz=False, want
     return dx, dz, dgamma, dbeta
 
 
-def channel_sum(x):
+def channel_sum(x, out=None):
     _require(x)
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
     L = _lib.load()
     ws = workspace(L.sivae_bn_workspace_bytes(B, C, HW), x.device)
-    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    out = _out(out, (C,), x.device)
     _lib.call("sivae_channel_sum", _p(x), _p(out), B, C, HW, _p(ws), ws.numel(), _s())
     return out
 
@@ -875,6 +892,15 @@ def adam_step_dev(param, grad, exp_avg, exp_avg_sq, state, beta1=0.9, beta2=0.99
     _require(param, grad, exp_avg, exp_avg_sq)
     _lib.call("sivae_adam_step_dev", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), _p(state),
               float(beta1), float(beta2), float(eps), float(grad_scale), _s())
+
+
+def sum_slabs(flat_grad, slabs):
+    """flat_grad += slabs[0] + slabs[1] + ... (<= 4 slabs; the per-use parameter-gradient slabs of optim.FlatAdam)"""
+    _require(flat_grad, *slabs)
+    n = flat_grad.numel()
+    assert 1 <= len(slabs) <= 4 and all(t.numel() == n for t in slabs)
+    ptrs = [_p(t) for t in slabs] + [None] * (4 - len(slabs))
+    _lib.call("sivae_sum_slabs", _p(flat_grad), ptrs[0], ptrs[1], ptrs[2], ptrs[3], n, _s(flat_grad))
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):

@@ -149,14 +149,14 @@ def conv2d(x, wp, Ci, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
     return (y, stats) if want_stats else y
 
 
-def conv2d_wgrad(x, dy, Ci, Co, ks, pro=None, upsample=False):
-    """-> dW fp32 [Co, Ci, ks, ks]  ([Co, Ci, 5, 1] for ks = KS51)"""
+def conv2d_wgrad(x, dy, Ci, Co, ks, pro=None, upsample=False, out=None):
+    """-> dW fp32 [Co, Ci, ks, ks]  ([Co, Ci, 5, 1] for ks = KS51); written into `out` when given"""
     _req16(x, dy)
     B, Cob, H, W, _ = dy.shape
     assert Cob == cblocks(Co) and x.shape[1] == cblocks(Ci)
     L = _lib.load()
     ws = ops.workspace(L.sivae_bf16_conv2d_wgrad_workspace_bytes(B, Ci, Co, H, W, ks), x.device)
-    dw = torch.empty((Co, Ci, 5, 1) if ks == KS51 else (Co, Ci, ks, ks), dtype=torch.float32, device=x.device)
+    dw = ops._out(out, (Co, Ci, 5, 1) if ks == KS51 else (Co, Ci, ks, ks), x.device)
     pm = pi = pg = pb = None
     slope = 1.0
     if pro is not None:
@@ -187,7 +187,7 @@ def bn_apply_act(x, res, mean, invstd, gamma, beta, C, slope=LRELU_SLOPE, res_up
 
 
 def bn_bwd(dy, y, x, mean, invstd, gamma, beta, C, slope=LRELU_SLOPE, dy_pooled=False, want_dz=False, dz_sum=False,
-           want_param_grads=True):
+           want_param_grads=True, pg_out=None):
     """-> dx, dz (full resolution, its 2x2 block sums with dz_sum, or None), dgamma, dbeta.
     y: the saved block output (bf16) or its sign mask (uint8 from bn_apply_act(want_mask=True)) — the sign of the
     activation —, or None to recompute the sign from x (needs beta)."""
@@ -206,8 +206,7 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, beta, C, slope=LRELU_SLOPE, dy_pooled=
         dz = torch.empty((B, Cb, H // 2, W // 2, 8), dtype=torch.bfloat16, device=x.device)
     elif want_dz:
         dz = torch.empty_like(x)
-    dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
-    dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if want_param_grads else None
+    dgamma, dbeta = ops._pg(pg_out, C, x.device, want_param_grads)
     _lib.call("sivae_bf16_bn_bwd", _p(dy), int(bool(dy_pooled)), _p(y), _p(mask), _p(x), _p(mean), _p(invstd), _p(gamma),
               _p(beta), float(slope), _p(dx), _p(dz), int(bool(dz_sum)), _p(dgamma), _p(dbeta), B, C, H, W, _p(ws),
               ws.numel(), _s(x))

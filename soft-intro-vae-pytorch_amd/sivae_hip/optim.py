@@ -38,11 +38,55 @@ class FlatAdam:
                 p.grad = self.flat_grad[off:off + k].view(p.shape)
                 off += k
         self.param_groups = [{"lr": self.lr, "params": self.params}]  # torch-like surface for schedulers
+        self.slabs = []        # per-use gradient slabs (enable_slabs): flat buffers laid out like flat_grad
+        self._slabs_used = 0   # slabs that hold gradients of the current backward
         SF.bump_generation(self.params)
+
+    def enable_slabs(self, k=4):
+        """Give every parameter k gradient slabs (functional._claim / _dst): each USE of a parameter inside one
+        backward writes its gradient straight into its own slab instead of going through autograd's accumulation
+        (one torch add per tensor and use), and `fold_slabs` sums them into flat_grad with one launch.  The owner of
+        the step (SoftIntroEngine) must call zero_grad() before and fold_slabs() after every backward."""
+        if self.slabs:
+            return
+        n = self.flat_grad.numel()
+        self.slabs = [torch.zeros(n, dtype=torch.float32, device=self.flat_grad.device) for _ in range(k)]
+        off = 0
+        for p in self.params:
+            c = p.numel()
+            p.__dict__["_sivae_slabs"] = [s[off:off + c].view(p.shape) for s in self.slabs]
+            p.__dict__["_sivae_use"] = 0
+            off += c
+
+    def disable_slabs(self):
+        for p in self.params:
+            p.__dict__.pop("_sivae_slabs", None)
+            p.__dict__.pop("_sivae_use", None)
+        self.slabs = []
+
+    def fold_slabs(self, lo=0, hi=None):
+        """flat_grad[lo:hi] += the slabs the current backward wrote (call once per element range, after backward)"""
+        k = self._slabs_used
+        if k == 0:
+            return
+        hi = self.flat_grad.numel() if hi is None else hi
+        if hi > lo:
+            ops.sum_slabs(self.flat_grad[lo:hi], [s[lo:hi] for s in self.slabs[:k]])
+
+    def _reset_uses(self):
+        for p in self.params:
+            if "_sivae_use" in p.__dict__:
+                p.__dict__["_sivae_use"] = 0
 
     def zero_grad(self, set_to_none=False):
         # gradients must stay views of the flat buffer, so they are zeroed in place, never set to None
         self.flat_grad.zero_()
+        if self.slabs:
+            # (called after the forward passes reserved their slab indices and before backward() fills them:
+            # only the slabs this backward will write need to be clean)
+            self._slabs_used = min(len(self.slabs), max((p.__dict__.get("_sivae_use", 0) for p in self.params), default=0))
+            for s_ in self.slabs[:self._slabs_used]:
+                s_.zero_()
         for p, g in zip(self.params, self._grad_views()):
             if p.grad is None or p.grad.data_ptr() != g.data_ptr():
                 p.grad = g
@@ -65,6 +109,7 @@ class FlatAdam:
         else:
             ops.adam_step(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.t, self.lr, self.betas[0],
                           self.betas[1], self.eps, grad_scale)
+        self._reset_uses()
         SF.bump_generation(self.params)
 
     def use_device_state(self):
@@ -82,6 +127,7 @@ class FlatAdam:
     def replayed(self, n=1):
         """bookkeeping after n HIP-graph replays of a captured step (the kernels ran, this python did not)"""
         self.t += n
+        self._reset_uses()
         SF.bump_generation(self.params)
 
 
