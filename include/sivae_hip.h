@@ -166,6 +166,19 @@ int sivae_conv2d_wgrad(const float* x, const float* dy, float* dw, const float* 
                        int B, int Ci, int Co, int H, int W, int ks, int upsample, void* workspace,
                        size_t workspace_bytes, sivae_stream_t stream);
 
+/* ---- 5x5 convolution FROM <= 3 channels INTO <= 64 with the whole contraction merged (K = 3*25 = 75) -----------
+ * The encoder stem's forward (:88-89: nn.Conv2d(cdim, 64, 5, 1, 2)) and the data gradient of Decoder.predict (:159):
+ * y[co][px] = sum_k W[co][k] X[k][px], k = (ci, kh, kw); 38 MFMA k-steps per 32x32 outputs instead of 50, weights in
+ * registers.  pack mode 0: w [n_big][n_small][5][5] (forward); mode 1: w [n_small][n_big][5][5] (data gradient:
+ * taps flipped, channels transposed).  stats_partial (optional): [sivae_conv5_k75_num_px_tiles(B, H, W)][Co][2]
+ * {sum, sumsq} partials for the BatchNorm that follows the stem. */
+size_t sivae_pack_conv5_k75_bytes(void);
+int sivae_pack_conv5_k75(const float* w, float* wq, int n_small, int n_big, int mode, sivae_stream_t stream);
+int sivae_conv5_k75_supported(int Ci, int Co);
+int sivae_conv5_k75_num_px_tiles(int B, int H, int W);
+int sivae_conv5_k75_fwd(const float* x, const float* wq, float* y, const float* bias, float* stats_partial, int B,
+                        int Ci, int Co, int H, int W, sivae_stream_t stream);
+
 /* ---- 5x5 convolutions with <= 3 channels on one side (Decoder.predict :159, Encoder stem :89) -------------
  * The small channel count is merged with the kernel column into one 16-wide MFMA dimension.
  *   pack: n_small = the <=3 side, n_big = the other; mode 0 = forward operand of a [n_small][n_big][5][5]

@@ -182,6 +182,8 @@ WINO_UP = os.environ.get("SIVAE_WINO_UP", "1") != "0"  # phase-decomposed F(2x2,
 # next-item prefetch, which costs more than the 14 ms reduction pass it removes) -> off by default.
 FUSE_BN_BWD = os.environ.get("SIVAE_FUSE_BN_BWD", "0") == "1"
 WINO_WGRAD = os.environ.get("SIVAE_WINO_WGRAD", os.environ.get("SIVAE_WINO", "1")) != "0"
+# merged-contraction kernel for the 5x5 convs from <= 3 into <= 64 channels (SIVAE_CONV5_K75=0: the direct kernel)
+CONV5_K75 = os.environ.get("SIVAE_CONV5_K75", "1") != "0"
 # 1-bit LeakyReLU sign mask written by the block's last BatchNorm pass and read by its backward instead of the saved
 # output (SIVAE_SIGNMASK=0: the backward reads the output tensor again)
 SIGNMASK = os.environ.get("SIVAE_SIGNMASK", "1") != "0"
@@ -215,6 +217,17 @@ class PackedW:
             _lib.call("sivae_pack_wino_up_dgrad_weight", _p(w), _p(ud), Co, Ci, _s())
             self._wino_up_dgrad = ud
         return self._wino_up_dgrad
+
+    def k75(self):
+        """merged-contraction operand [76][64] of a 5x5 conv from <= 3 into <= 64 channels (conv5_k75.hip); mode 0:
+        forward of w [Cb][Cs][5][5], mode 1: data gradient of w [Cs][Cb][5][5]"""
+        if getattr(self, "_k75", None) is None:
+            w = self.w
+            n_big, n_small = (w.shape[0], w.shape[1]) if self.mode == 0 else (w.shape[1], w.shape[0])
+            wq = torch.empty(_lib.load().sivae_pack_conv5_k75_bytes() // 4, dtype=torch.float32, device=w.device)
+            _lib.call("sivae_pack_conv5_k75", _p(w), _p(wq), n_small, n_big, self.mode, _s(w))
+            self._k75 = wq
+        return self._k75
 
     def wino_up(self):
         """phase-decomposed F(2x2,2x2) transform for the conv-after-upsample forward kernel (mode 0 only)"""
@@ -311,6 +324,19 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
     B, Ci, Hs, Ws = x.shape
     H, W = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
     L = _lib.load()
+    if (CONV5_K75 and ks == 5 and isinstance(wp, PackedW) and pro is None and not upsample and not accumulate
+            and out is None and L.sivae_conv5_k75_supported(Ci, Co) == 1):
+        # the encoder stem / the data gradient of Decoder.predict: whole contraction (K = 75) merged
+        _require(x, bias)
+        y = torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
+        stats = (torch.empty((L.sivae_conv5_k75_num_px_tiles(B, H, W), Co, 2), dtype=torch.float32, device=x.device)
+                 if want_stats else None)
+        t0 = TIMER.begin() if TIMER is not None else None
+        _lib.call("sivae_conv5_k75_fwd", _p(x), _p(wp.k75()), _p(y), _p(bias), _p(stats), B, Ci, Co, H, W, _s(x))
+        if t0 is not None:
+            TIMER.end("conv5_k75_kernel", 2.0 * B * H * W * Co * Ci * 25, t0,
+                      executed=2.0 * B * H * W * 64 * 76)  # (64 output rows x 76 contraction columns are issued)
+        return (y, stats) if want_stats else y
     wino = (WINO and ks == 3 and bias is None and isinstance(wp, PackedW)
             and L.sivae_conv2d_wino_supported(H, W) == 1)
     wino_up = (wino and WINO_UP and upsample and not accumulate and wp.mode == 0

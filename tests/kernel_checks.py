@@ -575,6 +575,22 @@ def check_up_dgrad_splitk():
     return res
 
 
+def check_conv5_k75():
+    """merged-contraction 5x5 kernel (<= 3 -> <= 64 channels): forward with BatchNorm partials / bias, ragged tiles,
+    1-3 input channels, fewer than 64 outputs; and as the data gradient of a 64 -> 3 conv (flipped pack)"""
+    from sivae_hip import lib
+    L = lib.load()
+    res = [("conv5_k75 supported", float(L.sivae_conv5_k75_supported(3, 64) != 1 or L.sivae_conv5_k75_supported(4, 64) != 0
+                                         or L.sivae_conv5_k75_supported(3, 65) != 0), 0.0)]
+    for shape in [(3, 3, 64, 32, 32, 5), (2, 1, 64, 28, 28, 5), (2, 3, 48, 20, 40, 5), (2, 2, 64, 9, 70, 5),
+                  (5, 3, 64, 64, 64, 5)]:
+        res += check_conv_fwd(shape, stats=True, wino=True)   # (wino=True: a PackedW, which is what selects the kernel)
+    res += check_conv_fwd((2, 3, 64, 24, 40, 5), bias=True, wino=True)
+    for shape in [(2, 64, 3, 32, 32, 5), (3, 40, 3, 20, 40, 5), (2, 64, 1, 28, 28, 5)]:
+        res += check_conv_dgrad(shape, wino=True)
+    return res
+
+
 def check_randn():
     from sivae_hip import ops
     a = ops.randn((1 << 20,), 1234, 0, torch.device(DEV))
@@ -915,6 +931,7 @@ def all_checks():
     checks.append(("wino_up_stats", lambda: check_conv_up((3, 32, 72, 32, 64, 3), stats=True)
                    + check_conv_up((2, 20, 33, 16, 32, 3), pro=True, stats=True)))
     checks.append(("up_dgrad_splitk", check_up_dgrad_splitk))
+    checks.append(("conv5_k75", check_conv5_k75))
     checks.append(("conv5_edge", check_conv5_edge))
     checks.append(("linear", check_linear))
     checks.append(("linear_fast", check_linear_fast))
