@@ -166,6 +166,15 @@ int sivae_conv2d_wgrad(const float* x, const float* dy, float* dw, const float* 
                        int B, int Ci, int Co, int H, int W, int ks, int upsample, void* workspace,
                        size_t workspace_bytes, sivae_stream_t stream);
 
+/* ---- 1x1 convolution as a streaming kernel (ResidualBlock.conv_expand :50-54, forward and data gradient) ---------
+ * y[b][co][p] (+)= sum_ci W[co][ci] x[b][ci][p] over planes of HW pixels; wp is the ks = 1 direct pack of
+ * sivae_pack_conv_weight (mode 0 forward, mode 1 data gradient).  x goes straight from 16-byte global loads into the MFMA
+ * B operand (a lane's four consecutive pixels serve four column tiles), the 64-channel weight tile lives in LDS, outputs
+ * leave as 16-byte stores.  _supported: HW % 4 == 0, Ci even and <= 256. */
+int sivae_conv1x1_stream_supported(int B, int Ci, int Co, int HW);
+int sivae_conv1x1_stream(const float* x, const float* wp, float* y, int B, int Ci, int Co, int HW, int accumulate,
+                         sivae_stream_t stream);
+
 /* ---- 5x5 convolution FROM <= 3 channels INTO <= 64 with the whole contraction merged (K = 3*25 = 75) -----------
  * The encoder stem's forward (:88-89: nn.Conv2d(cdim, 64, 5, 1, 2)) and the data gradient of Decoder.predict (:159):
  * y[co][px] = sum_k W[co][k] X[k][px], k = (ci, kh, kw); 38 MFMA k-steps per 32x32 outputs instead of 50, weights in

@@ -1,0 +1,170 @@
+// 1x1 convolution (ResidualBlock.conv_expand, soft_intro_vae/train_soft_intro_vae.py:50-54, forward and data gradient)
+// as a streaming kernel on v_mfma_f32_32x32x2_f32:   y[b][co][p] = sum_ci W[co][ci] x[b][ci][p],  p = pixel index of a plane.
+//
+// A 1x1 conv has no halo, so nothing about x needs LDS: a lane loads FOUR consecutive pixels of one input channel with
+// one 16-byte buffer load and the four components serve four MFMA column tiles — MFMA column n of tile e stands for
+// pixel 4n + e (any pixel <-> column map is legal as long as the epilogue knows it).  A wave therefore covers 128
+// consecutive pixels x 64 output channels (2 row tiles x 4 column tiles = 128 accumulators), and the accumulators of
+// one output channel at columns n of the four tiles are four CONSECUTIVE pixels: the epilogue is 32 sixteen-byte stores
+// per lane, no transpose.  The weights of the block's 64-channel group (the direct pack [ci][co_pad], 256 B per input
+// channel) sit in LDS for the whole life of the persistent block; per k-step (2 input channels) a wave issues 1
+// sixteen-byte x load (ring of two groups of 8 k-steps), 2 ds_read_b32 and 8 MFMAs.
+// The direct kernel (conv_fwd.hip) pushes x through LDS in 16-channel chunks with two barriers each and stores dwords.
+#include "common.h"
+
+struct Conv1sArgs {
+  const float* x;   // [B][Ci][HW]
+  const float* wp;  // direct pack [Ci_pad][Co_pad] (sivae_pack_conv_weight, ks = 1)
+  float* y;         // [B][Co][HW]
+  int B, Ci, Co, HW, Co_pad;
+  int n_px_tiles;   // 128-pixel tiles per image
+  int n_co_groups;  // 64-channel output groups
+  int n_pt_items;   // B * n_px_tiles / 4 rounded up: a block takes 4 pixel tiles (one per wave) at a time
+  int accumulate;
+};
+
+#define C1S_G 8  // k-steps per load group
+
+__global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(Conv1sArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [Ci][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, kk = lane >> 5;
+  const int HW = a.HW, Ci = a.Ci;
+  const int cog = blockIdx.x % a.n_co_groups;  // consecutive blocks: the co groups of the same pixel range (x shared in L2)
+  const int co0 = cog * 64;
+
+  for (int i = tid; i < Ci * 64; i += 256) {
+    const int k = i >> 6, c = i & 63;
+    wsm[i] = a.wp[(size_t)k * a.Co_pad + co0 + c];  // (co_pad is a multiple of 128: in range; padded channels are 0)
+  }
+  __syncthreads();
+
+  const int nks = Ci >> 1;  // k-steps (Ci is even)
+  const unsigned xlane = (unsigned)(kk * HW + 4 * l31) * 4u;  // channel kk, pixels 4*l31 .. +3 of the tile
+  const unsigned xkstep = (unsigned)HW * 8u;                  // two channels
+  const float* wl = wsm + kk * 64 + l31;
+
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  for (int it = blockIdx.x / a.n_co_groups; it < a.n_pt_items; it += gridDim.x / a.n_co_groups) {
+    const int t = it * 4 + wave;  // this wave's pixel tile
+    const int b = t / a.n_px_tiles, pt = t - b * a.n_px_tiles;
+    const bool live = b < a.B;
+    const int p0 = pt * 128;
+    // pixels past the end of the plane are masked through the buffer range (HW % 4 == 0: whole vectors in or out)
+    const __amdgpu_buffer_rsrc_t xrs =
+        make_rsrc(a.x + (size_t)(live ? b : 0) * Ci * HW, live ? (unsigned long long)Ci * HW * 4ull : 0ull);
+    const unsigned pin = (p0 + 4 * l31 < HW) ? (unsigned)p0 * 4u + xlane : SIVAE_OOB;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][e][r] = 0.f;
+
+    // (hipcc / ROCm 7.2: bit-cast the WHOLE loaded vector — a per-element cast of the u32x4 result narrows the load to one
+    // dword and replicates it: common.h, buf_load_f32x4)
+    f32x4 xa[C1S_G], xb[C1S_G];
+#define C1S_LOAD(BUF, S0)                                                                          \
+  _Pragma("unroll") for (int g = 0; g < C1S_G; ++g) {                                              \
+    const int s_ = (S0) + g;                                                                       \
+    BUF[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(s_ < nks ? pin : SIVAE_OOB), (int)((unsigned)s_ * xkstep), 0)); \
+  }
+#define C1S_MMA(BUF, S0)                                                                           \
+  _Pragma("unroll") for (int g = 0; g < C1S_G; ++g) {                                              \
+    const int s_ = (S0) + g;                                                                       \
+    if (s_ < nks) {                                                                                \
+      const float a0 = wl[s_ * 128], a1 = wl[s_ * 128 + 32];                                       \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                              \
+        const float bv = BUF[g][e];                                                                \
+        acc[0][e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0][e], 0, 0, 0);              \
+        acc[1][e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1][e], 0, 0, 0);              \
+      }                                                                                            \
+    }                                                                                              \
+  }
+    C1S_LOAD(xa, 0)
+    for (int s0 = 0; s0 < nks; s0 += 2 * C1S_G) {
+      C1S_LOAD(xb, s0 + C1S_G)
+      C1S_MMA(xa, s0)
+      C1S_LOAD(xa, s0 + 2 * C1S_G)
+      C1S_MMA(xb, s0 + C1S_G)
+    }
+#undef C1S_LOAD
+#undef C1S_MMA
+
+    // ---- epilogue: acc[m][e][r] = channel co0 + m*32 + (r&3) + 8*(r>>2) + 4*kk of pixel p0 + 4*l31 + e
+    const __amdgpu_buffer_rsrc_t yrs =
+        make_rsrc(a.y + (size_t)(live ? b : 0) * a.Co * HW, live ? (unsigned long long)a.Co * HW * 4ull : 0ull);
+    const unsigned pout = (p0 + 4 * l31 < HW) ? (unsigned)(p0 + 4 * l31) * 4u : SIVAE_OOB;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        const unsigned off = (co < a.Co && pout != SIVAE_OOB) ? pout + (unsigned)co * (unsigned)HW * 4u : SIVAE_OOB;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[m][e][r];
+        if (a.accumulate) {
+          const u32x4_t o = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)off, 0, 0);
+          v += __builtin_bit_cast(f32x4, o);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), yrs, (int)off, 0, 0);
+      }
+  }
+}
+
+// shapes the streaming kernel takes: whole 16-byte pixel vectors, an even number of input channels whose 64-channel
+// weight tile (256 B per input channel) leaves room for two blocks per CU
+extern "C" int sivae_conv1x1_stream_supported(int B, int Ci, int Co, int HW) {
+  if (B <= 0 || Ci <= 0 || Co <= 0 || HW <= 0) return 0;
+  if ((HW & 3) || (Ci & 1) || Ci > 256) return 0;
+  if ((long long)Ci * HW * 4 >= 0x7fffffffLL || (long long)Co * HW * 4 >= 0x7fffffffLL) return 0;
+  return 1;
+}
+
+extern "C" int sivae_conv1x1_stream(const float* x, const float* wp, float* y, int B, int Ci, int Co, int HW,
+                                    int accumulate, hipStream_t stream) {
+  if (!x || !wp || !y) return SIVAE_ERR_NULL;
+  if (!sivae_conv1x1_stream_supported(B, Ci, Co, HW)) return SIVAE_ERR_SHAPE;
+  Conv1sArgs a;
+  a.x = x;
+  a.wp = wp;
+  a.y = y;
+  a.B = B;
+  a.Ci = Ci;
+  a.Co = Co;
+  a.HW = HW;
+  a.Co_pad = ((Co + 127) / 128) * 128;
+  a.n_px_tiles = cdiv(HW, 128);
+  a.n_co_groups = cdiv(Co, 64);
+  const long long tiles = (long long)B * a.n_px_tiles;
+  a.n_pt_items = (int)((tiles + 3) / 4);
+  a.accumulate = accumulate;
+  int cus = 256;
+  {
+    static int cached = 0;
+    if (cached == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      cached = 256;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        cached = prop.multiProcessorCount;
+    }
+    cus = cached;
+  }
+  // grid: a multiple of the co-group count (block -> co group = blockIdx % groups), about two blocks per CU
+  long long per_group = (2LL * cus) / a.n_co_groups;
+  if (per_group < 1) per_group = 1;
+  if (per_group > a.n_pt_items) per_group = a.n_pt_items;
+  const long long grid = per_group * a.n_co_groups;
+  const size_t lds = (size_t)Ci * 64 * sizeof(float);
+  auto kern = conv1x1_stream_kernel;
+  static size_t lds_hwm = 0;
+  const int rc_lds = sivae_ensure_lds(reinterpret_cast<const void*>(kern), lds, &lds_hwm);
+  if (rc_lds != SIVAE_OK) return rc_lds;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, a);
+  return sivae_launch_status();
+}

@@ -182,6 +182,8 @@ WINO_UP = os.environ.get("SIVAE_WINO_UP", "1") != "0"  # phase-decomposed F(2x2,
 # next-item prefetch, which costs more than the 14 ms reduction pass it removes) -> off by default.
 FUSE_BN_BWD = os.environ.get("SIVAE_FUSE_BN_BWD", "0") == "1"
 WINO_WGRAD = os.environ.get("SIVAE_WINO_WGRAD", os.environ.get("SIVAE_WINO", "1")) != "0"
+# streaming kernel for the 1x1 convs (SIVAE_CONV1_STREAM=0: the LDS-tiled direct kernel)
+CONV1_STREAM = os.environ.get("SIVAE_CONV1_STREAM", "1") != "0"
 # merged-contraction kernel for the 5x5 convs from <= 3 into <= 64 channels (SIVAE_CONV5_K75=0: the direct kernel)
 CONV5_K75 = os.environ.get("SIVAE_CONV5_K75", "1") != "0"
 # 1-bit LeakyReLU sign mask written by the block's last BatchNorm pass and read by its backward instead of the saved
@@ -337,6 +339,18 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
             TIMER.end("conv5_k75_kernel", 2.0 * B * H * W * Co * Ci * 25, t0,
                       executed=2.0 * B * H * W * 64 * 76)  # (64 output rows x 76 contraction columns are issued)
         return (y, stats) if want_stats else y
+    if (CONV1_STREAM and ks == 1 and bias is None and pro is None and not upsample and not want_stats
+            and L.sivae_conv1x1_stream_supported(B, Ci, Co, H * W) == 1):
+        # ResidualBlock.conv_expand (forward / data gradient): x streamed straight into the MFMA operand
+        wd = wp.direct() if isinstance(wp, PackedW) else wp
+        _require(x, wd, out)
+        y = out if out is not None else torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
+        assert y.shape == (B, Co, H, W) and y.is_contiguous()
+        t0 = TIMER.begin() if TIMER is not None else None
+        _lib.call("sivae_conv1x1_stream", _p(x), _p(wd), _p(y), B, Ci, Co, H * W, int(bool(accumulate)), _s(x))
+        if t0 is not None:
+            TIMER.end("conv1x1_stream_kernel", 2.0 * B * H * W * Co * Ci, t0)
+        return y
     wino = (WINO and ks == 3 and bias is None and isinstance(wp, PackedW)
             and L.sivae_conv2d_wino_supported(H, W) == 1)
     wino_up = (wino and WINO_UP and upsample and not accumulate and wp.mode == 0

@@ -575,6 +575,28 @@ def check_up_dgrad_splitk():
     return res
 
 
+def check_conv1x1_stream():
+    """streaming 1x1 kernel: forward / data gradient / accumulate, ragged pixel tiles (HW not a multiple of 128), output
+    channel counts that are not multiples of 64, batch sizes that do not fill a block's four pixel tiles"""
+    from sivae_hip import lib, ops
+    L = lib.load()
+    res = [("conv1x1_stream supported", float(L.sivae_conv1x1_stream_supported(2, 64, 128, 1024) != 1
+                                              or L.sivae_conv1x1_stream_supported(2, 64, 128, 49) != 0
+                                              or L.sivae_conv1x1_stream_supported(2, 63, 128, 64) != 0
+                                              or L.sivae_conv1x1_stream_supported(2, 512, 128, 64) != 0), 0.0)]
+    for shape in [(2, 64, 128, 32, 32, 1), (5, 128, 64, 16, 16, 1), (3, 100, 200, 6, 10, 1), (1, 256, 72, 20, 36, 1),
+                  (7, 2, 3, 4, 8, 1), (2, 64, 128, 128, 128, 1)]:
+        res += check_conv_fwd(shape)
+        res += check_conv_dgrad(shape)
+    # accumulate (the expand conv's data gradient is added onto the conv1 branch's)
+    B, Ci, Co, H, W = 3, 128, 64, 12, 20
+    x, w, y0 = _rand(B, Ci, H, W, seed=1), _rand(Co, Ci, 1, 1, seed=2, scale=0.1), _rand(B, Co, H, W, seed=3)
+    y = _d(y0)
+    ops.conv2d_fwd(_d(x), ops.pack_weight(_d(w), 0), Co, 1, out=y, accumulate=True)
+    res.append(("conv1x1_stream accumulate", _err(y, y0 + _conv_ref(x, w)), 1e-5))
+    return res
+
+
 def check_conv5_k75():
     """merged-contraction 5x5 kernel (<= 3 -> <= 64 channels): forward with BatchNorm partials / bias, ragged tiles,
     1-3 input channels, fewer than 64 outputs; and as the data gradient of a 64 -> 3 conv (flipped pack)"""
@@ -932,6 +954,7 @@ def all_checks():
                    + check_conv_up((2, 20, 33, 16, 32, 3), pro=True, stats=True)))
     checks.append(("up_dgrad_splitk", check_up_dgrad_splitk))
     checks.append(("conv5_k75", check_conv5_k75))
+    checks.append(("conv1x1_stream", check_conv1x1_stream))
     checks.append(("conv5_edge", check_conv5_edge))
     checks.append(("linear", check_linear))
     checks.append(("linear_fast", check_linear_fast))
