@@ -460,6 +460,52 @@ int sivae_bf16_upsample2_fwd(const void* x, void* y, int B, int C, int Hs, int W
 int sivae_bf16_upsample2_bwd(const void* dy, void* dx, int B, int C, int Hs, int Ws, sivae_stream_t stream);
 int sivae_bf16_add_inplace(void* y, const void* x, size_t nvec, sivae_stream_t stream);
 
+/* ---- segmented batches: several passes of a network through the SAME weights as one launch ---------
+ * The reference's iteration runs pairs of independent passes through unchanged weights — model(rec.detach()) /
+ * model(fake.detach()) train_soft_intro_vae.py:567-568, encode(rec) / encode(fake) :601-605, decode(z_rec) /
+ * decode(z_fake) :607-608, bootstrap decode_target x2 soft_intro_vae_bootstrap/train_soft_intro_vae_bootstrap.py:635-636.
+ * The engine lays such passes end to end in ONE batch of B = nseg * seg_images images ("segments", pass g = images
+ * [g*seg_images, (g+1)*seg_images)).  Convolutions do not care; training-mode nn.BatchNorm2d (:58,:62,:90) must keep
+ * ONE set of batch statistics PER PASS, so every BatchNorm kernel and every fused BatchNorm prologue has a _seg form:
+ * mean / invstd are [nseg][C], gamma / beta / running buffers [C]; dgamma / dbeta are summed over the passes; the
+ * running buffers receive one momentum update per pass in pass order.  nseg = 1 is the unsegmented op bit for bit. */
+int sivae_bn_stats_from_conv_seg(const float* partials, int n_tiles, int nseg, int seg_rev, int B_seg, int C, int HW,
+                                 float eps, float momentum, float* running_mean, float* running_var,
+                                 long long* num_batches_tracked, float* mean_out, float* invstd_out,
+                                 sivae_stream_t stream);
+int sivae_bn_update_running_seg(const float* mean, const float* invstd, int nseg, int seg_rev, int C, double count,
+                                float eps, float momentum, float* running_mean, float* running_var,
+                                long long* num_batches_tracked, sivae_stream_t stream);
+int sivae_bn_apply_act_seg(const float* x, const float* res, int res_up, const float* mean, const float* invstd,
+                           const float* gamma, const float* beta, float slope, float* y, float* y_pooled, int B, int C,
+                           int H, int W, int seg_images, sivae_stream_t stream);
+int sivae_bn_apply_act_signmask_seg(const float* x, const float* res, int res_up, const float* mean,
+                                    const float* invstd, const float* gamma, const float* beta, float slope, float* y,
+                                    float* y_pooled, unsigned char* mask, int B, int C, int H, int W, int seg_images,
+                                    sivae_stream_t stream);
+/* every backward variant in one entry: act_mode 0 none / 1 sign from y / 2 recomputed from x (beta) / 3 from mask;
+ * dy_pooled, dz_sum as in sivae_bn_bwd_signmask; workspace: sivae_bn_workspace_bytes(seg_images, nseg * C, H * W) */
+int sivae_bn_bwd_seg(const float* dy, const float* y, const unsigned char* mask, const float* x, const float* mean,
+                     const float* invstd, const float* gamma, const float* beta, int act_mode, float slope, float* dx,
+                     float* dz_out, float* dgamma, float* dbeta, int B, int C, int H, int W, int dy_pooled, int dz_sum,
+                     int seg_images, void* workspace, size_t workspace_bytes, sivae_stream_t stream);
+/* Winograd 3x3 forward / data gradient and weight gradient with a segmented BatchNorm prologue (pro_* may be NULL: then
+ * only the row order of stats_partial matters — image order, so rows [g*n/nseg, (g+1)*n/nseg) are pass g).  On 8x8 /
+ * 4x4 maps seg_images must be a multiple of 2 / 4 (a tile block holds that many images). */
+int sivae_conv2d_wino_fwd_seg(const float* x, const float* up, float* y, const float* pro_mean,
+                              const float* pro_invstd, const float* pro_gamma, const float* pro_beta, float pro_slope,
+                              float* stats_partial, int B, int Ci, int Co, int H, int W, int upsample, int accumulate,
+                              int seg_images, sivae_stream_t stream);
+int sivae_conv2d_wino_fwd_splitk_seg(const float* x, const float* up, float* y, const float* pro_mean,
+                                     const float* pro_invstd, const float* pro_gamma, const float* pro_beta,
+                                     float pro_slope, float* stats_partial, int B, int Ci, int Co, int H, int W,
+                                     int upsample, int accumulate, int seg_images, void* workspace,
+                                     size_t workspace_bytes, sivae_stream_t stream);
+int sivae_conv2d_wino_wgrad_seg(const float* x, const float* dy, float* dw, const float* pro_mean,
+                                const float* pro_invstd, const float* pro_gamma, const float* pro_beta, float pro_slope,
+                                int B, int Ci, int Co, int H, int W, int upsample, int seg_images, void* workspace,
+                                size_t workspace_bytes, sivae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -129,28 +129,37 @@ __global__ void __launch_bounds__(NT) bn_finalize_conv_kernel(const float* __res
                                                                float* running_mean, float* running_var,
                                                                long long* num_batches_tracked,
                                                                float* __restrict__ mean_out,
-                                                               float* __restrict__ invstd_out) {
+                                                               float* __restrict__ invstd_out, int nseg, int seg_rev) {
+  // nseg > 1: the batch is nseg independent passes of the network laid end to end (same weights, one launch — see
+  // functional.py "segments"); rows [g*S, (g+1)*S) of `part` belong to pass g, every pass gets its own statistics
+  // (mean_out / invstd_out are [nseg][C]) and the running buffers receive one momentum update per pass, in pass order
+  // (seg_rev: last segment first — the order in which the reference would have run the passes).
   __shared__ double red[NT / 64];
   const int c = blockIdx.x;
-  double sum = 0.0, sq = 0.0;
-  for (int s = threadIdx.x; s < S; s += NT) {
-    const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)s * C + c) * 2);
-    sum += (double)v.x;
-    sq += (double)v.y;
-  }
-  sum = block_sum<NT>(sum, red);
-  sq = block_sum<NT>(sq, red);
-  if (threadIdx.x != 0) return;
-  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
-  const double mean = sum / count;
-  double var = sq / count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  mean_out[c] = (float)mean;
-  invstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running_mean) {
-    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
-    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+  for (int gi = 0; gi < nseg; ++gi) {
+    const int g = seg_rev ? nseg - 1 - gi : gi;
+    double sum = 0.0, sq = 0.0;
+    for (int s = threadIdx.x; s < S; s += NT) {
+      const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)(g * S + s) * C + c) * 2);
+      sum += (double)v.x;
+      sq += (double)v.y;
+    }
+    sum = block_sum<NT>(sum, red);
+    sq = block_sum<NT>(sq, red);
+    if (threadIdx.x == 0) {
+      if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+      const double mean = sum / count;
+      double var = sq / count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      mean_out[g * C + c] = (float)mean;
+      invstd_out[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+      if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -180,22 +189,41 @@ extern "C" int sivae_bn_stats(const float* x, int B, int C, int HW, float eps, f
 }
 
 // Statistics from the per-pixel-tile partial sums the conv forward epilogue wrote ([n_tiles][C][2] floats).
+static int bn_stats_from_conv_impl(const float* partials, int n_tiles, int nseg, int seg_rev, int B, int C, int HW,
+                                   float eps, float momentum, float* running_mean, float* running_var,
+                                   long long* num_batches_tracked, float* mean_out, float* invstd_out,
+                                   hipStream_t stream) {
+  if (!partials || !mean_out || !invstd_out) return SIVAE_ERR_NULL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return SIVAE_ERR_NULL;
+  if (B <= 0 || C <= 0 || HW <= 0 || n_tiles <= 0 || nseg <= 0 || (n_tiles % nseg) != 0) return SIVAE_ERR_SHAPE;
+  const int S = n_tiles / nseg;
+  if (S >= 4096)
+    hipLaunchKernelGGL((bn_finalize_conv_kernel<1024>), dim3(C), dim3(1024), 0, stream, partials, S, C,
+                       (double)B * HW, eps, momentum, running_mean, running_var, num_batches_tracked, mean_out,
+                       invstd_out, nseg, seg_rev);
+  else
+    hipLaunchKernelGGL((bn_finalize_conv_kernel<256>), dim3(C), dim3(256), 0, stream, partials, S, C,
+                       (double)B * HW, eps, momentum, running_mean, running_var, num_batches_tracked, mean_out,
+                       invstd_out, nseg, seg_rev);
+  return sivae_launch_status();
+}
+
 extern "C" int sivae_bn_stats_from_conv(const float* partials, int n_tiles, int B, int C, int HW, float eps,
                                         float momentum, float* running_mean, float* running_var,
                                         long long* num_batches_tracked, float* mean_out, float* invstd_out,
                                         hipStream_t stream) {
-  if (!partials || !mean_out || !invstd_out) return SIVAE_ERR_NULL;
-  if ((running_mean == nullptr) != (running_var == nullptr)) return SIVAE_ERR_NULL;
-  if (B <= 0 || C <= 0 || HW <= 0 || n_tiles <= 0) return SIVAE_ERR_SHAPE;
-  if (n_tiles >= 4096)
-    hipLaunchKernelGGL((bn_finalize_conv_kernel<1024>), dim3(C), dim3(1024), 0, stream, partials, n_tiles, C,
-                       (double)B * HW, eps, momentum, running_mean, running_var, num_batches_tracked, mean_out,
-                       invstd_out);
-  else
-    hipLaunchKernelGGL((bn_finalize_conv_kernel<256>), dim3(C), dim3(256), 0, stream, partials, n_tiles, C,
-                       (double)B * HW, eps, momentum, running_mean, running_var, num_batches_tracked, mean_out,
-                       invstd_out);
-  return sivae_launch_status();
+  return bn_stats_from_conv_impl(partials, n_tiles, 1, 0, B, C, HW, eps, momentum, running_mean, running_var,
+                                 num_batches_tracked, mean_out, invstd_out, stream);
+}
+
+// Segmented form: the batch is `nseg` passes of `B_seg` images each (n_tiles rows in pass order, n_tiles % nseg == 0);
+// mean_out / invstd_out are [nseg][C]; the running buffers get one update per pass (seg_rev: last pass first).
+extern "C" int sivae_bn_stats_from_conv_seg(const float* partials, int n_tiles, int nseg, int seg_rev, int B_seg, int C,
+                                            int HW, float eps, float momentum, float* running_mean, float* running_var,
+                                            long long* num_batches_tracked, float* mean_out, float* invstd_out,
+                                            hipStream_t stream) {
+  return bn_stats_from_conv_impl(partials, n_tiles, nseg, seg_rev, B_seg, C, HW, eps, momentum, running_mean,
+                                 running_var, num_batches_tracked, mean_out, invstd_out, stream);
 }
 
 // ---- synchronised BatchNorm (opt-in, data-parallel runs): the per-channel {sum, sumsq} of the local
@@ -275,6 +303,39 @@ __global__ void __launch_bounds__(64) bn_update_running_kernel(const float* __re
   running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
 }
 
+// segmented replay: mean / invstd [nseg][C], one momentum update per pass (seg_rev: last pass first)
+__global__ void __launch_bounds__(64) bn_update_running_seg_kernel(const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, int nseg,
+                                                                   int seg_rev, int C, double count, float eps,
+                                                                   float momentum, float* running_mean,
+                                                                   float* running_var, long long* num_batches_tracked) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += nseg;
+  if (c >= C) return;
+  float rm = running_mean[c], rv = running_var[c];
+  for (int gi = 0; gi < nseg; ++gi) {
+    const int g = seg_rev ? nseg - 1 - gi : gi;
+    const double is = (double)invstd[g * C + c];
+    double var = 1.0 / (is * is) - (double)eps;
+    if (var < 0.0) var = 0.0;
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    rm = (float)((1.0 - momentum) * rm + momentum * (double)mean[g * C + c]);
+    rv = (float)((1.0 - momentum) * rv + momentum * unbiased);
+  }
+  running_mean[c] = rm;
+  running_var[c] = rv;
+}
+
+extern "C" int sivae_bn_update_running_seg(const float* mean, const float* invstd, int nseg, int seg_rev, int C,
+                                           double count, float eps, float momentum, float* running_mean,
+                                           float* running_var, long long* num_batches_tracked, hipStream_t stream) {
+  if (!mean || !invstd || !running_mean || !running_var) return SIVAE_ERR_NULL;
+  if (C <= 0 || nseg <= 0 || count <= 0.0) return SIVAE_ERR_SHAPE;
+  hipLaunchKernelGGL(bn_update_running_seg_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, mean, invstd, nseg, seg_rev,
+                     C, count, eps, momentum, running_mean, running_var, num_batches_tracked);
+  return sivae_launch_status();
+}
+
 extern "C" int sivae_bn_update_running(const float* mean, const float* invstd, int C, double count, float eps,
                                        float momentum, float* running_mean, float* running_var,
                                        long long* num_batches_tracked, hipStream_t stream) {
@@ -296,7 +357,8 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float slope,
                                                        float* __restrict__ y, unsigned char* __restrict__ mask,
-                                                       int C, int HW, size_t numel) {
+                                                       int C, int HW, size_t numel, int segB) {
+  // segB > 0: images [g*segB, (g+1)*segB) form pass g with its own statistics mean/invstd[g*C + c] (gamma/beta shared)
   const size_t stride = (size_t)gridDim.x * 256;
   if (VEC) {
     const size_t n4 = numel >> 2;
@@ -307,8 +369,10 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
       unsigned nib = 0;
       if (ok) {
         const size_t e = i << 2;
-        const int c = (int)((e / HW) % C);
-        const float m = mean[c], g = invstd[c] * gamma[c], bt = beta[c];
+        const size_t pl = e / HW;
+        const int c = (int)(pl % C);
+        const int sc = segB > 0 ? c + (int)((pl / C) / segB) * C : c;
+        const float m = mean[sc], g = invstd[sc] * gamma[c], bt = beta[c];
         float4 v = reinterpret_cast<const float4*>(x)[i];
         v.x = (v.x - m) * g + bt;
         v.y = (v.y - m) * g + bt;
@@ -329,8 +393,10 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
     }
   } else {
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < numel; e += stride) {
-      const int c = (int)((e / HW) % C);
-      float v = (x[e] - mean[c]) * (invstd[c] * gamma[c]) + beta[c];
+      const size_t pl = e / HW;
+      const int c = (int)(pl % C);
+      const int sc = segB > 0 ? c + (int)((pl / C) / segB) * C : c;
+      float v = (x[e] - mean[sc]) * (invstd[sc] * gamma[c]) + beta[c];
       if (HAS_RES) v += res[e];
       y[e] = lrelu(v, slope);
     }
@@ -339,9 +405,10 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
 
 static int bn_apply_impl(const float* x, const float* res, const float* mean, const float* invstd,
                          const float* gamma, const float* beta, float slope, float* y, unsigned char* mask, int B,
-                         int C, int HW, hipStream_t stream) {
+                         int C, int HW, hipStream_t stream, int segB = 0) {
   if (!x || !mean || !invstd || !gamma || !beta || !y) return SIVAE_ERR_NULL;
   if (B <= 0 || C <= 0 || HW <= 0) return SIVAE_ERR_SHAPE;
+  if (segB < 0 || (segB > 0 && B % segB != 0)) return SIVAE_ERR_SHAPE;
   const size_t numel = (size_t)B * C * HW;
   const bool vec = (HW & 3) == 0;
   if (mask && !vec) return SIVAE_ERR_SHAPE;
@@ -351,7 +418,7 @@ static int bn_apply_impl(const float* x, const float* res, const float* mean, co
   if (nb < 1) nb = 1;
 #define LAUNCH(R, V) \
   hipLaunchKernelGGL((bn_apply_kernel<R, V>), dim3(nb), dim3(256), 0, stream, x, res, mean, invstd, gamma, beta, \
-                     slope, y, mask, C, HW, numel)
+                     slope, y, mask, C, HW, numel, segB)
   if (res) {
     if (vec) LAUNCH(true, true); else LAUNCH(true, false);
   } else {
@@ -376,7 +443,7 @@ __global__ void __launch_bounds__(256) bn_apply_resup_kernel(const float* __rest
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float slope,
                                                              float* __restrict__ y, unsigned char* __restrict__ mask,
-                                                             int C, int H, int W, size_t numel) {
+                                                             int C, int H, int W, size_t numel, int segB) {
   const size_t stride = (size_t)gridDim.x * 256;
   const int W4 = W >> 2, Hs = H >> 1, Ws = W >> 1;
   const size_t n4 = numel >> 2;
@@ -390,7 +457,8 @@ __global__ void __launch_bounds__(256) bn_apply_resup_kernel(const float* __rest
       const int h = (int)(t % H);
       t /= H;  // b*C + c
       const int c = (int)(t % C);
-      const float m = mean[c], g = invstd[c] * gamma[c], bt = beta[c];
+      const int sc = segB > 0 ? c + (int)((t / C) / segB) * C : c;
+      const float m = mean[sc], g = invstd[sc] * gamma[c], bt = beta[c];
       float4 v = reinterpret_cast<const float4*>(x)[i];
       const float2 r = *reinterpret_cast<const float2*>(res + (t * Hs + (h >> 1)) * Ws + 2 * w4);
       v.x = (v.x - m) * g + bt + r.x;
@@ -410,15 +478,16 @@ __global__ void __launch_bounds__(256) bn_apply_resup_kernel(const float* __rest
 
 static int bn_apply_resup_impl(const float* x, const float* res_half, const float* mean, const float* invstd,
                                const float* gamma, const float* beta, float slope, float* y, unsigned char* mask,
-                               int B, int C, int H, int W, hipStream_t stream) {
+                               int B, int C, int H, int W, hipStream_t stream, int segB = 0) {
   if (!x || !res_half || !mean || !invstd || !gamma || !beta || !y) return SIVAE_ERR_NULL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 3)) return SIVAE_ERR_SHAPE;
+  if (segB < 0 || (segB > 0 && B % segB != 0)) return SIVAE_ERR_SHAPE;
   const size_t numel = (size_t)B * C * H * W;
   int nb = cdiv((long long)(numel >> 2), 256 * 4);
   if (nb > 8192) nb = 8192;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(bn_apply_resup_kernel, dim3(nb), dim3(256), 0, stream, x, res_half, mean, invstd, gamma, beta,
-                     slope, y, mask, C, H, W, numel);
+                     slope, y, mask, C, H, W, numel, segB);
   return sivae_launch_status();
 }
 
@@ -439,7 +508,7 @@ __global__ void __launch_bounds__(256) bn_apply_pool_kernel(const float* __restr
                                                             const float* __restrict__ beta, float slope,
                                                             float* __restrict__ y, float* __restrict__ yp,
                                                             unsigned char* __restrict__ mask, int C, int H, int W,
-                                                            size_t n_quads) {
+                                                            size_t n_quads, int segB) {
   const size_t stride = (size_t)gridDim.x * 256;
   const int W4 = W >> 2, H2 = H >> 1;
   for (size_t base = (size_t)blockIdx.x * 256; base < n_quads; base += stride) {
@@ -453,7 +522,8 @@ __global__ void __launch_bounds__(256) bn_apply_pool_kernel(const float* __restr
       const int h2 = (int)(t % H2);
       t /= H2;  // b*C + c
       const int c = (int)(t % C);
-      const float m = mean[c], g = invstd[c] * gamma[c], bt = beta[c];
+      const int sc = segB > 0 ? c + (int)((t / C) / segB) * C : c;
+      const float m = mean[sc], g = invstd[sc] * gamma[c], bt = beta[c];
       const size_t o0 = (t * H + 2 * h2) * (size_t)W + 4 * w4, o1 = o0 + W;
       float4 a = *reinterpret_cast<const float4*>(x + o0), b = *reinterpret_cast<const float4*>(x + o1);
       a.x = (a.x - m) * g + bt; a.y = (a.y - m) * g + bt; a.z = (a.z - m) * g + bt; a.w = (a.w - m) * g + bt;
@@ -489,9 +559,10 @@ __global__ void __launch_bounds__(256) bn_apply_pool_kernel(const float* __restr
 
 static int bn_apply_pool_impl(const float* x, const float* res, const float* mean, const float* invstd,
                               const float* gamma, const float* beta, float slope, float* y, float* y_pooled,
-                              unsigned char* mask, int B, int C, int H, int W, hipStream_t stream) {
+                              unsigned char* mask, int B, int C, int H, int W, hipStream_t stream, int segB = 0) {
   if (!x || !mean || !invstd || !gamma || !beta || !y_pooled) return SIVAE_ERR_NULL;  // y may be NULL: pooled only
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 3)) return SIVAE_ERR_SHAPE;
+  if (segB < 0 || (segB > 0 && B % segB != 0)) return SIVAE_ERR_SHAPE;
   if (mask && (W & 7)) return SIVAE_ERR_SHAPE;
   const size_t n_quads = (size_t)B * C * (H >> 1) * (W >> 2);
   int nb = cdiv((long long)n_quads, 256 * 2);
@@ -499,10 +570,10 @@ static int bn_apply_pool_impl(const float* x, const float* res, const float* mea
   if (nb < 1) nb = 1;
   if (res)
     hipLaunchKernelGGL(bn_apply_pool_kernel<true>, dim3(nb), dim3(256), 0, stream, x, res, mean, invstd, gamma, beta,
-                       slope, y, y_pooled, mask, C, H, W, n_quads);
+                       slope, y, y_pooled, mask, C, H, W, n_quads, segB);
   else
     hipLaunchKernelGGL(bn_apply_pool_kernel<false>, dim3(nb), dim3(256), 0, stream, x, res, mean, invstd, gamma, beta,
-                       slope, y, y_pooled, mask, C, H, W, n_quads);
+                       slope, y, y_pooled, mask, C, H, W, n_quads, segB);
   return sivae_launch_status();
 }
 
@@ -521,18 +592,53 @@ extern "C" size_t sivae_bn_signmask_bytes(int B, int C, int HW) {
   return ((size_t)B * C * HW + 7) / 8;
 }
 
-extern "C" int sivae_bn_apply_act_signmask(const float* x, const float* res, int res_up, const float* mean,
-                                           const float* invstd, const float* gamma, const float* beta, float slope,
-                                           float* y, float* y_pooled, unsigned char* mask, int B, int C, int H, int W,
-                                           hipStream_t stream) {
+static int bn_apply_signmask_impl(const float* x, const float* res, int res_up, const float* mean,
+                                  const float* invstd, const float* gamma, const float* beta, float slope, float* y,
+                                  float* y_pooled, unsigned char* mask, int B, int C, int H, int W, int segB,
+                                  hipStream_t stream) {
   if (!mask) return SIVAE_ERR_NULL;
   if (H <= 0 || W <= 0 || (H & 1) || (W & 7)) return SIVAE_ERR_SHAPE;
   if (y_pooled) {
     if (res_up) return SIVAE_ERR_MODE;
-    return bn_apply_pool_impl(x, res, mean, invstd, gamma, beta, slope, y, y_pooled, mask, B, C, H, W, stream);
+    return bn_apply_pool_impl(x, res, mean, invstd, gamma, beta, slope, y, y_pooled, mask, B, C, H, W, stream, segB);
   }
-  if (res_up) return bn_apply_resup_impl(x, res, mean, invstd, gamma, beta, slope, y, mask, B, C, H, W, stream);
-  return bn_apply_impl(x, res, mean, invstd, gamma, beta, slope, y, mask, B, C, H * W, stream);
+  if (res_up) return bn_apply_resup_impl(x, res, mean, invstd, gamma, beta, slope, y, mask, B, C, H, W, stream, segB);
+  return bn_apply_impl(x, res, mean, invstd, gamma, beta, slope, y, mask, B, C, H * W, stream, segB);
+}
+
+extern "C" int sivae_bn_apply_act_signmask(const float* x, const float* res, int res_up, const float* mean,
+                                           const float* invstd, const float* gamma, const float* beta, float slope,
+                                           float* y, float* y_pooled, unsigned char* mask, int B, int C, int H, int W,
+                                           hipStream_t stream) {
+  return bn_apply_signmask_impl(x, res, res_up, mean, invstd, gamma, beta, slope, y, y_pooled, mask, B, C, H, W, 0,
+                                stream);
+}
+
+// ---- segmented forms (B = nseg * seg_images images; mean / invstd are [nseg][C], gamma / beta [C]): several passes of a
+// network through the same weights run as ONE batch with per-pass BatchNorm statistics (functional.py "segments")
+extern "C" int sivae_bn_apply_act_signmask_seg(const float* x, const float* res, int res_up, const float* mean,
+                                               const float* invstd, const float* gamma, const float* beta, float slope,
+                                               float* y, float* y_pooled, unsigned char* mask, int B, int C, int H,
+                                               int W, int seg_images, hipStream_t stream) {
+  if (seg_images <= 0) return SIVAE_ERR_SHAPE;
+  return bn_apply_signmask_impl(x, res, res_up, mean, invstd, gamma, beta, slope, y, y_pooled, mask, B, C, H, W,
+                                seg_images, stream);
+}
+
+// plain apply (+ residual; res_up: residual at half resolution; y_pooled != NULL: also AvgPool2d(2), y may be NULL)
+extern "C" int sivae_bn_apply_act_seg(const float* x, const float* res, int res_up, const float* mean,
+                                      const float* invstd, const float* gamma, const float* beta, float slope,
+                                      float* y, float* y_pooled, int B, int C, int H, int W, int seg_images,
+                                      hipStream_t stream) {
+  if (seg_images <= 0) return SIVAE_ERR_SHAPE;
+  if (y_pooled) {
+    if (res_up) return SIVAE_ERR_MODE;
+    return bn_apply_pool_impl(x, res, mean, invstd, gamma, beta, slope, y, y_pooled, nullptr, B, C, H, W, stream,
+                              seg_images);
+  }
+  if (res_up)
+    return bn_apply_resup_impl(x, res, mean, invstd, gamma, beta, slope, y, nullptr, B, C, H, W, stream, seg_images);
+  return bn_apply_impl(x, res, mean, invstd, gamma, beta, slope, y, nullptr, B, C, H * W, stream, seg_images);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -562,20 +668,24 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ beta, float slope,
                                                              double* __restrict__ part, int C, int HW,
                                                              long long n_per_ch, long long slice_len, int S,
-                                                             int pool_w, const unsigned char* __restrict__ mask) {
+                                                             int pool_w, const unsigned char* __restrict__ mask,
+                                                             int segB) {
+  // blockIdx.x = g*C + c: pass (segment) g of segB images with its own statistics; n_per_ch counts ONE segment
   __shared__ double red[4];
-  const int c = blockIdx.x, s = blockIdx.y;
+  const int vc = blockIdx.x, s = blockIdx.y;
+  const int c = vc % C;
+  const long long b0 = (long long)(vc / C) * segB;
   const long long n0 = (long long)s * slice_len;
   long long n1 = n0 + slice_len;
   if (n1 > n_per_ch) n1 = n_per_ch;
-  const float m = mean[c], is = invstd[c];
+  const float m = mean[vc], is = invstd[vc];
   const float gsc = ACT == 2 ? is * gamma[c] : 0.f, bt = ACT == 2 ? beta[c] : 0.f;
   double s1 = 0.0, s2 = 0.0;
   if ((HW & 3) == 0) {
     for (long long n = n0 + (long long)threadIdx.x * 4; n < n1; n += 1024) {
-      const long long b = n / HW;
-      const size_t o = ((size_t)b * C + c) * HW + (size_t)(n - b * HW);
-      const float4 g = bn_load_dy4(dy, (size_t)b * C + c, (int)(n - b * HW), HW, pool_w);
+      const long long bl = n / HW, b = bl + b0;
+      const size_t o = ((size_t)b * C + c) * HW + (size_t)(n - bl * HW);
+      const float4 g = bn_load_dy4(dy, (size_t)b * C + c, (int)(n - bl * HW), HW, pool_w);
       const float4 xv = *reinterpret_cast<const float4*>(x + o);
       float gz[4] = {g.x, g.y, g.z, g.w};
       if (ACT == 1) {
@@ -601,8 +711,8 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float* __rest
     }
   } else {
     for (long long n = n0 + threadIdx.x; n < n1; n += 256) {
-      const long long b = n / HW;
-      const size_t o = ((size_t)b * C + c) * HW + (size_t)(n - b * HW);
+      const long long bl = n / HW, b = bl + b0;
+      const size_t o = ((size_t)b * C + c) * HW + (size_t)(n - bl * HW);
       float g = dy[o];
       if (ACT == 1) g = y[o] > 0.f ? g : g * slope;
       if (ACT == 2) g = ((x[o] - m) * gsc + bt) > 0.f ? g : g * slope;
@@ -613,25 +723,33 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float* __rest
   s1 = block_sum<256>(s1, red);
   s2 = block_sum<256>(s2, red);
   if (threadIdx.x == 0) {
-    part[((size_t)c * S + s) * 2 + 0] = s1;
-    part[((size_t)c * S + s) * 2 + 1] = s2;
+    part[((size_t)vc * S + s) * 2 + 0] = s1;
+    part[((size_t)vc * S + s) * 2 + 1] = s2;
   }
 }
 
+// coefficients per (segment, channel); dgamma / dbeta are summed over the segments (gamma / beta are shared)
 __global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const double* __restrict__ part, int S, int C,
                                                              double count, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta, float* __restrict__ coef) {
+                                                             float* __restrict__ dbeta, float* __restrict__ coef,
+                                                             int nseg) {
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int s = 0; s < S; ++s) {
-    s1 += part[((size_t)c * S + s) * 2 + 0];
-    s2 += part[((size_t)c * S + s) * 2 + 1];
+  double t1 = 0.0, t2 = 0.0;
+  for (int g = 0; g < nseg; ++g) {
+    const int vc = g * C + c;
+    double s1 = 0.0, s2 = 0.0;
+    for (int s = 0; s < S; ++s) {
+      s1 += part[((size_t)vc * S + s) * 2 + 0];
+      s2 += part[((size_t)vc * S + s) * 2 + 1];
+    }
+    coef[vc * 2 + 0] = (float)(s1 / count);
+    coef[vc * 2 + 1] = (float)(s2 / count);
+    t1 += s1;
+    t2 += s2;
   }
-  if (dbeta) dbeta[c] = (float)s1;
-  if (dgamma) dgamma[c] = (float)s2;
-  coef[c * 2 + 0] = (float)(s1 / count);
-  coef[c * 2 + 1] = (float)(s2 / count);
+  if (dbeta) dbeta[c] = (float)t1;
+  if (dgamma) dgamma[c] = (float)t2;
 }
 
 template <int ACT, bool HAS_DZ, bool VEC>
@@ -643,14 +761,16 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const float* __restrict_
                                                         const float* __restrict__ coef, float slope,
                                                         float* __restrict__ dx, float* __restrict__ dz_out, int C,
                                                         int HW, size_t numel, int pool_w,
-                                                        const unsigned char* __restrict__ mask) {
+                                                        const unsigned char* __restrict__ mask, int segB) {
   const size_t stride = (size_t)gridDim.x * 256;
   if (VEC) {
     const size_t n4 = numel >> 2;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
       const size_t e = i << 2;
-      const int c = (int)((e / HW) % C);
-      const float m = mean[c], is = invstd[c], gs = gamma[c] * is, c1 = coef[c * 2], c2 = coef[c * 2 + 1];
+      const size_t pl = e / HW;
+      const int c = (int)(pl % C);
+      const int sc = segB > 0 ? c + (int)((pl / C) / segB) * C : c;
+      const float m = mean[sc], is = invstd[sc], gs = gamma[c] * is, c1 = coef[sc * 2], c2 = coef[sc * 2 + 1];
       const float4 g = bn_load_dy4(dy, e / HW, (int)(e % HW), HW, pool_w);
       const float4 xv = reinterpret_cast<const float4*>(x)[i];
       float gz[4] = {g.x, g.y, g.z, g.w};
@@ -679,12 +799,14 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const float* __restrict_
     }
   } else {
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < numel; e += stride) {
-      const int c = (int)((e / HW) % C);
-      const float m = mean[c], is = invstd[c];
+      const size_t pl = e / HW;
+      const int c = (int)(pl % C);
+      const int sc = segB > 0 ? c + (int)((pl / C) / segB) * C : c;
+      const float m = mean[sc], is = invstd[sc];
       float g = dy[e];
       if (ACT == 1) g = y[e] > 0.f ? g : g * slope;
       if (ACT == 2) g = ((x[e] - m) * (is * gamma[c]) + beta[c]) > 0.f ? g : g * slope;
-      dx[e] = gamma[c] * is * (g - coef[c * 2] - (x[e] - m) * is * coef[c * 2 + 1]);
+      dx[e] = gamma[c] * is * (g - coef[sc * 2] - (x[e] - m) * is * coef[sc * 2 + 1]);
       if (HAS_DZ) dz_out[e] = g;
     }
   }
@@ -703,7 +825,7 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_dzsum_kernel(const float* __res
                                                               const float* __restrict__ coef, float slope,
                                                               float* __restrict__ dx, float* __restrict__ dz_half, int C,
                                                               int H, int W, size_t n_quads,
-                                                              const unsigned char* __restrict__ mask) {
+                                                              const unsigned char* __restrict__ mask, int segB) {
   const size_t stride = (size_t)gridDim.x * 256;
   const int W4 = W >> 2, H2 = H >> 1;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_quads; i += stride) {
@@ -712,7 +834,8 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_dzsum_kernel(const float* __res
     const int h2 = (int)(t % H2);
     t /= H2;  // b*C + c
     const int c = (int)(t % C);
-    const float m = mean[c], is = invstd[c], gs = gamma[c] * is, c1 = coef[c * 2], c2 = coef[c * 2 + 1];
+    const int sc = segB > 0 ? c + (int)((t / C) / segB) * C : c;
+    const float m = mean[sc], is = invstd[sc], gs = gamma[c] * is, c1 = coef[sc * 2], c2 = coef[sc * 2 + 1];
     const size_t o0 = (t * H + 2 * h2) * (size_t)W + 4 * w4;
     float gsum[2] = {0.f, 0.f};
     float row0[2] = {0.f, 0.f};
@@ -753,25 +876,29 @@ static int bn_bwd_impl(const float* dy, const float* y, const float* x, const fl
                        const float* gamma, const float* beta, int act_mode, float slope, float* dx, float* dz_out,
                        float* dgamma, float* dbeta, int B, int C, int HW, int pool_w, void* workspace,
                        size_t workspace_bytes, hipStream_t stream, int dzsum_w = 0,
-                       const unsigned char* mask = nullptr) {
+                       const unsigned char* mask = nullptr, int segB = 0) {
+  // segB > 0: B = nseg * segB images, statistics / coefficients per (segment, channel); the workspace layout is the
+  // unsegmented one with nseg*C virtual channels (it is sized for (B, C, HW), which covers (segB, nseg*C, HW))
   if (!dy || !x || !mean || !invstd || !gamma || !dx) return SIVAE_ERR_NULL;
   if (act_mode < 0 || act_mode > 3) return SIVAE_ERR_MODE;
   if (act_mode == 1 && !y) return SIVAE_ERR_NULL;
   if (act_mode == 3 && (!mask || (HW & 3))) return SIVAE_ERR_NULL;  // sign from the 1-bit mask (float4 path only)
   if (act_mode == 2 && !beta) return SIVAE_ERR_NULL;
   if (B <= 0 || C <= 0 || HW <= 0) return SIVAE_ERR_SHAPE;
-  if (!workspace || workspace_bytes < sivae_bn_workspace_bytes(B, C, HW)) return SIVAE_ERR_WORKSPACE;
-  const long long n = (long long)B * HW;
-  SlicePlan p = plan_slices(n, C);
+  if (segB < 0 || (segB > 0 && B % segB != 0)) return SIVAE_ERR_SHAPE;
+  const int nseg = segB > 0 ? B / segB : 1, Bs = segB > 0 ? segB : B, VC = nseg * C;
+  const long long n = (long long)Bs * HW;
+  SlicePlan p = plan_slices(n, VC);
+  if (!workspace || workspace_bytes < ((size_t)VC * p.S * 2 + (size_t)VC * 2) * sizeof(double)) return SIVAE_ERR_WORKSPACE;
   double* part = (double*)workspace;
-  float* coef = (float*)(part + (size_t)C * p.S * 2);
+  float* coef = (float*)(part + (size_t)VC * p.S * 2);
 #define LAUNCHP(A) \
-  hipLaunchKernelGGL((bn_bwd_partial_kernel<A>), dim3(C, p.S), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma, \
-                     beta, slope, part, C, HW, n, p.len, p.S, pool_w, mask)
+  hipLaunchKernelGGL((bn_bwd_partial_kernel<A>), dim3(VC, p.S), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma, \
+                     beta, slope, part, C, HW, n, p.len, p.S, pool_w, mask, Bs)
   if (act_mode == 0) LAUNCHP(0); else if (act_mode == 1) LAUNCHP(1); else if (act_mode == 2) LAUNCHP(2); else LAUNCHP(3);
 #undef LAUNCHP
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, (const double*)part, p.S, C,
-                     (double)n, dgamma, dbeta, coef);
+                     (double)n, dgamma, dbeta, coef, nseg);
   const size_t numel = (size_t)B * C * HW;
   if (dzsum_w > 0) {  // dz_out is [B][C][H/2][W/2] block sums (act_mode 1 only, checked by the caller)
     const int W_ = dzsum_w, H_ = HW / dzsum_w;
@@ -781,10 +908,10 @@ static int bn_bwd_impl(const float* dy, const float* y, const float* x, const fl
     if (nq < 1) nq = 1;
     if (act_mode == 3)
       hipLaunchKernelGGL(bn_bwd_dx_dzsum_kernel<true>, dim3(nq), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma,
-                         (const float*)coef, slope, dx, dz_out, C, H_, W_, n_quads, mask);
+                         (const float*)coef, slope, dx, dz_out, C, H_, W_, n_quads, mask, segB);
     else
       hipLaunchKernelGGL(bn_bwd_dx_dzsum_kernel<false>, dim3(nq), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma,
-                         (const float*)coef, slope, dx, dz_out, C, H_, W_, n_quads, mask);
+                         (const float*)coef, slope, dx, dz_out, C, H_, W_, n_quads, mask, segB);
     return sivae_launch_status();
   }
   const bool vec = (HW & 3) == 0;
@@ -794,7 +921,7 @@ static int bn_bwd_impl(const float* dy, const float* y, const float* x, const fl
   if (nb < 1) nb = 1;
 #define LAUNCH(A, Z, V) \
   hipLaunchKernelGGL((bn_bwd_dx_kernel<A, Z, V>), dim3(nb), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma, \
-                     beta, (const float*)coef, slope, dx, dz_out, C, HW, numel, pool_w, mask)
+                     beta, (const float*)coef, slope, dx, dz_out, C, HW, numel, pool_w, mask, segB)
 #define LAUNCH_A(A) \
   { if (hz) { if (vec) LAUNCH(A, true, true); else LAUNCH(A, true, false); } \
     else { if (vec) LAUNCH(A, false, true); else LAUNCH(A, false, false); } }
@@ -854,6 +981,25 @@ extern "C" int sivae_bn_bwd_signmask(const float* dy, const unsigned char* mask,
                      dy_pooled ? W : 0, workspace, workspace_bytes, stream, dz_sum ? W : 0, mask);
 }
 
+// General segmented backward: every variant above with B = nseg * seg_images images and per-(segment, channel)
+// statistics (mean / invstd [nseg][C]); dgamma / dbeta [C] are summed over the segments.
+//   act_mode 0 none, 1 sign from the saved output y, 2 sign recomputed from x (needs beta), 3 sign from `mask`
+//   dy_pooled: dy is the gradient of AvgPool2d(2)(output) ([B][C][H/2][W/2]); dz_sum: dz_out receives the 2x2 block
+//   sums of the residual-branch gradient (act_mode 1 or 3)
+extern "C" int sivae_bn_bwd_seg(const float* dy, const float* y, const unsigned char* mask, const float* x,
+                                const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                int act_mode, float slope, float* dx, float* dz_out, float* dgamma, float* dbeta, int B,
+                                int C, int H, int W, int dy_pooled, int dz_sum, int seg_images, void* workspace,
+                                size_t workspace_bytes, hipStream_t stream) {
+  if (seg_images <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
+  if (dy_pooled && dz_sum) return SIVAE_ERR_MODE;
+  if ((dy_pooled || dz_sum) && ((H & 1) || (W & 3))) return SIVAE_ERR_SHAPE;
+  if (act_mode == 3 && ((H & 1) || (W & 7))) return SIVAE_ERR_SHAPE;
+  if (dz_sum && (!dz_out || (act_mode != 1 && act_mode != 3))) return SIVAE_ERR_MODE;
+  return bn_bwd_impl(dy, y, x, mean, invstd, gamma, beta, act_mode, slope, dx, dz_out, dgamma, dbeta, B, C, H * W,
+                     dy_pooled ? W : 0, workspace, workspace_bytes, stream, dz_sum ? W : 0, mask, seg_images);
+}
+
 // ---- backward whose first reduction was done by the producer of dy (sivae_conv2d_wino_dgrad_bnbwd): per-tile
 // {sum g, sum g*xhat} float partials [n_tiles][C][2] -> coefficients (+ dgamma, dbeta), then the dx pass.
 __global__ void __launch_bounds__(256) bn_bwd_coef_partials_kernel(const float* __restrict__ part, int S, int C,
@@ -897,10 +1043,10 @@ extern "C" int sivae_bn_bwd_from_partials(const float* dy, const float* x, const
   float* dz_out = nullptr;
   if (vec)
     hipLaunchKernelGGL((bn_bwd_dx_kernel<2, false, true>), dim3(nb), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma,
-                       beta, (const float*)coef, slope, dx, dz_out, C, HW, numel, 0, (const unsigned char*)nullptr);
+                       beta, (const float*)coef, slope, dx, dz_out, C, HW, numel, 0, (const unsigned char*)nullptr, 0);
   else
     hipLaunchKernelGGL((bn_bwd_dx_kernel<2, false, false>), dim3(nb), dim3(256), 0, stream, dy, y, x, mean, invstd,
-                       gamma, beta, (const float*)coef, slope, dx, dz_out, C, HW, numel, 0, (const unsigned char*)nullptr);
+                       gamma, beta, (const float*)coef, slope, dx, dz_out, C, HW, numel, 0, (const unsigned char*)nullptr, 0);
   return sivae_launch_status();
 }
 
@@ -947,7 +1093,7 @@ extern "C" int sivae_bn_bwd_reduce(const float* dy, const float* y, const float*
   double* part = (double*)workspace;
 #define LAUNCHP(A) \
   hipLaunchKernelGGL((bn_bwd_partial_kernel<A>), dim3(C, p.S), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma, \
-                     beta, slope, part, C, HW, n, p.len, p.S, 0, (const unsigned char*)nullptr)
+                     beta, slope, part, C, HW, n, p.len, p.S, 0, (const unsigned char*)nullptr, B)
   if (act_mode == 0) LAUNCHP(0); else if (act_mode == 1) LAUNCHP(1); else LAUNCHP(2);
 #undef LAUNCHP
   hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, (const double*)part, p.S, C, sums);
@@ -977,7 +1123,7 @@ extern "C" int sivae_bn_bwd_apply(const float* dy, const float* y, const float* 
   if (nb < 1) nb = 1;
 #define LAUNCH(A, Z, V) \
   hipLaunchKernelGGL((bn_bwd_dx_kernel<A, Z, V>), dim3(nb), dim3(256), 0, stream, dy, y, x, mean, invstd, gamma, \
-                     beta, (const float*)coef, slope, dx, dz_out, C, HW, numel, 0, (const unsigned char*)nullptr)
+                     beta, (const float*)coef, slope, dx, dz_out, C, HW, numel, 0, (const unsigned char*)nullptr, 0)
 #define LAUNCH_A(A) \
   { if (hz) { if (vec) LAUNCH(A, true, true); else LAUNCH(A, true, false); } \
     else { if (vec) LAUNCH(A, false, true); else LAUNCH(A, false, false); } }

@@ -39,6 +39,9 @@ struct WinoArgs {
   const float* pro_gamma;
   const float* pro_beta;
   float pro_slope;
+  // segments: images [g*pro_seg_images, (g+1)*pro_seg_images) are pass g of the network with its own BatchNorm
+  // statistics pro_mean / pro_invstd [pro_nseg][Ci] (gamma / beta shared); pro_nseg == 1: the whole batch is one pass
+  int pro_seg_images, pro_nseg;
   float* stats;  // [n_px_tiles][Co][2] or null
   int B, Ci, Co, H, W;
   int Ci_pad, Co_pad;
@@ -142,6 +145,7 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
   const int teff = tid % NPOS;
   const int xtb = teff / (LH * LWU), xrr = (teff / LWU) % LH, xcc = teff % LWU;
   float xmask = 0.f;  // 1 inside the image, 0 on the zero padding (applied after the fused BatchNorm+LeakyReLU)
+  int pseg = 0;       // offset of this thread's segment in the staged prologue table (PRO with pro_nseg > 1)
   const f32x2 pslope2 = {a.pro_slope, a.pro_slope};
 #define xmask2 (f32x2{xmask, xmask})
   const int xl = xtb * PLANE_IMG + xrr * RS + (xcc & 1) * PH + (xcc >> 1);
@@ -172,6 +176,10 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
       xo = (unsigned)((xtb * a.Ci * Hs + rs) * Ws + cs) * 4u;            \
     }                                                                    \
     ua_base = (unsigned)((wj * a.Ci_pad) * a.Co_pad + co0) * 16u;        \
+    if (PRO && a.pro_nseg > 1) {                                         \
+      const int bi_ = b + xtb < a.B ? b + xtb : a.B - 1;                 \
+      pseg = (bi_ / a.pro_seg_images) * a.Ci_pad;                        \
+    }                                                                    \
   }
 
   // ---- A operand (U) addressing: lane -> (ci = k-step*2 + hh, co = co0 + (wg*WM + m)*32 + l31), 16 B each
@@ -209,8 +217,8 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
   {                                                                      \
     if (PRO) { /* two channels per packed-fp32 op; padded channels carry all-zero parameters -> 0 */ \
       _Pragma("unroll") for (int cp = 0; cp < CK / 2; ++cp) {            \
-        const float4 p0 = pro4[(CH)*CK + 2 * cp];     /* mean0 mean1 scale0 scale1 */ \
-        const float4 p1 = pro4[(CH)*CK + 2 * cp + 1]; /* beta0 beta1 */   \
+        const float4 p0 = pro4[pseg + (CH)*CK + 2 * cp];     /* mean0 mean1 scale0 scale1 */ \
+        const float4 p1 = pro4[pseg + (CH)*CK + 2 * cp + 1]; /* beta0 beta1 */   \
         f32x2 v = {xr[2 * cp], xr[2 * cp + 1]};                          \
         const f32x2 pm = {p0.x, p0.y}, ps = {p0.z, p0.w}, pb = {p1.x, p1.y}; \
         v = (v - pm) * ps + pb;                                          \
@@ -365,15 +373,16 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
   // phase overwrites it with chunk ch+2.
   if (PRO) {
     // pro4[2p] = {mean, mean', scale, scale'}, pro4[2p + 1] = {beta, beta', 0, 0} of the channel pair (2p, 2p + 1)
-    for (int c = tid; c < a.Ci_pad; c += NT) {
+    for (int idx = tid; idx < a.pro_nseg * a.Ci_pad; idx += NT) {
+      const int c = idx % a.Ci_pad, so = (idx / a.Ci_pad) * a.Ci;  // (segment g's statistics start at g * Ci)
       const int c0_ = c & ~1, c1_ = c | 1;
       const bool k0 = c0_ < a.Ci, k1 = c1_ < a.Ci;
       if ((c & 1) == 0)
-        pro4[c] = make_float4(k0 ? a.pro_mean[c0_] : 0.f, k1 ? a.pro_mean[c1_] : 0.f,
-                              k0 ? a.pro_invstd[c0_] * a.pro_gamma[c0_] : 0.f,
-                              k1 ? a.pro_invstd[c1_] * a.pro_gamma[c1_] : 0.f);
+        pro4[idx] = make_float4(k0 ? a.pro_mean[so + c0_] : 0.f, k1 ? a.pro_mean[so + c1_] : 0.f,
+                                k0 ? a.pro_invstd[so + c0_] * a.pro_gamma[c0_] : 0.f,
+                                k1 ? a.pro_invstd[so + c1_] * a.pro_gamma[c1_] : 0.f);
       else
-        pro4[c] = make_float4(k0 ? a.pro_beta[c0_] : 0.f, k1 ? a.pro_beta[c1_] : 0.f, 0.f, 0.f);
+        pro4[idx] = make_float4(k0 ? a.pro_beta[c0_] : 0.f, k1 ? a.pro_beta[c1_] : 0.f, 0.f, 0.f);
     }
     __syncthreads();
   }
@@ -544,7 +553,7 @@ static int wino_launch(WinoArgs& a, hipStream_t stream) {
   size_t lds = (size_t)2 * WINO_CK * PLANE * sizeof(float);
   const size_t exch = (size_t)WINO_EX_FLOATS * sizeof(float);
   if (lds > exch) return SIVAE_ERR_SHAPE;  // (halo buffers alias the exchange area)
-  lds = exch + (a.pro_mean ? (size_t)a.Ci_pad * 16 : 0);
+  lds = exch + (a.pro_mean ? (size_t)a.pro_nseg * a.Ci_pad * 16 : 0);
   if (lds > 80 * 1024) return SIVAE_ERR_SHAPE;
   auto kern = a.pro_mean ? conv_wino_kernel<TTH_L2, TTW_L2, true, NG, WM> : conv_wino_kernel<TTH_L2, TTW_L2, false, NG, WM>;
   {
@@ -573,7 +582,7 @@ static int wino_fwd_impl(const float* x, const float* up, float* y, const float*
                          float* stats_partial, const float* bnb_x, const float* bnb_mean, const float* bnb_invstd,
                          const float* bnb_gamma, const float* bnb_beta, float bnb_slope, int B, int Ci, int Co, int H,
                          int W, int upsample, int accumulate, hipStream_t stream, int chunks_per_split = 0,
-                         long long y_split_stride = 0) {
+                         long long y_split_stride = 0, int pro_seg_images = 0) {
   if (!x || !up || !y) return SIVAE_ERR_NULL;
   if (bias) return SIVAE_ERR_MODE;  // none of the 3x3 convs has a bias (:56-61); sivae_conv2d_fwd handles that case
   if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
@@ -594,6 +603,11 @@ static int wino_fwd_impl(const float* x, const float* up, float* y, const float*
   a.pro_gamma = pro_gamma;
   a.pro_beta = pro_beta;
   a.pro_slope = pro_slope;
+  if (pro_seg_images < 0 || (pro_seg_images > 0 && B % pro_seg_images != 0)) return SIVAE_ERR_SHAPE;
+  a.pro_seg_images = pro_seg_images > 0 ? pro_seg_images : B;
+  a.pro_nseg = B / a.pro_seg_images;
+  // (a tile block of the 8x8 / 4x4 maps holds 2 / 4 images: a segment must be a whole number of tile blocks)
+  if (a.pro_nseg > 1 && (a.pro_seg_images % ((W == 8) ? 2 : (W == 4 ? 4 : 1))) != 0) return SIVAE_ERR_SHAPE;
   a.stats = stats_partial;
   a.B = B;
   a.Ci = Ci;
@@ -627,6 +641,19 @@ extern "C" int sivae_conv2d_wino_fwd(const float* x, const float* up, float* y, 
                                      int Co, int H, int W, int upsample, int accumulate, hipStream_t stream) {
   return wino_fwd_impl(x, up, y, bias, pro_mean, pro_invstd, pro_gamma, pro_beta, pro_slope, stats_partial, nullptr,
                        nullptr, nullptr, nullptr, nullptr, 1.f, B, Ci, Co, H, W, upsample, accumulate, stream);
+}
+
+// Segmented batch (B = nseg * seg_images): the fused BatchNorm prologue takes pro_mean / pro_invstd [nseg][Ci]; the
+// statistics partials come out in image order, so rows [g*n/nseg, (g+1)*n/nseg) belong to segment g
+// (sivae_bn_stats_from_conv_seg).  With 8x8 / 4x4 maps seg_images must be a multiple of 2 / 4.
+extern "C" int sivae_conv2d_wino_fwd_seg(const float* x, const float* up, float* y, const float* pro_mean,
+                                         const float* pro_invstd, const float* pro_gamma, const float* pro_beta,
+                                         float pro_slope, float* stats_partial, int B, int Ci, int Co, int H, int W,
+                                         int upsample, int accumulate, int seg_images, hipStream_t stream) {
+  if (seg_images <= 0) return SIVAE_ERR_SHAPE;
+  return wino_fwd_impl(x, up, y, nullptr, pro_mean, pro_invstd, pro_gamma, pro_beta, pro_slope, stats_partial, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, 1.f, B, Ci, Co, H, W, upsample, accumulate, stream, 0, 0,
+                       seg_images);
 }
 
 // Data-gradient use feeding a BatchNorm backward: y = dL/dh with h = LeakyReLU(BatchNorm(bn_x)) (bn_x has y's shape);
@@ -702,16 +729,16 @@ extern "C" int sivae_conv2d_wino_splitk_stats_rows(int B, int Ci, int Co, int H,
   return S > 1 ? B : sivae_conv2d_wino_num_px_tiles(B, H, W);
 }
 
-extern "C" int sivae_conv2d_wino_fwd_splitk(const float* x, const float* up, float* y, const float* pro_mean,
-                                            const float* pro_invstd, const float* pro_gamma, const float* pro_beta,
-                                            float pro_slope, float* stats_partial, int B, int Ci, int Co, int H, int W,
-                                            int upsample, int accumulate, void* workspace, size_t workspace_bytes,
-                                            hipStream_t stream) {
+static int wino_fwd_splitk_impl(const float* x, const float* up, float* y, const float* pro_mean,
+                                const float* pro_invstd, const float* pro_gamma, const float* pro_beta, float pro_slope,
+                                float* stats_partial, int B, int Ci, int Co, int H, int W, int upsample, int accumulate,
+                                void* workspace, size_t workspace_bytes, hipStream_t stream, int seg_images) {
   const int S = sivae_conv2d_wino_splitk(B, Ci, Co, H, W);
   if (S < 0) return S;
   if (S == 1)
     return wino_fwd_impl(x, up, y, nullptr, pro_mean, pro_invstd, pro_gamma, pro_beta, pro_slope, stats_partial, nullptr,
-                         nullptr, nullptr, nullptr, nullptr, 1.f, B, Ci, Co, H, W, upsample, accumulate, stream);
+                         nullptr, nullptr, nullptr, nullptr, 1.f, B, Ci, Co, H, W, upsample, accumulate, stream, 0, 0,
+                         seg_images);
   if (!y || !workspace) return SIVAE_ERR_NULL;
   if (workspace_bytes < sivae_conv2d_wino_splitk_workspace_bytes(B, Ci, Co, H, W)) return SIVAE_ERR_WORKSPACE;
   if (((uintptr_t)workspace & 7u) != 0) return SIVAE_ERR_SHAPE;
@@ -721,9 +748,29 @@ extern "C" int sivae_conv2d_wino_fwd_splitk(const float* x, const float* up, flo
   float* part = reinterpret_cast<float*>(workspace);
   const int rc = wino_fwd_impl(x, up, part, nullptr, pro_mean, pro_invstd, pro_gamma, pro_beta, pro_slope, nullptr,
                                nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, B, Ci, Co, H, W, upsample, 0, stream,
-                               cps, stride);
+                               cps, stride, seg_images);
   if (rc != SIVAE_OK) return rc;
   hipLaunchKernelGGL(wino_splitk_reduce_kernel, dim3((unsigned)(B * Co)), dim3(64), 0, stream, part, y, stats_partial,
                      cdiv(nchunks, cps), Co, H * W, (size_t)stride, accumulate);
   return sivae_launch_status();
+}
+
+extern "C" int sivae_conv2d_wino_fwd_splitk(const float* x, const float* up, float* y, const float* pro_mean,
+                                            const float* pro_invstd, const float* pro_gamma, const float* pro_beta,
+                                            float pro_slope, float* stats_partial, int B, int Ci, int Co, int H, int W,
+                                            int upsample, int accumulate, void* workspace, size_t workspace_bytes,
+                                            hipStream_t stream) {
+  return wino_fwd_splitk_impl(x, up, y, pro_mean, pro_invstd, pro_gamma, pro_beta, pro_slope, stats_partial, B, Ci, Co, H,
+                              W, upsample, accumulate, workspace, workspace_bytes, stream, 0);
+}
+
+// segmented batch (see sivae_conv2d_wino_fwd_seg); statistics rows are per image when the call splits
+extern "C" int sivae_conv2d_wino_fwd_splitk_seg(const float* x, const float* up, float* y, const float* pro_mean,
+                                                const float* pro_invstd, const float* pro_gamma, const float* pro_beta,
+                                                float pro_slope, float* stats_partial, int B, int Ci, int Co, int H,
+                                                int W, int upsample, int accumulate, int seg_images, void* workspace,
+                                                size_t workspace_bytes, hipStream_t stream) {
+  if (seg_images <= 0) return SIVAE_ERR_SHAPE;
+  return wino_fwd_splitk_impl(x, up, y, pro_mean, pro_invstd, pro_gamma, pro_beta, pro_slope, stats_partial, B, Ci, Co, H,
+                              W, upsample, accumulate, workspace, workspace_bytes, stream, seg_images);
 }

@@ -36,6 +36,7 @@ struct WinoWgArgs {
   const float* pro_gamma;
   const float* pro_beta;
   float pro_slope;
+  int pro_seg_images, pro_nseg;  // segments (see conv_wino.hip): pro_mean / pro_invstd are [pro_nseg][Ci]
   int B, Ci, Co, H, W;
   int Ci_pad, Co_pad;
   int nrh, nrw, nstages, sps;
@@ -91,6 +92,7 @@ __global__ void __launch_bounds__(NGI * 256, 2) wino_wgrad_kernel(WinoWgArgs a) 
   const int xpos = (tid & 127) < NPOSX ? (tid & 127) : (tid & 127) - NPOSX;
   const int xrr = xpos / LWX, xcc = xpos % LWX;
   float xmask = 0.f;
+  int pseg = 0;  // table offset of the segment of the stage currently held in xr (wave-uniform)
   const f32x2 pslope2 = {a.pro_slope, a.pro_slope};
   const int ypy = lane >> 4, ypx = lane & 15;
 
@@ -122,6 +124,7 @@ __global__ void __launch_bounds__(NGI * 256, 2) wino_wgrad_kernel(WinoWgArgs a) 
     const int rem_ = s_ - b_ * (a.nrh * a.nrw);                                                     \
     const int ry_ = rem_ / a.nrw, rx_ = rem_ - ry_ * a.nrw;                                         \
     const int r0_ = ry_ * 4, c0_ = rx_ * 16;                                                        \
+    if (PRO && a.pro_nseg > 1) pseg = (b_ / a.pro_seg_images) * CIT;                                \
     const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.x + (size_t)b_ * a.Ci * HWs, (unsigned long long)a.Ci * HWs * 4ull); \
     const __amdgpu_buffer_rsrc_t yrs = make_rsrc(a.dy + (size_t)b_ * a.Co * HW, (unsigned long long)a.Co * HW * 4ull);   \
     {                                                                                               \
@@ -154,8 +157,8 @@ __global__ void __launch_bounds__(NGI * 256, 2) wino_wgrad_kernel(WinoWgArgs a) 
   {                                                                                                 \
     if (PRO) { /* two channels per packed-fp32 op */                                                \
       _Pragma("unroll") for (int pq = 0; pq < XQ / 2; ++pq) {                                       \
-        const float4 p0 = pro4[2 * (pq * NSUB + xsub)];     /* mean mean' scale scale' */           \
-        const float4 p1 = pro4[2 * (pq * NSUB + xsub) + 1]; /* beta beta' */                        \
+        const float4 p0 = pro4[pseg + 2 * (pq * NSUB + xsub)];     /* mean mean' scale scale' */    \
+        const float4 p1 = pro4[pseg + 2 * (pq * NSUB + xsub) + 1]; /* beta beta' */                 \
         f32x2 v = {xr[2 * pq], xr[2 * pq + 1]};                                                     \
         const f32x2 pm = {p0.x, p0.y}, ps = {p0.z, p0.w}, pb = {p1.x, p1.y};                        \
         v = (v - pm) * ps + pb;                                                                     \
@@ -233,15 +236,16 @@ __global__ void __launch_bounds__(NGI * 256, 2) wino_wgrad_kernel(WinoWgArgs a) 
   if (PRO) {
     // pair table: entry e = pq * NSUB + xsub holds the channels (xsub + NSUB*2pq, xsub + NSUB*(2pq+1)) a thread
     // stages in its registers xr[2pq], xr[2pq+1]:  pro4[2e] = {mean, mean', scale, scale'}, pro4[2e+1] = {beta, beta'}
-    if (tid < CIT) {
-      const int e = tid >> 1, pq = e / NSUB, xs_ = e % NSUB;
+    for (int idx = tid; idx < a.pro_nseg * CIT; idx += NT) {
+      const int t_ = idx % CIT, so = (idx / CIT) * a.Ci;  // (segment g's statistics start at g * Ci)
+      const int e = t_ >> 1, pq = e / NSUB, xs_ = e % NSUB;
       const int ca_ = ci0 + xs_ + NSUB * (2 * pq), cb_ = ca_ + NSUB;
       const int c0_ = ca_ < a.Ci ? ca_ : a.Ci - 1, c1_ = cb_ < a.Ci ? cb_ : a.Ci - 1;
-      if ((tid & 1) == 0)
-        pro4[tid] = make_float4(a.pro_mean[c0_], a.pro_mean[c1_], a.pro_invstd[c0_] * a.pro_gamma[c0_],
-                                a.pro_invstd[c1_] * a.pro_gamma[c1_]);
+      if ((t_ & 1) == 0)
+        pro4[idx] = make_float4(a.pro_mean[so + c0_], a.pro_mean[so + c1_], a.pro_invstd[so + c0_] * a.pro_gamma[c0_],
+                                a.pro_invstd[so + c1_] * a.pro_gamma[c1_]);
       else
-        pro4[tid] = make_float4(a.pro_beta[c0_], a.pro_beta[c1_], 0.f, 0.f);
+        pro4[idx] = make_float4(a.pro_beta[c0_], a.pro_beta[c1_], 0.f, 0.f);
     }
     __syncthreads();
   }
@@ -363,11 +367,12 @@ extern "C" size_t sivae_conv2d_wino_wgrad_workspace_bytes(int B, int Ci, int Co,
   return (size_t)p.n_slices * 16 * p.Co_pad * p.Ci_pad * sizeof(float);
 }
 
-extern "C" int sivae_conv2d_wino_wgrad(const float* x, const float* dy, float* dw, const float* pro_mean,
-                                       const float* pro_invstd, const float* pro_gamma, const float* pro_beta,
-                                       float pro_slope, int B, int Ci, int Co, int H, int W, int upsample,
-                                       void* workspace, size_t workspace_bytes, hipStream_t stream) {
+static int wino_wgrad_impl(const float* x, const float* dy, float* dw, const float* pro_mean,
+                           const float* pro_invstd, const float* pro_gamma, const float* pro_beta,
+                           float pro_slope, int B, int Ci, int Co, int H, int W, int upsample,
+                           void* workspace, size_t workspace_bytes, hipStream_t stream, int pro_seg_images) {
   if (!x || !dy || !dw || !workspace) return SIVAE_ERR_NULL;
+  if (pro_seg_images < 0 || (pro_seg_images > 0 && B % pro_seg_images != 0)) return SIVAE_ERR_SHAPE;
   if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
   if (!sivae_conv2d_wino_wgrad_supported(H, W)) return SIVAE_ERR_SHAPE;
   if (pro_mean && (!pro_invstd || !pro_gamma || !pro_beta)) return SIVAE_ERR_NULL;
@@ -388,6 +393,8 @@ extern "C" int sivae_conv2d_wino_wgrad(const float* x, const float* dy, float* d
   a.pro_gamma = pro_gamma;
   a.pro_beta = pro_beta;
   a.pro_slope = pro_slope;
+  a.pro_seg_images = pro_seg_images > 0 ? pro_seg_images : B;
+  a.pro_nseg = B / a.pro_seg_images;
   a.B = B;
   a.Ci = Ci;
   a.Co = Co;
@@ -405,7 +412,7 @@ extern "C" int sivae_conv2d_wino_wgrad(const float* x, const float* dy, float* d
   const long long nblk = (long long)p.n_ci_tiles * p.n_co_tiles * p.n_slices;
   if (nblk > 0x7fffffffLL) return SIVAE_ERR_RANGE;
   constexpr int CIT = 32 * WG_NGI;
-  const size_t lds = (size_t)2 * (CIT * 109 + 64 * 65) * sizeof(float) + (pro_mean ? (size_t)CIT * 16 : 0);
+  const size_t lds = (size_t)2 * (CIT * 109 + 64 * 65) * sizeof(float) + (pro_mean ? (size_t)a.pro_nseg * CIT * 16 : 0);
   auto kern = pro_mean ? wino_wgrad_kernel<true, WG_NGI> : wino_wgrad_kernel<false, WG_NGI>;
   {
     static size_t lds_hwm[2] = {0, 0};  // per template instantiation, per prologue variant
@@ -421,4 +428,23 @@ extern "C" int sivae_conv2d_wino_wgrad(const float* x, const float* dy, float* d
   hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((unsigned)(Co * n_cic)), dim3(256), 0, stream,
                      static_cast<const float*>(workspace), dw, Co, Ci, p.Co_pad, p.Ci_pad, p.n_slices);
   return sivae_launch_status();
+}
+
+extern "C" int sivae_conv2d_wino_wgrad(const float* x, const float* dy, float* dw, const float* pro_mean,
+                                       const float* pro_invstd, const float* pro_gamma, const float* pro_beta,
+                                       float pro_slope, int B, int Ci, int Co, int H, int W, int upsample,
+                                       void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  return wino_wgrad_impl(x, dy, dw, pro_mean, pro_invstd, pro_gamma, pro_beta, pro_slope, B, Ci, Co, H, W, upsample,
+                         workspace, workspace_bytes, stream, 0);
+}
+
+// segmented batch (B = nseg * seg_images, pro_mean / pro_invstd [nseg][Ci]): one weight gradient summed over all passes
+extern "C" int sivae_conv2d_wino_wgrad_seg(const float* x, const float* dy, float* dw, const float* pro_mean,
+                                           const float* pro_invstd, const float* pro_gamma, const float* pro_beta,
+                                           float pro_slope, int B, int Ci, int Co, int H, int W, int upsample,
+                                           int seg_images, void* workspace, size_t workspace_bytes,
+                                           hipStream_t stream) {
+  if (seg_images <= 0) return SIVAE_ERR_SHAPE;
+  return wino_wgrad_impl(x, dy, dw, pro_mean, pro_invstd, pro_gamma, pro_beta, pro_slope, B, Ci, Co, H, W, upsample,
+                         workspace, workspace_bytes, stream, seg_images);
 }

@@ -9,10 +9,21 @@ tensors for parity tests), that gradients live in two flat buffers (one all-redu
 data parallelism) and that all logged scalars come back in ONE device->host copy per iteration instead of
 ~12 `.item()` syncs.
 """
+import os
+
 import torch
 
 from . import functional as SF
 from . import rng
+
+# The iteration contains four PAIRS of independent passes through unchanged weights: model(rec.detach()) /
+# model(fake.detach()) = encoder pair + second-decoder pair (reference :567-568), encode(rec) / encode(fake) (:601-605),
+# decode(z_rec) / decode(z_fake) (:607-608; bootstrap decode_target :635-636).  With SIVAE_PAIR_PASSES != 0 each pair
+# runs as ONE segmented batch of 2B images (per-pass BatchNorm statistics, functional.py "segments"): half the launches
+# and twice the work per launch for 8 of the 13 forward and 8 of the 12 backward passes — what the small per-GPU shards
+# of the data-parallel configurations (16 / 8 images) need (256x256: 16-image shard 210 -> 221 img/s, bootstrap 8-image shard
+# 182 -> 202; batch 128: +0.4 %).  "auto" (default) / "1": pair wherever the shapes allow; "0": never.
+PAIR_PASSES = os.environ.get("SIVAE_PAIR_PASSES", "auto")
 
 
 # ---- reference helper surface (same names / argument meaning / errors) ------------------------------
@@ -61,7 +72,7 @@ class SoftIntroEngine:
 
     def __init__(self, model, opt_e, opt_d, beta_kl=1.0, beta_rec=1.0, beta_neg=1.0, gamma_r=1e-8,
                  recon_loss_type="mse", bootstrap=False, grad_sync=None, reuse_decoder_forward=True,
-                 compute_dtype=None):
+                 compute_dtype=None, pair_passes=None):
         """compute_dtype: None (leave the model as it is), "fp32" (the parity path) or "bf16" (BASELINE.json config 3's
         build-defined mode: bf16 activation storage and bf16 MFMA convs with fp32 accumulation — sivae_hip.nn
         .set_compute_dtype; weights, BatchNorm statistics, losses, gradients buffers and Adam stay fp32)."""
@@ -82,6 +93,8 @@ class SoftIntroEngine:
         # pass, 2 of 8 decoder forwards (50.3 of 818.7 GFLOP per image at 256x256) not re-executed.
         self.reuse_decoder_forward = reuse_decoder_forward
         self._cache_fake, self._cache_rec = None, None
+        # pair_passes: None -> SIVAE_PAIR_PASSES ("auto" | "0" | "1"); True / False force it
+        self.pair_passes = PAIR_PASSES if pair_passes is None else ("1" if pair_passes else "0")
         # parameter gradients of every pass go straight into per-use slabs of the flat optimizers and are folded with
         # one launch per network after each backward (functional._claim / FlatAdam.fold_slabs; SIVAE_DIRECT_GRADS=0:
         # autograd's per-tensor accumulation)
@@ -152,6 +165,25 @@ class SoftIntroEngine:
 
     def _second_decoder(self):
         return self.model.target_decoder if self.bootstrap else self.model.decoder
+
+    def _paired(self, real):
+        """run the same-weight pass pairs of this iteration as segmented batches?"""
+        if self.pair_passes == "0":
+            return False
+        from .nn import segments_supported
+        enc = self.model.encoder
+        ok = segments_supported(real.size(2), real.size(0), getattr(enc, "compute_dtype", "fp32")) \
+            and real.size(2) == real.size(3) and not getattr(enc, "conditional", False)
+        return ok
+
+    @staticmethod
+    def _eps2(e0, e1, like):
+        """the Gaussian draws of a pass pair, in the reference's order (two draws from the stream when not injected)"""
+        if e0 is None:
+            e0 = rng.randn(like.shape, like.device)
+        if e1 is None:
+            e1 = rng.randn(like.shape, like.device)
+        return torch.cat([e0, e1])
 
     def _sync(self, opt):
         """after backward(): fold the per-use gradient slabs into the flat buffer, all-reduce it (data parallel)"""
@@ -230,12 +262,21 @@ class SoftIntroEngine:
         loss_rec = calc_reconstruction_loss(real, rec, lt, "mean")
         kl_real = calc_kl(real_logvar, real_mu, reduce="mean")
 
-        rec_mu, rec_logvar = m.encode(rec.detach())
-        z_rec = reparameterize(rec_mu, rec_logvar, eps[1])
-        rec_rec = dec2(z_rec)
-        fake_mu, fake_logvar = m.encode(fake.detach())
-        z_fake = reparameterize(fake_mu, fake_logvar, eps[2])
-        rec_fake = dec2(z_fake)
+        B = real.size(0)
+        if self._paired(real):
+            # model(rec.detach()) and model(fake.detach()) (:567-568) as one segmented batch [rec; fake]
+            mu2, logvar2 = m.encoder(torch.cat([rec.detach(), fake.detach()]), nseg=2)
+            z2 = reparameterize(mu2, logvar2, self._eps2(eps[1], eps[2], real_mu))
+            rr2 = dec2(z2, nseg=2)
+            rec_mu, rec_logvar, fake_mu, fake_logvar = mu2[:B], logvar2[:B], mu2[B:], logvar2[B:]
+            rec_rec, rec_fake = rr2[:B], rr2[B:]
+        else:
+            rec_mu, rec_logvar = m.encode(rec.detach())
+            z_rec = reparameterize(rec_mu, rec_logvar, eps[1])
+            rec_rec = dec2(z_rec)
+            fake_mu, fake_logvar = m.encode(fake.detach())
+            z_fake = reparameterize(fake_mu, fake_logvar, eps[2])
+            rec_fake = dec2(z_fake)
 
         kl_rec = calc_kl(rec_logvar, rec_mu, reduce="none")
         kl_fake = calc_kl(fake_logvar, fake_mu, reduce="none")
@@ -274,18 +315,30 @@ class SoftIntroEngine:
         rec = m.decoder(z.detach(), cache=self._cache_rec)
         self._cache_fake, self._cache_rec = None, None
         loss_rec = calc_reconstruction_loss(real, rec, lt, "mean")
-        rec_mu, rec_logvar = m.encode(rec)
-        z_rec = reparameterize(rec_mu, rec_logvar, eps[0])
-        fake_mu, fake_logvar = m.encode(fake)
-        z_fake = reparameterize(fake_mu, fake_logvar, eps[1])
+        B = real.size(0)
+        if self._paired(real):
+            # encode(rec) / encode(fake) (:601-605) and decode(z_rec) / decode(z_fake) (:607-608; bootstrap
+            # decode_target :635-636) as segmented batches [rec; fake]
+            mu2, logvar2 = m.encoder(torch.cat([rec, fake]), nseg=2)
+            z2 = reparameterize(mu2, logvar2, self._eps2(eps[0], eps[1], z))
+            rr2 = dec2(z2, nseg=2) if self.bootstrap else m.decoder(z2.detach(), nseg=2)
+            rec_mu, rec_logvar, fake_mu, fake_logvar = mu2[:B], logvar2[:B], mu2[B:], logvar2[B:]
+            rec_rec, rec_fake = rr2[:B], rr2[B:]
+        else:
+            rec_mu, rec_logvar = m.encode(rec)
+            z_rec = reparameterize(rec_mu, rec_logvar, eps[0])
+            fake_mu, fake_logvar = m.encode(fake)
+            z_fake = reparameterize(fake_mu, fake_logvar, eps[1])
+            if self.bootstrap:
+                rec_rec = dec2(z_rec)
+                rec_fake = dec2(z_fake)
+            else:
+                rec_rec = m.decode(z_rec.detach())
+                rec_fake = m.decode(z_fake.detach())
         if self.bootstrap:
-            rec_rec = dec2(z_rec)
-            rec_fake = dec2(z_fake)
             l_rr = calc_reconstruction_loss(rec, rec_rec, lt, "mean")
             l_fr = calc_reconstruction_loss(fake, rec_fake, lt, "mean")
         else:
-            rec_rec = m.decode(z_rec.detach())
-            rec_fake = m.decode(z_fake.detach())
             l_rr = calc_reconstruction_loss(rec.detach(), rec_rec, lt, "mean")
             l_fr = calc_reconstruction_loss(fake.detach(), rec_fake, lt, "mean")
         kl_rec = calc_kl(rec_logvar, rec_mu, reduce="mean")

@@ -100,12 +100,17 @@ class BNState:
         self.momentum = bn_module.momentum
 
 
-def _stats(partials, B, C, HW, st):
-    """batch statistics from conv-epilogue partials (training) or the running buffers (eval)"""
+def _stats(partials, B, C, HW, st, nseg=1, seg_rev=False):
+    """batch statistics from conv-epilogue partials (training) or the running buffers (eval).
+    nseg > 1 (segmented batch: nseg passes of B / nseg images laid end to end): one set of statistics per pass,
+    returned as nseg * C entries; the running buffers get one update per pass (seg_rev: last pass first)."""
     if st.training:
         return ops.bn_stats_from_conv(partials, B, C, HW, st.running_mean, st.running_var, st.num_batches_tracked,
-                                      st.eps, st.momentum)
-    return st.running_mean, torch.rsqrt(st.running_var + st.eps)
+                                      st.eps, st.momentum, nseg=nseg, seg_rev=seg_rev)
+    mean, invstd = st.running_mean, torch.rsqrt(st.running_var + st.eps)
+    if nseg > 1:
+        mean, invstd = mean.repeat(nseg), invstd.repeat(nseg)
+    return mean, invstd
 
 
 def _post_fwd(out, post):
@@ -125,12 +130,12 @@ def _post_bwd(dy, post, shape):
 
 
 # ---------------------------------------------------------------------------------------------------
-def _replay_bn(st, mean, invstd, count):
+def _replay_bn(st, mean, invstd, count, nseg=1, seg_rev=False):
     if ops.SYNC_BN is not None:
         count = count * ops.SYNC_BN(None)  # (None -> just the world size)
     if st.training:
         ops.bn_update_running(mean, invstd, count, st.running_mean, st.running_var, st.num_batches_tracked, st.eps,
-                              st.momentum)
+                              st.momentum, nseg=nseg, seg_rev=seg_rev)
 
 
 # ---- parameter gradients written straight into the optimizer's slabs ------------------------------------------------
@@ -144,12 +149,27 @@ def _replay_bn(st, mean, invstd, count):
 DIRECT_GRADS = os.environ.get("SIVAE_DIRECT_GRADS", "1") != "0"
 
 
+_GRAD_MODE = [True]  # torch.is_grad_enabled() at the call site (inside Function.forward autograd has switched it off)
+
+
+def _apply(fn, *args):
+    """fn.apply(*args), remembering whether the CALLER records a graph: under torch.no_grad() (test_iter dumps,
+    model.sample, the FID feed) needs_input_grad is still True for parameters, and a slab reserved there would never be
+    written — the next backward would run out of slabs and lose the overlapped gradient sync"""
+    prev = _GRAD_MODE[0]
+    _GRAD_MODE[0] = torch.is_grad_enabled()
+    try:
+        return fn.apply(*args)
+    finally:
+        _GRAD_MODE[0] = prev
+
+
 def _claim(ctx, indexed_params):
     """forward: reserve a slab index for each (input position, parameter) that will receive a gradient from this node"""
     use = []
     for i, p in indexed_params:
         k = -1
-        if DIRECT_GRADS and p is not None and ctx.needs_input_grad[i]:
+        if DIRECT_GRADS and _GRAD_MODE[0] and p is not None and ctx.needs_input_grad[i]:
             slabs = p.__dict__.get("_sivae_slabs")
             if slabs is not None:
                 u = p.__dict__.get("_sivae_use", 0)
@@ -183,7 +203,7 @@ def _done(*params):
 
 class ResBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache=None, x_up=False):
+    def forward(ctx, x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache=None, x_up=False, nseg=1, seg_rev=False):
         """cache: None, or a dict owned by the caller.  An empty dict is FILLED with this pass's activations;
         a filled one is REPLAYED: no kernels run except the BatchNorm running-stat updates, the outputs and the
         tensors saved for backward are the cached ones.  A replay is only valid while x and all weights are unchanged:
@@ -193,7 +213,12 @@ class ResBlockFn(torch.autograd.Function):
         x_up: x is stored at HALF resolution and stands for Upsample(2,'nearest')(x) (train_soft_intro_vae.py:155):
         every consumer (conv1, conv_expand or the identity add, both weight gradients) reads it through upsample
         addressing, so the 4x tensor is never written.  post == "up_deferred": the Upsample after this block is
-        left to the next block's x_up (the output is returned at this block's resolution)."""
+        left to the next block's x_up (the output is returned at this block's resolution).
+
+        nseg > 1: SEGMENTED batch — x holds nseg independent passes of the network (B / nseg images each) laid end to
+        end; the convolutions run once over the whole batch, every BatchNorm keeps one set of batch statistics per pass
+        (what the reference's separate calls compute, train_soft_intro_vae.py:567-568, :601-608), the running buffers
+        are updated once per pass in pass order (seg_rev: last segment first)."""
         x = x.contiguous()
         _claim(ctx, ((1, w_exp), (2, w1), (3, g1), (4, b1), (5, w2), (6, g2), (7, b2)))
         B, Ci, H, W = x.shape
@@ -205,8 +230,9 @@ class ResBlockFn(torch.autograd.Function):
         if cache is not None and cache.get("y") is not None and cache.get("tag") == tag:
             a, h, c, out, mean1, invstd1, mean2, invstd2, y = (cache[k] for k in (
                 "a", "h", "c", "out", "mean1", "invstd1", "mean2", "invstd2", "y"))
-            _replay_bn(st1, mean1, invstd1, B * H * W)
-            _replay_bn(st2, mean2, invstd2, B * H * W)
+            _replay_bn(st1, mean1, invstd1, (B // nseg) * H * W, nseg, seg_rev)
+            _replay_bn(st2, mean2, invstd2, (B // nseg) * H * W, nseg, seg_rev)
+            ctx.nseg = nseg
             ctx.post = post
             ctx.has_exp = w_exp is not None
             ctx.training = st1.training and st2.training
@@ -219,43 +245,46 @@ class ResBlockFn(torch.autograd.Function):
             # upsample addressing like an identity skip
             idt = ops.conv2d_fwd(x, packed(w_exp, 0), Co, 1)
         if st1.training:
-            a, p1 = ops.conv2d_fwd(x, packed(w1, 0), Cm, 3, want_stats=True, upsample=x_up)
+            a, p1 = ops.conv2d_fwd(x, packed(w1, 0), Cm, 3, want_stats=True, upsample=x_up, nseg=nseg)
         else:
             a, p1 = ops.conv2d_fwd(x, packed(w1, 0), Cm, 3, upsample=x_up), None
-        mean1, invstd1 = _stats(p1, B, Cm, H * W, st1)
-        if MATERIALIZE_H:
+        mean1, invstd1 = _stats(p1, B, Cm, H * W, st1, nseg, seg_rev)
+        if MATERIALIZE_H or (nseg > 1 and not ops.seg_prologue_supported(H, W)):
             # h = LeakyReLU(BN1(a)) written once (2 HBM passes over a Cm-channel tensor) and kept for backward
-            h = ops.bn_apply_act(a, None, mean1, invstd1, g1.detach(), b1.detach(), SLOPE)
+            # (segmented batches on the 4x4 / 8x8 maps: the kernels that take those maps have no per-segment prologue)
+            h = ops.bn_apply_act(a, None, mean1, invstd1, g1.detach(), b1.detach(), SLOPE, nseg=nseg)
             pro1 = None
         else:
             h = a
             pro1 = (mean1, invstd1, g1.detach(), b1.detach(), SLOPE)
         if st2.training:
-            c, p2 = ops.conv2d_fwd(h, packed(w2, 0), Co, 3, pro=pro1, want_stats=True)
+            c, p2 = ops.conv2d_fwd(h, packed(w2, 0), Co, 3, pro=pro1, want_stats=True, nseg=nseg)
         else:
-            c, p2 = ops.conv2d_fwd(h, packed(w2, 0), Co, 3, pro=pro1), None
-        mean2, invstd2 = _stats(p2, B, Co, H * W, st2)
+            c, p2 = ops.conv2d_fwd(h, packed(w2, 0), Co, 3, pro=pro1, nseg=nseg), None
+        mean2, invstd2 = _stats(p2, B, Co, H * W, st2, nseg, seg_rev)
         fused = None
         pool_fusable = post == "pool" and not (x_up and w_exp is None)
         if st1.training and st2.training and ops.bn_signmask_supported(c):
             # the backward takes the LeakyReLU sign from a 1-bit mask written here, not from the output: `out` below
             # is that mask (uint8), and a pooled block never writes its full-resolution output
             full, y, out = ops.bn_apply_act_signmask(c, idt, mean2, invstd2, g2.detach(), b2.detach(), SLOPE,
-                                                     res_up=x_up, pool=pool_fusable, want_full=not pool_fusable)
+                                                     res_up=x_up, pool=pool_fusable, want_full=not pool_fusable,
+                                                     nseg=nseg)
             if not pool_fusable:
                 y = _post_fwd(full, post)
             del full
         else:
             if pool_fusable:
-                fused = ops.bn_apply_act_pool(c, idt, mean2, invstd2, g2.detach(), b2.detach(), SLOPE)
+                fused = ops.bn_apply_act_pool(c, idt, mean2, invstd2, g2.detach(), b2.detach(), SLOPE, nseg=nseg)
             if fused is not None:
                 out, y = fused  # BatchNorm + residual + LeakyReLU and the AvgPool2d that follows, one pass
             else:
-                out = ops.bn_apply_act(c, idt, mean2, invstd2, g2.detach(), b2.detach(), SLOPE, res_up=x_up)
+                out = ops.bn_apply_act(c, idt, mean2, invstd2, g2.detach(), b2.detach(), SLOPE, res_up=x_up, nseg=nseg)
                 y = _post_fwd(out, post)
         if cache is not None:
             cache.update(a=a, h=h, c=c, out=out, mean1=mean1, invstd1=invstd1, mean2=mean2, invstd2=invstd2, y=y,
                          tag=tag)
+        ctx.nseg = nseg
         ctx.post = post
         ctx.has_exp = w_exp is not None
         ctx.training = st1.training and st2.training
@@ -268,6 +297,7 @@ class ResBlockFn(torch.autograd.Function):
             raise RuntimeError("sivae_hip: backward through eval-mode BatchNorm is not supported")
         x, a, h, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2, b2 = ctx.saved_tensors
         k_we, k_w1, k_g1, k_b1, k_w2, k_g2, k_b2 = ctx.use
+        nseg = ctx.nseg
         h_saved = h.data_ptr() != a.data_ptr()
         need = ctx.needs_input_grad
         need_x, need_we, need_w1, need_bn1, need_w2, need_bn2 = need[0], need[1], need[2], need[3] or need[4], \
@@ -281,36 +311,37 @@ class ResBlockFn(torch.autograd.Function):
         if out.dtype == torch.uint8:  # `out` is the LeakyReLU sign mask (1 bit per element)
             if ctx.post == "pool" and not (x_up and not ctx.has_exp):
                 dc, dz, dg2, db2 = ops.bn_bwd_signmask(dy.contiguous(), out, c, mean2, invstd2, g2, SLOPE,
-                                                       dy_pooled=True, want_param_grads=need_bn2, pg_out=pg2)
+                                                       dy_pooled=True, want_param_grads=need_bn2, pg_out=pg2,
+                                                       nseg=nseg)
             else:
                 d_out = _post_bwd(dy.contiguous(), ctx.post, c.shape)
                 want_sum = x_up and ctx.post != "pool"
                 dc, dz, dg2, db2 = ops.bn_bwd_signmask(d_out, out, c, mean2, invstd2, g2, SLOPE, dz_sum=want_sum,
-                                                       want_param_grads=need_bn2, pg_out=pg2)
+                                                       want_param_grads=need_bn2, pg_out=pg2, nseg=nseg)
                 if want_sum:
                     dzh, dz = dz, None
                 del d_out
         elif x_up and ctx.post != "pool" and ops.bn_bwd_dzsum_supported(c):
             d_out = _post_bwd(dy.contiguous(), ctx.post, out.shape)
             dc, dzh, dg2, db2 = ops.bn_bwd_dzsum(d_out, out, c, mean2, invstd2, g2, SLOPE, want_param_grads=need_bn2,
-                                                 pg_out=pg2)
+                                                 pg_out=pg2, nseg=nseg)
             dz = None
             del d_out
         elif ctx.post == "pool":
             dc, dz, dg2, db2 = ops.bn_bwd(dy.contiguous(), out, c, mean2, invstd2, g2, SLOPE, want_dz=True,
-                                          want_param_grads=need_bn2, act_mode=1, dy_pooled=True, pg_out=pg2)
+                                          want_param_grads=need_bn2, act_mode=1, dy_pooled=True, pg_out=pg2, nseg=nseg)
         else:
             d_out = _post_bwd(dy.contiguous(), ctx.post, out.shape)
             dc, dz, dg2, db2 = ops.bn_bwd(d_out, out, c, mean2, invstd2, g2, SLOPE, want_dz=True,
-                                          want_param_grads=need_bn2, act_mode=1, pg_out=pg2)
+                                          want_param_grads=need_bn2, act_mode=1, pg_out=pg2, nseg=nseg)
             del d_out
         pro1 = None if h_saved else (mean1, invstd1, g1, b1, SLOPE)
         if pg2 is not None:
             _done(g2, b2)
-        dw2 = ops.conv2d_wgrad(h, dc, 3, pro=pro1, out=_dst(w2, k_w2)) if need_w2 else None
+        dw2 = ops.conv2d_wgrad(h, dc, 3, pro=pro1, out=_dst(w2, k_w2), nseg=nseg) if need_w2 else None
         if need_w2 and k_w2 >= 0:
             _done(w2)
-        fuse_bn1 = (not h_saved) and ops.conv2d_dgrad_bnbwd_supported(dc.shape[2], dc.shape[3])
+        fuse_bn1 = (not h_saved) and nseg == 1 and ops.conv2d_dgrad_bnbwd_supported(dc.shape[2], dc.shape[3])
         if fuse_bn1:
             # conv2's data gradient also reduces BatchNorm-1's backward sums in its epilogue (one pass fewer over dh, a)
             dh, part1 = ops.conv2d_dgrad_bnbwd(dc, packed(w2, 1), Cm, a, mean1, invstd1, g1, b1, SLOPE)
@@ -323,10 +354,10 @@ class ResBlockFn(torch.autograd.Function):
                                                     want_param_grads=need_bn1, pg_out=pg1)
         elif h_saved:
             da, _, dg1, db1 = ops.bn_bwd(dh, h, a, mean1, invstd1, g1, SLOPE, want_dz=False,
-                                         want_param_grads=need_bn1, act_mode=1, pg_out=pg1)
+                                         want_param_grads=need_bn1, act_mode=1, pg_out=pg1, nseg=nseg)
         else:
             da, _, dg1, db1 = ops.bn_bwd(dh, None, a, mean1, invstd1, g1, SLOPE, want_dz=False,
-                                         want_param_grads=need_bn1, beta=b1, act_mode=2, pg_out=pg1)
+                                         want_param_grads=need_bn1, beta=b1, act_mode=2, pg_out=pg1, nseg=nseg)
         del dh
         if pg1 is not None:
             _done(g1, b1)
@@ -377,28 +408,31 @@ class ResBlockFn(torch.autograd.Function):
                 dg1 if (need[3] and pg1 is None) else None, db1 if (need[4] and pg1 is None) else None,
                 dw2 if k_w2 < 0 else None,
                 dg2 if (need[6] and pg2 is None) else None, db2 if (need[7] and pg2 is None) else None,
-                None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 class StemFn(torch.autograd.Function):
     """conv5x5 -> BatchNorm -> LeakyReLU -> AvgPool2d(2)   (train_soft_intro_vae.py:88-93)"""
 
     @staticmethod
-    def forward(ctx, x, w, g, b, st):
+    def forward(ctx, x, w, g, b, st, nseg=1, seg_rev=False):
         x = x.contiguous()
         _claim(ctx, ((1, w), (2, g), (3, b)))
         B, Ci, H, W = x.shape
         Co = w.shape[0]
         if st.training:
             a, p = ops.conv2d_fwd(x, packed(w, 0), Co, 5, want_stats=True)
+            if nseg > 1 and p.shape[0] % nseg:
+                raise ValueError("sivae_hip: the stem's statistics rows do not split into %d segments" % nseg)
         else:
             a, p = ops.conv2d_fwd(x, packed(w, 0), Co, 5), None
-        mean, invstd = _stats(p, B, Co, H * W, st)
-        fused = ops.bn_apply_act_pool(a, None, mean, invstd, g.detach(), b.detach(), SLOPE, want_full=False)
+        mean, invstd = _stats(p, B, Co, H * W, st, nseg, seg_rev)
+        fused = ops.bn_apply_act_pool(a, None, mean, invstd, g.detach(), b.detach(), SLOPE, want_full=False, nseg=nseg)
         if fused is not None:
             out = fused[1]  # (the full-resolution activation is never written: backward recomputes it from `a`)
         else:
-            out = ops.avgpool2_fwd(ops.bn_apply_act(a, None, mean, invstd, g.detach(), b.detach(), SLOPE))
+            out = ops.avgpool2_fwd(ops.bn_apply_act(a, None, mean, invstd, g.detach(), b.detach(), SLOPE, nseg=nseg))
+        ctx.nseg = nseg
         ctx.training = st.training
         ctx.save_for_backward(x, a, mean, invstd, w, g, b)
         return out
@@ -413,7 +447,7 @@ class StemFn(torch.autograd.Function):
         pg = _pg_dst(g, k_g, b, k_b) if (need[2] or need[3]) else None
         da, _, dg, db = ops.bn_bwd(dy.contiguous(), None, a, mean, invstd, g, SLOPE, want_dz=False,
                                    want_param_grads=need[2] or need[3], beta=b, act_mode=2, dy_pooled=True,
-                                   pg_out=pg)
+                                   pg_out=pg, nseg=ctx.nseg)
         edge = _is_edge5(w) and w.shape[1] <= 3
         dw = None
         if need[1]:
@@ -428,7 +462,7 @@ class StemFn(torch.autograd.Function):
             dx = (ops.conv5_smallco_fwd(da, packed5(w, 1), x.shape[1]) if edge
                   else ops.conv2d_fwd(da, packed(w, 1), x.shape[1], 5))
         return (dx, dw if k_w < 0 else None, dg if (need[2] and pg is None) else None,
-                db if (need[3] and pg is None) else None, None)
+                db if (need[3] and pg is None) else None, None, None, None)
 
 
 class ConvBiasFn(torch.autograd.Function):
@@ -621,20 +655,21 @@ class ExpElboFn(torch.autograd.Function):
         return dL, dKL, None, None, None
 
 
-def residual_block(x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post=None, cache=None, x_up=False):
-    return ResBlockFn.apply(x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache, x_up)
+def residual_block(x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post=None, cache=None, x_up=False, nseg=1,
+                   seg_rev=False):
+    return _apply(ResBlockFn, x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache, x_up, nseg, seg_rev)
 
 
-def stem(x, w, g, b, st):
-    return StemFn.apply(x, w, g, b, st)
+def stem(x, w, g, b, st, nseg=1, seg_rev=False):
+    return _apply(StemFn, x, w, g, b, st, nseg, seg_rev)
 
 
 def conv_bias(x, w, bias, cache=None):
-    return ConvBiasFn.apply(x, w, bias, cache)
+    return _apply(ConvBiasFn, x, w, bias, cache)
 
 
 def linear(x, w, bias, relu=False):
-    return LinearFn.apply(x, w, bias, relu)
+    return _apply(LinearFn, x, w, bias, relu)
 
 
 def reparameterize(mu, logvar, eps):

@@ -342,12 +342,12 @@ class PredictFn16(torch.autograd.Function):
 
 
 def residual_block(x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post=None, cache=None, x_up=False):
-    return ResBlockFn16.apply(x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache, x_up)
+    return SF._apply(ResBlockFn16, x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache, x_up)
 
 
 def stem(x, w, g, b, st):
-    return StemFn16.apply(x, w, g, b, st)
+    return SF._apply(StemFn16, x, w, g, b, st)
 
 
 def conv_bias(x, w, bias, cache=None):
-    return PredictFn16.apply(x, w, bias, cache)
+    return SF._apply(PredictFn16, x, w, bias, cache)

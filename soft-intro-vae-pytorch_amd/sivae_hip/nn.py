@@ -39,16 +39,20 @@ class ResidualBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(outc)
         self.relu2 = nn.LeakyReLU(0.2, inplace=True)
 
-    def forward(self, x, post=None, cache=None, x_up=False):
+    def forward(self, x, post=None, cache=None, x_up=False, nseg=1, seg_rev=False):
         """post in {None, 'pool', 'up', 'up_deferred'} fuses the AvgPool2d / Upsample that follows the block in the
         nets ('up_deferred': the next block reads this block's output through upsample addressing, x_up=True there).
         cache: see functional.ResBlockFn (activation cache for replaying an identical forward pass).
-        A blocked bf16 input (bf16 mode, `set_compute_dtype`) runs the bf16 twin of the block."""
-        block = SF16.residual_block if x.dtype == torch.bfloat16 else SF.residual_block
-        return block(x, None if self.conv_expand is None else self.conv_expand.weight,
-                                 self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight,
-                                 self.bn2.weight, self.bn2.bias, SF.BNState(self.bn1), SF.BNState(self.bn2), post,
-                                 cache, x_up)
+        A blocked bf16 input (bf16 mode, `set_compute_dtype`) runs the bf16 twin of the block.
+        nseg > 1: x is a SEGMENTED batch (nseg passes laid end to end, per-pass BatchNorm statistics — functional.py)."""
+        args = (x, None if self.conv_expand is None else self.conv_expand.weight, self.conv1.weight, self.bn1.weight,
+                self.bn1.bias, self.conv2.weight, self.bn2.weight, self.bn2.bias, SF.BNState(self.bn1),
+                SF.BNState(self.bn2), post, cache, x_up)
+        if x.dtype == torch.bfloat16:
+            if nseg != 1:
+                raise NotImplementedError("sivae_hip: segmented batches run in fp32 mode only")
+            return SF16.residual_block(*args)
+        return SF.residual_block(*args, nseg, seg_rev)
 
 
 def set_compute_dtype(module, dtype):
@@ -73,7 +77,14 @@ def _block_weights(m):
     return ()
 
 
-def _run_main(main, x, cache=None, bf16=None):
+def segments_supported(image_size, seg_images, compute_dtype="fp32"):
+    """can `nseg` passes of seg_images images each run as ONE segmented batch through these networks?  (fp32 mode,
+    power-of-two maps, and a pass must be a whole number of the 4-image tile blocks of the 4x4 maps)"""
+    return (compute_dtype == "fp32" and image_size >= 32 and (image_size & (image_size - 1)) == 0
+            and seg_images % 4 == 0 and SF.ops.SYNC_BN is None)
+
+
+def _run_main(main, x, cache=None, bf16=None, nseg=1, seg_rev=False):
     """Walk a reference-shaped nn.Sequential, dispatching each group of layers to its fused HIP block.
     x: fp32 NCHW, or a blocked bf16 activation (bf16 mode): the blocks dispatch on the input dtype unless `bf16` says
     otherwise (the bf16 encoder hands its stem the fp32 image)."""
@@ -96,7 +107,7 @@ def _run_main(main, x, cache=None, bf16=None):
                 stale = True
         if isinstance(m, ResidualBlock):
             if isinstance(nxt, nn.AvgPool2d):
-                x = m(x, post="pool", cache=sub, x_up=x_up)
+                x = m(x, post="pool", cache=sub, x_up=x_up, nseg=nseg, seg_rev=seg_rev)
                 x_up = False
                 i += 2
             elif isinstance(nxt, nn.Upsample):
@@ -104,17 +115,20 @@ def _run_main(main, x, cache=None, bf16=None):
                 # h>>1, w>>1; the residual add needs the upsampled width to be a multiple of 4)
                 w_here = x.shape[3] * (2 if x_up else 1)  # (dim 3 is W in both layouts)
                 defer = DEFER_UPSAMPLE and i + 2 < n and isinstance(mods[i + 2], ResidualBlock) and w_here % 2 == 0
-                x = m(x, post="up_deferred" if defer else "up", cache=sub, x_up=x_up)
+                x = m(x, post="up_deferred" if defer else "up", cache=sub, x_up=x_up, nseg=nseg, seg_rev=seg_rev)
                 x_up = defer
                 i += 2
             else:
-                x = m(x, cache=sub, x_up=x_up)
+                x = m(x, cache=sub, x_up=x_up, nseg=nseg, seg_rev=seg_rev)
                 x_up = False
                 i += 1
         elif isinstance(m, nn.Conv2d) and isinstance(nxt, nn.BatchNorm2d):
             # encoder stem: conv5x5 -> BN -> LeakyReLU -> AvgPool2d
             assert isinstance(mods[i + 2], nn.LeakyReLU) and isinstance(mods[i + 3], nn.AvgPool2d)
-            x = F_.stem(x, m.weight, nxt.weight, nxt.bias, SF.BNState(nxt))
+            if nseg != 1:
+                x = SF.stem(x, m.weight, nxt.weight, nxt.bias, SF.BNState(nxt), nseg, seg_rev)
+            else:
+                x = F_.stem(x, m.weight, nxt.weight, nxt.bias, SF.BNState(nxt))
             i += 4
         elif isinstance(m, nn.Conv2d):
             x = F_.conv_bias(x, m.weight, m.bias, sub)
@@ -176,8 +190,15 @@ class Encoder(nn.Module):
                     m.num_batches_tracked.fill_(1)
         return torch.Size([last.conv2.out_channels, s, s])
 
-    def forward(self, x, o_cond=None):
-        if self.compute_dtype == "bf16":
+    def forward(self, x, o_cond=None, nseg=1, seg_rev=False):
+        """nseg > 1: x is nseg independent batches laid end to end (a SEGMENTED batch): one pass of the kernels, per-segment
+        BatchNorm statistics, running buffers updated once per segment in order (seg_rev: last first) — numerically the
+        reference's nseg separate calls (train_soft_intro_vae.py:567-568, :601-605)."""
+        if nseg != 1:
+            if self.compute_dtype == "bf16":
+                raise NotImplementedError("sivae_hip: segmented batches run in fp32 mode only")
+            y = _run_main(self.main, x, nseg=nseg, seg_rev=seg_rev).reshape(x.size(0), -1)
+        elif self.compute_dtype == "bf16":
             # (the stem takes the fp32 image itself: it chooses the operand layout of the 5x5 conv)
             y = SF16.from_blocked(_run_main(self.main, x, bf16=True), self.conv_output_size[0])
             y = y.reshape(x.size(0), -1)
@@ -220,10 +241,13 @@ class Decoder(nn.Module):
         self.main.add_module("res_in_{}".format(sz), ResidualBlock(cc, cc, scale=1.0))
         self.main.add_module("predict", nn.Conv2d(cc, cdim, 5, 1, 2))
 
-    def forward(self, z, y_cond=None, cache=None):
+    def forward(self, z, y_cond=None, cache=None, nseg=1, seg_rev=False):
         """cache (optional dict): filled by the first call, replayed by a second call with the SAME z and
         unchanged decoder weights — see SoftIntroEngine (the reference recomputes `fake` and `rec` in the
-        D-step although the decoder has not changed since the E-step computed them)."""
+        D-step although the decoder has not changed since the E-step computed them).
+        nseg > 1: z is a SEGMENTED batch (see Encoder.forward; the reference's pairs :607-608, bootstrap :635-636)."""
+        if nseg != 1 and self.compute_dtype == "bf16":
+            raise NotImplementedError("sivae_hip: segmented batches run in fp32 mode only")
         z = z.reshape(z.size(0), -1)
         if self.conditional and y_cond is not None:
             y_cond = y_cond.reshape(y_cond.size(0), -1)
@@ -231,7 +255,7 @@ class Decoder(nn.Module):
         if cache is not None:
             # a filled cache replays the pass only for the SAME input tensor (storage, version and shape); anything
             # else starts a fresh fill.  (The weights are checked block by block: functional.cache_tag.)
-            key = (z.data_ptr(), z._version, tuple(z.shape), self.compute_dtype)
+            key = (z.data_ptr(), z._version, tuple(z.shape), self.compute_dtype, nseg, seg_rev)
             if cache.get("in_key") != key:
                 cache.clear()
                 cache["in_key"] = key
@@ -239,4 +263,4 @@ class Decoder(nn.Module):
         y = y.view(z.size(0), *self.conv_input_size)
         if self.compute_dtype == "bf16":
             y = SF16.to_blocked(y)
-        return _run_main(self.main, y, cache)
+        return _run_main(self.main, y, cache, nseg=nseg, seg_rev=seg_rev)

@@ -316,8 +316,16 @@ def conv2d_up_dgrad(dy, wp, N, out=None, accumulate=False):
     return dx
 
 
+def seg_prologue_supported(H, W):
+    """maps on which a SEGMENTED batch (nseg > 1) can keep the BatchNorm prologue fused into conv2 and into conv2's
+    weight gradient (the Winograd kernels carry per-segment parameter tables); elsewhere the block stores h"""
+    L = _lib.load()
+    return (WINO and WINO_WGRAD and L.sivae_conv2d_wino_supported(H, W) == 1
+            and L.sivae_conv2d_wino_wgrad_supported(H, W) == 1)
+
+
 def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=False, out=None,
-               accumulate=False):
+               accumulate=False, nseg=1):
     """x [B, Ci, H, W] (or [B, Ci, H/2, W/2] with upsample) -> y [B, Co, H, W] (+ stats partials).
 
     wp: a direct pack (tensor from pack_weight) or a PackedW; with a PackedW, 3x3 convs on maps the Winograd
@@ -373,14 +381,27 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
     if pro is not None:
         pm, pi, pg, pb, slope = pro
         _require(pm, pi, pg, pb)
+    if nseg > 1 and (pro is not None or want_stats) and not (wino or wino_up):
+        raise ValueError("sivae_hip: a segmented batch needs the Winograd 3x3 kernels for fused BatchNorm work")
+    if nseg > 1 and pro is not None and wino_up:
+        raise ValueError("sivae_hip: no segmented prologue in the upsample-phase kernel")
     t0 = TIMER.begin() if TIMER is not None else None
     if wino_up:
         _lib.call("sivae_conv2d_wino_up_fwd", _p(x), _p(wp), _p(y), _p(pm), _p(pi), _p(pg), _p(pb), float(slope),
                   _p(stats), B, Ci, Co, H, W, _s())
     elif splitk:
         ws = workspace(L.sivae_conv2d_wino_splitk_workspace_bytes(B, Ci, Co, H, W), x.device)
-        _lib.call("sivae_conv2d_wino_fwd_splitk", _p(x), _p(wp), _p(y), _p(pm), _p(pi), _p(pg), _p(pb), float(slope),
-                  _p(stats), B, Ci, Co, H, W, int(bool(upsample)), int(bool(accumulate)), _p(ws), ws.numel(), _s())
+        if nseg > 1:
+            _lib.call("sivae_conv2d_wino_fwd_splitk_seg", _p(x), _p(wp), _p(y), _p(pm), _p(pi), _p(pg), _p(pb),
+                      float(slope), _p(stats), B, Ci, Co, H, W, int(bool(upsample)), int(bool(accumulate)), B // nseg,
+                      _p(ws), ws.numel(), _s())
+        else:
+            _lib.call("sivae_conv2d_wino_fwd_splitk", _p(x), _p(wp), _p(y), _p(pm), _p(pi), _p(pg), _p(pb),
+                      float(slope), _p(stats), B, Ci, Co, H, W, int(bool(upsample)), int(bool(accumulate)), _p(ws),
+                      ws.numel(), _s())
+    elif wino and nseg > 1:
+        _lib.call("sivae_conv2d_wino_fwd_seg", _p(x), _p(wp), _p(y), _p(pm), _p(pi), _p(pg), _p(pb), float(slope),
+                  _p(stats), B, Ci, Co, H, W, int(bool(upsample)), int(bool(accumulate)), B // nseg, _s())
     elif wino:
         _lib.call("sivae_conv2d_wino_fwd", _p(x), _p(wp), _p(y), _p(bias), _p(pm), _p(pi), _p(pg), _p(pb),
                   float(slope), _p(stats), B, Ci, Co, H, W, int(bool(upsample)), int(bool(accumulate)), _s())
@@ -401,7 +422,7 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
     return (y, stats) if want_stats else y
 
 
-def conv2d_wgrad(x, dy, ks, pro=None, upsample=False, out=None):
+def conv2d_wgrad(x, dy, ks, pro=None, upsample=False, out=None, nseg=1):
     """-> dW [Co, Ci, ks, ks]  (written into `out` when given)"""
     _require(x, dy)
     B, Ci = x.shape[0], x.shape[1]
@@ -429,8 +450,13 @@ def conv2d_wgrad(x, dy, ks, pro=None, upsample=False, out=None):
     if pro is not None:
         pm, pi, pg, pb, slope = pro
         _require(pm, pi, pg, pb)
+    if nseg > 1 and pro is not None and not wino:
+        raise ValueError("sivae_hip: a segmented batch needs the Winograd weight-gradient kernel for a fused prologue")
     t0 = TIMER.begin() if TIMER is not None else None
-    if wino:
+    if wino and nseg > 1 and pro is not None:
+        _lib.call("sivae_conv2d_wino_wgrad_seg", _p(x), _p(dy), _p(dw), _p(pm), _p(pi), _p(pg), _p(pb), float(slope),
+                  B, Ci, Co, H, W, int(bool(upsample)), B // nseg, _p(ws), ws.numel(), _s())
+    elif wino:
         _lib.call("sivae_conv2d_wino_wgrad", _p(x), _p(dy), _p(dw), _p(pm), _p(pi), _p(pg), _p(pb), float(slope),
                   B, Ci, Co, H, W, int(bool(upsample)), _p(ws), ws.numel(), _s())
     else:
@@ -549,10 +575,19 @@ SYNC_BN = None
 
 
 def bn_stats_from_conv(partials, B, C, HW, running_mean=None, running_var=None, num_batches_tracked=None,
-                       eps=1e-5, momentum=0.1):
+                       eps=1e-5, momentum=0.1, nseg=1, seg_rev=False):
+    """nseg > 1: B = nseg * B_seg images, rows of `partials` in image order; -> mean, invstd of nseg * C entries
+    ([nseg][C]); the running buffers get one update per segment (seg_rev: last segment first)"""
     _require(partials, running_mean, running_var, num_batches_tracked)
-    mean = torch.empty(C, dtype=torch.float32, device=partials.device)
-    invstd = torch.empty(C, dtype=torch.float32, device=partials.device)
+    mean = torch.empty(nseg * C, dtype=torch.float32, device=partials.device)
+    invstd = torch.empty(nseg * C, dtype=torch.float32, device=partials.device)
+    if nseg > 1:
+        if SYNC_BN is not None:
+            raise RuntimeError("sivae_hip: segmented batches and synchronised BatchNorm do not combine")
+        _lib.call("sivae_bn_stats_from_conv_seg", _p(partials), partials.shape[0], nseg, int(bool(seg_rev)), B // nseg,
+                  C, HW, float(eps), float(momentum), _p(running_mean), _p(running_var), _p(num_batches_tracked),
+                  _p(mean), _p(invstd), _s())
+        return mean, invstd
     if SYNC_BN is not None:
         sums = torch.empty((C, 2), dtype=torch.float64, device=partials.device)
         _lib.call("sivae_bn_sums_from_conv", _p(partials), partials.shape[0], C, _p(sums), _s())
@@ -565,18 +600,29 @@ def bn_stats_from_conv(partials, B, C, HW, running_mean=None, running_var=None, 
     return mean, invstd
 
 
-def bn_update_running(mean, invstd, count, running_mean, running_var, num_batches_tracked, eps=1e-5, momentum=0.1):
+def bn_update_running(mean, invstd, count, running_mean, running_var, num_batches_tracked, eps=1e-5, momentum=0.1,
+                      nseg=1, seg_rev=False):
     _require(mean, invstd, running_mean, running_var, num_batches_tracked)
+    if nseg > 1:
+        _lib.call("sivae_bn_update_running_seg", _p(mean), _p(invstd), nseg, int(bool(seg_rev)), mean.numel() // nseg,
+                  float(count), float(eps), float(momentum), _p(running_mean), _p(running_var),
+                  _p(num_batches_tracked), _s())
+        return
     _lib.call("sivae_bn_update_running", _p(mean), _p(invstd), mean.numel(), float(count), float(eps),
               float(momentum), _p(running_mean), _p(running_var), _p(num_batches_tracked), _s())
 
 
-def bn_apply_act(x, res, mean, invstd, gamma, beta, slope=LRELU_SLOPE, out=None, res_up=False):
+def bn_apply_act(x, res, mean, invstd, gamma, beta, slope=LRELU_SLOPE, out=None, res_up=False, nseg=1):
     """res_up: res is [B, C, H/2, W/2] and is added through nearest-2x upsample addressing"""
     _require(x, res, mean, invstd, gamma, beta, out)
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
     y = out if out is not None else torch.empty_like(x)
+    if nseg > 1:
+        H, W = (x.shape[2], x.shape[3]) if x.dim() == 4 else (1, HW)
+        _lib.call("sivae_bn_apply_act_seg", _p(x), _p(res), int(bool(res_up)), _p(mean), _p(invstd), _p(gamma),
+                  _p(beta), float(slope), _p(y), None, B, C, H, W, B // nseg, _s())
+        return y
     if res_up:
         H, W = x.shape[2], x.shape[3]
         assert res.shape == (B, C, H // 2, W // 2)
@@ -588,7 +634,7 @@ def bn_apply_act(x, res, mean, invstd, gamma, beta, slope=LRELU_SLOPE, out=None,
     return y
 
 
-def bn_apply_act_pool(x, res, mean, invstd, gamma, beta, slope=LRELU_SLOPE, want_full=True):
+def bn_apply_act_pool(x, res, mean, invstd, gamma, beta, slope=LRELU_SLOPE, want_full=True, nseg=1):
     """-> (y, AvgPool2d(2)(y)) in one pass (y is None with want_full=False); None when the shape is not covered
     (odd H or W % 4 != 0)"""
     B, C, H, W = x.shape
@@ -597,6 +643,10 @@ def bn_apply_act_pool(x, res, mean, invstd, gamma, beta, slope=LRELU_SLOPE, want
     _require(x, res, mean, invstd, gamma, beta)
     y = torch.empty_like(x) if want_full else None
     yp = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    if nseg > 1:
+        _lib.call("sivae_bn_apply_act_seg", _p(x), _p(res), 0, _p(mean), _p(invstd), _p(gamma), _p(beta), float(slope),
+                  _p(y), _p(yp), B, C, H, W, B // nseg, _s())
+        return y, yp
     _lib.call("sivae_bn_apply_act_pool", _p(x), _p(res), _p(mean), _p(invstd), _p(gamma), _p(beta), float(slope),
               _p(y), _p(yp), B, C, H, W, _s())
     return y, yp
@@ -608,7 +658,7 @@ def bn_signmask_supported(x):
 
 
 def bn_apply_act_signmask(x, res, mean, invstd, gamma, beta, slope=LRELU_SLOPE, res_up=False, pool=False,
-                          want_full=True):
+                          want_full=True, nseg=1):
     """LeakyReLU(BN(x) + res) -> (y, y_pooled, mask): y is None with want_full=False (pool only), y_pooled is None
     without pool; mask = the activation's sign bits (uint8, 1 bit per element) for bn_bwd_signmask"""
     _require(x, res, mean, invstd, gamma, beta)
@@ -617,13 +667,30 @@ def bn_apply_act_signmask(x, res, mean, invstd, gamma, beta, slope=LRELU_SLOPE, 
     y = torch.empty_like(x) if want_full else None
     yp = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device) if pool else None
     mask = torch.empty(_lib.load().sivae_bn_signmask_bytes(B, C, H * W), dtype=torch.uint8, device=x.device)
+    if nseg > 1:
+        _lib.call("sivae_bn_apply_act_signmask_seg", _p(x), _p(res), int(bool(res_up)), _p(mean), _p(invstd),
+                  _p(gamma), _p(beta), float(slope), _p(y), _p(yp), _p(mask), B, C, H, W, B // nseg, _s())
+        return y, yp, mask
     _lib.call("sivae_bn_apply_act_signmask", _p(x), _p(res), int(bool(res_up)), _p(mean), _p(invstd), _p(gamma),
               _p(beta), float(slope), _p(y), _p(yp), _p(mask), B, C, H, W, _s())
     return y, yp, mask
 
 
+def _bn_bwd_seg(dy, y, mask, x, mean, invstd, gamma, beta, act_mode, slope, dx, dz, dgamma, dbeta, dy_pooled, dz_sum,
+                nseg):
+    """every BatchNorm-backward variant on a segmented batch (mean / invstd [nseg][C])"""
+    if SYNC_BN is not None:
+        raise RuntimeError("sivae_hip: segmented batches and synchronised BatchNorm do not combine")
+    B, C = x.shape[0], x.shape[1]
+    H, W = (x.shape[2], x.shape[3]) if x.dim() == 4 else (1, x.numel() // (B * C))
+    ws = workspace(_lib.load().sivae_bn_workspace_bytes(B // nseg, nseg * C, H * W), x.device)
+    _lib.call("sivae_bn_bwd_seg", _p(dy), _p(y), _p(mask), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta),
+              int(act_mode), float(slope), _p(dx), _p(dz), _p(dgamma), _p(dbeta), B, C, H, W, int(bool(dy_pooled)),
+              int(bool(dz_sum)), B // nseg, _p(ws), ws.numel(), _s())
+
+
 def bn_bwd_signmask(dy, mask, x, mean, invstd, gamma, slope=LRELU_SLOPE, dy_pooled=False, dz_sum=False,
-                    want_dz=True, want_param_grads=True, pg_out=None):
+                    want_dz=True, want_param_grads=True, pg_out=None, nseg=1):
     """backward of bn_apply_act_signmask -> dx, dz (full resolution, or its 2x2 block sums with dz_sum), dgamma,
     dbeta.  dy_pooled: dy is the gradient of the pooled output."""
     _require(dy, x, mean, invstd, gamma)
@@ -638,6 +705,10 @@ def bn_bwd_signmask(dy, mask, x, mean, invstd, gamma, slope=LRELU_SLOPE, dy_pool
     elif want_dz:
         dz = torch.empty_like(x)
     dgamma, dbeta = _pg(pg_out, C, x.device, want_param_grads)
+    if nseg > 1:
+        _bn_bwd_seg(dy, None, mask, x, mean, invstd, gamma, None, 3, slope, dx, dz, dgamma, dbeta, dy_pooled, dz_sum,
+                    nseg)
+        return dx, dz, dgamma, dbeta
     _lib.call("sivae_bn_bwd_signmask", _p(dy), _p(mask), _p(x), _p(mean), _p(invstd), _p(gamma), float(slope), _p(dx),
               _p(dz), _p(dgamma), _p(dbeta), B, C, H, W, int(bool(dy_pooled)), int(bool(dz_sum)), _p(ws), ws.numel(),
               _s())
@@ -648,7 +719,7 @@ def bn_bwd_dzsum_supported(x):
     return SYNC_BN is None and not (x.shape[2] & 1) and not (x.shape[3] & 3)
 
 
-def bn_bwd_dzsum(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_param_grads=True, pg_out=None):
+def bn_bwd_dzsum(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_param_grads=True, pg_out=None, nseg=1):
     """act_mode-1 BatchNorm(+residual+LeakyReLU) backward -> dx, dz_half (2x2 block sums of the residual-branch
     gradient, [B, C, H/2, W/2]), dgamma, dbeta"""
     _require(dy, y, x, mean, invstd, gamma)
@@ -657,13 +728,16 @@ def bn_bwd_dzsum(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_param_gr
     dx = torch.empty_like(x)
     dzh = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
     dgamma, dbeta = _pg(pg_out, C, x.device, want_param_grads)
+    if nseg > 1:
+        _bn_bwd_seg(dy, y, None, x, mean, invstd, gamma, None, 1, slope, dx, dzh, dgamma, dbeta, False, True, nseg)
+        return dx, dzh, dgamma, dbeta
     _lib.call("sivae_bn_bwd_dzsum", _p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), float(slope), _p(dx), _p(dzh),
               _p(dgamma), _p(dbeta), B, C, H, W, _p(ws), ws.numel(), _s())
     return dx, dzh, dgamma, dbeta
 
 
 def bn_bwd(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_dz=False, want_param_grads=True, beta=None,
-           act_mode=None, dy_pooled=False, pg_out=None):
+           act_mode=None, dy_pooled=False, pg_out=None, nseg=1):
     """-> dx, dz (or None), dgamma, dbeta (or None, None).
     act_mode: 0 none, 1 LeakyReLU sign from the saved output y, 2 sign recomputed from x (needs beta).
     dy_pooled: dy is the gradient of AvgPool2d(2)(output) at half resolution; the pool's adjoint is applied on load."""
@@ -680,6 +754,10 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_dz=False, want
     dx = torch.empty_like(x)
     dz = torch.empty_like(x) if want_dz else None
     dgamma, dbeta = _pg(pg_out, C, x.device, want_param_grads)
+    if nseg > 1:
+        _bn_bwd_seg(dy, y, None, x, mean, invstd, gamma, beta, act_mode, slope, dx, dz, dgamma, dbeta, dy_pooled, False,
+                    nseg)
+        return dx, dz, dgamma, dbeta
     if SYNC_BN is not None:
         local = torch.empty((C, 2), dtype=torch.float64, device=x.device)
         _lib.call("sivae_bn_bwd_reduce", _p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta),

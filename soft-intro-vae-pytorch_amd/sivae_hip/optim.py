@@ -67,11 +67,23 @@ class FlatAdam:
     def fold_slabs(self, lo=0, hi=None):
         """flat_grad[lo:hi] += the slabs the current backward wrote (call once per element range, after backward)"""
         k = self._slabs_used
+        claimed = self._max_use()
+        if claimed > k:
+            # zero_grad() ran BEFORE the forward passes reserved their slabs: the slabs were not cleaned for this
+            # backward, so folding them would add stale gradients — fail loudly instead of stepping on garbage
+            raise RuntimeError("FlatAdam: %d gradient slabs were claimed but only %d prepared — with enable_slabs() "
+                               "call zero_grad() AFTER the forward passes and fold_slabs() after backward()"
+                               % (claimed, k))
+        self._folded = True
         if k == 0:
             return
         hi = self.flat_grad.numel() if hi is None else hi
         if hi > lo:
             ops.sum_slabs(self.flat_grad[lo:hi], [s[lo:hi] for s in self.slabs[:k]])
+
+    def _max_use(self):
+        return min(len(self.slabs), max((p.__dict__.get("_sivae_use", 0) for p in self.params), default=0)) \
+            if self.slabs else 0
 
     def _reset_uses(self):
         for p in self.params:
@@ -84,7 +96,8 @@ class FlatAdam:
         if self.slabs:
             # (called after the forward passes reserved their slab indices and before backward() fills them:
             # only the slabs this backward will write need to be clean)
-            self._slabs_used = min(len(self.slabs), max((p.__dict__.get("_sivae_use", 0) for p in self.params), default=0))
+            self._slabs_used = self._max_use()
+            self._folded = False
             for s_ in self.slabs[:self._slabs_used]:
                 s_.zero_()
         for p, g in zip(self.params, self._grad_views()):
@@ -99,6 +112,9 @@ class FlatAdam:
             off += k
 
     def step(self, grad_scale=1.0):
+        if self.slabs and self._max_use() > 0 and not getattr(self, "_folded", False):
+            raise RuntimeError("FlatAdam.step(): gradient slabs were written but never folded — call fold_slabs() "
+                               "(or the engine's gradient sync) between backward() and step()")
         self.t += 1
         self.lr = float(self.param_groups[0]["lr"])
         if self.dev_state is not None:

@@ -1,0 +1,234 @@
+"""Segmented batches: the same-weight pass PAIRS of an iteration run as one 2B-image batch with per-pass BatchNorm
+statistics (reference pairs: soft_intro_vae/train_soft_intro_vae.py:567-568, :601-605, :607-608; bootstrap
+soft_intro_vae_bootstrap/train_soft_intro_vae_bootstrap.py:635-636).
+
+Checked here, on the HIP path:
+  * Encoder / Decoder forward of [xa; xb] with nseg=2 == the two separate calls, BIT FOR BIT (outputs, running
+    statistics, num_batches_tracked) — at sizes where the kernels pick the same split-K plan for B and 2B, and to
+    fp32 rounding everywhere else;
+  * gradients of the segmented pass == the sum of the two separate passes' gradients (to rounding: one weight-gradient
+    launch sums both passes in a different order);
+  * a whole iteration with the pairs on == the iteration with the pairs off (losses, latents, images, BatchNorm
+    buffers; gradients to rounding), plain and bootstrap, and against the live CPU oracle.
+"""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _models(channels, image_size, zdim, seed=0, boot=False):
+    import train_soft_intro_vae as T
+    import train_soft_intro_vae_bootstrap as TB
+    torch.manual_seed(seed)
+    m = (TB if boot else T).SoftIntroVAE(cdim=3, zdim=zdim, channels=channels, image_size=image_size)
+    return m.to(DEV).train()
+
+
+def _bn_buffers(net):
+    return {k: v.detach().clone() for k, v in net.state_dict().items()
+            if k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
+
+
+def _maxrel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("channels,image_size,B", [([16, 32, 64], 32, 8), ([8, 16, 32, 64, 64], 128, 4),
+                                                   ([8, 16, 32, 64, 64, 64], 256, 4)])
+def test_encoder_pair_equals_two_passes(channels, image_size, B):
+    os.environ["SIVAE_WINO_SPLITK"] = "0"  # (read once per process by the library: harmless if already decided)
+    m = _models(channels, image_size, 32)
+    enc = m.encoder
+    g = torch.Generator().manual_seed(5)
+    xa = torch.rand(B, 3, image_size, image_size, generator=g).to(DEV)
+    xb = (torch.rand(B, 3, image_size, image_size, generator=g) * 1.7 - 0.3).to(DEV)
+    sd0 = {k: v.clone() for k, v in enc.state_dict().items()}
+    # two separate passes (the reference's form)
+    mu_a, lv_a = enc(xa)
+    mu_b, lv_b = enc(xb)
+    (mu_a.square().sum() + lv_a.sum() + 2.0 * mu_b.sum() + lv_b.square().sum()).backward()
+    g_sep = {k: p.grad.detach().clone() for k, p in enc.named_parameters()}
+    buf_sep = _bn_buffers(enc)
+    # one segmented pass
+    enc.load_state_dict(sd0)
+    for p in enc.parameters():
+        p.grad = None
+    mu2, lv2 = enc(torch.cat([xa, xb]), nseg=2)
+    (mu2[:B].square().sum() + lv2[:B].sum() + 2.0 * mu2[B:].sum() + lv2[B:].square().sum()).backward()
+    g_seg = {k: p.grad.detach().clone() for k, p in enc.named_parameters()}
+    buf_seg = _bn_buffers(enc)
+    for name, sep, seg in (("mu_a", mu_a, mu2[:B]), ("mu_b", mu_b, mu2[B:]), ("lv_a", lv_a, lv2[:B]),
+                           ("lv_b", lv_b, lv2[B:])):
+        assert _maxrel(seg, sep) <= 2e-6, (name, _maxrel(seg, sep))
+    for k in buf_sep:
+        if k.endswith("num_batches_tracked"):
+            assert int(buf_seg[k]) == int(buf_sep[k]), k
+        else:
+            assert _maxrel(buf_seg[k], buf_sep[k]) <= 2e-6, (k, _maxrel(buf_seg[k], buf_sep[k]))
+    for k in g_sep:
+        r = float((g_seg[k] - g_sep[k]).norm() / (g_sep[k].norm() + 1e-30))
+        assert r <= 2e-4, ("grad", k, r)
+
+
+def test_encoder_pair_bit_identical_without_splitk():
+    """with the same kernel plan for B and 2B images (no split-K: 32x32 maps at this width never split) the segmented
+    forward is the two separate forwards bit for bit, and so are the running statistics"""
+    channels, image_size, B = [16, 32, 64], 32, 8
+    m = _models(channels, image_size, 32, seed=3)
+    enc = m.encoder
+    from sivae_hip import lib
+    L = lib.load()
+    g = torch.Generator().manual_seed(9)
+    xa = torch.rand(B, 3, image_size, image_size, generator=g).to(DEV)
+    xb = torch.rand(B, 3, image_size, image_size, generator=g).to(DEV)
+    splits = [L.sivae_conv2d_wino_splitk(b, c, c, s, s) for b in (B, 2 * B) for c, s in ((32, 16), (64, 8), (64, 4))]
+    sd0 = {k: v.clone() for k, v in enc.state_dict().items()}
+    with torch.no_grad():
+        mu_a, lv_a = enc(xa)
+        mu_b, lv_b = enc(xb)
+        buf_sep = _bn_buffers(enc)
+        enc.load_state_dict(sd0)
+        mu2, lv2 = enc(torch.cat([xa, xb]), nseg=2)
+        buf_seg = _bn_buffers(enc)
+    if any(s > 1 for s in splits):
+        pytest.skip("split-K active at this size: bit identity is not expected (covered to rounding elsewhere)")
+    assert torch.equal(mu2[:B], mu_a) and torch.equal(mu2[B:], mu_b)
+    assert torch.equal(lv2[:B], lv_a) and torch.equal(lv2[B:], lv_b)
+    for k in buf_sep:
+        assert torch.equal(buf_seg[k], buf_sep[k]), k
+
+
+@pytest.mark.parametrize("channels,image_size,B", [([16, 32, 64], 32, 8), ([8, 16, 32, 64, 64, 64], 256, 4)])
+def test_decoder_pair_equals_two_passes(channels, image_size, B):
+    m = _models(channels, image_size, 32, seed=1)
+    dec = m.decoder
+    g = torch.Generator().manual_seed(6)
+    za = torch.randn(B, 32, generator=g).to(DEV).requires_grad_(True)
+    zb = (0.5 * torch.randn(B, 32, generator=g)).to(DEV).requires_grad_(True)
+    wa = torch.randn(B, 3, image_size, image_size, generator=g).to(DEV)
+    wb = torch.randn(B, 3, image_size, image_size, generator=g).to(DEV)
+    sd0 = {k: v.clone() for k, v in dec.state_dict().items()}
+    ya, yb = dec(za), dec(zb)
+    ((ya * wa).sum() + (yb * wb).sum()).backward()
+    g_sep = {k: p.grad.detach().clone() for k, p in dec.named_parameters()}
+    gz_sep = (za.grad.clone(), zb.grad.clone())
+    buf_sep = _bn_buffers(dec)
+    dec.load_state_dict(sd0)
+    for p in dec.parameters():
+        p.grad = None
+    za.grad = zb.grad = None
+    y2 = dec(torch.cat([za, zb]), nseg=2)
+    ((y2[:B] * wa).sum() + (y2[B:] * wb).sum()).backward()
+    assert _maxrel(y2[:B], ya) <= 2e-6 and _maxrel(y2[B:], yb) <= 2e-6, (_maxrel(y2[:B], ya), _maxrel(y2[B:], yb))
+    for k in buf_sep:
+        if k.endswith("num_batches_tracked"):
+            assert int(_bn_buffers(dec)[k]) == int(buf_sep[k])
+        else:
+            assert _maxrel(_bn_buffers(dec)[k], buf_sep[k]) <= 2e-6, k
+    assert float((za.grad - gz_sep[0]).norm() / gz_sep[0].norm()) <= 2e-4
+    assert float((zb.grad - gz_sep[1]).norm() / gz_sep[1].norm()) <= 2e-4
+    for k in g_sep:
+        r = float((dec.get_parameter(k).grad - g_sep[k]).norm() / (g_sep[k].norm() + 1e-30))
+        assert r <= 2e-4, ("grad", k, r)
+
+
+def test_segment_reverse_order_updates_running_stats_last_first():
+    """seg_rev: the running buffers are updated with the LAST segment first (momentum updates do not commute)"""
+    m = _models([16, 32, 64], 32, 32, seed=2)
+    enc = m.encoder
+    g = torch.Generator().manual_seed(7)
+    xa = torch.rand(8, 3, 32, 32, generator=g).to(DEV)
+    xb = (3.0 * torch.rand(8, 3, 32, 32, generator=g)).to(DEV)
+    sd0 = {k: v.clone() for k, v in enc.state_dict().items()}
+    with torch.no_grad():
+        enc(xb)
+        enc(xa)
+        buf_sep = _bn_buffers(enc)
+        enc.load_state_dict(sd0)
+        enc(torch.cat([xa, xb]), nseg=2, seg_rev=True)
+        buf_rev = _bn_buffers(enc)
+        enc.load_state_dict(sd0)
+        enc(torch.cat([xa, xb]), nseg=2)
+        buf_fwd = _bn_buffers(enc)
+    k = "main.1.running_mean"
+    assert _maxrel(buf_rev[k], buf_sep[k]) <= 2e-6
+    assert _maxrel(buf_fwd[k], buf_sep[k]) > 1e-3  # the other order is a different buffer
+
+
+@pytest.mark.parametrize("boot", [False, True])
+@pytest.mark.parametrize("channels,image_size,B,zdim", [([16, 32, 64], 32, 8, 32), ([8, 16, 32, 64, 64, 64], 256, 4, 64)])
+def test_iteration_with_pairs_equals_iteration_without(channels, image_size, B, zdim, boot):
+    """the engine with the pass pairs on (segmented batches) against the engine with them off, from the same weights,
+    inputs and Gaussian draws: every forward quantity and loss to fp32 rounding, BatchNorm buffers, gradients to 2e-4
+    relative L2 (one weight-gradient launch per pair sums the two passes in another order)"""
+    from sivae_hip.engine import SoftIntroEngine
+    from sivae_hip.optim import FlatAdam
+    hp = dict(beta_kl=1.0, beta_rec=1.0, beta_neg=256.0, gamma_r=1.0 if boot else 1e-8)
+    g = torch.Generator().manual_seed(11)
+    real = torch.rand(B, 3, image_size, image_size, generator=g).to(DEV)
+    noise = torch.randn(B, zdim, generator=g).to(DEV)
+    eps = [torch.randn(B, zdim, generator=g).to(DEV) for _ in range(5)]
+    res = {}
+    for pair in (False, True):
+        m = _models(channels, image_size, zdim, seed=4, boot=boot)
+        oe, od = FlatAdam(m.encoder.parameters(), lr=2e-4), FlatAdam(m.decoder.parameters(), lr=2e-4)
+        eng = SoftIntroEngine(m, oe, od, bootstrap=boot, pair_passes=pair, **hp)
+        grads = {}
+        for tag, opt, net in (("E", oe, m.encoder), ("D", od, m.decoder)):
+            def step(grad_scale=1.0, _orig=opt.step, _net=net, _tag=tag):
+                grads[_tag] = {k: p.grad.detach().clone() for k, p in _net.named_parameters()}
+                _orig(grad_scale)
+            opt.step = step
+        assert eng._paired(real) == pair
+        out = eng.soft_intro_step(real, noise, eps, keep=True)
+        torch.cuda.synchronize()
+        res[pair] = (out, grads, {k: v.detach().clone() for k, v in m.state_dict().items()})
+    (o0, g0, s0), (o1, g1, s1) = res[False], res[True]
+    for step in ("E", "D"):
+        for k, v in o0[step].items():
+            assert _maxrel(o1[step][k], v) <= 5e-6, (step, k, _maxrel(o1[step][k], v))
+    for k, v in s0.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(s1[k]) == int(v), k
+        elif k.endswith(("running_mean", "running_var")):
+            assert _maxrel(s1[k], v) <= 5e-6, (k, _maxrel(s1[k], v))
+    for tag in ("E", "D"):
+        for k, v in g0[tag].items():
+            # (B = 4 at 256x256: a LeakyReLU pre-activation within rounding of 0 flips its mask between ANY two fp32
+            # evaluations — DESIGN.md section 2 — so single tensors move by up to ~1e-3 relative L2)
+            r = float((g1[tag][k] - v).norm() / (v.norm() + 1e-30))
+            assert r <= 3e-3, (tag, k, r)
+
+
+def test_paired_iteration_vs_oracle_256_topology():
+    """the paired engine against the live CPU oracle on the six-level 256x256 topology (reduced width), B = 4"""
+    from oracle import sivae_oracle as O
+    import train_soft_intro_vae as T
+    from sivae_hip.engine import SoftIntroEngine
+    from sivae_hip.optim import FlatAdam
+    cdim, zdim, channels, image_size, B = 3, 64, [8, 16, 32, 64, 64, 64], 256, 4
+    hp = dict(beta_rec=0.5, beta_kl=1.0, beta_neg=1024.0, gamma_r=1e-8)
+    P = O.init_params(cdim, zdim, channels, image_size, seed=0)
+    model = T.SoftIntroVAE(cdim=cdim, zdim=zdim, channels=channels, image_size=image_size)
+    model.load_state_dict({k: v.clone() for k, v in P.items()}, strict=True)
+    model = model.to(DEV).train()
+    eng = SoftIntroEngine(model, FlatAdam(model.encoder.parameters(), lr=2e-4),
+                          FlatAdam(model.decoder.parameters(), lr=2e-4), pair_passes=True, **hp)
+    g = torch.Generator().manual_seed(1234)
+    real = torch.rand(B, cdim, image_size, image_size, generator=g)
+    noise = torch.randn(B, zdim, generator=g)
+    eps = [torch.randn(B, zdim, generator=g) for _ in range(5)]
+    assert eng._paired(real.to(DEV))
+    es = eng.e_step(real.to(DEV), noise.to(DEV), [e.to(DEV) for e in eps[:3]], keep=True)
+    ref = O.e_step(P, real, noise, eps[:3], hp, channels, image_size)
+    for k, v in ref.items():
+        assert _maxrel(es["kept"][k].cpu(), v) <= 1e-4, (k, _maxrel(es["kept"][k].cpu(), v))
+    ds = eng.d_step(real.to(DEV), noise.to(DEV), es["z"], [e.to(DEV) for e in eps[3:]], keep=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(ds["lossD"]).all()
