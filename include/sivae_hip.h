@@ -484,11 +484,14 @@ int sivae_bn_apply_act_signmask_seg(const float* x, const float* res, int res_up
                                     float* y_pooled, unsigned char* mask, int B, int C, int H, int W, int seg_images,
                                     sivae_stream_t stream);
 /* every backward variant in one entry: act_mode 0 none / 1 sign from y / 2 recomputed from x (beta) / 3 from mask;
- * dy_pooled, dz_sum as in sivae_bn_bwd_signmask; workspace: sivae_bn_workspace_bytes(seg_images, nseg * C, H * W) */
+ * dy_pooled, dz_sum as in sivae_bn_bwd_signmask; workspace: sivae_bn_workspace_bytes(seg_images, nseg * C, H * W).
+ * counters: NULL, or >= C zero-initialised unsigned ints the call leaves zero (caller-owned, one stream at a time): the
+ * per-channel finalize then runs inside the reduction kernel instead of as its own launch — same fixed summation order */
 int sivae_bn_bwd_seg(const float* dy, const float* y, const unsigned char* mask, const float* x, const float* mean,
                      const float* invstd, const float* gamma, const float* beta, int act_mode, float slope, float* dx,
                      float* dz_out, float* dgamma, float* dbeta, int B, int C, int H, int W, int dy_pooled, int dz_sum,
-                     int seg_images, void* workspace, size_t workspace_bytes, sivae_stream_t stream);
+                     int seg_images, unsigned int* counters, void* workspace, size_t workspace_bytes,
+                     sivae_stream_t stream);
 /* Winograd 3x3 forward / data gradient and weight gradient with a segmented BatchNorm prologue (pro_* may be NULL: then
  * only the row order of stats_partial matters — image order, so rows [g*n/nseg, (g+1)*n/nseg) are pass g).  On 8x8 /
  * 4x4 maps seg_images must be a multiple of 2 / 4 (a tile block holds that many images). */

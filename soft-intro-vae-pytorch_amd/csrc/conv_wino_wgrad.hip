@@ -346,7 +346,14 @@ int wino_wg_plan(int B, int Ci, int Co, int H, int W, WinoWgPlan* p) {
   const int ntiles = p->n_ci_tiles * p->n_co_tiles;
   // enough blocks for two full rounds of the 512 block slots, but at least 16 stages per slice so the
   // 128 KB partial-dU write-out of a block stays small next to its MFMA work
-  int n_slices = cdiv(1024, ntiles);
+  // SIVAE_WG_SLOTS: target number of blocks (default 1024 = two rounds of the 512 block slots)
+  static int slots = 0;
+  if (slots == 0) {
+    const char* e = getenv("SIVAE_WG_SLOTS");
+    slots = e ? atoi(e) : 1024;
+    if (slots <= 0) slots = 1024;
+  }
+  int n_slices = cdiv(slots, ntiles);
   const int max_slices = p->nstages / 16 > 0 ? p->nstages / 16 : 1;
   if (n_slices > max_slices) n_slices = max_slices;
   p->sps = cdiv(p->nstages, n_slices);

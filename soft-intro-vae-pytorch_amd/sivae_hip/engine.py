@@ -93,6 +93,7 @@ class SoftIntroEngine:
         # pass, 2 of 8 decoder forwards (50.3 of 818.7 GFLOP per image at 256x256) not re-executed.
         self.reuse_decoder_forward = reuse_decoder_forward
         self._cache_fake, self._cache_rec = None, None
+        self._cache_pair, self._zn, self._zn_src = None, None, None
         # pair_passes: None -> SIVAE_PAIR_PASSES ("auto" | "0" | "1"); True / False force it
         self.pair_passes = PAIR_PASSES if pair_passes is None else ("1" if pair_passes else "0")
         # parameter gradients of every pass go straight into per-use slabs of the flat optimizers and are folded with
@@ -255,17 +256,37 @@ class SoftIntroEngine:
         self._train_encoder_only()
         self._cache_fake = {} if self.reuse_decoder_forward else None
         self._cache_rec = {} if self.reuse_decoder_forward else None
-        fake = m.decoder(noise, cache=self._cache_fake)
-        real_mu, real_logvar = m.encode(real)
-        z = reparameterize(real_mu, real_logvar, eps[0])
-        rec = m.decoder(z, cache=self._cache_rec)
+        self._cache_pair, self._zn = None, None
+        B = real.size(0)
+        paired = self._paired(real)
+        pair_dec = paired and self.reuse_decoder_forward
+        if pair_dec:
+            # sample(noise) and decoder(z) (:557,:561) as ONE segmented batch [z; noise] -> [rec; fake].  `fake` has no
+            # graph (frozen decoder, leaf noise) and `rec` only needs a data gradient, so the pair runs WITHOUT a graph
+            # and fills a replay cache; the graph of `rec` is then a replay of segment 0 of that cache (no kernels), and
+            # the D-step replays the whole pair (:597-598).  The running statistics see `fake` first (seg_rev), as in
+            # the reference's call order.
+            real_mu, real_logvar = m.encode(real)
+            z = reparameterize(real_mu, real_logvar, eps[0])
+            self._cache_pair = {}
+            with torch.no_grad():
+                self._zn = torch.cat([z.detach(), noise])
+                self._zn_src = (z.data_ptr(), z._version, noise.data_ptr(), noise._version)
+                y2 = m.decoder(self._zn, cache=self._cache_pair, nseg=2, seg_rev=True)
+            fake = y2[B:]
+            rec = m.decoder(z, cache=SF.cache_segment(self._cache_pair, 0, 2), replay_update=False, check_input=False)
+        else:
+            fake = m.decoder(noise, cache=self._cache_fake)
+            real_mu, real_logvar = m.encode(real)
+            z = reparameterize(real_mu, real_logvar, eps[0])
+            rec = m.decoder(z, cache=self._cache_rec)
         loss_rec = calc_reconstruction_loss(real, rec, lt, "mean")
         kl_real = calc_kl(real_logvar, real_mu, reduce="mean")
 
-        B = real.size(0)
-        if self._paired(real):
+        if paired:
             # model(rec.detach()) and model(fake.detach()) (:567-568) as one segmented batch [rec; fake]
-            mu2, logvar2 = m.encoder(torch.cat([rec.detach(), fake.detach()]), nseg=2)
+            x2 = y2 if pair_dec else torch.cat([rec.detach(), fake.detach()])
+            mu2, logvar2 = m.encoder(x2, nseg=2)
             z2 = reparameterize(mu2, logvar2, self._eps2(eps[1], eps[2], real_mu))
             rr2 = dec2(z2, nseg=2)
             rec_mu, rec_logvar, fake_mu, fake_logvar = mu2[:B], logvar2[:B], mu2[B:], logvar2[B:]
@@ -311,15 +332,23 @@ class SoftIntroEngine:
         br, bk, gr, lt = self.beta_rec, self.beta_kl, self.gamma_r, self.loss_type
         dec2 = self._second_decoder()
         self._train_decoder_only()
-        fake = m.decoder(noise, cache=self._cache_fake)
-        rec = m.decoder(z.detach(), cache=self._cache_rec)
-        self._cache_fake, self._cache_rec = None, None
-        loss_rec = calc_reconstruction_loss(real, rec, lt, "mean")
         B = real.size(0)
+        y2 = None
+        if (self._cache_pair is not None and self._zn is not None and self._zn.shape[0] == 2 * B
+                and self._zn_src == (z.data_ptr(), z._version, noise.data_ptr(), noise._version)):
+            # replay of the E-step's [rec; fake] pair (same inputs, unchanged decoder), now WITH a graph: one segmented
+            # backward instead of two
+            y2 = m.decoder(self._zn, cache=self._cache_pair, nseg=2, seg_rev=True)
+            rec, fake = y2[:B], y2[B:]
+        else:
+            fake = m.decoder(noise, cache=self._cache_fake)
+            rec = m.decoder(z.detach(), cache=self._cache_rec)
+        self._cache_fake, self._cache_rec, self._cache_pair, self._zn = None, None, None, None
+        loss_rec = calc_reconstruction_loss(real, rec, lt, "mean")
         if self._paired(real):
             # encode(rec) / encode(fake) (:601-605) and decode(z_rec) / decode(z_fake) (:607-608; bootstrap
             # decode_target :635-636) as segmented batches [rec; fake]
-            mu2, logvar2 = m.encoder(torch.cat([rec, fake]), nseg=2)
+            mu2, logvar2 = m.encoder(y2 if y2 is not None else torch.cat([rec, fake]), nseg=2)
             z2 = reparameterize(mu2, logvar2, self._eps2(eps[0], eps[1], z))
             rr2 = dec2(z2, nseg=2) if self.bootstrap else m.decoder(z2.detach(), nseg=2)
             rec_mu, rec_logvar, fake_mu, fake_logvar = mu2[:B], logvar2[:B], mu2[B:], logvar2[B:]

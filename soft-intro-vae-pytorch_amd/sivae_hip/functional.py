@@ -203,7 +203,8 @@ def _done(*params):
 
 class ResBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache=None, x_up=False, nseg=1, seg_rev=False):
+    def forward(ctx, x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache=None, x_up=False, nseg=1, seg_rev=False,
+                replay_update=True):
         """cache: None, or a dict owned by the caller.  An empty dict is FILLED with this pass's activations;
         a filled one is REPLAYED: no kernels run except the BatchNorm running-stat updates, the outputs and the
         tensors saved for backward are the cached ones.  A replay is only valid while x and all weights are unchanged:
@@ -218,7 +219,9 @@ class ResBlockFn(torch.autograd.Function):
         nseg > 1: SEGMENTED batch — x holds nseg independent passes of the network (B / nseg images each) laid end to
         end; the convolutions run once over the whole batch, every BatchNorm keeps one set of batch statistics per pass
         (what the reference's separate calls compute, train_soft_intro_vae.py:567-568, :601-608), the running buffers
-        are updated once per pass in pass order (seg_rev: last segment first)."""
+        are updated once per pass in pass order (seg_rev: last segment first).
+        replay_update=False: a replay leaves the running buffers alone (the pass that filled the cache already counted:
+        `cache_segment` views)."""
         x = x.contiguous()
         _claim(ctx, ((1, w_exp), (2, w1), (3, g1), (4, b1), (5, w2), (6, g2), (7, b2)))
         B, Ci, H, W = x.shape
@@ -230,8 +233,9 @@ class ResBlockFn(torch.autograd.Function):
         if cache is not None and cache.get("y") is not None and cache.get("tag") == tag:
             a, h, c, out, mean1, invstd1, mean2, invstd2, y = (cache[k] for k in (
                 "a", "h", "c", "out", "mean1", "invstd1", "mean2", "invstd2", "y"))
-            _replay_bn(st1, mean1, invstd1, (B // nseg) * H * W, nseg, seg_rev)
-            _replay_bn(st2, mean2, invstd2, (B // nseg) * H * W, nseg, seg_rev)
+            if replay_update:
+                _replay_bn(st1, mean1, invstd1, (B // nseg) * H * W, nseg, seg_rev)
+                _replay_bn(st2, mean2, invstd2, (B // nseg) * H * W, nseg, seg_rev)
             ctx.nseg = nseg
             ctx.post = post
             ctx.has_exp = w_exp is not None
@@ -408,7 +412,7 @@ class ResBlockFn(torch.autograd.Function):
                 dg1 if (need[3] and pg1 is None) else None, db1 if (need[4] and pg1 is None) else None,
                 dw2 if k_w2 < 0 else None,
                 dg2 if (need[6] and pg2 is None) else None, db2 if (need[7] and pg2 is None) else None,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
 class StemFn(torch.autograd.Function):
@@ -656,8 +660,33 @@ class ExpElboFn(torch.autograd.Function):
 
 
 def residual_block(x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post=None, cache=None, x_up=False, nseg=1,
-                   seg_rev=False):
-    return _apply(ResBlockFn, x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache, x_up, nseg, seg_rev)
+                   seg_rev=False, replay_update=True):
+    return _apply(ResBlockFn, x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache, x_up, nseg, seg_rev,
+                  replay_update)
+
+
+def cache_segment(cache, g, nseg):
+    """A view of segment g of a FILLED replay cache of a segmented pass (Decoder.forward(..., cache=, nseg=)): the same
+    activations / statistics restricted to that pass's images, usable as the cache of an UNsegmented replay.  The
+    engine builds the autograd graph of ONE pass of a pair this way (E-step: `rec` needs a data gradient, `fake` has no
+    graph at all — reference :557-561) after the pair ran as one batch without a graph."""
+    def cut(t, n_rows=None):
+        if t is None:
+            return None
+        n = t.shape[0] // nseg
+        return t[g * n:(g + 1) * n]
+    out = {}
+    for k, sub in cache.items():
+        if not isinstance(sub, dict):
+            continue
+        if sub.get("y") is None:
+            return None  # (not filled)
+        v = {"tag": sub.get("tag"), "y": cut(sub["y"])}
+        for name in ("a", "h", "c", "out", "mean1", "invstd1", "mean2", "invstd2"):
+            if name in sub:
+                v[name] = cut(sub[name])
+        out[k] = v
+    return out
 
 
 def stem(x, w, g, b, st, nseg=1, seg_rev=False):

@@ -39,7 +39,7 @@ class ResidualBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(outc)
         self.relu2 = nn.LeakyReLU(0.2, inplace=True)
 
-    def forward(self, x, post=None, cache=None, x_up=False, nseg=1, seg_rev=False):
+    def forward(self, x, post=None, cache=None, x_up=False, nseg=1, seg_rev=False, replay_update=True):
         """post in {None, 'pool', 'up', 'up_deferred'} fuses the AvgPool2d / Upsample that follows the block in the
         nets ('up_deferred': the next block reads this block's output through upsample addressing, x_up=True there).
         cache: see functional.ResBlockFn (activation cache for replaying an identical forward pass).
@@ -52,7 +52,7 @@ class ResidualBlock(nn.Module):
             if nseg != 1:
                 raise NotImplementedError("sivae_hip: segmented batches run in fp32 mode only")
             return SF16.residual_block(*args)
-        return SF.residual_block(*args, nseg, seg_rev)
+        return SF.residual_block(*args, nseg, seg_rev, replay_update)
 
 
 def set_compute_dtype(module, dtype):
@@ -84,7 +84,7 @@ def segments_supported(image_size, seg_images, compute_dtype="fp32"):
             and seg_images % 4 == 0 and SF.ops.SYNC_BN is None)
 
 
-def _run_main(main, x, cache=None, bf16=None, nseg=1, seg_rev=False):
+def _run_main(main, x, cache=None, bf16=None, nseg=1, seg_rev=False, replay_update=True):
     """Walk a reference-shaped nn.Sequential, dispatching each group of layers to its fused HIP block.
     x: fp32 NCHW, or a blocked bf16 activation (bf16 mode): the blocks dispatch on the input dtype unless `bf16` says
     otherwise (the bf16 encoder hands its stem the fp32 image)."""
@@ -107,7 +107,7 @@ def _run_main(main, x, cache=None, bf16=None, nseg=1, seg_rev=False):
                 stale = True
         if isinstance(m, ResidualBlock):
             if isinstance(nxt, nn.AvgPool2d):
-                x = m(x, post="pool", cache=sub, x_up=x_up, nseg=nseg, seg_rev=seg_rev)
+                x = m(x, post="pool", cache=sub, x_up=x_up, nseg=nseg, seg_rev=seg_rev, replay_update=replay_update)
                 x_up = False
                 i += 2
             elif isinstance(nxt, nn.Upsample):
@@ -115,11 +115,12 @@ def _run_main(main, x, cache=None, bf16=None, nseg=1, seg_rev=False):
                 # h>>1, w>>1; the residual add needs the upsampled width to be a multiple of 4)
                 w_here = x.shape[3] * (2 if x_up else 1)  # (dim 3 is W in both layouts)
                 defer = DEFER_UPSAMPLE and i + 2 < n and isinstance(mods[i + 2], ResidualBlock) and w_here % 2 == 0
-                x = m(x, post="up_deferred" if defer else "up", cache=sub, x_up=x_up, nseg=nseg, seg_rev=seg_rev)
+                x = m(x, post="up_deferred" if defer else "up", cache=sub, x_up=x_up, nseg=nseg, seg_rev=seg_rev,
+                      replay_update=replay_update)
                 x_up = defer
                 i += 2
             else:
-                x = m(x, cache=sub, x_up=x_up, nseg=nseg, seg_rev=seg_rev)
+                x = m(x, cache=sub, x_up=x_up, nseg=nseg, seg_rev=seg_rev, replay_update=replay_update)
                 x_up = False
                 i += 1
         elif isinstance(m, nn.Conv2d) and isinstance(nxt, nn.BatchNorm2d):
@@ -241,18 +242,21 @@ class Decoder(nn.Module):
         self.main.add_module("res_in_{}".format(sz), ResidualBlock(cc, cc, scale=1.0))
         self.main.add_module("predict", nn.Conv2d(cc, cdim, 5, 1, 2))
 
-    def forward(self, z, y_cond=None, cache=None, nseg=1, seg_rev=False):
+    def forward(self, z, y_cond=None, cache=None, nseg=1, seg_rev=False, replay_update=True, check_input=True):
         """cache (optional dict): filled by the first call, replayed by a second call with the SAME z and
         unchanged decoder weights — see SoftIntroEngine (the reference recomputes `fake` and `rec` in the
         D-step although the decoder has not changed since the E-step computed them).
-        nseg > 1: z is a SEGMENTED batch (see Encoder.forward; the reference's pairs :607-608, bootstrap :635-636)."""
+        nseg > 1: z is a SEGMENTED batch (see Encoder.forward; the reference's pairs :607-608, bootstrap :635-636).
+        replay_update=False / check_input=False: replay a `functional.cache_segment` view (one pass of a pair that already
+        ran as a segmented batch): the running statistics were counted by that pass, and the cache belongs to the pair's
+        input tensor, not to this z."""
         if nseg != 1 and self.compute_dtype == "bf16":
             raise NotImplementedError("sivae_hip: segmented batches run in fp32 mode only")
         z = z.reshape(z.size(0), -1)
         if self.conditional and y_cond is not None:
             y_cond = y_cond.reshape(y_cond.size(0), -1)
             z = torch.cat([z, y_cond], dim=1)
-        if cache is not None:
+        if cache is not None and check_input:
             # a filled cache replays the pass only for the SAME input tensor (storage, version and shape); anything
             # else starts a fresh fill.  (The weights are checked block by block: functional.cache_tag.)
             key = (z.data_ptr(), z._version, tuple(z.shape), self.compute_dtype, nseg, seg_rev)
@@ -263,4 +267,4 @@ class Decoder(nn.Module):
         y = y.view(z.size(0), *self.conv_input_size)
         if self.compute_dtype == "bf16":
             y = SF16.to_blocked(y)
-        return _run_main(self.main, y, cache, nseg=nseg, seg_rev=seg_rev)
+        return _run_main(self.main, y, cache, nseg=nseg, seg_rev=seg_rev, replay_update=replay_update)

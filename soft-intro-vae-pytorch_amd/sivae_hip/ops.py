@@ -124,6 +124,26 @@ def workspace(nbytes, device):
     return buf
 
 
+_counters = {}
+# SIVAE_BN_FUSED_FINALIZE=1: the per-channel finalize of the BatchNorm backward runs in the last block of the reduction
+# kernel (agent-scope fence + counter) instead of as its own ~5 us launch.  Measured a LOSS (round 3, one call, 256x256):
+# 16-image shard 213.9 vs 227.3 img/s, bootstrap 8-image shard 196.4 vs 215.0 — the release fence every block needs
+# (buffer_wbl2 + buffer_inv at agent scope: the 8 XCD L2s are not coherent inside a kernel) costs far more than the
+# ~110 launches it removes -> off by default.
+BN_FUSED_FINALIZE = os.environ.get("SIVAE_BN_FUSED_FINALIZE", "0") == "1"
+
+
+def counters(device):
+    """8192 zero-initialised unsigned ints per (device, stream) for kernels that finish a reduction in their last block
+    (each such kernel leaves them zero)"""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _counters.get(key)
+    if buf is None:
+        buf = torch.zeros(8192, dtype=torch.int32, device=device)
+        _counters[key] = buf
+    return buf
+
+
 def _out(out, shape, device):
     """a caller-provided destination (a contiguous fp32 device tensor of exactly `shape`: the parameter-gradient slab
     views of optim.FlatAdam) or a fresh tensor"""
@@ -678,15 +698,17 @@ def bn_apply_act_signmask(x, res, mean, invstd, gamma, beta, slope=LRELU_SLOPE, 
 
 def _bn_bwd_seg(dy, y, mask, x, mean, invstd, gamma, beta, act_mode, slope, dx, dz, dgamma, dbeta, dy_pooled, dz_sum,
                 nseg):
-    """every BatchNorm-backward variant on a segmented batch (mean / invstd [nseg][C])"""
+    """every BatchNorm-backward variant (local statistics), segmented or not (mean / invstd [nseg][C]), with the
+    per-channel finalize fused into the reduction kernel"""
     if SYNC_BN is not None:
         raise RuntimeError("sivae_hip: segmented batches and synchronised BatchNorm do not combine")
     B, C = x.shape[0], x.shape[1]
     H, W = (x.shape[2], x.shape[3]) if x.dim() == 4 else (1, x.numel() // (B * C))
     ws = workspace(_lib.load().sivae_bn_workspace_bytes(B // nseg, nseg * C, H * W), x.device)
+    cnt = counters(x.device) if (BN_FUSED_FINALIZE and C <= 8192) else None
     _lib.call("sivae_bn_bwd_seg", _p(dy), _p(y), _p(mask), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta),
               int(act_mode), float(slope), _p(dx), _p(dz), _p(dgamma), _p(dbeta), B, C, H, W, int(bool(dy_pooled)),
-              int(bool(dz_sum)), B // nseg, _p(ws), ws.numel(), _s())
+              int(bool(dz_sum)), B // nseg, _p(cnt), _p(ws), ws.numel(), _s())
 
 
 def bn_bwd_signmask(dy, mask, x, mean, invstd, gamma, slope=LRELU_SLOPE, dy_pooled=False, dz_sum=False,
@@ -705,7 +727,7 @@ def bn_bwd_signmask(dy, mask, x, mean, invstd, gamma, slope=LRELU_SLOPE, dy_pool
     elif want_dz:
         dz = torch.empty_like(x)
     dgamma, dbeta = _pg(pg_out, C, x.device, want_param_grads)
-    if nseg > 1:
+    if nseg > 1 or (BN_FUSED_FINALIZE and SYNC_BN is None):
         _bn_bwd_seg(dy, None, mask, x, mean, invstd, gamma, None, 3, slope, dx, dz, dgamma, dbeta, dy_pooled, dz_sum,
                     nseg)
         return dx, dz, dgamma, dbeta
@@ -728,7 +750,7 @@ def bn_bwd_dzsum(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_param_gr
     dx = torch.empty_like(x)
     dzh = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
     dgamma, dbeta = _pg(pg_out, C, x.device, want_param_grads)
-    if nseg > 1:
+    if nseg > 1 or (BN_FUSED_FINALIZE and SYNC_BN is None):
         _bn_bwd_seg(dy, y, None, x, mean, invstd, gamma, None, 1, slope, dx, dzh, dgamma, dbeta, False, True, nseg)
         return dx, dzh, dgamma, dbeta
     _lib.call("sivae_bn_bwd_dzsum", _p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(gamma), float(slope), _p(dx), _p(dzh),
@@ -754,7 +776,7 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_dz=False, want
     dx = torch.empty_like(x)
     dz = torch.empty_like(x) if want_dz else None
     dgamma, dbeta = _pg(pg_out, C, x.device, want_param_grads)
-    if nseg > 1:
+    if nseg > 1 or (BN_FUSED_FINALIZE and SYNC_BN is None and x.dim() == 4):
         _bn_bwd_seg(dy, y, None, x, mean, invstd, gamma, beta, act_mode, slope, dx, dz, dgamma, dbeta, dy_pooled, False,
                     nseg)
         return dx, dz, dgamma, dbeta
