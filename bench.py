@@ -24,6 +24,13 @@ Prints ONE JSON line (rank 0). Besides the contract keys it carries
                 `step` carries the whole-iteration figures (13 F_E + 19 F_D - 3 f_conv0 per image)
   cpu_baseline  the CPU oracle (oracle/sivae_oracle.py, a torch-CPU restatement pinned to the reference by
                 golden vectors) timed on this host's cores on a bounded sample of the same workload.
+  value_untimed the same workload re-timed in the same process WITHOUT the per-launch HIP events (`value` is the
+                instrumented run the roofline object comes from: ~1 % slower in fp32, ~5 % in bf16 mode)
+  also          (N = 1, default invocation) the other BASELINE.json configurations and the per-GPU shards of the
+                data-parallel ones, each measured in this same process: celeb256 at the 16-image shard (config 4 on 8
+                GPUs), soft_intro_vae_bootstrap at batch 64 and at its 8-image shard (config 5), cifar10 batch 256
+                (config 2), celeb128 batch 128 in bf16 mode (config 3, with its HBM fraction).  `value` there is the
+                untimed rate; `mfma_issued_frac` comes from a few instrumented iterations of the same engine.
 """
 import argparse
 import contextlib
@@ -188,9 +195,12 @@ def _pmc_traffic(kernel_key, config, dtype):
     return None
 
 
-def measure(args, cfg, gbatch, world, rank, dev, scaling):
+def measure(args, cfg, gbatch, world, rank, dev, scaling, steps=None, warmup=None, untimed_steps=0):
     """build a fresh model + engine for `gbatch` images over `world` ranks, run warm-up + timed steps
-    -> dict(dt, per, stats, timer_summary)"""
+    -> dict(dt, per, stats, timer_summary); untimed_steps > 0: a second region of that many steps without the per-launch
+    HIP events (dt_untimed)"""
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     from sivae_hip import dp, ops, rng
     from sivae_hip.engine import SoftIntroEngine
     from sivae_hip.optim import FlatAdam
@@ -216,7 +226,7 @@ def measure(args, cfg, gbatch, world, rank, dev, scaling):
     g = torch.Generator().manual_seed(1234 + rank)
     real = torch.rand(per, 3, image_size, image_size, generator=g).to(dev)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         eng.soft_intro_step(real)
     no_timing = args.no_kernel_timing
     if args.hip_graph:
@@ -234,13 +244,24 @@ def measure(args, cfg, gbatch, world, rank, dev, scaling):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     last = None
-    for _ in range(args.steps):
+    for _ in range(steps):
         last = step_fn(real)
     torch.cuda.synchronize()
     dp.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None
+    dt_untimed = None
+    if untimed_steps > 0:
+        torch.cuda.synchronize()
+        dp.barrier()
+        t1 = time.perf_counter()
+        for _ in range(untimed_steps):
+            last = step_fn(real)
+        torch.cuda.synchronize()
+        dp.barrier()
+        torch.cuda.synchronize()
+        dt_untimed = time.perf_counter() - t1
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -250,7 +271,53 @@ def measure(args, cfg, gbatch, world, rank, dev, scaling):
     summ = timer.summary() if timer is not None else None
     del eng, model, opt_e, opt_d, real, last
     torch.cuda.empty_cache()
-    return dict(dt=dt, per=per, gbatch=gbatch, stats=stats, summ=summ, sync_bn=sync_bn, scaling=scaling, gamma_r=gr)
+    return dict(dt=dt, per=per, gbatch=gbatch, stats=stats, summ=summ, sync_bn=sync_bn, scaling=scaling, gamma_r=gr,
+                steps=steps, dt_untimed=dt_untimed, untimed_steps=untimed_steps,
+                paired=os.environ.get("SIVAE_PAIR_PASSES", "auto") != "0")
+
+
+def also_legs(args, world, rank, dev):
+    """the other BASELINE.json configurations / per-GPU shards, measured in this process (N = 1): -> dict"""
+    import copy
+    legs = [  # name, config, global batch, bootstrap, dtype, untimed steps, instrumented steps, warm-up
+        ("celeb256_fp32_bs16_shard", "celeb256", 16, False, "fp32", 16, 4, 3),
+        ("bootstrap256_fp32_bs64", "celeb256", 64, True, "fp32", 6, 2, 2),
+        ("bootstrap256_fp32_bs8_shard", "celeb256", 8, True, "fp32", 20, 4, 3),
+        ("cifar10_fp32_bs256", "cifar10", 256, False, "fp32", 25, 5, 5),
+        ("celeb128_bf16_bs128", "celeb128", 128, False, "bf16", 14, 4, 4),
+    ]
+    out = {}
+    for name, config, gb, boot, dtype, n_untimed, n_timed, n_warm in legs:
+        a = copy.copy(args)
+        a.bootstrap, a.dtype, a.config, a.hip_graph, a.no_kernel_timing = boot, dtype, config, False, False
+        cfg = CONFIGS[config]
+        image_size, channels, zdim = cfg[0], cfg[1], cfg[2]
+        r = measure(a, cfg, gb, world, rank, dev, "strong", steps=n_timed, warmup=n_warm, untimed_steps=n_untimed)
+        peak = PEAK_FP32_MFMA_TFLOPS if dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
+        fe, fd, f0 = forward_flops(channels, image_size, zdim)
+        flops_img = 13 * fe + (17 if boot else 19) * fd - 3 * f0
+        value = gb * n_untimed / r["dt_untimed"]
+        summ = r["summ"]
+        issued = sum(v["executed_flops"] for v in summ.values()) / r["dt"] / 1e12
+        key = max(summ, key=lambda k: summ[k]["total_ms"])
+        d = summ[key]
+        leg = {"value": round(value, 2), "unit": "img/s", "ms_per_step": round(1e3 * r["dt_untimed"] / n_untimed, 3),
+               "steps": n_untimed, "warmup": n_warm + n_timed, "global_batch": gb, "dtype": "f32" if dtype == "fp32" else "bf16",
+               "workload": "soft_intro_vae%s %s %dx%d zdim=%d" % ("_bootstrap" if boot else "", config, image_size,
+                                                                 image_size, zdim),
+               "algorithmic_tflops": round(flops_img * value / 1e12, 2),
+               "mfma_issued_frac": round(issued / peak, 4), "mfma_peak_tflops": peak,
+               "instrumented": {"value": round(gb * n_timed / r["dt"], 2), "steps": n_timed, "dominant_kernel": key,
+                                "dominant_kernel_issued_frac": round(d["executed_flops"] / (d["total_ms"] * 1e-3) / 1e12 / peak, 4),
+                                "dominant_kernel_avg_ms": round(d["avg_ms"], 4)}}
+        if dtype == "bf16":
+            tr = _pmc_traffic(key, config, dtype)
+            if tr is not None and tr["step_bytes"]:
+                tbs = tr["step_bytes"] / (r["dt_untimed"] / n_untimed) / 1e12
+                leg["hbm"] = dict(step_bytes=tr["step_bytes"], achieved_tbs=round(tbs, 3), peak_tbs=PEAK_HBM_TBS,
+                                  frac=round(tbs / PEAK_HBM_TBS, 4), source=tr["source"])
+        out[name] = leg
+    return out
 
 
 def main():
@@ -273,6 +340,9 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0: short thread sweep, the best count is used")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the `also` object (the other configurations / shard sizes measured in the same process) and "
+                         "the untimed re-run of the headline")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
                     help="testing only: every rank uses cuda:0 (with --backend gloo) to exercise the DP path on one GPU")
@@ -308,7 +378,11 @@ def main():
             runs.append(("strong", base))
         if args.scaling in ("both", "weak"):
             runs.append(("weak", base * world))
-    results = [measure(args, cfg, gb, world, rank, dev, sc) for sc, gb in runs]
+    headline_run = (world == 1 and args.config == "celeb256" and not args.bootstrap and args.dtype == "fp32"
+                    and not args.global_batch and not args.hip_graph and not args.no_kernel_timing and not args.no_also)
+    results = [measure(args, cfg, gb, world, rank, dev, sc, untimed_steps=8 if (headline_run and i == 0) else 0)
+               for i, (sc, gb) in enumerate(runs)]
+    also = also_legs(args, world, rank, dev) if headline_run else None
     if rank != 0:
         return
     head = results[0]
@@ -386,6 +460,17 @@ def main():
                    "final_stats": stats},
         "roofline": roof,
     }
+    if head["dt_untimed"]:
+        out["value_untimed"] = round(gbatch * head["untimed_steps"] / head["dt_untimed"], 3)
+        out["value_untimed_note"] = ("%d further iterations of the same engine without the per-launch HIP events; `value` "
+                                     "is the instrumented region the roofline object is measured in" % head["untimed_steps"])
+    if also is not None:
+        ref = out.get("value_untimed", value)
+        for k in ("celeb256_fp32_bs16_shard",):
+            also[k]["rate_vs_bs128"] = round(also[k]["value"] / ref, 4)
+        also["bootstrap256_fp32_bs8_shard"]["rate_vs_bs64"] = round(
+            also["bootstrap256_fp32_bs8_shard"]["value"] / also["bootstrap256_fp32_bs64"]["value"], 4)
+        out["also"] = also
     for r in results[1:]:
         out[r["scaling"]] = {"value": round(r["gbatch"] * args.steps / r["dt"], 3), "unit": "img/s",
                              "ms_per_step": round(1e3 * r["dt"] / args.steps, 3), "global_batch": r["gbatch"],

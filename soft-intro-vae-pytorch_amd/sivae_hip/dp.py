@@ -9,6 +9,7 @@ is folded into the fused Adam kernel (grad_scale), so the reduced buffer is touc
 BatchNorm statistics stay per-rank ("local BN", what DDP does to this model; broadcast_buffers=False in
 the style precedent).  Works on any device the process group supports (gloo on CPU in the tests).
 """
+import datetime
 import os
 
 import torch
@@ -28,8 +29,48 @@ def init(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # rank 0 alone computes FID / writes checkpoints between iterations while the others already wait in the next
+        # collective: the default watchdog limit (10 min) is shorter than an Inception pass over 50 000 images
+        timeout = datetime.timedelta(seconds=int(os.environ.get("SIVAE_DP_TIMEOUT_S", "7200")))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return world, rank, local
+
+
+def _coll_device(device=None):
+    """device a small helper tensor must live on for a collective of the current backend (RCCL: the GPU)"""
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def broadcast_int(value, src=0, device=None):
+    """rank `src`'s python int on every rank (e.g. the unseeded run's stream seed: DistributedSampler only partitions
+    the dataset when every rank permutes with the SAME seed)"""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=_coll_device(device))
+    dist.broadcast(t, src=src)
+    return int(t.item())
+
+
+def any_rank(flag, device=None):
+    """True on EVERY rank if `flag` is true on any rank: abort decisions (NaN loss, negative KL difference) must be
+    collective — a rank that raises alone leaves the others hanging in the next all-reduce"""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return bool(flag)
+    t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float32, device=_coll_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(t.item() > 0.0)
+
+
+def mean_over_ranks(values, device=None):
+    """element-wise mean over the ranks of a short list of python floats (epoch statistics: every rank logs / decides
+    on the GLOBAL figure, not on its own shard's)"""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=_coll_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) / dist.get_world_size() for v in t.tolist()]
 
 
 def world_size():
@@ -77,7 +118,13 @@ class GradSync:
     the call after the backward reduces the head and waits for the tail.  Same values, same two buffers per iteration —
     only the issue time moves.  overlap=False (or SIVAE_DP_OVERLAP=0) keeps the single post-backward all-reduce."""
 
-    TAIL_FRACTION = 0.6  # at least this share of the elements goes into the early (tail) bucket
+    # The early bucket is the second half of the PARAMETER LIST, i.e. the parameters whose gradients become final in the
+    # first half of the backward.  Encoder (stem ... deep blocks, fc): that half holds the 512-channel blocks and fc —
+    # > 90 % of the bytes — and it is final while the expensive shallow layers still run.  Decoder (fc, deep blocks ...
+    # shallow blocks, predict): the same half is the shallow blocks — few bytes; its fc / 512-channel gradients only
+    # become final at the very end of lossD.backward() (every pass reaches them last), so they cannot be overlapped
+    # with anything and are reduced after the backward.  (Round 2 cut by bytes — 60 % from the tail — which for the
+    # decoder reached into those late blocks and fired the "early" bucket at the end.)
 
     def __init__(self, overlap=None):
         self.world = world_size()
@@ -95,15 +142,13 @@ class GradSync:
         plan = self._plans.get(id(opt))
         if plan is None:
             total = opt.flat_grad.numel()
-            acc, split, tail = 0, total, []
+            split, tail = total, []
             off = total
-            for p in reversed(opt.params):
+            n_tail = (len(opt.params) + 1) // 2
+            for p in list(reversed(opt.params))[:n_tail]:
                 off -= p.numel()
                 tail.append(p)
-                acc += p.numel()
                 split = off
-                if acc >= self.TAIL_FRACTION * total:
-                    break
             if split == 0:  # (a single giant tensor: nothing left to overlap with)
                 tail, split = [], total
             plan = (split, tail)

@@ -218,8 +218,13 @@ def _train(dataset, z_dim, lr_e, lr_d, batch_size, num_workers, start_epoch, exi
             print("random seed: ", seed)
         stream_seed = seed
     else:
-        # unseeded (the reference's default): every run / every call draws fresh noise, like torch.randn does
+        # unseeded (the reference's default): every run / every call draws fresh noise, like torch.randn does.  Under DP
+        # rank 0's draw is broadcast: DistributedSampler partitions the dataset only if every rank permutes it with the
+        # SAME seed (the per-rank offset stays in the noise stream and in the prefetcher's mirror draws)
         stream_seed = int.from_bytes(os.urandom(7), "little")
+        if world > 1:
+            stream_seed = _dp.broadcast_int(stream_seed, device=torch.device("cuda", local)
+                                            if os.environ.get("SIVAE_DP_SAME_DEVICE", "0") != "1" else None)
         _rng.manual_seed(stream_seed, rank)
     arch_key = dataset[len("synthetic-"):] if dataset.startswith("synthetic-") else dataset
     if arch_key not in _ARCH:
@@ -288,9 +293,13 @@ def _train(dataset, z_dim, lr_e, lr_d, batch_size, num_workers, start_epoch, exi
                     best_fid = fid
                     prefix = "{}_{}_betas_{}_{}_{}_fid_{}_".format(dataset, tag, beta_kl, beta_neg, beta_rec, fid)
                     save_checkpoint(model, epoch, cur_iter, prefix)
+        # (every checkpoint is written at an epoch boundary, after the previous epoch's last drain(): a NaN iteration
+        # raises before its weights can be saved, whatever SIVAE_NAN_CHECK_EVERY is)
         if main_rank and epoch % save_interval == 0 and epoch > 0:
             prefix = "{}_{}_betas_{}_{}_{}_".format(dataset, tag, beta_kl, beta_neg, beta_rec)
             save_checkpoint(model, (epoch // save_interval) * save_interval, cur_iter, prefix)
+        if world > 1:
+            _dp.barrier()  # the other ranks wait here, not inside the first all-reduce, while rank 0 runs FID / saves
         model.train()
         ep = {k: [] for k in hist}
         diff_kls = []
@@ -301,7 +310,9 @@ def _train(dataset, z_dim, lr_e, lr_d, batch_size, num_workers, start_epoch, exi
                 return
             rows = torch.stack(pending).cpu()  # ONE device->host copy for the whole interval
             pending.clear()
-            if torch.isnan(rows[:, :2]).any():
+            # the abort is COLLECTIVE under DP: every rank drains at the same iterations, the flag is all-reduced, and
+            # all ranks raise together (a rank raising alone would leave the others in the next all-reduce)
+            if _dp.any_rank(bool(torch.isnan(rows[:, :2]).any()), device if world > 1 else None):
                 raise SystemError
             for r in rows.tolist():
                 s = dict(zip(_engine.STAT_NAMES, r))
@@ -338,22 +349,29 @@ def _train(dataset, z_dim, lr_e, lr_d, batch_size, num_workers, start_epoch, exi
         d_scheduler.step()
         if bootstrap and epoch % copy_to_target_freq == 0:
             model.target_decoder.load_state_dict(model.decoder.state_dict())
-        if exit_on_negative_diff and epoch > 50 and np.mean(diff_kls) < -1.0:
-            print(f"the kl difference [{np.mean(diff_kls):.3f}] between fake and real is negative "
-                  f"(no sampling improvement)")
-            print("try to lower beta_neg hyperparameter")
-            print("exiting...")
+        # epoch statistics: the mean over the GLOBAL batch stream (every rank logs and decides on the same numbers)
+        keys = list(hist)
+        local_means = [float(np.mean(ep[k])) if ep[k] else 0.0 for k in keys] + \
+            [float(np.mean(diff_kls)) if diff_kls else 0.0]
+        glob = _dp.mean_over_ranks(local_means, device) if world > 1 else local_means
+        diff_kl_mean = glob[-1]
+        if exit_on_negative_diff and epoch > 50 and diff_kl_mean < -1.0:
+            if main_rank:
+                print(f"the kl difference [{diff_kl_mean:.3f}] between fake and real is negative "
+                      f"(no sampling improvement)")
+                print("try to lower beta_neg hyperparameter")
+                print("exiting...")
             raise SystemError("Negative KL Difference")
         if epoch > num_vae - 1:
-            for k in hist:
-                hist[k].append(np.mean(ep[k]))
+            for k, v in zip(keys, glob):
+                hist[k].append(v)
         if main_rank and epoch > num_vae - 1:
             print("#" * 50)
             print(f"Epoch {epoch} Summary:")
             print(f"beta_rec: {beta_rec}, beta_kl: {beta_kl}, beta_neg: {beta_neg}")
             print(f"rec: {hist['rec_err'][-1]:.3f}, kl: {hist['kl_real'][-1]:.3f}, "
                   f"kl_fake: {hist['kl_fake'][-1]:.3f}, kl_rec: {hist['kl_rec'][-1]:.3f}")
-            print(f"diff_kl: {np.mean(diff_kls):.3f}, exp_elbo_f: {hist['exp_elbo_f'][-1]:.4e}, "
+            print(f"diff_kl: {diff_kl_mean:.3f}, exp_elbo_f: {hist['exp_elbo_f'][-1]:.4e}, "
                   f"exp_elbo_r: {hist['exp_elbo_r'][-1]:.4e}")
             print(f"time: {time.time() - start_time}")
             print("#" * 50)

@@ -41,18 +41,20 @@ def _run(direct, dtype):
         eng.soft_intro_step(real, noise, eps)
         torch.cuda.synchronize()
         uses_after = max(p.__dict__.get("_sivae_use", 0) for p in list(model.parameters()))
-        return grads, used, uses_after, (oe.flat.detach().clone(), od.flat.detach().clone())
+        return grads, used, uses_after, (oe.flat.detach().clone(), od.flat.detach().clone()), eng._paired(real)
     finally:
         SF.DIRECT_GRADS = old
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_slab_gradients_equal_autograd_accumulation(dtype):
-    gd, used, uses_after, wd = _run(True, dtype)
-    ga, used_a, _, wa = _run(False, dtype)
+    gd, used, uses_after, wd, paired = _run(True, dtype)
+    ga, used_a, _, wa, _ = _run(False, dtype)
     # the encoder runs three times inside lossE (:566-571), the decoder four times inside lossD (fake, rec and the two
-    # reconstructions of their re-encodings, :601-619)
-    assert used == {"E": 3, "D": 4}
+    # reconstructions of their re-encodings, :601-619); with the same-weight pass pairs run as segmented batches (fp32
+    # mode, engine.PAIR_PASSES) that is two uses each: real + [rec; fake], and [rec; fake] + [rec_rec; rec_fake]
+    assert paired == (dtype == "fp32")
+    assert used == ({"E": 2, "D": 2} if paired else {"E": 3, "D": 4})
     assert used_a == {"E": 0, "D": 0}
     assert uses_after == 0                   # the use counters are reset by the optimizer step
     for k in ("E", "D"):

@@ -97,3 +97,68 @@ def test_shard_batch_rules():
     with pytest.raises(ValueError):
         dp.shard_batch(10, 4, 0)
     assert dp.env_world()[0] >= 1
+
+
+def _decision_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "soft-intro-vae-pytorch_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from sivae_hip import dp
+    dp.init(backend="gloo")
+    # an abort condition seen by ONE rank must be seen by all (NaN loss / negative KL difference: a rank raising alone
+    # would leave the others in the next all-reduce)
+    seen = dp.any_rank(rank == 1)
+    none = dp.any_rank(False)
+    # the unseeded run's stream seed: rank 0's draw everywhere (DistributedSampler needs ONE seed)
+    seed = dp.broadcast_int(1234567 + 1000 * rank)
+    # epoch statistics: every rank logs the global mean
+    means = dp.mean_over_ranks([float(rank), 10.0 + rank])
+    # the sampler partitions the dataset with the broadcast seed: no sample repeated, none dropped
+    ds = torch.utils.data.TensorDataset(torch.arange(64))
+    sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True, seed=seed)
+    idx = torch.tensor(list(iter(sampler)))
+    torch.save(dict(seen=seen, none=none, seed=seed, means=means, idx=idx), os.path.join(out_dir, "dec%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_collective_decisions_and_seed_broadcast(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_decision_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / ("dec%d.pt" % k)) for k in range(world)]
+    assert all(x["seen"] for x in r) and not any(x["none"] for x in r)
+    assert r[0]["seed"] == r[1]["seed"] == 1234567
+    assert r[0]["means"] == r[1]["means"] == [0.5, 10.5]
+    both = torch.cat([r[0]["idx"], r[1]["idx"]])
+    assert sorted(both.tolist()) == list(range(64))
+
+
+def test_gradsync_early_bucket_is_the_early_final_half():
+    """the overlapped bucket = the second half of the parameter list (final in the first half of the backward); for the
+    decoder that is the shallow blocks, never the fc / 512-channel gradients that only become final at the end"""
+    sys.path.insert(0, os.path.join(REPO, "soft-intro-vae-pytorch_amd"))
+    from sivae_hip import dp
+
+    class P:
+        def __init__(self, n):
+            self._n = n
+            self.__dict__["_sivae_on_grad"] = None
+
+        def numel(self):
+            return self._n
+
+        def register_post_accumulate_grad_hook(self, h):
+            pass
+
+    class Opt:
+        def __init__(self, sizes):
+            self.params = [P(n) for n in sizes]
+            self.flat_grad = torch.zeros(sum(sizes))
+    sync = dp.GradSync(overlap=False)
+    dec = Opt([1000, 900, 800, 50, 40, 30, 20, 10])  # decoder-like: big tensors first
+    split, tail = sync._plan(dec)
+    assert split == 1000 + 900 + 800 + 50 and len(tail) == 4
+    enc = Opt([10, 20, 30, 40, 50, 800, 900, 1000])  # encoder-like: big tensors last
+    split, tail = sync._plan(enc)
+    assert split == 10 + 20 + 30 + 40 and sum(p.numel() for p in tail) == 2750

@@ -1,5 +1,5 @@
-"""GPU: data parallelism of the HIP engine with LOCAL BatchNorm (the default DP mode) — two ranks (gloo, both
-on cuda:0).
+"""GPU: data parallelism of the HIP engine with LOCAL BatchNorm (the default DP mode) — two ranks: RCCL
+("nccl") with one device per rank when the box has >= 2 GPUs, gloo with both ranks on cuda:0 otherwise.
 
   * engine level: each rank runs its shard through the HIP engine, the flat gradient buffers are all-reduced; the
     result must equal the T4 oracle "run the CPU restatement on each shard from identical weights, average the
@@ -27,9 +27,22 @@ def _free_port():
     return p
 
 
+def _multi_gpu(world=2):
+    return torch.cuda.device_count() >= world
+
+
+def _backend(world=2):
+    return "nccl" if _multi_gpu(world) else "gloo"
+
+
+def _device(rank, world=2):
+    return torch.device("cuda", rank if _multi_gpu(world) else 0)
+
+
 def _env(rank, world, port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), SIVAE_DP_SAME_DEVICE="1", SIVAE_DP_BACKEND="gloo")
+                      LOCAL_RANK=str(rank), SIVAE_DP_SAME_DEVICE="0" if _multi_gpu(world) else "1",
+                      SIVAE_DP_BACKEND=_backend(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
     for p in (REPO, os.path.join(REPO, "soft-intro-vae-pytorch_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -43,8 +56,8 @@ def _engine_worker(rank, world, port, out_dir):
     from sivae_hip import dp
     from sivae_hip.engine import SoftIntroEngine
     from sivae_hip.optim import FlatAdam
-    dp.init(backend="gloo")
-    dev = torch.device("cuda:0")
+    dp.init(backend=_backend(world))
+    dev = _device(rank, world)
     torch.cuda.set_device(dev)
     cdim, zdim, channels, image_size, B = 3, 16, [16, 32, 64], 32, 16
     hp = dict(beta_rec=1.0, beta_kl=1.0, beta_neg=256.0, gamma_r=1e-8)
@@ -79,7 +92,12 @@ def _engine_worker(rank, world, port, out_dir):
                 for k, v in ref.items())
     keys = O.trainable_keys(P, "encoder.")
     gshard = torch.cat([P[k].grad.reshape(-1) for k in keys])
-    dist.all_reduce(gshard)
+    if dist.get_backend() == "nccl":  # (RCCL reduces device tensors)
+        gdev = gshard.to(dev)
+        dist.all_reduce(gdev)
+        gshard = gdev.cpu()
+    else:
+        dist.all_reduce(gshard)
     gmean = gshard / world
     hip = torch.cat([p.reshape(-1) for p in [captured["flat_grad"].cpu()]])
     # FlatAdam's flat buffer is in encoder.parameters() order == state_dict order of the trainable keys
@@ -113,7 +131,7 @@ def _train_worker(rank, world, port, out_dir):
     import train_soft_intro_vae as T
     model = T.train_soft_intro_vae(dataset="synthetic-cifar10", z_dim=16, batch_size=16, num_workers=0, num_epochs=2,
                                    num_vae=0, beta_kl=1.0, beta_rec=1.0, beta_neg=256, seed=5, test_iter=3,
-                                   save_interval=1, device=torch.device("cuda:0"))
+                                   save_interval=1, device=_device(rank, world))
     sd = model.state_dict()
     torch.save({k: v.cpu() for k, v in sd.items()}, os.path.join(out_dir, "sd_rank%d.pt" % rank))
     dist.barrier()
