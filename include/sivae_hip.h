@@ -509,6 +509,18 @@ int sivae_conv2d_wino_wgrad_seg(const float* x, const float* dy, float* dw, cons
                                 int B, int Ci, int Co, int H, int W, int upsample, int seg_images, void* workspace,
                                 size_t workspace_bytes, sivae_stream_t stream);
 
+/* ---- Winograd F(4x4,3x3) for the large-map 3x3 convs (nn.Conv2d k=3, train_soft_intro_vae.py:56-61) ----
+ * 36 multiplies per 4x4 output tile: 1.78x fewer matrix-pipe passes than F(2x2,3x3) (sivae_conv2d_wino_fwd) at 1.2e-5
+ * relative error per layer in fp32 (3.3e-5 on the reconstruction of the six-level network end to end).  Maps: H % 16 == 0,
+ * W % 32 == 0.  up: [6][Ci_pad][Co_pad][6] from sivae_pack_wino4_weight (mode 0 forward, 1 data gradient).
+ * stats_partial: [sivae_conv2d_wino4_num_px_tiles][Co][2] rows in image order (sivae_bn_stats_from_conv[_seg]). */
+size_t sivae_pack_wino4_weight_bytes(int Co, int Ci, int mode);
+int sivae_pack_wino4_weight(const float* w, float* up, int Co, int Ci, int mode, sivae_stream_t stream);
+int sivae_conv2d_wino4_supported(int H, int W);
+int sivae_conv2d_wino4_num_px_tiles(int B, int H, int W);
+int sivae_conv2d_wino4_fwd(const float* x, const float* up, float* y, float* stats_partial, int B, int Ci, int Co, int H,
+                           int W, int accumulate, sivae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

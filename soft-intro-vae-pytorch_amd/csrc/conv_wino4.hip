@@ -1,0 +1,493 @@
+// Winograd F(4x4, 3x3) stride-1 "same" convolution for gfx950 on the exact-fp32 matrix pipe
+// (v_mfma_f32_32x32x2_f32): 36 multiplies per 4x4 output tile = 2.25 per output pixel instead of the 4 of
+// F(2x2,3x3) (conv_wino.hip) and the 9 of the direct form — 1.78x fewer MFMA passes than conv_wino.hip for the same
+// nn.Conv2d(k=3, s=1, p=1) (reference: soft_intro_vae/train_soft_intro_vae.py:56-61).  Forward and — fed the flipped /
+// transposed weight transform — the data gradient, for the large-map layers (H % 16 == 0, W % 32 == 0); the deep
+// 4x4 ... 16x16 layers stay on F(2x2,3x3).
+//
+//   V = B^T d B   (6x6 input patch d of a tile, per input channel)          B^T, G, A^T: Lavin & Gray's F(4x4,3x3)
+//   U = G g G^T   (3x3 filter g -> 6x6, per (co, ci); once per optimizer step by sivae_pack_wino4_weight)
+//   M[i][j] = sum_ci U[i][j][co][ci] * V[i][j][ci][tile]      <- 36 independent GEMMs, K = Ci
+//   Y = A^T M A   (4x4 outputs of the tile)
+// fp32 cost of the larger transforms (coefficients up to 8 and 1/24): 1.2e-5 relative on a 512-channel layer, 3.3e-5 on
+// the reconstruction of the six-level 256x256 network end to end (profiles/r1_wino_numerics.txt) — inside the 1e-4 gate.
+//
+// Work split: a block is 12 waves = 64 output channels x 32 tiles (8 x 4 tiles = 32 x 16 pixels) x 36 frequencies.
+// Wave (j, s) owns frequency COLUMN j (i = 0..5) of the 32-channel subtile s: 6 accumulators of 32x32 = 96 registers, so
+// three waves fit a SIMD (168 registers) and one block fills a CU.  As in conv_wino.hip nothing the MFMA loop consumes
+// is shared between waves except the raw zero-padded input halo in LDS:
+//   * B operand: a lane (tile t = lane & 31, channel k = lane >> 5) reads six rows of its tile's patch — one aligned
+//     16-byte ds_read per row for patch columns 1..4 (the LDS column origin is skewed by 3 so that column 1 of every
+//     tile is 16-byte aligned; row stride 40: the four 16-lane groups of a ds_read_b128 hit 64 distinct banks) plus one
+//     dword for column 0 / 5 —, forms t[r] = (row r of d) . (column j of B) with wave-uniform coefficients and
+//     V[0..5] = B^T t in 12 more VALU ops.  The transformed tile is never stored.
+//   * A operand: U is packed [j][ci][co][i], 24 bytes per (co, ci): one 16-byte + one 8-byte buffer load per k-step,
+//     two k-steps ahead, straight into registers.
+//   * halo: 34 x 18 raw pixels x 16 channels per chunk, HBM -> LDS by LDS-direct buffer loads (no staging registers:
+//     the 96 accumulators leave none), double-buffered, one barrier per chunk; the first chunk of the NEXT work item is
+//     requested during the last chunk of the current one.
+// After the K loop: the row transform A^T M in registers (6 -> 4 values), then four rounds (one per output row of the
+// tiles) of a 48 KB exchange through LDS (aliasing the halo buffer the item finished on) for the column transform
+// across the six frequency-column waves; outputs leave as 16-byte stores (four consecutive pixels of one channel per
+// lane) with the usual fused epilogues (accumulate, BatchNorm sum / sumsq partials).
+#include "common.h"
+#include <stdlib.h>
+
+struct Wino4Args {
+  const float* x;
+  const float* up;  // packed U [6(j)][Ci_pad][Co_pad][6(i)]
+  float* y;
+  float* stats;  // [n_px_tiles][Co][2] or null
+  int B, Ci, Co, H, W;
+  int Ci_pad, Co_pad;
+  int nbh, nbw;
+  int n_co_tiles;
+  int accumulate;
+  int n_items;
+  int xcd_group;
+};
+
+#define W4_CK 16
+#define W4_RS 40
+#define W4_LH 18
+#define W4_PLANE 768  // 18 rows x 40 = 720, padded to 12 waves x 64 lanes: a wave's LDS-direct load fills 64 slots
+#define W4_XBUF (W4_CK * W4_PLANE)
+#define W4_NT 768
+#define W4_TCO 64
+#define W4_PXH 16
+#define W4_PXW 32
+
+__device__ __forceinline__ void buf_store_f32x4(__amdgpu_buffer_rsrc_t r, float4 v, unsigned voff) {
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  f32x4 f = {v.x, v.y, v.z, v.w};
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f), r, (int)voff, 0, 0);
+}
+
+__global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
+  constexpr int CK = W4_CK, RS = W4_RS, PLANE = W4_PLANE, XBUF = W4_XBUF;
+  // two SEPARATE static LDS arrays (not one dynamic block): the compiler orders a ds_read behind every in-flight
+  // LDS-direct load it cannot prove disjoint (vmcnt(0) before the read); reads of one halo buffer and the loads that fill
+  // the OTHER are disjoint objects this way
+  __shared__ __attribute__((aligned(16))) float xs0[XBUF];
+  __shared__ __attribute__((aligned(16))) float xs1[XBUF];
+#define XS(BUF) ((BUF) ? xs1 : xs0)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int wj = wave % 6, ws = wave / 6;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int tx = l31 & 7, ty = l31 >> 3;
+
+  // column j of B (= row j of B^T) as five wave-uniform coefficients: t = ce*e + c1*d1 + c2*d2 + c3*d3 + c4*d4, where e is
+  // patch column 0 (j == 0) or 5 (j == 5)
+  float ce = 0.f, c1, c2, c3, c4;
+  int eoff = -1;
+  switch (wj) {
+    case 0: ce = 4.f; c1 = 0.f; c2 = -5.f; c3 = 0.f; c4 = 1.f; break;
+    case 1: c1 = -4.f; c2 = -4.f; c3 = 1.f; c4 = 1.f; break;
+    case 2: c1 = 4.f; c2 = -4.f; c3 = -1.f; c4 = 1.f; break;
+    case 3: c1 = -2.f; c2 = -1.f; c3 = 2.f; c4 = 1.f; break;
+    case 4: c1 = 2.f; c2 = -1.f; c3 = -2.f; c4 = 1.f; break;
+    default: ce = 1.f; c1 = 4.f; c2 = 0.f; c3 = -5.f; c4 = 0.f; eoff = 4; break;
+  }
+  const bool use_e = wj == 0 || wj == 5;
+  // raw-read base (floats): channel plane hh, tile row 4*ty, patch column 1 at LDS column 4*tx + 4
+  const int rb = hh * PLANE + 4 * ty * RS + 4 * tx + 4;
+
+  // halo slots of this thread.  A channel plane is 192 groups of four consecutive floats (18 rows x 10 groups + padding);
+  // one 16-byte LDS-direct load per lane moves a group, so a plane is three wave-instructions: wave w fills third
+  // w % 3 of the planes w / 3 + 4n (n = 0..3) of a chunk — four instructions per wave and chunk.  Group k of a row holds
+  // the image columns c0 - 4 + 4k .. + 3: entirely inside or entirely outside the image (W % 32 == 0).
+  const int dsub = wave % 3, dpl0 = wave / 3;
+  const int pg = dsub * 64 + lane, prow = pg / 10, pk = pg - prow * 10;
+  const bool pvalid = pg < 180;
+
+  const int n_items = a.n_items;
+  const int nchunks = a.Ci_pad / CK;  // even (Ci_pad is a multiple of 32)
+  const int ksteps = nchunks * (CK / 2);
+  const __amdgpu_buffer_rsrc_t ursrc = make_rsrc(a.up, 36ull * a.Ci_pad * a.Co_pad * 4ull);
+  const unsigned va0 = (unsigned)(hh * a.Co_pad + ws * 32 + l31) * 24u;
+  const unsigned ua_step = (unsigned)a.Co_pad * 24u;  // bytes per input channel
+
+  // Consecutive blockIdx go round-robin to the 8 XCDs.  With xcd_group the block on XCD x, slot j starts at item
+  // x * (grid / 8) + j: the co-tiles of one pixel tile (consecutive items) run on ONE XCD at the same time and share the
+  // halo in its L2 (the halo stream is 2.4 KB per input channel and item: 2.6 TB/s at full matrix rate with one reader)
+  int item = blockIdx.x;
+  if (a.xcd_group) item = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+  int b, r0, c0, co0, pt;
+  __amdgpu_buffer_rsrc_t xrsrc;
+  unsigned xo, ua_base;
+#define W4_SETUP(ITEM)                                                   \
+  {                                                                      \
+    const int co_tile = (ITEM) % a.n_co_tiles;                           \
+    pt = (ITEM) / a.n_co_tiles;                                          \
+    const int tbx = pt % a.nbw;                                          \
+    const int t2 = pt / a.nbw;                                           \
+    const int tby = t2 % a.nbh;                                          \
+    b = t2 / a.nbh;                                                      \
+    r0 = tby * W4_PXH;                                                   \
+    c0 = tbx * W4_PXW;                                                   \
+    co0 = co_tile * W4_TCO;                                              \
+    xrsrc = make_rsrc(a.x + (size_t)b * a.Ci * HW, (unsigned long long)a.Ci * HW * 4ull); \
+    const int r = r0 - 1 + prow, c = c0 - 4 + 4 * pk;                    \
+    xo = (pvalid && r >= 0 && r < H && c >= 0 && c < W) ? (unsigned)(r * W + c) * 4u : SIVAE_OOB; \
+    ua_base = (unsigned)((wj * a.Ci_pad) * a.Co_pad + co0) * 24u;        \
+  }
+  // halo chunk CH -> LDS buffer BUF (out-of-image / padding slots receive 0; channels beyond Ci re-read the last
+  // one: their U is zero)
+#define W4_DMA1(CH, BUF, N)                                              \
+  {                                                                      \
+    const int ck = dpl0 + 4 * (N);                                       \
+    const int ci = (CH)*CK + ck;                                         \
+    const int cic = ci < a.Ci ? ci : a.Ci - 1;                           \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(                            \
+        xrsrc, (float __attribute__((address_space(3)))*)(XS(BUF) + ck * PLANE + dsub * 256), 16, xo, \
+        (unsigned)cic * (unsigned)HW * 4u, 0, 0);                        \
+  }
+#define W4_DMA(CH, BUF)                                                  \
+  {                                                                      \
+    W4_DMA1(CH, BUF, 0)                                                  \
+    W4_DMA1(CH, BUF, 1)                                                  \
+    W4_DMA1(CH, BUF, 2)                                                  \
+    W4_DMA1(CH, BUF, 3)                                                  \
+  }
+
+  f32x16 acc[6];
+  float4 U4[2];
+  float2 U2[2];
+#define W4_LOAD_A(UBASE, KS_ABS, SLOT)                                   \
+  {                                                                      \
+    const unsigned so = (UBASE) + (unsigned)(2 * (KS_ABS)) * ua_step;    \
+    U4[SLOT] = buf_load_f32x4(ursrc, va0, so);                           \
+    U2[SLOT] = buf_load_f32x2(ursrc, va0 + 16u, so);                     \
+  }
+  // raw reads of k-step KK: six rows x (patch columns 1..4 as one 16-byte read + column 0 or 5)
+#define W4_READ(BUF, KK, D, E, USEE)                                     \
+  {                                                                      \
+    const float* p_ = XS(BUF) + 2 * (KK)*PLANE + rb;                     \
+    _Pragma("unroll") for (int r = 0; r < 6; ++r) {                      \
+      D[r] = *reinterpret_cast<const float4*>(p_ + r * RS);              \
+      /* (only frequency columns 0 and 5 touch patch column 0 / 5; a 4-way bank conflict: tiles are 4 dwords apart) */ \
+      E[r] = (USEE) ? p_[r * RS + eoff] : 0.f;                           \
+    }                                                                    \
+  }
+  // V = B^T (d . B[:, j]) for the wave's frequency column
+#define W4_XFORM(D, E, V)                                                \
+  {                                                                      \
+    float t[6];                                                          \
+    _Pragma("unroll") for (int r = 0; r < 6; ++r)                        \
+      t[r] = fmaf(ce, E[r], fmaf(c1, D[r].x, fmaf(c2, D[r].y, fmaf(c3, D[r].z, c4 * D[r].w)))); \
+    const float A_ = fmaf(-4.f, t[2], t[4]), B_ = fmaf(-4.f, t[1], t[3]); \
+    const float C_ = t[4] - t[2], D_ = t[3] - t[1];                      \
+    V[0] = fmaf(4.f, t[0], fmaf(-5.f, t[2], t[4]));                      \
+    V[1] = A_ + B_;                                                      \
+    V[2] = A_ - B_;                                                      \
+    V[3] = fmaf(2.f, D_, C_);                                            \
+    V[4] = fmaf(-2.f, D_, C_);                                           \
+    V[5] = fmaf(4.f, t[1], fmaf(-5.f, t[3], t[5]));                      \
+  }
+  // One k-step = six MFMA slots.  The three waves of a SIMD run in lockstep (one barrier per chunk), so a wave that
+  // issued its six MFMAs back to back and THEN did its ~45 VALU / LDS operations left the matrix pipe idle for that long
+  // on every k-step (measured: 50 % busy).  Instead the transform of the NEXT k-step's rows is cut into slices that sit
+  // between this k-step's MFMAs (fenced scheduling regions — hipcc does not interleave them by itself): slot 0-2 the
+  // column dot products of two rows each, slot 3 the first half of B^T t and the request for the rows after next, slot 4
+  // the second half, slot 5 the U refill (k-step + 2) and one 16-byte piece of the next halo chunk.
+  // (the U refill is UNCONDITIONAL with a selected base / clamped index: a load inside an `if` makes hipcc assume no
+  // younger load is outstanding at the join and turns every later wait into vmcnt(0))
+#define W4_FENCE __builtin_amdgcn_sched_barrier(0);
+#define W4_DOT(USEE, R)                                                  \
+  ((USEE) ? fmaf(ce, e_[R], fmaf(c1, d_[R].x, fmaf(c2, d_[R].y, fmaf(c3, d_[R].z, c4 * d_[R].w)))) \
+          : fmaf(c1, d_[R].x, fmaf(c2, d_[R].y, fmaf(c3, d_[R].z, c4 * d_[R].w))))
+#define W4_KSTEP(CH, BUF, KK, USEE, DCH, VC, VN)                         \
+  {                                                                      \
+    constexpr bool nx_ = (KK) + 1 < CK / 2;                              \
+    float t0_ = 0.f, t1_ = 0.f, t2_ = 0.f, t3_ = 0.f, t4_ = 0.f, t5_ = 0.f; \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(U4[(KK)&1].x, VC[0], acc[0], 0, 0, 0); \
+    W4_FENCE                                                             \
+    if (nx_) { t0_ = W4_DOT(USEE, 0); t1_ = W4_DOT(USEE, 1); }           \
+    W4_FENCE                                                             \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(U4[(KK)&1].y, VC[1], acc[1], 0, 0, 0); \
+    W4_FENCE                                                             \
+    if (nx_) { t2_ = W4_DOT(USEE, 2); t3_ = W4_DOT(USEE, 3); }           \
+    W4_FENCE                                                             \
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(U4[(KK)&1].z, VC[2], acc[2], 0, 0, 0); \
+    W4_FENCE                                                             \
+    if (nx_) { t4_ = W4_DOT(USEE, 4); t5_ = W4_DOT(USEE, 5); }           \
+    W4_FENCE                                                             \
+    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(U4[(KK)&1].w, VC[3], acc[3], 0, 0, 0); \
+    W4_FENCE                                                             \
+    if ((KK) + 2 < CK / 2) W4_READ(BUF, (KK) + 2, d_, e_, USEE)          \
+    if (nx_) {                                                           \
+      const float A_ = fmaf(-4.f, t2_, t4_), B_ = fmaf(-4.f, t1_, t3_);  \
+      VN[0] = fmaf(4.f, t0_, fmaf(-5.f, t2_, t4_));                      \
+      VN[1] = A_ + B_;                                                   \
+      VN[2] = A_ - B_;                                                   \
+    }                                                                    \
+    W4_FENCE                                                             \
+    acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(U2[(KK)&1].x, VC[4], acc[4], 0, 0, 0); \
+    W4_FENCE                                                             \
+    if (nx_) {                                                           \
+      const float C_ = t4_ - t2_, D_ = t3_ - t1_;                        \
+      VN[3] = fmaf(2.f, D_, C_);                                         \
+      VN[4] = fmaf(-2.f, D_, C_);                                        \
+      VN[5] = fmaf(4.f, t1_, fmaf(-5.f, t3_, t5_));                      \
+    }                                                                    \
+    W4_FENCE                                                             \
+    acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(U2[(KK)&1].y, VC[5], acc[5], 0, 0, 0); \
+    W4_FENCE                                                             \
+    {                                                                    \
+      const int ks2 = (CH) * (CK / 2) + (KK) + 2;                        \
+      const bool in_item = ks2 < ksteps;                                 \
+      const unsigned ub_ = (in_item || !has_next) ? ua_cur : ua_base;    \
+      const int kq_ = in_item ? ks2 : (has_next ? ks2 - ksteps : ksteps - 1); \
+      W4_LOAD_A(ub_, kq_, (KK)&1)                                        \
+    }                                                                    \
+    /* the next chunk's halo, one 16-byte piece per k-step behind the U refill: loads complete in order, so a burst of */ \
+    /* HBM-latency halo loads in front of the U ring would stall the MFMAs two k-steps later */ \
+    if ((KK) < 4) W4_DMA1(DCH, (BUF) ^ 1, KK)                            \
+    W4_FENCE                                                             \
+  }
+#define W4_CHUNK(CH, BUF, USEE, DCH)                                     \
+  {                                                                      \
+    float4 d_[6];                                                        \
+    float e_[6];                                                         \
+    W4_READ(BUF, 0, d_, e_, USEE)                                        \
+    W4_XFORM(d_, e_, Va)                                                 \
+    W4_READ(BUF, 1, d_, e_, USEE)                                        \
+    W4_FENCE                                                             \
+    W4_KSTEP(CH, BUF, 0, USEE, DCH, Va, Vb)                              \
+    W4_KSTEP(CH, BUF, 1, USEE, DCH, Vb, Va)                              \
+    W4_KSTEP(CH, BUF, 2, USEE, DCH, Va, Vb)                              \
+    W4_KSTEP(CH, BUF, 3, USEE, DCH, Vb, Va)                              \
+    W4_KSTEP(CH, BUF, 4, USEE, DCH, Va, Vb)                              \
+    W4_KSTEP(CH, BUF, 5, USEE, DCH, Vb, Va)                              \
+    W4_KSTEP(CH, BUF, 6, USEE, DCH, Va, Vb)                              \
+    W4_KSTEP(CH, BUF, 7, USEE, DCH, Vb, Va)                              \
+    /* vmcnt(4): everything but the four U loads of k-steps 6 and 7 — i.e. this wave's share of the next halo chunk — */ \
+    /* has landed (a vmcnt(0) here would expose the L2 latency of those U loads once per chunk) */ \
+    __builtin_amdgcn_s_waitcnt(0x0F74);                                  \
+    __syncthreads();                                                     \
+  }
+  // two chunks (halo buffers 0 then 1); the halo of the chunk after next is requested as soon as its buffer is free —
+  // at the end of an item that is the first chunk of the NEXT item
+  // (the last item of a block re-requests its own first chunk into the free buffer: unconditional loads)
+#define W4_PAIR(CH, USEE)                                                \
+  {                                                                      \
+    W4_CHUNK(CH, 0, USEE, (CH) + 1)                                      \
+    const bool more_ = (CH) + 2 < nchunks;                               \
+    if (!more_ && has_next) W4_SETUP(next)                               \
+    const int dch_ = more_ ? (CH) + 2 : 0;                               \
+    W4_CHUNK((CH) + 1, 1, USEE, dch_)                                    \
+  }
+
+  W4_SETUP(item)
+  W4_DMA(0, 0)
+  unsigned ua_cur = ua_base;
+  W4_LOAD_A(ua_cur, 0, 0)
+  W4_LOAD_A(ua_cur, 1, 1)
+  float Va[6], Vb[6];
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    // coordinates of the item being accumulated (W4_SETUP overwrites b, r0, ... for the next one in the last chunk)
+    const int e_pt = pt, e_b = b, e_r0 = r0, e_c0 = c0, e_co0 = co0;
+    const int next = item + (int)gridDim.x;
+    const bool has_next = next < n_items;
+    if (use_e) {
+      for (int ch = 0; ch < nchunks; ch += 2) W4_PAIR(ch, true)
+    } else {
+      for (int ch = 0; ch < nchunks; ch += 2) W4_PAIR(ch, false)
+    }
+
+    // ---- output transform.  acc[i][r]: frequency (i, wj), tile = l31, channel = ws*32 + (r&3) + 8*(r>>2) + 4*hh.
+    // Round a = output row a of every tile: Z[a][j] = sum_i A^T[a][i] M[i][j] in registers -> ex[j][s][r][lane] (48 KB,
+    // the halo buffer the item finished on); then pair q = (s, r) of this wave: Y[a][0..3] = Z[a][.] A, one 16-byte store.
+    {
+      float* ex = xs1;
+      const __amdgpu_buffer_rsrc_t yrsrc =
+          make_rsrc(a.y + (size_t)e_b * a.Co * HW, (unsigned long long)a.Co * HW * 4ull);
+      float ssum[3] = {0.f, 0.f, 0.f}, ssq[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ar = 0; ar < 4; ++ar) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
+          float z;
+          if (ar == 0) z = m0 + (m1 + m2) + (m3 + m4);
+          else if (ar == 1) z = (m1 - m2) + 2.f * (m3 - m4);
+          else if (ar == 2) z = (m1 + m2) + 4.f * (m3 + m4);
+          else z = (m1 - m2) + 8.f * (m3 - m4) + m5;
+          ex[((wj * 2 + ws) * 16 + r) * 64 + lane] = z;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qi = 0; qi < 3; ++qi) {
+          const int q = wave + 12 * qi;
+          if (q < 32) {
+            const int s = q >> 4, r = q & 15;
+            float z[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) z[j] = ex[((j * 2 + s) * 16 + r) * 64 + lane];
+            float4 o;
+            o.x = z[0] + (z[1] + z[2]) + (z[3] + z[4]);
+            o.y = (z[1] - z[2]) + 2.f * (z[3] - z[4]);
+            o.z = (z[1] + z[2]) + 4.f * (z[3] + z[4]);
+            o.w = (z[1] - z[2]) + 8.f * (z[3] - z[4]) + z[5];
+            const int chn = e_co0 + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const unsigned off = chn < a.Co ? (unsigned)((chn * H + e_r0 + 4 * ty + ar) * W + e_c0 + 4 * tx) * 4u : SIVAE_OOB;
+            if (a.accumulate) {
+              const float4 old = buf_load_f32x4(yrsrc, off, 0u);
+              o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+            }
+            buf_store_f32x4(yrsrc, o, off);
+            ssum[qi] += (o.x + o.y) + (o.z + o.w);
+            ssq[qi] += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+          }
+        }
+        __syncthreads();
+      }
+      if (a.stats != nullptr) {
+#pragma unroll
+        for (int qi = 0; qi < 3; ++qi) {
+          const int q = wave + 12 * qi;
+          const float s_ = half_wave_sum_hi(ssum[qi]);
+          const float q_ = half_wave_sum_hi(ssq[qi]);
+          if (q < 32) {
+            const int chn = e_co0 + (q >> 4) * 32 + (q & 3) + 8 * ((q & 15) >> 2) + 4 * hh;
+            if (l31 == 31 && chn < a.Co) {
+              float* dst = a.stats + ((size_t)e_pt * a.Co + chn) * 2;
+              dst[0] = s_;
+              dst[1] = q_;
+            }
+          }
+        }
+      }
+    }
+    if (!has_next) break;
+    item = next;
+    ua_cur = ua_base;
+  }
+#undef W4_SETUP
+#undef W4_DMA
+#undef W4_LOAD_A
+#undef W4_READ
+#undef W4_XFORM
+#undef W4_KSTEP
+#undef W4_FENCE
+#undef W4_DOT
+#undef W4_CHUNK
+#undef W4_PAIR
+#undef XS
+}
+
+// ---- weight transform U = G g G^T (6x6), packed [j][ci_pad][co_pad][i]; padding entries are zero
+//   mode 0 (forward): g = w[n][k]            (n = output channel, k = input channel)
+//   mode 1 (dgrad):   g = flip180(w[k][n])   (k = w's output channel is the GEMM's input channel)
+__global__ void __launch_bounds__(256) pack_wino4_kernel(const float* __restrict__ w, float* __restrict__ up, int Co,
+                                                         int Ci, int mode, int kdim, int ndim, int kpad, int npad) {
+  const float G[6][3] = {{0.25f, 0.f, 0.f},
+                         {-1.f / 6.f, -1.f / 6.f, -1.f / 6.f},
+                         {-1.f / 6.f, 1.f / 6.f, -1.f / 6.f},
+                         {1.f / 24.f, 1.f / 12.f, 1.f / 6.f},
+                         {1.f / 24.f, -1.f / 12.f, 1.f / 6.f},
+                         {0.f, 0.f, 1.f}};
+  const size_t total = (size_t)kpad * npad;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int n = (int)(idx % npad), k = (int)(idx / npad);
+    float g[3][3];
+    const bool ok = k < kdim && n < ndim;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float v = 0.f;
+        if (ok) v = (mode == 0) ? w[((size_t)n * Ci + k) * 9 + r * 3 + c] : w[((size_t)k * Ci + n) * 9 + (2 - r) * 3 + (2 - c)];
+        g[r][c] = v;
+      }
+    float gg[6][3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gg[i][c] = G[i][0] * g[0][c] + G[i][1] * g[1][c] + G[i][2] * g[2][c];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float* dst = up + (((size_t)j * kpad + k) * npad + n) * 6;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dst[i] = gg[i][0] * G[j][0] + gg[i][1] * G[j][1] + gg[i][2] * G[j][2];
+    }
+  }
+}
+
+static inline int w4_kpad(int k) { return ((k + 31) / 32) * 32; }  // an even number of 16-channel chunks
+static inline int w4_npad(int n) { return ((n + W4_TCO - 1) / W4_TCO) * W4_TCO; }
+
+extern "C" size_t sivae_pack_wino4_weight_bytes(int Co, int Ci, int mode) {
+  if (Co <= 0 || Ci <= 0 || (mode != 0 && mode != 1)) return 0;
+  const int kdim = mode == 0 ? Ci : Co, ndim = mode == 0 ? Co : Ci;
+  return (size_t)36 * w4_kpad(kdim) * w4_npad(ndim) * sizeof(float);
+}
+
+extern "C" int sivae_pack_wino4_weight(const float* w, float* up, int Co, int Ci, int mode, hipStream_t stream) {
+  if (!w || !up) return SIVAE_ERR_NULL;
+  if (Co <= 0 || Ci <= 0) return SIVAE_ERR_SHAPE;
+  if (mode != 0 && mode != 1) return SIVAE_ERR_MODE;
+  const int kdim = mode == 0 ? Ci : Co, ndim = mode == 0 ? Co : Ci;
+  const int kpad = w4_kpad(kdim), npad = w4_npad(ndim);
+  int nb = cdiv((long long)kpad * npad, 256);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(pack_wino4_kernel, dim3(nb), dim3(256), 0, stream, w, up, Co, Ci, mode, kdim, ndim, kpad, npad);
+  return sivae_launch_status();
+}
+
+// maps the F(4x4,3x3) kernel takes: whole 32 x 16 pixel tile blocks
+extern "C" int sivae_conv2d_wino4_supported(int H, int W) {
+  return (H >= 16 && W >= 32 && (H % W4_PXH) == 0 && (W % W4_PXW) == 0) ? 1 : 0;
+}
+
+extern "C" int sivae_conv2d_wino4_num_px_tiles(int B, int H, int W) {
+  if (B <= 0 || !sivae_conv2d_wino4_supported(H, W)) return SIVAE_ERR_SHAPE;
+  return B * (H / W4_PXH) * (W / W4_PXW);
+}
+
+// y[B][Co][H][W] (+)= conv3x3(x, U);  stats_partial (optional): [sivae_conv2d_wino4_num_px_tiles][Co][2] per-tile {sum, sumsq}
+// of y in image order (sivae_bn_stats_from_conv / _seg).  The data gradient is this function on dy with the mode-1 pack.
+extern "C" int sivae_conv2d_wino4_fwd(const float* x, const float* up, float* y, float* stats_partial, int B, int Ci,
+                                      int Co, int H, int W, int accumulate, hipStream_t stream) {
+  if (!x || !up || !y) return SIVAE_ERR_NULL;
+  if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
+  if (!sivae_conv2d_wino4_supported(H, W)) return SIVAE_ERR_SHAPE;
+  if (((uintptr_t)y & 15u) != 0) return SIVAE_ERR_SHAPE;  // 16-byte stores
+  const long long hw = (long long)H * W;
+  if ((long long)Ci * hw * 4 >= 0x7fffffffLL || (long long)Co * hw * 4 >= 0x7fffffffLL) return SIVAE_ERR_RANGE;
+  Wino4Args a;
+  a.x = x;
+  a.up = up;
+  a.y = y;
+  a.stats = stats_partial;
+  a.B = B;
+  a.Ci = Ci;
+  a.Co = Co;
+  a.H = H;
+  a.W = W;
+  a.Ci_pad = w4_kpad(Ci);
+  a.Co_pad = w4_npad(Co);
+  if (36ull * a.Ci_pad * a.Co_pad * 4ull >= 0xffffffffull) return SIVAE_ERR_RANGE;
+  a.nbh = H / W4_PXH;
+  a.nbw = W / W4_PXW;
+  a.n_co_tiles = a.Co_pad / W4_TCO;
+  a.accumulate = accumulate;
+  const long long nitems = (long long)B * a.nbh * a.nbw * a.n_co_tiles;
+  if (nitems > 0x7fffffffLL) return SIVAE_ERR_RANGE;
+  a.n_items = (int)nitems;
+  // (96 KB of static LDS: one block per CU)
+  const int cus = sivae_num_cus();
+  const int grid = nitems < cus ? (int)nitems : cus;
+  a.xcd_group = (sivae_xcd_remap() && a.n_co_tiles > 1 && !(grid & 7)) ? 1 : 0;
+  hipLaunchKernelGGL(conv_wino4_kernel, dim3((unsigned)grid), dim3(W4_NT), 0, stream, a);
+  return sivae_launch_status();
+}

@@ -197,6 +197,10 @@ def pack_wino(w, mode):
 # SIVAE_WINO=0 keeps every 3x3 conv on the direct implicit-GEMM kernel (A/B measurements, debugging)
 WINO = os.environ.get("SIVAE_WINO", "1") != "0"
 WINO_UP = os.environ.get("SIVAE_WINO_UP", "1") != "0"  # phase-decomposed F(2x2,2x2) kernel for conv-after-upsample
+# Winograd F(4x4,3x3) for the large-map 3x3 convs without a fused prologue (SIVAE_WINO4=0: F(2x2,3x3) everywhere);
+# SIVAE_WINO4_MAXC: largest channel count it takes (its U slab per 64-channel tile is 2.25x the F(2x2,3x3) one)
+WINO4 = os.environ.get("SIVAE_WINO4", "1") != "0"
+WINO4_MAXC = int(os.environ.get("SIVAE_WINO4_MAXC", "256"))
 # SIVAE_FUSE_BN_BWD=1: reduce BatchNorm-1's backward sums in the epilogue of conv2's data gradient.  Measured a LOSS at
 # 256x256 bs128 (593 vs 585 ms per iteration: the extra tensor read sits on the kernel's critical path and disables its
 # next-item prefetch, which costs more than the 14 ms reduction pass it removes) -> off by default.
@@ -228,6 +232,17 @@ class PackedW:
         if self._wino is None:
             self._wino = pack_wino(self.w, self.mode)
         return self._wino
+
+    def wino4(self):
+        """F(4x4,3x3) filter transform [6][Ci_pad][Co_pad][6] (conv_wino4.hip)"""
+        if getattr(self, "_wino4", None) is None:
+            w = self.w
+            Co, Ci = w.shape[0], w.shape[1]
+            nbytes = _lib.load().sivae_pack_wino4_weight_bytes(Co, Ci, self.mode)
+            up = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+            _lib.call("sivae_pack_wino4_weight", _p(w), _p(up), Co, Ci, self.mode, _s(w))
+            self._wino4 = up
+        return self._wino4
 
     def wino_up_dgrad(self):
         if getattr(self, "_wino_up_dgrad", None) is None:
@@ -379,6 +394,21 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
         if t0 is not None:
             TIMER.end("conv1x1_stream_kernel", 2.0 * B * H * W * Co * Ci, t0)
         return y
+    if (WINO and WINO4 and ks == 3 and bias is None and pro is None and not upsample and isinstance(wp, PackedW)
+            and max(Ci, Co) <= WINO4_MAXC and Ci >= 16 and L.sivae_conv2d_wino4_supported(H, W) == 1):
+        # large maps, no fused prologue: F(4x4,3x3) — 2.25 multiplies per output pixel instead of 4
+        _require(x, out)
+        y = out if out is not None else torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
+        assert y.shape == (B, Co, H, W) and y.is_contiguous()
+        stats = (torch.empty((L.sivae_conv2d_wino4_num_px_tiles(B, H, W), Co, 2), dtype=torch.float32, device=x.device)
+                 if want_stats else None)
+        t0 = TIMER.begin() if TIMER is not None else None
+        _lib.call("sivae_conv2d_wino4_fwd", _p(x), _p(wp.wino4()), _p(y), _p(stats), B, Ci, Co, H, W,
+                  int(bool(accumulate)), _s(x))
+        if t0 is not None:
+            flops = 2.0 * B * H * W * Co * Ci * 9
+            TIMER.end("conv_wino4_kernel", flops, t0, executed=flops * 36.0 / 144.0)
+        return (y, stats) if want_stats else y
     wino = (WINO and ks == 3 and bias is None and isinstance(wp, PackedW)
             and L.sivae_conv2d_wino_supported(H, W) == 1)
     wino_up = (wino and WINO_UP and upsample and not accumulate and wp.mode == 0

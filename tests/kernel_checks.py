@@ -597,6 +597,48 @@ def check_conv1x1_stream():
     return res
 
 
+WINO4_TOL = 4e-5  # F(4x4,3x3) in fp32: transform coefficients up to 8 and 1/24 (measured 0.5-1.5e-5 per layer)
+
+
+def check_wino4(shape, accumulate=False, stats=False, mode=0):
+    """F(4x4,3x3) kernel (conv_wino4.hip) vs the fp64 convolution: forward (mode 0) / data gradient (mode 1)"""
+    from sivae_hip import lib, ops
+    B, Ci, Co, H, W = shape
+    L = lib.load()
+    assert L.sivae_conv2d_wino4_supported(H, W) == 1
+    x = _rand(B, Ci, H, W, seed=1)
+    res = []
+    if mode == 0:
+        w = _rand(Co, Ci, 3, 3, seed=2, scale=1.0 / math.sqrt(Ci * 9))
+        ref = _conv_ref(x, w)
+    else:  # data gradient of a conv with weight [Ci_in_of_grad = Ci][Co]...: x plays dy, result has Co channels
+        w = _rand(Ci, Co, 3, 3, seed=2, scale=1.0 / math.sqrt(Ci * 9))
+        xin = _rand(B, Co, H, W, seed=5).requires_grad_()
+        _conv_ref(xin, w).backward(x)
+        ref = xin.grad
+    wp = ops.PackedW(_d(w), mode)
+    up = wp.wino4()
+    y0 = _rand(B, Co, H, W, seed=7) if accumulate else None
+    y = _d(y0) if accumulate else torch.empty((B, Co, H, W), dtype=torch.float32, device=DEV)
+    part = (torch.empty((L.sivae_conv2d_wino4_num_px_tiles(B, H, W), Co, 2), dtype=torch.float32, device=DEV)
+            if stats else None)
+    lib.call("sivae_conv2d_wino4_fwd", ops._p(_d(x)), ops._p(up), ops._p(y), ops._p(part), B, Ci, Co, H, W,
+             int(accumulate), ops._s())
+    torch.cuda.synchronize()
+    if accumulate:
+        ref = ref + y0
+    tag = "wino4_%s%s%s" % ("fwd" if mode == 0 else "dgrad", "_acc" if accumulate else "", shape)
+    res.append((tag, _err(y, ref), WINO4_TOL))
+    if stats:
+        s = part.double().sum(0).cpu()
+        res.append((tag + "_stats_sum", _err(s[:, 0], ref.sum((0, 2, 3))), 4e-5))
+        res.append((tag + "_stats_sq", _err(s[:, 1], (ref * ref).sum((0, 2, 3))), 4e-5))
+        # rows are in image order (segmented BatchNorm statistics rely on it)
+        per_img = part.double().view(B, -1, Co, 2).sum(1).cpu()
+        res.append((tag + "_stats_rows", _err(per_img[..., 0], ref.sum((2, 3))), 4e-5))
+    return res
+
+
 def check_conv5_k75():
     """merged-contraction 5x5 kernel (<= 3 -> <= 64 channels): forward with BatchNorm partials / bias, ragged tiles,
     1-3 input channels, fewer than 64 outputs; and as the data gradient of a 64 -> 3 conv (flipped pack)"""
@@ -954,6 +996,10 @@ def all_checks():
                    + check_conv_up((2, 20, 33, 16, 32, 3), pro=True, stats=True)))
     checks.append(("up_dgrad_splitk", check_up_dgrad_splitk))
     checks.append(("conv5_k75", check_conv5_k75))
+    for s in [(2, 64, 64, 32, 32), (1, 64, 128, 16, 64), (3, 128, 64, 32, 32), (2, 32, 40, 16, 32), (1, 256, 256, 32, 32),
+              (2, 100, 72, 48, 64)]:
+        checks.append(("wino4%s" % (s,), lambda s=s: check_wino4(s, stats=True) + check_wino4(s, accumulate=True)
+                       + check_wino4(s, mode=1)))
     checks.append(("conv1x1_stream", check_conv1x1_stream))
     checks.append(("conv5_edge", check_conv5_edge))
     checks.append(("linear", check_linear))

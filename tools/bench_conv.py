@@ -51,7 +51,14 @@ for (Ci, Co, H, ks) in SHAPES:
                 pro = (torch.zeros(Ci, device="cuda"), torch.ones(Ci, device="cuda"), torch.ones(Ci, device="cuda"),
                        torch.zeros(Ci, device="cuda"), 0.2)
             t = timeit(lambda: ops.conv2d_fwd(x, wq, Co, ks, want_stats=True, pro=pro))
-            out += "  wino %7.3f ms %6.1f TF(alg) %5.1f TF(exec)" % (t, fl / t / 1e9, fl * 16 / 36 / t / 1e9)
+            if pro is None and ops.WINO4 and max(Ci, Co) <= ops.WINO4_MAXC and H % 32 == 0:
+                ops.WINO4 = False
+                t2 = timeit(lambda: ops.conv2d_fwd(x, wq, Co, ks, want_stats=True, pro=pro))
+                ops.WINO4 = True
+                out += "  F(4,3) %7.3f ms %6.1f TF(alg) %5.1f TF(exec) | F(2,3) %7.3f ms (x%.2f)" % (
+                    t, fl / t / 1e9, fl / 4 / t / 1e9, t2, t2 / t)
+            else:
+                out += "  wino %7.3f ms %6.1f TF(alg) %5.1f TF(exec)" % (t, fl / t / 1e9, fl * 16 / 36 / t / 1e9)
     if "up" in what and ks == 3 and H >= 32:
         xs_ = torch.randn(B, Ci, H // 2, H // 2, device="cuda")
         wq = ops.PackedW(w, 0)
