@@ -517,9 +517,16 @@ int sivae_conv2d_wino_wgrad_seg(const float* x, const float* dy, float* dw, cons
 size_t sivae_pack_wino4_weight_bytes(int Co, int Ci, int mode);
 int sivae_pack_wino4_weight(const float* w, float* up, int Co, int Ci, int mode, sivae_stream_t stream);
 int sivae_conv2d_wino4_supported(int H, int W);
+int sivae_conv2d_wino4_pays(int B, int Ci, int Co, int H, int W); /* supported AND >= one work item per CU */
 int sivae_conv2d_wino4_num_px_tiles(int B, int H, int W);
 int sivae_conv2d_wino4_fwd(const float* x, const float* up, float* y, float* stats_partial, int B, int Ci, int Co, int H,
                            int W, int accumulate, sivae_stream_t stream);
+/* the same with the producer BatchNorm2d + LeakyReLU fused into the input read (:58-59; pro_* as in sivae_conv2d_fwd);
+ * seg_images > 0: segmented batch with pro_mean / pro_invstd [B / seg_images][Ci]; segments * padded Ci <= 1024 */
+int sivae_conv2d_wino4_fwd_pro(const float* x, const float* up, float* y, const float* pro_mean, const float* pro_invstd,
+                               const float* pro_gamma, const float* pro_beta, float pro_slope, float* stats_partial,
+                               int B, int Ci, int Co, int H, int W, int accumulate, int seg_images,
+                               sivae_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -38,6 +38,15 @@ struct Wino4Args {
   const float* up;  // packed U [6(j)][Ci_pad][Co_pad][6(i)]
   float* y;
   float* stats;  // [n_px_tiles][Co][2] or null
+  // fused producer BatchNorm + LeakyReLU on the input (conv2 of a ResidualBlock reads LeakyReLU(BN1(conv1)) that is never
+  // written, train_soft_intro_vae.py:58-61): x' = max(v, slope*v), v = (x - mean[c]) * invstd[c]*gamma[c] + beta[c];
+  // segments: images [g*pro_seg_images, ...) use the statistics row g of pro_mean / pro_invstd ([pro_nseg][Ci])
+  const float* pro_mean;
+  const float* pro_invstd;
+  const float* pro_gamma;
+  const float* pro_beta;
+  float pro_slope;
+  int pro_seg_images, pro_nseg;
   int B, Ci, Co, H, W;
   int Ci_pad, Co_pad;
   int nbh, nbw;
@@ -63,6 +72,9 @@ __device__ __forceinline__ void buf_store_f32x4(__amdgpu_buffer_rsrc_t r, float4
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f), r, (int)voff, 0, 0);
 }
 
+#define W4_PRO_MAX 1024  // prologue table entries (segments x padded input channels)
+
+template <bool PRO>
 __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
   constexpr int CK = W4_CK, RS = W4_RS, PLANE = W4_PLANE, XBUF = W4_XBUF;
   // two SEPARATE static LDS arrays (not one dynamic block): the compiler orders a ds_read behind every in-flight
@@ -71,6 +83,8 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
   __shared__ __attribute__((aligned(16))) float xs0[XBUF];
   __shared__ __attribute__((aligned(16))) float xs1[XBUF];
 #define XS(BUF) ((BUF) ? xs1 : xs0)
+  // {mean, invstd*gamma, beta, -} per (segment, input channel); padded channels carry zeros (-> x' = 0)
+  __shared__ float4 pro4[PRO ? W4_PRO_MAX : 1];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,6 +132,7 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
   int b, r0, c0, co0, pt;
   __amdgpu_buffer_rsrc_t xrsrc;
   unsigned xo, ua_base;
+  int pseg = 0;  // table offset of the segment of the item whose halo is being requested
 #define W4_SETUP(ITEM)                                                   \
   {                                                                      \
     const int co_tile = (ITEM) % a.n_co_tiles;                           \
@@ -133,6 +148,29 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
     const int r = r0 - 1 + prow, c = c0 - 4 + 4 * pk;                    \
     xo = (pvalid && r >= 0 && r < H && c >= 0 && c < W) ? (unsigned)(r * W + c) * 4u : SIVAE_OOB; \
     ua_base = (unsigned)((wj * a.Ci_pad) * a.Co_pad + co0) * 24u;        \
+    if (PRO) pseg = (b / a.pro_seg_images) * a.Ci_pad;                   \
+  }
+  // The fused BatchNorm + LeakyReLU prologue: the halo arrives RAW in LDS (LDS-direct loads bypass the registers), so
+  // every thread rewrites the four 16-byte groups IT requested (no other thread touches them before the chunk's
+  // barrier): x' = max(v, slope * v) * inside-the-image, v = (x - mean) * scale + beta.  ~1.3 VALU per MFMA.
+#define W4_FIXUP(CH, BUF)                                                \
+  {                                                                      \
+    const float msk_ = xo != SIVAE_OOB ? 1.f : 0.f;                      \
+    _Pragma("unroll") for (int n_ = 0; n_ < 4; ++n_) {                   \
+      const int ck = dpl0 + 4 * n_;                                      \
+      float4* q_ = reinterpret_cast<float4*>(XS(BUF) + ck * PLANE + dsub * 256 + lane * 4); \
+      const float4 p_ = pro4[pseg + (CH)*CK + ck];                       \
+      float4 v_ = *q_;                                                   \
+      v_.x = fmaf(v_.x - p_.x, p_.y, p_.z);                              \
+      v_.y = fmaf(v_.y - p_.x, p_.y, p_.z);                              \
+      v_.z = fmaf(v_.z - p_.x, p_.y, p_.z);                              \
+      v_.w = fmaf(v_.w - p_.x, p_.y, p_.z);                              \
+      v_.x = fmaxf(v_.x, v_.x * a.pro_slope) * msk_;                     \
+      v_.y = fmaxf(v_.y, v_.y * a.pro_slope) * msk_;                     \
+      v_.z = fmaxf(v_.z, v_.z * a.pro_slope) * msk_;                     \
+      v_.w = fmaxf(v_.w, v_.w * a.pro_slope) * msk_;                     \
+      *q_ = v_;                                                          \
+    }                                                                    \
   }
   // halo chunk CH -> LDS buffer BUF (out-of-image / padding slots receive 0; channels beyond Ci re-read the last
   // one: their U is zero)
@@ -236,6 +274,13 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
     W4_FENCE                                                             \
     acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(U2[(KK)&1].y, VC[5], acc[5], 0, 0, 0); \
     W4_FENCE                                                             \
+    /* (k-step 5: the four halo pieces of the next chunk were requested in k-steps 0..3 — every load older than the */ \
+    /* U refills of k-steps 3 and 4 — and have landed by now: apply the prologue to them, before this k-step's refill) */ \
+    if (PRO && (KK) == 5) {                                              \
+      __builtin_amdgcn_s_waitcnt(0x0F70);                                \
+      W4_FIXUP(DCH, (BUF) ^ 1)                                           \
+      W4_FENCE                                                           \
+    }                                                                    \
     {                                                                    \
       const int ks2 = (CH) * (CK / 2) + (KK) + 2;                        \
       const bool in_item = ks2 < ksteps;                                 \
@@ -281,8 +326,20 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
     W4_CHUNK((CH) + 1, 1, USEE, dch_)                                    \
   }
 
+  if (PRO) {
+    for (int idx = tid; idx < a.pro_nseg * a.Ci_pad; idx += W4_NT) {
+      const int c = idx % a.Ci_pad, so = (idx / a.Ci_pad) * a.Ci;  // (segment g's statistics start at g * Ci)
+      pro4[idx] = c < a.Ci ? make_float4(a.pro_mean[so + c], a.pro_invstd[so + c] * a.pro_gamma[c], a.pro_beta[c], 0.f)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+  }
   W4_SETUP(item)
   W4_DMA(0, 0)
+  if (PRO) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    W4_FIXUP(0, 0)
+  }
   unsigned ua_cur = ua_base;
   W4_LOAD_A(ua_cur, 0, 0)
   W4_LOAD_A(ua_cur, 1, 1)
@@ -373,6 +430,7 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
     ua_cur = ua_base;
   }
 #undef W4_SETUP
+#undef W4_FIXUP
 #undef W4_DMA
 #undef W4_LOAD_A
 #undef W4_READ
@@ -449,6 +507,16 @@ extern "C" int sivae_conv2d_wino4_supported(int H, int W) {
   return (H >= 16 && W >= 32 && (H % W4_PXH) == 0 && (W % W4_PXW) == 0) ? 1 : 0;
 }
 
+// does the F(4x4,3x3) kernel beat F(2x2,3x3) for this launch?  Its work item is 64 channels x 512 pixels and a CU holds
+// ONE block: below one item per CU (the 512-channel 32x32 layers of an 8-image shard: 128 items) half the chip idles and
+// the F(2x2,3x3) kernel with its 4x smaller items and split-K wins (measured 0.78x); from one item per CU up it is
+// 1.27-1.57x (256x256 shard sizes 8 / 16 / 32 / 128 images).
+extern "C" int sivae_conv2d_wino4_pays(int B, int Ci, int Co, int H, int W) {
+  if (B <= 0 || Ci < 16 || Co <= 0 || !sivae_conv2d_wino4_supported(H, W)) return 0;
+  const long long items = (long long)B * (H / W4_PXH) * (W / W4_PXW) * ((Co + W4_TCO - 1) / W4_TCO);
+  return items >= sivae_num_cus() ? 1 : 0;
+}
+
 extern "C" int sivae_conv2d_wino4_num_px_tiles(int B, int H, int W) {
   if (B <= 0 || !sivae_conv2d_wino4_supported(H, W)) return SIVAE_ERR_SHAPE;
   return B * (H / W4_PXH) * (W / W4_PXW);
@@ -456,9 +524,13 @@ extern "C" int sivae_conv2d_wino4_num_px_tiles(int B, int H, int W) {
 
 // y[B][Co][H][W] (+)= conv3x3(x, U);  stats_partial (optional): [sivae_conv2d_wino4_num_px_tiles][Co][2] per-tile {sum, sumsq}
 // of y in image order (sivae_bn_stats_from_conv / _seg).  The data gradient is this function on dy with the mode-1 pack.
-extern "C" int sivae_conv2d_wino4_fwd(const float* x, const float* up, float* y, float* stats_partial, int B, int Ci,
-                                      int Co, int H, int W, int accumulate, hipStream_t stream) {
+static int wino4_impl(const float* x, const float* up, float* y, const float* pro_mean, const float* pro_invstd,
+                      const float* pro_gamma, const float* pro_beta, float pro_slope, float* stats_partial, int B, int Ci,
+                      int Co, int H, int W, int accumulate, int seg_images, hipStream_t stream) {
   if (!x || !up || !y) return SIVAE_ERR_NULL;
+  if (pro_mean && (!pro_invstd || !pro_gamma || !pro_beta)) return SIVAE_ERR_NULL;
+  if (pro_mean && !(pro_slope >= 0.f && pro_slope <= 1.f)) return SIVAE_ERR_MODE;  // prologue uses max(v, v*slope)
+  if (seg_images < 0 || (seg_images > 0 && B % seg_images != 0)) return SIVAE_ERR_SHAPE;
   if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
   if (!sivae_conv2d_wino4_supported(H, W)) return SIVAE_ERR_SHAPE;
   if (((uintptr_t)y & 15u) != 0) return SIVAE_ERR_SHAPE;  // 16-byte stores
@@ -469,6 +541,13 @@ extern "C" int sivae_conv2d_wino4_fwd(const float* x, const float* up, float* y,
   a.up = up;
   a.y = y;
   a.stats = stats_partial;
+  a.pro_mean = pro_mean;
+  a.pro_invstd = pro_invstd;
+  a.pro_gamma = pro_gamma;
+  a.pro_beta = pro_beta;
+  a.pro_slope = pro_slope;
+  a.pro_seg_images = seg_images > 0 ? seg_images : B;
+  a.pro_nseg = B / a.pro_seg_images;
   a.B = B;
   a.Ci = Ci;
   a.Co = Co;
@@ -476,6 +555,7 @@ extern "C" int sivae_conv2d_wino4_fwd(const float* x, const float* up, float* y,
   a.W = W;
   a.Ci_pad = w4_kpad(Ci);
   a.Co_pad = w4_npad(Co);
+  if (pro_mean && a.pro_nseg * a.Ci_pad > W4_PRO_MAX) return SIVAE_ERR_SHAPE;
   if (36ull * a.Ci_pad * a.Co_pad * 4ull >= 0xffffffffull) return SIVAE_ERR_RANGE;
   a.nbh = H / W4_PXH;
   a.nbw = W / W4_PXW;
@@ -488,6 +568,25 @@ extern "C" int sivae_conv2d_wino4_fwd(const float* x, const float* up, float* y,
   const int cus = sivae_num_cus();
   const int grid = nitems < cus ? (int)nitems : cus;
   a.xcd_group = (sivae_xcd_remap() && a.n_co_tiles > 1 && !(grid & 7)) ? 1 : 0;
-  hipLaunchKernelGGL(conv_wino4_kernel, dim3((unsigned)grid), dim3(W4_NT), 0, stream, a);
+  if (pro_mean)
+    hipLaunchKernelGGL(conv_wino4_kernel<true>, dim3((unsigned)grid), dim3(W4_NT), 0, stream, a);
+  else
+    hipLaunchKernelGGL(conv_wino4_kernel<false>, dim3((unsigned)grid), dim3(W4_NT), 0, stream, a);
   return sivae_launch_status();
+}
+
+extern "C" int sivae_conv2d_wino4_fwd(const float* x, const float* up, float* y, float* stats_partial, int B, int Ci,
+                                      int Co, int H, int W, int accumulate, hipStream_t stream) {
+  return wino4_impl(x, up, y, nullptr, nullptr, nullptr, nullptr, 1.f, stats_partial, B, Ci, Co, H, W, accumulate, 0,
+                    stream);
+}
+
+// with the producer BatchNorm + LeakyReLU fused into the input (pro_mean != NULL); seg_images > 0: segmented batch,
+// pro_mean / pro_invstd are [B / seg_images][Ci].  Ci_pad * segments <= 1024.
+extern "C" int sivae_conv2d_wino4_fwd_pro(const float* x, const float* up, float* y, const float* pro_mean,
+                                          const float* pro_invstd, const float* pro_gamma, const float* pro_beta,
+                                          float pro_slope, float* stats_partial, int B, int Ci, int Co, int H, int W,
+                                          int accumulate, int seg_images, hipStream_t stream) {
+  return wino4_impl(x, up, y, pro_mean, pro_invstd, pro_gamma, pro_beta, pro_slope, stats_partial, B, Ci, Co, H, W,
+                    accumulate, seg_images, stream);
 }

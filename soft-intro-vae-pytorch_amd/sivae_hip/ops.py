@@ -200,7 +200,8 @@ WINO_UP = os.environ.get("SIVAE_WINO_UP", "1") != "0"  # phase-decomposed F(2x2,
 # Winograd F(4x4,3x3) for the large-map 3x3 convs without a fused prologue (SIVAE_WINO4=0: F(2x2,3x3) everywhere);
 # SIVAE_WINO4_MAXC: largest channel count it takes (its U slab per 64-channel tile is 2.25x the F(2x2,3x3) one)
 WINO4 = os.environ.get("SIVAE_WINO4", "1") != "0"
-WINO4_MAXC = int(os.environ.get("SIVAE_WINO4_MAXC", "256"))
+WINO4_MAXC = int(os.environ.get("SIVAE_WINO4_MAXC", "512"))
+WINO4_PRO = os.environ.get("SIVAE_WINO4_PRO", "1") != "0"  # ... also with a fused BatchNorm prologue (conv2 forward)
 # SIVAE_FUSE_BN_BWD=1: reduce BatchNorm-1's backward sums in the epilogue of conv2's data gradient.  Measured a LOSS at
 # 256x256 bs128 (593 vs 585 ms per iteration: the extra tensor read sits on the kernel's critical path and disables its
 # next-item prefetch, which costs more than the 14 ms reduction pass it removes) -> off by default.
@@ -394,20 +395,29 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
         if t0 is not None:
             TIMER.end("conv1x1_stream_kernel", 2.0 * B * H * W * Co * Ci, t0)
         return y
-    if (WINO and WINO4 and ks == 3 and bias is None and pro is None and not upsample and isinstance(wp, PackedW)
-            and max(Ci, Co) <= WINO4_MAXC and Ci >= 16 and L.sivae_conv2d_wino4_supported(H, W) == 1):
-        # large maps, no fused prologue: F(4x4,3x3) — 2.25 multiplies per output pixel instead of 4
+    if (WINO and WINO4 and ks == 3 and bias is None and not upsample and isinstance(wp, PackedW)
+            and max(Ci, Co) <= WINO4_MAXC and L.sivae_conv2d_wino4_pays(B, Ci, Co, H, W) == 1
+            and (pro is None or (WINO4_PRO and nseg * ((Ci + 31) // 32) * 32 <= 1024))):
+        # large maps: F(4x4,3x3) — 2.25 multiplies per output pixel instead of 4
         _require(x, out)
         y = out if out is not None else torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
         assert y.shape == (B, Co, H, W) and y.is_contiguous()
         stats = (torch.empty((L.sivae_conv2d_wino4_num_px_tiles(B, H, W), Co, 2), dtype=torch.float32, device=x.device)
                  if want_stats else None)
         t0 = TIMER.begin() if TIMER is not None else None
-        _lib.call("sivae_conv2d_wino4_fwd", _p(x), _p(wp.wino4()), _p(y), _p(stats), B, Ci, Co, H, W,
-                  int(bool(accumulate)), _s(x))
+        if pro is not None:
+            pm, pi, pg, pb, slope = pro
+            _require(pm, pi, pg, pb)
+            _lib.call("sivae_conv2d_wino4_fwd_pro", _p(x), _p(wp.wino4()), _p(y), _p(pm), _p(pi), _p(pg), _p(pb),
+                      float(slope), _p(stats), B, Ci, Co, H, W, int(bool(accumulate)), (B // nseg) if nseg > 1 else 0,
+                      _s(x))
+        else:
+            _lib.call("sivae_conv2d_wino4_fwd", _p(x), _p(wp.wino4()), _p(y), _p(stats), B, Ci, Co, H, W,
+                      int(bool(accumulate)), _s(x))
         if t0 is not None:
             flops = 2.0 * B * H * W * Co * Ci * 9
-            TIMER.end("conv_wino4_kernel", flops, t0, executed=flops * 36.0 / 144.0)
+            TIMER.end("conv_wino4_kernel<%s>" % ("true" if pro is not None else "false"), flops, t0,
+                      executed=flops * 36.0 / 144.0)
         return (y, stats) if want_stats else y
     wino = (WINO and ks == 3 and bias is None and isinstance(wp, PackedW)
             and L.sivae_conv2d_wino_supported(H, W) == 1)

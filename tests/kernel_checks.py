@@ -622,7 +622,8 @@ def check_wino4(shape, accumulate=False, stats=False, mode=0):
     y = _d(y0) if accumulate else torch.empty((B, Co, H, W), dtype=torch.float32, device=DEV)
     part = (torch.empty((L.sivae_conv2d_wino4_num_px_tiles(B, H, W), Co, 2), dtype=torch.float32, device=DEV)
             if stats else None)
-    lib.call("sivae_conv2d_wino4_fwd", ops._p(_d(x)), ops._p(up), ops._p(y), ops._p(part), B, Ci, Co, H, W,
+    xd = _d(x)  # (named: a temporary would be freed — and its block reused — before the launch reads it)
+    lib.call("sivae_conv2d_wino4_fwd", ops._p(xd), ops._p(up), ops._p(y), ops._p(part), B, Ci, Co, H, W,
              int(accumulate), ops._s())
     torch.cuda.synchronize()
     if accumulate:
@@ -637,6 +638,38 @@ def check_wino4(shape, accumulate=False, stats=False, mode=0):
         per_img = part.double().view(B, -1, Co, 2).sum(1).cpu()
         res.append((tag + "_stats_rows", _err(per_img[..., 0], ref.sum((2, 3))), 4e-5))
     return res
+
+
+def check_wino4_pro(shape, nseg=1):
+    """F(4x4,3x3) with the fused BatchNorm + LeakyReLU prologue (and per-segment statistics) vs fp64"""
+    from sivae_hip import ops
+    B, Ci, Co, H, W = shape
+    x = _rand(B, Ci, H, W, seed=1)
+    w = _rand(Co, Ci, 3, 3, seed=2, scale=1.0 / math.sqrt(Ci * 9))
+    mean = _rand(nseg, Ci, seed=3, scale=0.3)
+    invstd = (_rand(nseg, Ci, seed=4).abs() + 0.5)
+    gamma = _rand(Ci, seed=5) + 1.0
+    beta = _rand(Ci, seed=6, scale=0.2)
+    Bs = B // nseg
+    xs = []
+    for g in range(nseg):
+        v = (x[g * Bs:(g + 1) * Bs] - mean[g].view(1, -1, 1, 1)) * (invstd[g] * gamma).view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+        xs.append(torch.where(v > 0, v, 0.2 * v))
+    ref = _conv_ref(torch.cat(xs), w)
+    from sivae_hip import lib
+    L = lib.load()
+    wp = ops.PackedW(_d(w), 0)
+    y = torch.empty((B, Co, H, W), dtype=torch.float32, device=DEV)
+    part = torch.empty((L.sivae_conv2d_wino4_num_px_tiles(B, H, W), Co, 2), dtype=torch.float32, device=DEV)
+    pm, pi, pg, pb = _d(mean.reshape(-1)), _d(invstd.reshape(-1)), _d(gamma), _d(beta)
+    xd, up = _d(x), wp.wino4()  # (named: a temporary would be freed — and its block reused — before the launch reads it)
+    # (straight through the C ABI: ops.conv2d_fwd only picks this kernel from one work item per CU up)
+    lib.call("sivae_conv2d_wino4_fwd_pro", ops._p(xd), ops._p(up), ops._p(y), ops._p(pm), ops._p(pi), ops._p(pg),
+             ops._p(pb), 0.2, ops._p(part), B, Ci, Co, H, W, 0, (B // nseg) if nseg > 1 else 0, ops._s())
+    torch.cuda.synchronize()
+    tag = "wino4_pro%s%s" % ("_seg%d" % nseg if nseg > 1 else "", shape)
+    s_ = part.double().sum(0).cpu()
+    return [(tag, _err(y, ref), WINO4_TOL), (tag + "_stats_sum", _err(s_[:, 0], ref.sum((0, 2, 3))), 4e-5)]
 
 
 def check_conv5_k75():
@@ -1000,6 +1033,8 @@ def all_checks():
               (2, 100, 72, 48, 64)]:
         checks.append(("wino4%s" % (s,), lambda s=s: check_wino4(s, stats=True) + check_wino4(s, accumulate=True)
                        + check_wino4(s, mode=1)))
+    for s in [(2, 64, 64, 32, 32), (4, 128, 64, 16, 32), (2, 100, 72, 48, 64), (2, 512, 64, 16, 32)]:
+        checks.append(("wino4_pro%s" % (s,), lambda s=s: check_wino4_pro(s) + check_wino4_pro(s, nseg=2)))
     checks.append(("conv1x1_stream", check_conv1x1_stream))
     checks.append(("conv5_edge", check_conv5_edge))
     checks.append(("linear", check_linear))

@@ -41,8 +41,12 @@ def _maxrel(a, b):
 
 @pytest.mark.parametrize("channels,image_size,B", [([16, 32, 64], 32, 8), ([8, 16, 32, 64, 64], 128, 4),
                                                    ([8, 16, 32, 64, 64, 64], 256, 4)])
-def test_encoder_pair_equals_two_passes(channels, image_size, B):
+def test_encoder_pair_equals_two_passes(channels, image_size, B, monkeypatch):
     os.environ["SIVAE_WINO_SPLITK"] = "0"  # (read once per process by the library: harmless if already decided)
+    # the kernel a layer runs on depends on its batch (F(4x4,3x3) from one work item per CU up): B and 2B images may pick
+    # different ones, 1e-5 apart.  This test is about the SEGMENT semantics, so it pins the 3x3 convs to F(2x2,3x3)
+    from sivae_hip import ops
+    monkeypatch.setattr(ops, "WINO4", False)
     m = _models(channels, image_size, 32)
     enc = m.encoder
     g = torch.Generator().manual_seed(5)
@@ -105,7 +109,9 @@ def test_encoder_pair_bit_identical_without_splitk():
 
 
 @pytest.mark.parametrize("channels,image_size,B", [([16, 32, 64], 32, 8), ([8, 16, 32, 64, 64, 64], 256, 4)])
-def test_decoder_pair_equals_two_passes(channels, image_size, B):
+def test_decoder_pair_equals_two_passes(channels, image_size, B, monkeypatch):
+    from sivae_hip import ops
+    monkeypatch.setattr(ops, "WINO4", False)  # (see test_encoder_pair_equals_two_passes)
     m = _models(channels, image_size, 32, seed=1)
     dec = m.decoder
     g = torch.Generator().manual_seed(6)
@@ -163,12 +169,14 @@ def test_segment_reverse_order_updates_running_stats_last_first():
 
 @pytest.mark.parametrize("boot", [False, True])
 @pytest.mark.parametrize("channels,image_size,B,zdim", [([16, 32, 64], 32, 8, 32), ([8, 16, 32, 64, 64, 64], 256, 4, 64)])
-def test_iteration_with_pairs_equals_iteration_without(channels, image_size, B, zdim, boot):
+def test_iteration_with_pairs_equals_iteration_without(channels, image_size, B, zdim, boot, monkeypatch):
     """the engine with the pass pairs on (segmented batches) against the engine with them off, from the same weights,
     inputs and Gaussian draws: every forward quantity and loss to fp32 rounding, BatchNorm buffers, gradients to 2e-4
     relative L2 (one weight-gradient launch per pair sums the two passes in another order)"""
+    from sivae_hip import ops
     from sivae_hip.engine import SoftIntroEngine
     from sivae_hip.optim import FlatAdam
+    monkeypatch.setattr(ops, "WINO4", False)  # (see test_encoder_pair_equals_two_passes)
     hp = dict(beta_kl=1.0, beta_rec=1.0, beta_neg=256.0, gamma_r=1.0 if boot else 1e-8)
     g = torch.Generator().manual_seed(11)
     real = torch.rand(B, 3, image_size, image_size, generator=g).to(DEV)
