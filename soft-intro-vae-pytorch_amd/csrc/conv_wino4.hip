@@ -174,8 +174,13 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
   }
   // halo chunk CH -> LDS buffer BUF (out-of-image / padding slots receive 0; channels beyond Ci re-read the last
   // one: their U is zero)
+// Timing ablations (compile with -DW4_ABLATE=<bits>; results are WRONG with any bit set — tools/r3_w4_ablate.sh):
+//   1 no halo loads in the K loop, 2 no U refills, 4 no output transform / stores, 8 no chunk barriers
+#ifndef W4_ABLATE
+#define W4_ABLATE 0
+#endif
 #define W4_DMA1(CH, BUF, N)                                              \
-  {                                                                      \
+  if (!((W4_ABLATE & 1) && item >= 0)) {                                 \
     const int ck = dpl0 + 4 * (N);                                       \
     const int ci = (CH)*CK + ck;                                         \
     const int cic = ci < a.Ci ? ci : a.Ci - 1;                           \
@@ -194,8 +199,12 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
   f32x16 acc[6];
   float4 U4[2];
   float2 U2[2];
+#if W4_ABLATE & 2
+  U4[0] = U4[1] = make_float4(1.f, 0.5f, 0.25f, 2.f);
+  U2[0] = U2[1] = make_float2(1.f, 0.5f);
+#endif
 #define W4_LOAD_A(UBASE, KS_ABS, SLOT)                                   \
-  {                                                                      \
+  if (!(W4_ABLATE & 2)) {                                                \
     const unsigned so = (UBASE) + (unsigned)(2 * (KS_ABS)) * ua_step;    \
     U4[SLOT] = buf_load_f32x4(ursrc, va0, so);                           \
     U2[SLOT] = buf_load_f32x2(ursrc, va0 + 16u, so);                     \
@@ -312,7 +321,7 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
     /* vmcnt(4): everything but the four U loads of k-steps 6 and 7 — i.e. this wave's share of the next halo chunk — */ \
     /* has landed (a vmcnt(0) here would expose the L2 latency of those U loads once per chunk) */ \
     __builtin_amdgcn_s_waitcnt(0x0F74);                                  \
-    __syncthreads();                                                     \
+    if (!(W4_ABLATE & 8)) __syncthreads();                               \
   }
   // two chunks (halo buffers 0 then 1); the halo of the chunk after next is requested as soon as its buffer is free —
   // at the end of an item that is the first chunk of the NEXT item
@@ -364,7 +373,7 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
     // ---- output transform.  acc[i][r]: frequency (i, wj), tile = l31, channel = ws*32 + (r&3) + 8*(r>>2) + 4*hh.
     // Round a = output row a of every tile: Z[a][j] = sum_i A^T[a][i] M[i][j] in registers -> ex[j][s][r][lane] (48 KB,
     // the halo buffer the item finished on); then pair q = (s, r) of this wave: Y[a][0..3] = Z[a][.] A, one 16-byte store.
-    {
+    if (!(W4_ABLATE & 4)) {
       float* ex = xs1;
       const __amdgpu_buffer_rsrc_t yrsrc =
           make_rsrc(a.y + (size_t)e_b * a.Co * HW, (unsigned long long)a.Co * HW * 4ull);
