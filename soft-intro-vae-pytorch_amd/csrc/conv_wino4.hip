@@ -56,11 +56,13 @@ struct Wino4Args {
   int xcd_group;
 };
 
-#define W4_CK 16
+#define W4_CK 8
 #define W4_RS 40
 #define W4_LH 18
-#define W4_PLANE 768  // 18 rows x 40 = 720, padded to 12 waves x 64 lanes: a wave's LDS-direct load fills 64 slots
-#define W4_XBUF (W4_CK * W4_PLANE)
+#define W4_PLANE 768  // 18 rows x 40 = 720, padded to 3 x 64 groups of 16 bytes: a wave's LDS-direct load fills 64 groups
+#define W4_XBUF (W4_CK * W4_PLANE)  // raw halo of one chunk: 6144 floats (24 KB)
+#define W4_VBUF (36 * W4_CK * 32)   // transformed chunk V[freq][ch][tile]: 9216 floats (36 KB)
+#define W4_EXF 12288                // output-transform exchange: 48 KB = the second V buffer + 12 KB behind it
 #define W4_NT 768
 #define W4_TCO 64
 #define W4_PXH 16
@@ -74,15 +76,37 @@ __device__ __forceinline__ void buf_store_f32x4(__amdgpu_buffer_rsrc_t r, float4
 
 #define W4_PRO_MAX 1024  // prologue table entries (segments x padded input channels)
 
+// Timing ablations (compile with -DW4_ABLATE=<bits>; results are WRONG with any bit set — tools/r3_w4_ablate.sh):
+//   1 no halo loads in the K loop, 2 no U refills, 8 no chunk barriers
+#ifndef W4_ABLATE
+#define W4_ABLATE 0
+#endif
+
+// Structure (round 3, second form).  On gfx950 the fp32 "matrix" instruction runs at the fp32 VECTOR rate and — measured
+// here: a k-step costs 18 MFMA x 64 + (all other VALU of the SIMD's three waves) x 4 cycles — its time and the time of
+// ordinary VALU instructions on the same SIMD ADD.  The first form of this kernel let every wave transform its own B
+// operand from the raw halo (7.5 VALU per MFMA: +47 %).  Now the input transform is done ONCE per block and chunk:
+//   * transform role: thread = (tile, channel, column pair) — the frequency columns come in pairs that share their
+//     partial sums ((1,2): (d4-4d2) +- (d3-4d1); (3,4): (d4-d2) +- 2(d3-d1); (0,5) stand alone) — reads six patch rows
+//     (one aligned 16-byte ds_read each, + two dwords for the (0,5) pair), and writes its 12 transformed values to
+//     V[freq][channel][tile] in LDS: ~54 VALU per thread and chunk = 2.25 per MFMA;
+//   * MFMA role: wave (j, s) = frequency column j x 32-channel subtile s as before (6 accumulators = 96 registers, three
+//     waves per SIMD, one block per CU); its B operand is ONE conflict-free ds_read_b32 per MFMA out of V, its A operand
+//     (U, packed [j][ci][co][i]) a 16-byte + an 8-byte buffer load per k-step, two k-steps ahead.
+// Pipeline per 8-channel chunk c (one barrier): MFMAs on V[c & 1]  ||  transform of the raw halo of chunk c+1 (slices
+// between the MFMAs) into V[(c+1) & 1]  ||  LDS-direct 16-byte loads of the halo of chunk c+2 (two per wave) into the raw
+// buffer chunk c's transform freed; across work items the chunk numbering simply continues (the first two chunks of the
+// NEXT item are requested / transformed during the last two chunks of the current one).  With the fused BatchNorm +
+// LeakyReLU prologue every thread rewrites the two groups it requested before the barrier publishes them.
 template <bool PRO>
 __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
-  constexpr int CK = W4_CK, RS = W4_RS, PLANE = W4_PLANE, XBUF = W4_XBUF;
-  // two SEPARATE static LDS arrays (not one dynamic block): the compiler orders a ds_read behind every in-flight
-  // LDS-direct load it cannot prove disjoint (vmcnt(0) before the read); reads of one halo buffer and the loads that fill
-  // the OTHER are disjoint objects this way
-  __shared__ __attribute__((aligned(16))) float xs0[XBUF];
-  __shared__ __attribute__((aligned(16))) float xs1[XBUF];
-#define XS(BUF) ((BUF) ? xs1 : xs0)
+  constexpr int CK = W4_CK, RS = W4_RS, PLANE = W4_PLANE, XBUF = W4_XBUF, VBUF = W4_VBUF;
+  // the two raw-halo buffers are SEPARATE static arrays: the compiler orders a ds_read behind every in-flight LDS-direct
+  // load it cannot prove disjoint (vmcnt(0) before the read); the transform reads one buffer while the loads fill the other
+  __shared__ __attribute__((aligned(16))) float raw0[XBUF];
+  __shared__ __attribute__((aligned(16))) float raw1[XBUF];
+  __shared__ __attribute__((aligned(16))) float vx[VBUF + W4_EXF];  // V0 | V1 + spare (= the epilogue's exchange area)
+#define RAWB(BUF) ((BUF) ? raw1 : raw0)
   // {mean, invstd*gamma, beta, -} per (segment, input channel); padded channels carry zeros (-> x' = 0)
   __shared__ float4 pro4[PRO ? W4_PRO_MAX : 1];
 
@@ -93,32 +117,28 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
   const int H = a.H, W = a.W, HW = H * W;
   const int tx = l31 & 7, ty = l31 >> 3;
 
-  // column j of B (= row j of B^T) as five wave-uniform coefficients: t = ce*e + c1*d1 + c2*d2 + c3*d3 + c4*d4, where e is
-  // patch column 0 (j == 0) or 5 (j == 5)
-  float ce = 0.f, c1, c2, c3, c4;
-  int eoff = -1;
-  switch (wj) {
-    case 0: ce = 4.f; c1 = 0.f; c2 = -5.f; c3 = 0.f; c4 = 1.f; break;
-    case 1: c1 = -4.f; c2 = -4.f; c3 = 1.f; c4 = 1.f; break;
-    case 2: c1 = 4.f; c2 = -4.f; c3 = -1.f; c4 = 1.f; break;
-    case 3: c1 = -2.f; c2 = -1.f; c3 = 2.f; c4 = 1.f; break;
-    case 4: c1 = 2.f; c2 = -1.f; c3 = -2.f; c4 = 1.f; break;
-    default: ce = 1.f; c1 = 4.f; c2 = 0.f; c3 = -5.f; c4 = 0.f; eoff = 4; break;
-  }
-  const bool use_e = wj == 0 || wj == 5;
-  // raw-read base (floats): channel plane hh, tile row 4*ty, patch column 1 at LDS column 4*tx + 4
-  const int rb = hh * PLANE + 4 * ty * RS + 4 * tx + 4;
+  // ---- transform role: column pair tp, item (tile tt, channel tc) of the chunk
+  const int tp = wave >> 2;                       // 0: columns (1,2)   1: columns (3,4)   2: columns (0,5)
+  const int ti = (wave & 3) * 64 + lane, tt = ti & 31, tc = ti >> 5;
+  const int trb = tc * PLANE + 4 * (tt >> 3) * RS + 4 * (tt & 7) + 4;  // patch column 1 at LDS column 4*tx + 4
+  const int jA = tp == 0 ? 1 : (tp == 1 ? 3 : 0), jB = tp == 0 ? 2 : (tp == 1 ? 4 : 5);
+  const int tvb = tc * 32 + tt;
+  const float t_al = tp == 0 ? -4.f : -1.f;  // a = d4 + al*d2
+  const float t_be = tp == 0 ? 1.f : 2.f;    // b = be*d3 + ga*d1
+  const float t_ga = tp == 0 ? -4.f : -2.f;
+  const bool pair05 = tp == 2;
+  // ---- MFMA role: B operand V[(i*6 + wj)][2*kk + hh][l31]
+  const int vrb = (wj * CK + hh) * 32 + l31;
 
-  // halo slots of this thread.  A channel plane is 192 groups of four consecutive floats (18 rows x 10 groups + padding);
-  // one 16-byte LDS-direct load per lane moves a group, so a plane is three wave-instructions: wave w fills third
-  // w % 3 of the planes w / 3 + 4n (n = 0..3) of a chunk — four instructions per wave and chunk.  Group k of a row holds
-  // the image columns c0 - 4 + 4k .. + 3: entirely inside or entirely outside the image (W % 32 == 0).
+  // ---- halo role: a channel plane is 192 groups of four floats (18 rows x 10 groups + padding), three wave-instructions;
+  // wave w fills third w % 3 of the planes w / 3 + 4n (n = 0, 1).  Group k of a row = image columns c0 - 4 + 4k .. + 3:
+  // entirely inside or entirely outside the image (W % 32 == 0).
   const int dsub = wave % 3, dpl0 = wave / 3;
   const int pg = dsub * 64 + lane, prow = pg / 10, pk = pg - prow * 10;
   const bool pvalid = pg < 180;
 
   const int n_items = a.n_items;
-  const int nchunks = a.Ci_pad / CK;  // even (Ci_pad is a multiple of 32)
+  const int nchunks = a.Ci_pad / CK;  // a multiple of 4 (Ci_pad is a multiple of 32)
   const int ksteps = nchunks * (CK / 2);
   const __amdgpu_buffer_rsrc_t ursrc = make_rsrc(a.up, 36ull * a.Ci_pad * a.Co_pad * 4ull);
   const unsigned va0 = (unsigned)(hh * a.Co_pad + ws * 32 + l31) * 24u;
@@ -150,15 +170,26 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
     ua_base = (unsigned)((wj * a.Ci_pad) * a.Co_pad + co0) * 24u;        \
     if (PRO) pseg = (b / a.pro_seg_images) * a.Ci_pad;                   \
   }
+  // piece N (0, 1) of halo chunk CH -> raw buffer BUF (out-of-image / padding groups receive 0; channels beyond Ci
+  // re-read the last one: their U is zero)
+#define W4_DMA1(CH, BUF, N)                                              \
+  if (!((W4_ABLATE & 1) && item >= 0)) {                                 \
+    const int ck = dpl0 + 4 * (N);                                       \
+    const int ci = (CH)*CK + ck;                                         \
+    const int cic = ci < a.Ci ? ci : a.Ci - 1;                           \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(                            \
+        xrsrc, (float __attribute__((address_space(3)))*)(RAWB(BUF) + ck * PLANE + dsub * 256), 16, xo, \
+        (unsigned)cic * (unsigned)HW * 4u, 0, 0);                        \
+  }
   // The fused BatchNorm + LeakyReLU prologue: the halo arrives RAW in LDS (LDS-direct loads bypass the registers), so
-  // every thread rewrites the four 16-byte groups IT requested (no other thread touches them before the chunk's
-  // barrier): x' = max(v, slope * v) * inside-the-image, v = (x - mean) * scale + beta.  ~1.3 VALU per MFMA.
+  // every thread rewrites the two 16-byte groups IT requested (no other thread touches them before the chunk's barrier):
+  // x' = max(v, slope * v) * inside-the-image, v = (x - mean) * scale + beta.
 #define W4_FIXUP(CH, BUF)                                                \
   {                                                                      \
     const float msk_ = xo != SIVAE_OOB ? 1.f : 0.f;                      \
-    _Pragma("unroll") for (int n_ = 0; n_ < 4; ++n_) {                   \
+    _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_) {                   \
       const int ck = dpl0 + 4 * n_;                                      \
-      float4* q_ = reinterpret_cast<float4*>(XS(BUF) + ck * PLANE + dsub * 256 + lane * 4); \
+      float4* q_ = reinterpret_cast<float4*>(RAWB(BUF) + ck * PLANE + dsub * 256 + lane * 4); \
       const float4 p_ = pro4[pseg + (CH)*CK + ck];                       \
       float4 v_ = *q_;                                                   \
       v_.x = fmaf(v_.x - p_.x, p_.y, p_.z);                              \
@@ -172,29 +203,6 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
       *q_ = v_;                                                          \
     }                                                                    \
   }
-  // halo chunk CH -> LDS buffer BUF (out-of-image / padding slots receive 0; channels beyond Ci re-read the last
-  // one: their U is zero)
-// Timing ablations (compile with -DW4_ABLATE=<bits>; results are WRONG with any bit set — tools/r3_w4_ablate.sh):
-//   1 no halo loads in the K loop, 2 no U refills, 4 no output transform / stores, 8 no chunk barriers
-#ifndef W4_ABLATE
-#define W4_ABLATE 0
-#endif
-#define W4_DMA1(CH, BUF, N)                                              \
-  if (!((W4_ABLATE & 1) && item >= 0)) {                                 \
-    const int ck = dpl0 + 4 * (N);                                       \
-    const int ci = (CH)*CK + ck;                                         \
-    const int cic = ci < a.Ci ? ci : a.Ci - 1;                           \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(                            \
-        xrsrc, (float __attribute__((address_space(3)))*)(XS(BUF) + ck * PLANE + dsub * 256), 16, xo, \
-        (unsigned)cic * (unsigned)HW * 4u, 0, 0);                        \
-  }
-#define W4_DMA(CH, BUF)                                                  \
-  {                                                                      \
-    W4_DMA1(CH, BUF, 0)                                                  \
-    W4_DMA1(CH, BUF, 1)                                                  \
-    W4_DMA1(CH, BUF, 2)                                                  \
-    W4_DMA1(CH, BUF, 3)                                                  \
-  }
 
   f32x16 acc[6];
   float4 U4[2];
@@ -203,136 +211,146 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
   U4[0] = U4[1] = make_float4(1.f, 0.5f, 0.25f, 2.f);
   U2[0] = U2[1] = make_float2(1.f, 0.5f);
 #endif
+  // (the U refill is UNCONDITIONAL with a selected base / clamped index: a load inside an `if` makes hipcc assume no
+  // younger load is outstanding at the join and turns every later wait into vmcnt(0))
 #define W4_LOAD_A(UBASE, KS_ABS, SLOT)                                   \
   if (!(W4_ABLATE & 2)) {                                                \
     const unsigned so = (UBASE) + (unsigned)(2 * (KS_ABS)) * ua_step;    \
     U4[SLOT] = buf_load_f32x4(ursrc, va0, so);                           \
     U2[SLOT] = buf_load_f32x2(ursrc, va0 + 16u, so);                     \
   }
-  // raw reads of k-step KK: six rows x (patch columns 1..4 as one 16-byte read + column 0 or 5)
-#define W4_READ(BUF, KK, D, E, USEE)                                     \
+#define W4_REFILL(CH, KK)                                                \
   {                                                                      \
-    const float* p_ = XS(BUF) + 2 * (KK)*PLANE + rb;                     \
-    _Pragma("unroll") for (int r = 0; r < 6; ++r) {                      \
-      D[r] = *reinterpret_cast<const float4*>(p_ + r * RS);              \
-      /* (only frequency columns 0 and 5 touch patch column 0 / 5; a 4-way bank conflict: tiles are 4 dwords apart) */ \
-      E[r] = (USEE) ? p_[r * RS + eoff] : 0.f;                           \
-    }                                                                    \
+    const int ks2 = (CH) * (CK / 2) + (KK) + 2;                          \
+    const bool in_item = ks2 < ksteps;                                   \
+    const unsigned ub_ = (in_item || !has_next) ? ua_cur : ua_base;      \
+    const int kq_ = in_item ? ks2 : (has_next ? ks2 - ksteps : ksteps - 1); \
+    W4_LOAD_A(ub_, kq_, (KK)&1)                                          \
   }
-  // V = B^T (d . B[:, j]) for the wave's frequency column
-#define W4_XFORM(D, E, V)                                                \
-  {                                                                      \
-    float t[6];                                                          \
-    _Pragma("unroll") for (int r = 0; r < 6; ++r)                        \
-      t[r] = fmaf(ce, E[r], fmaf(c1, D[r].x, fmaf(c2, D[r].y, fmaf(c3, D[r].z, c4 * D[r].w)))); \
-    const float A_ = fmaf(-4.f, t[2], t[4]), B_ = fmaf(-4.f, t[1], t[3]); \
-    const float C_ = t[4] - t[2], D_ = t[3] - t[1];                      \
-    V[0] = fmaf(4.f, t[0], fmaf(-5.f, t[2], t[4]));                      \
-    V[1] = A_ + B_;                                                      \
-    V[2] = A_ - B_;                                                      \
-    V[3] = fmaf(2.f, D_, C_);                                            \
-    V[4] = fmaf(-2.f, D_, C_);                                           \
-    V[5] = fmaf(4.f, t[1], fmaf(-5.f, t[3], t[5]));                      \
-  }
-  // One k-step = six MFMA slots.  The three waves of a SIMD run in lockstep (one barrier per chunk), so a wave that
-  // issued its six MFMAs back to back and THEN did its ~45 VALU / LDS operations left the matrix pipe idle for that long
-  // on every k-step (measured: 50 % busy).  Instead the transform of the NEXT k-step's rows is cut into slices that sit
-  // between this k-step's MFMAs (fenced scheduling regions — hipcc does not interleave them by itself): slot 0-2 the
-  // column dot products of two rows each, slot 3 the first half of B^T t and the request for the rows after next, slot 4
-  // the second half, slot 5 the U refill (k-step + 2) and one 16-byte piece of the next halo chunk.
-  // (the U refill is UNCONDITIONAL with a selected base / clamped index: a load inside an `if` makes hipcc assume no
-  // younger load is outstanding at the join and turns every later wait into vmcnt(0))
 #define W4_FENCE __builtin_amdgcn_sched_barrier(0);
-#define W4_DOT(USEE, R)                                                  \
-  ((USEE) ? fmaf(ce, e_[R], fmaf(c1, d_[R].x, fmaf(c2, d_[R].y, fmaf(c3, d_[R].z, c4 * d_[R].w)))) \
-          : fmaf(c1, d_[R].x, fmaf(c2, d_[R].y, fmaf(c3, d_[R].z, c4 * d_[R].w))))
-#define W4_KSTEP(CH, BUF, KK, USEE, DCH, VC, VN)                         \
+  // B operands of k-step KK of the transformed chunk in V buffer VB
+#define W4_READB(VB, KK, BV)                                             \
   {                                                                      \
-    constexpr bool nx_ = (KK) + 1 < CK / 2;                              \
-    float t0_ = 0.f, t1_ = 0.f, t2_ = 0.f, t3_ = 0.f, t4_ = 0.f, t5_ = 0.f; \
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(U4[(KK)&1].x, VC[0], acc[0], 0, 0, 0); \
-    W4_FENCE                                                             \
-    if (nx_) { t0_ = W4_DOT(USEE, 0); t1_ = W4_DOT(USEE, 1); }           \
-    W4_FENCE                                                             \
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(U4[(KK)&1].y, VC[1], acc[1], 0, 0, 0); \
-    W4_FENCE                                                             \
-    if (nx_) { t2_ = W4_DOT(USEE, 2); t3_ = W4_DOT(USEE, 3); }           \
-    W4_FENCE                                                             \
-    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(U4[(KK)&1].z, VC[2], acc[2], 0, 0, 0); \
-    W4_FENCE                                                             \
-    if (nx_) { t4_ = W4_DOT(USEE, 4); t5_ = W4_DOT(USEE, 5); }           \
-    W4_FENCE                                                             \
-    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(U4[(KK)&1].w, VC[3], acc[3], 0, 0, 0); \
-    W4_FENCE                                                             \
-    if ((KK) + 2 < CK / 2) W4_READ(BUF, (KK) + 2, d_, e_, USEE)          \
-    if (nx_) {                                                           \
-      const float A_ = fmaf(-4.f, t2_, t4_), B_ = fmaf(-4.f, t1_, t3_);  \
-      VN[0] = fmaf(4.f, t0_, fmaf(-5.f, t2_, t4_));                      \
-      VN[1] = A_ + B_;                                                   \
-      VN[2] = A_ - B_;                                                   \
+    const float* p_ = vx + (VB)*VBUF + 2 * (KK)*32 + vrb;                \
+    _Pragma("unroll") for (int i = 0; i < 6; ++i) BV[i] = p_[i * 6 * CK * 32]; \
+  }
+  // ---- transform slices.  Rows R0..R0+2 of this thread's patch -> the pair's column dot products tA[r], tB[r]
+#define W4_TREAD(RB, R0, P05)                                               \
+  {                                                                      \
+    const float* p_ = RAWB(RB) + trb + (R0)*RS;                          \
+    _Pragma("unroll") for (int r = 0; r < 3; ++r) {                      \
+      td_[r] = *reinterpret_cast<const float4*>(p_ + r * RS);            \
+      if (P05) {                                                         \
+        te0_[r] = p_[r * RS - 1];                                        \
+        te5_[r] = p_[r * RS + 4];                                        \
+      }                                                                  \
     }                                                                    \
-    W4_FENCE                                                             \
-    acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(U2[(KK)&1].x, VC[4], acc[4], 0, 0, 0); \
-    W4_FENCE                                                             \
-    if (nx_) {                                                           \
-      const float C_ = t4_ - t2_, D_ = t3_ - t1_;                        \
-      VN[3] = fmaf(2.f, D_, C_);                                         \
-      VN[4] = fmaf(-2.f, D_, C_);                                        \
-      VN[5] = fmaf(4.f, t1_, fmaf(-5.f, t3_, t5_));                      \
+  }
+#define W4_TDOT(R0, P05)                                                    \
+  {                                                                      \
+    _Pragma("unroll") for (int r = 0; r < 3; ++r) {                      \
+      if (P05) {                                                         \
+        tA_[(R0) + r] = fmaf(4.f, te0_[r], fmaf(-5.f, td_[r].y, td_[r].w)); \
+        tB_[(R0) + r] = fmaf(4.f, td_[r].x, fmaf(-5.f, td_[r].z, te5_[r])); \
+      } else {                                                           \
+        const float a_ = fmaf(t_al, td_[r].y, td_[r].w);                 \
+        const float b_ = fmaf(t_ga, td_[r].x, t_be * td_[r].z);          \
+        tA_[(R0) + r] = a_ + b_;                                         \
+        tB_[(R0) + r] = a_ - b_;                                         \
+      }                                                                  \
     }                                                                    \
+  }
+  // V[.][J] = B^T t (the row direction) for one column of the pair -> V buffer VN
+#define W4_TCOL(VN, T, J)                                                \
+  {                                                                      \
+    const float A_ = fmaf(-4.f, T[2], T[4]), B_ = fmaf(-4.f, T[1], T[3]); \
+    const float C_ = T[4] - T[2], D_ = T[3] - T[1];                      \
+    float* q_ = vx + (VN)*VBUF + (J)*CK * 32 + tvb;                      \
+    q_[0 * 6 * CK * 32] = fmaf(4.f, T[0], fmaf(-5.f, T[2], T[4]));       \
+    q_[1 * 6 * CK * 32] = A_ + B_;                                       \
+    q_[2 * 6 * CK * 32] = A_ - B_;                                       \
+    q_[3 * 6 * CK * 32] = fmaf(2.f, D_, C_);                             \
+    q_[4 * 6 * CK * 32] = fmaf(-2.f, D_, C_);                            \
+    q_[5 * 6 * CK * 32] = fmaf(4.f, T[1], fmaf(-5.f, T[3], T[5]));       \
+  }
+#define W4_MF(I, UV, BV) acc[I] = __builtin_amdgcn_mfma_f32_32x32x2f32(UV, BV[I], acc[I], 0, 0, 0);
+  // One chunk: four k-steps of six MFMAs on V buffer VB; between them the transform of raw buffer VB^1 into V buffer VB^1
+  // (k-step 0: rows 0-2, k-step 1: rows 3-5, k-step 2 / 3: the pair's two columns), the two halo pieces of chunk DCH
+  // into raw buffer VB (behind the U refills of k-steps 0 and 1: loads complete in order), and with the prologue their
+  // fix-up in k-step 3.  vmcnt(4) before the barrier: everything but the U refills of k-steps 2 and 3 has landed.
+#define W4_CHUNK(CH, VB, DCH, P05)                                       \
+  {                                                                      \
+    float4 td_[3];                                                       \
+    float te0_[3], te5_[3], tA_[6], tB_[6];                              \
+    float b0_[6], b1_[6];                                                \
+    W4_READB(VB, 0, b0_)                                                 \
+    W4_TREAD((VB) ^ 1, 0, P05)                                             \
     W4_FENCE                                                             \
-    acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(U2[(KK)&1].y, VC[5], acc[5], 0, 0, 0); \
+    /* k-step 0 */                                                       \
+    W4_READB(VB, 1, b1_)                                                 \
+    W4_MF(0, U4[0].x, b0_) W4_MF(1, U4[0].y, b0_) W4_FENCE               \
+    W4_TDOT(0, P05)                                                      \
     W4_FENCE                                                             \
-    /* (k-step 5: the four halo pieces of the next chunk were requested in k-steps 0..3 — every load older than the */ \
-    /* U refills of k-steps 3 and 4 — and have landed by now: apply the prologue to them, before this k-step's refill) */ \
-    if (PRO && (KK) == 5) {                                              \
+    W4_MF(2, U4[0].z, b0_) W4_MF(3, U4[0].w, b0_) W4_FENCE               \
+    W4_TREAD((VB) ^ 1, 3, P05)                                             \
+    W4_FENCE                                                             \
+    W4_MF(4, U2[0].x, b0_) W4_MF(5, U2[0].y, b0_) W4_FENCE               \
+    W4_REFILL(CH, 0)                                                     \
+    W4_DMA1(DCH, VB, 0)                                                  \
+    W4_FENCE                                                             \
+    /* k-step 1 */                                                       \
+    W4_READB(VB, 2, b0_)                                                 \
+    W4_MF(0, U4[1].x, b1_) W4_MF(1, U4[1].y, b1_) W4_FENCE               \
+    W4_TDOT(3, P05)                                                      \
+    W4_FENCE                                                             \
+    W4_MF(2, U4[1].z, b1_) W4_MF(3, U4[1].w, b1_) W4_MF(4, U2[1].x, b1_) W4_MF(5, U2[1].y, b1_) W4_FENCE \
+    W4_REFILL(CH, 1)                                                     \
+    W4_DMA1(DCH, VB, 1)                                                  \
+    W4_FENCE                                                             \
+    /* k-step 2 */                                                       \
+    W4_READB(VB, 3, b1_)                                                 \
+    W4_MF(0, U4[0].x, b0_) W4_MF(1, U4[0].y, b0_) W4_MF(2, U4[0].z, b0_) W4_FENCE \
+    W4_TCOL((VB) ^ 1, tA_, jA)                                           \
+    W4_FENCE                                                             \
+    W4_MF(3, U4[0].w, b0_) W4_MF(4, U2[0].x, b0_) W4_MF(5, U2[0].y, b0_) W4_FENCE \
+    W4_REFILL(CH, 2)                                                     \
+    W4_FENCE                                                             \
+    /* k-step 3 */                                                       \
+    W4_MF(0, U4[1].x, b1_) W4_MF(1, U4[1].y, b1_) W4_MF(2, U4[1].z, b1_) W4_FENCE \
+    W4_TCOL((VB) ^ 1, tB_, jB)                                           \
+    W4_FENCE                                                             \
+    W4_MF(3, U4[1].w, b1_) W4_MF(4, U2[1].x, b1_) W4_MF(5, U2[1].y, b1_) W4_FENCE \
+    if (PRO) {                                                           \
       __builtin_amdgcn_s_waitcnt(0x0F70);                                \
-      W4_FIXUP(DCH, (BUF) ^ 1)                                           \
+      W4_FIXUP(DCH, VB)                                                  \
       W4_FENCE                                                           \
     }                                                                    \
-    {                                                                    \
-      const int ks2 = (CH) * (CK / 2) + (KK) + 2;                        \
-      const bool in_item = ks2 < ksteps;                                 \
-      const unsigned ub_ = (in_item || !has_next) ? ua_cur : ua_base;    \
-      const int kq_ = in_item ? ks2 : (has_next ? ks2 - ksteps : ksteps - 1); \
-      W4_LOAD_A(ub_, kq_, (KK)&1)                                        \
-    }                                                                    \
-    /* the next chunk's halo, one 16-byte piece per k-step behind the U refill: loads complete in order, so a burst of */ \
-    /* HBM-latency halo loads in front of the U ring would stall the MFMAs two k-steps later */ \
-    if ((KK) < 4) W4_DMA1(DCH, (BUF) ^ 1, KK)                            \
+    W4_REFILL(CH, 3)                                                     \
     W4_FENCE                                                             \
-  }
-#define W4_CHUNK(CH, BUF, USEE, DCH)                                     \
-  {                                                                      \
-    float4 d_[6];                                                        \
-    float e_[6];                                                         \
-    W4_READ(BUF, 0, d_, e_, USEE)                                        \
-    W4_XFORM(d_, e_, Va)                                                 \
-    W4_READ(BUF, 1, d_, e_, USEE)                                        \
-    W4_FENCE                                                             \
-    W4_KSTEP(CH, BUF, 0, USEE, DCH, Va, Vb)                              \
-    W4_KSTEP(CH, BUF, 1, USEE, DCH, Vb, Va)                              \
-    W4_KSTEP(CH, BUF, 2, USEE, DCH, Va, Vb)                              \
-    W4_KSTEP(CH, BUF, 3, USEE, DCH, Vb, Va)                              \
-    W4_KSTEP(CH, BUF, 4, USEE, DCH, Va, Vb)                              \
-    W4_KSTEP(CH, BUF, 5, USEE, DCH, Vb, Va)                              \
-    W4_KSTEP(CH, BUF, 6, USEE, DCH, Va, Vb)                              \
-    W4_KSTEP(CH, BUF, 7, USEE, DCH, Vb, Va)                              \
-    /* vmcnt(4): everything but the four U loads of k-steps 6 and 7 — i.e. this wave's share of the next halo chunk — */ \
-    /* has landed (a vmcnt(0) here would expose the L2 latency of those U loads once per chunk) */ \
     __builtin_amdgcn_s_waitcnt(0x0F74);                                  \
     if (!(W4_ABLATE & 8)) __syncthreads();                               \
   }
-  // two chunks (halo buffers 0 then 1); the halo of the chunk after next is requested as soon as its buffer is free —
-  // at the end of an item that is the first chunk of the NEXT item
-  // (the last item of a block re-requests its own first chunk into the free buffer: unconditional loads)
-#define W4_PAIR(CH, USEE)                                                \
+  // the whole transform of raw buffer RB into V buffer VN in one go (the very first chunk of a block)
+#define W4_TRANSFORM_ALL(RB, VN, P05)                                    \
   {                                                                      \
-    W4_CHUNK(CH, 0, USEE, (CH) + 1)                                      \
-    const bool more_ = (CH) + 2 < nchunks;                               \
-    if (!more_ && has_next) W4_SETUP(next)                               \
-    const int dch_ = more_ ? (CH) + 2 : 0;                               \
-    W4_CHUNK((CH) + 1, 1, USEE, dch_)                                    \
+    float4 td_[3];                                                       \
+    float te0_[3], te5_[3], tA_[6], tB_[6];                              \
+    W4_TREAD(RB, 0, P05)                                                 \
+    W4_TDOT(0, P05)                                                      \
+    W4_TREAD(RB, 3, P05)                                                 \
+    W4_TDOT(3, P05)                                                      \
+    W4_TCOL(VN, tA_, jA)                                                 \
+    W4_TCOL(VN, tB_, jB)                                                 \
+  }
+  // two chunks (V buffers 0 then 1).  During the last pair of an item the halo requests / transforms already belong to
+  // the NEXT item's chunks 0 and 1 (the last item of a block re-requests its own: unconditional loads)
+#define W4_PAIR(CH, P05)                                                 \
+  {                                                                      \
+    const bool lastp_ = (CH) + 2 >= nchunks;                             \
+    if (lastp_ && has_next) W4_SETUP(next)                               \
+    const int d0_ = lastp_ ? 0 : (CH) + 2, d1_ = lastp_ ? 1 : (CH) + 3;  \
+    W4_CHUNK(CH, 0, d0_, P05)                                            \
+    W4_CHUNK((CH) + 1, 1, d1_, P05)                                      \
   }
 
   if (PRO) {
@@ -344,40 +362,51 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
     __syncthreads();
   }
   W4_SETUP(item)
-  W4_DMA(0, 0)
-  if (PRO) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    W4_FIXUP(0, 0)
-  }
+  W4_DMA1(0, 0, 0)
+  W4_DMA1(0, 0, 1)
+  W4_DMA1(1, 1, 0)
+  W4_DMA1(1, 1, 1)
   unsigned ua_cur = ua_base;
   W4_LOAD_A(ua_cur, 0, 0)
   W4_LOAD_A(ua_cur, 1, 1)
-  float Va[6], Vb[6];
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  if (PRO) {
+    W4_FIXUP(0, 0)
+    W4_FIXUP(1, 1)
+  }
+  __syncthreads();
+  if (pair05) W4_TRANSFORM_ALL(0, 0, true) else W4_TRANSFORM_ALL(0, 0, false)
+  __syncthreads();
   for (;;) {
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-    // coordinates of the item being accumulated (W4_SETUP overwrites b, r0, ... for the next one in the last chunk)
+    // coordinates of the item being accumulated (W4_SETUP overwrites b, r0, ... for the next one in the last pair)
     const int e_pt = pt, e_b = b, e_r0 = r0, e_c0 = c0, e_co0 = co0;
     const int next = item + (int)gridDim.x;
     const bool has_next = next < n_items;
-    if (use_e) {
+    if (pair05) {
       for (int ch = 0; ch < nchunks; ch += 2) W4_PAIR(ch, true)
     } else {
       for (int ch = 0; ch < nchunks; ch += 2) W4_PAIR(ch, false)
     }
 
     // ---- output transform.  acc[i][r]: frequency (i, wj), tile = l31, channel = ws*32 + (r&3) + 8*(r>>2) + 4*hh.
-    // Round a = output row a of every tile: Z[a][j] = sum_i A^T[a][i] M[i][j] in registers -> ex[j][s][r][lane] (48 KB,
-    // the halo buffer the item finished on); then pair q = (s, r) of this wave: Y[a][0..3] = Z[a][.] A, one 16-byte store.
-    if (!(W4_ABLATE & 4)) {
-      float* ex = xs1;
+    // Round a = output row a of every tile: Z[a][j] = sum_i A^T[a][i] M[i][j] in registers -> ex[j][s][r][lane] (48 KB:
+    // the V buffer the item finished on + the spare behind it; V buffer 0 already holds the next item's first chunk);
+    // then pair q = (s, r) of this wave: Y[a][0..3] = Z[a][.] A, one 16-byte store.
+    {
+      float* ex = vx + VBUF;
       const __amdgpu_buffer_rsrc_t yrsrc =
           make_rsrc(a.y + (size_t)e_b * a.Co * HW, (unsigned long long)a.Co * HW * 4ull);
       float ssum[3] = {0.f, 0.f, 0.f}, ssq[3] = {0.f, 0.f, 0.f};
+      // The lane index is laundered once per item: otherwise hipcc hoists the lane-dependent LDS / global offsets of this
+      // epilogue out of the persistent item loop, spills them, and reloads each one behind an s_waitcnt vmcnt(0) — which
+      // also waits for every output store issued so far (stores share vmcnt on gfx9): ~25 K cycles per item.
+      int lane_ = lane;
+      asm volatile("" : "+v"(lane_));
+      const int tx_ = lane_ & 7, ty_ = (lane_ >> 3) & 3, hh_ = lane_ >> 5;
 #pragma unroll
       for (int ar = 0; ar < 4; ++ar) {
 #pragma unroll
@@ -388,7 +417,7 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
           else if (ar == 1) z = (m1 - m2) + 2.f * (m3 - m4);
           else if (ar == 2) z = (m1 + m2) + 4.f * (m3 + m4);
           else z = (m1 - m2) + 8.f * (m3 - m4) + m5;
-          ex[((wj * 2 + ws) * 16 + r) * 64 + lane] = z;
+          ex[((wj * 2 + ws) * 16 + r) * 64 + lane_] = z;
         }
         __syncthreads();
 #pragma unroll
@@ -398,14 +427,14 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
             const int s = q >> 4, r = q & 15;
             float z[6];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) z[j] = ex[((j * 2 + s) * 16 + r) * 64 + lane];
+            for (int j = 0; j < 6; ++j) z[j] = ex[((j * 2 + s) * 16 + r) * 64 + lane_];
             float4 o;
             o.x = z[0] + (z[1] + z[2]) + (z[3] + z[4]);
             o.y = (z[1] - z[2]) + 2.f * (z[3] - z[4]);
             o.z = (z[1] + z[2]) + 4.f * (z[3] + z[4]);
             o.w = (z[1] - z[2]) + 8.f * (z[3] - z[4]) + z[5];
-            const int chn = e_co0 + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const unsigned off = chn < a.Co ? (unsigned)((chn * H + e_r0 + 4 * ty + ar) * W + e_c0 + 4 * tx) * 4u : SIVAE_OOB;
+            const int chn = e_co0 + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh_;
+            const unsigned off = chn < a.Co ? (unsigned)((chn * H + e_r0 + 4 * ty_ + ar) * W + e_c0 + 4 * tx_) * 4u : SIVAE_OOB;
             if (a.accumulate) {
               const float4 old = buf_load_f32x4(yrsrc, off, 0u);
               o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
@@ -440,16 +469,19 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
   }
 #undef W4_SETUP
 #undef W4_FIXUP
-#undef W4_DMA
+#undef W4_DMA1
 #undef W4_LOAD_A
-#undef W4_READ
-#undef W4_XFORM
-#undef W4_KSTEP
+#undef W4_REFILL
+#undef W4_READB
+#undef W4_TREAD
+#undef W4_TDOT
+#undef W4_TCOL
+#undef W4_MF
 #undef W4_FENCE
-#undef W4_DOT
 #undef W4_CHUNK
+#undef W4_TRANSFORM_ALL
 #undef W4_PAIR
-#undef XS
+#undef RAWB
 }
 
 // ---- weight transform U = G g G^T (6x6), packed [j][ci_pad][co_pad][i]; padding entries are zero
