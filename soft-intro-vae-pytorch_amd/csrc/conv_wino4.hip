@@ -184,13 +184,13 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
   // The fused BatchNorm + LeakyReLU prologue: the halo arrives RAW in LDS (LDS-direct loads bypass the registers), so
   // every thread rewrites the two 16-byte groups IT requested (no other thread touches them before the chunk's barrier):
   // x' = max(v, slope * v) * inside-the-image, v = (x - mean) * scale + beta.
-#define W4_FIXUP(CH, BUF)                                                \
+#define W4_FIXUP(CH, BUF, XO, PSEG)                                      \
   {                                                                      \
-    const float msk_ = xo != SIVAE_OOB ? 1.f : 0.f;                      \
+    const float msk_ = (XO) != SIVAE_OOB ? 1.f : 0.f;                    \
     _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_) {                   \
       const int ck = dpl0 + 4 * n_;                                      \
       float4* q_ = reinterpret_cast<float4*>(RAWB(BUF) + ck * PLANE + dsub * 256 + lane * 4); \
-      const float4 p_ = pro4[pseg + (CH)*CK + ck];                       \
+      const float4 p_ = pro4[(PSEG) + (CH)*CK + ck];                     \
       float4 v_ = *q_;                                                   \
       v_.x = fmaf(v_.x - p_.x, p_.y, p_.z);                              \
       v_.y = fmaf(v_.y - p_.x, p_.y, p_.z);                              \
@@ -228,6 +228,12 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
     W4_LOAD_A(ub_, kq_, (KK)&1)                                          \
   }
 #define W4_FENCE __builtin_amdgcn_sched_barrier(0);
+  // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a full fence: with LDS-direct loads in flight
+  // (they write LDS, so the compiler counts them) it emits s_waitcnt vmcnt(0) in front of the barrier — i.e. every chunk
+  // would wait out the HBM latency of the halo pieces requested a moment earlier.  Those loads are ordered by hand (their
+  // consumer sits two chunks later, behind U-operand waits that complete after them), so the barriers inside the K loop
+  // wait for this wave's LDS reads / writes only.
+#define W4_LDS_BARRIER asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   // B operands of k-step KK of the transformed chunk in V buffer VB
 #define W4_READB(VB, KK, BV)                                             \
   {                                                                      \
@@ -274,17 +280,20 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
     q_[5 * 6 * CK * 32] = fmaf(4.f, T[1], fmaf(-5.f, T[3], T[5]));       \
   }
 #define W4_MF(I, UV, BV) acc[I] = __builtin_amdgcn_mfma_f32_32x32x2f32(UV, BV[I], acc[I], 0, 0, 0);
-  // One chunk: four k-steps of six MFMAs on V buffer VB; between them the transform of raw buffer VB^1 into V buffer VB^1
-  // (k-step 0: rows 0-2, k-step 1: rows 3-5, k-step 2 / 3: the pair's two columns), the two halo pieces of chunk DCH
-  // into raw buffer VB (behind the U refills of k-steps 0 and 1: loads complete in order), and with the prologue their
-  // fix-up in k-step 3.  vmcnt(4) before the barrier: everything but the U refills of k-steps 2 and 3 has landed.
-#define W4_CHUNK(CH, VB, DCH, P05)                                       \
+  // One chunk c: four k-steps of six MFMAs on V buffer VB; between them the transform of raw buffer VB^1 (chunk c+1)
+  // into V buffer VB^1 — all six patch rows are requested in k-step 0, then a MID barrier: raw buffer VB^1 is free from
+  // there on and receives the halo of chunk c+3 (DCH; both pieces in k-step 3, behind that k-step's U refill: loads
+  // complete in order) — a lead of five k-steps before chunk c+2's transform needs it, against HBM latency under load (the
+  // first form requested chunk c+2 here: three k-steps, and the 128x128 / 256x256 layers, whose inputs stream from HBM,
+  // paid ~25 % more per k-step than the 32x32 ones).  With the prologue the pieces of chunk c+2 (FCH, raw buffer VB,
+  // requested during chunk c-1 with the offsets / segment XOF / PSF of that time) are fixed up in k-step 2.
+#define W4_CHUNK(CH, VB, DCH, FCH, P05)                                  \
   {                                                                      \
     float4 td_[3];                                                       \
     float te0_[3], te5_[3], tA_[6], tB_[6];                              \
     float b0_[6], b1_[6];                                                \
     W4_READB(VB, 0, b0_)                                                 \
-    W4_TREAD((VB) ^ 1, 0, P05)                                             \
+    W4_TREAD((VB) ^ 1, 0, P05)                                           \
     W4_FENCE                                                             \
     /* k-step 0 */                                                       \
     W4_READB(VB, 1, b1_)                                                 \
@@ -292,11 +301,13 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
     W4_TDOT(0, P05)                                                      \
     W4_FENCE                                                             \
     W4_MF(2, U4[0].z, b0_) W4_MF(3, U4[0].w, b0_) W4_FENCE               \
-    W4_TREAD((VB) ^ 1, 3, P05)                                             \
+    W4_TREAD((VB) ^ 1, 3, P05)                                           \
     W4_FENCE                                                             \
     W4_MF(4, U2[0].x, b0_) W4_MF(5, U2[0].y, b0_) W4_FENCE               \
     W4_REFILL(CH, 0)                                                     \
-    W4_DMA1(DCH, VB, 0)                                                  \
+    W4_FENCE                                                             \
+    /* every wave has read its rows of raw buffer VB^1 (the reads have returned: lgkmcnt(0)) */ \
+    if (!(W4_ABLATE & 8)) W4_LDS_BARRIER                                 \
     W4_FENCE                                                             \
     /* k-step 1 */                                                       \
     W4_READB(VB, 2, b0_)                                                 \
@@ -305,7 +316,6 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
     W4_FENCE                                                             \
     W4_MF(2, U4[1].z, b1_) W4_MF(3, U4[1].w, b1_) W4_MF(4, U2[1].x, b1_) W4_MF(5, U2[1].y, b1_) W4_FENCE \
     W4_REFILL(CH, 1)                                                     \
-    W4_DMA1(DCH, VB, 1)                                                  \
     W4_FENCE                                                             \
     /* k-step 2 */                                                       \
     W4_READB(VB, 3, b1_)                                                 \
@@ -313,6 +323,10 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
     W4_TCOL((VB) ^ 1, tA_, jA)                                           \
     W4_FENCE                                                             \
     W4_MF(3, U4[0].w, b0_) W4_MF(4, U2[0].x, b0_) W4_MF(5, U2[0].y, b0_) W4_FENCE \
+    if (PRO) {                                                           \
+      W4_FIXUP(FCH, VB, xo_f, pseg_f)                                    \
+      W4_FENCE                                                           \
+    }                                                                    \
     W4_REFILL(CH, 2)                                                     \
     W4_FENCE                                                             \
     /* k-step 3 */                                                       \
@@ -320,15 +334,14 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
     W4_TCOL((VB) ^ 1, tB_, jB)                                           \
     W4_FENCE                                                             \
     W4_MF(3, U4[1].w, b1_) W4_MF(4, U2[1].x, b1_) W4_MF(5, U2[1].y, b1_) W4_FENCE \
-    if (PRO) {                                                           \
-      __builtin_amdgcn_s_waitcnt(0x0F70);                                \
-      W4_FIXUP(DCH, VB)                                                  \
-      W4_FENCE                                                           \
-    }                                                                    \
     W4_REFILL(CH, 3)                                                     \
+    W4_DMA1(DCH, (VB) ^ 1, 0)                                            \
+    W4_DMA1(DCH, (VB) ^ 1, 1)                                            \
+    xo_f = xo;                                                           \
+    pseg_f = pseg;                                                       \
     W4_FENCE                                                             \
-    __builtin_amdgcn_s_waitcnt(0x0F74);                                  \
-    if (!(W4_ABLATE & 8)) __syncthreads();                               \
+    /* (the halo requested during the PREVIOUS chunk has landed: the U operands of this k-step, younger, were waited for) */ \
+    if (!(W4_ABLATE & 8)) W4_LDS_BARRIER                                 \
   }
   // the whole transform of raw buffer RB into V buffer VN in one go (the very first chunk of a block)
 #define W4_TRANSFORM_ALL(RB, VN, P05)                                    \
@@ -342,15 +355,18 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
     W4_TCOL(VN, tA_, jA)                                                 \
     W4_TCOL(VN, tB_, jB)                                                 \
   }
-  // two chunks (V buffers 0 then 1).  During the last pair of an item the halo requests / transforms already belong to
-  // the NEXT item's chunks 0 and 1 (the last item of a block re-requests its own: unconditional loads)
+  // two chunks (V buffers 0 then 1).  Chunk c requests the halo of chunk c+3 and fixes up / will transform chunk c+2:
+  // from the item's third-last chunk on these belong to the NEXT item's chunks 0, 1, 2 (the chunk numbering simply runs
+  // on; the last item of a block re-requests its own: unconditional loads)
 #define W4_PAIR(CH, P05)                                                 \
   {                                                                      \
-    const bool lastp_ = (CH) + 2 >= nchunks;                             \
-    if (lastp_ && has_next) W4_SETUP(next)                               \
-    const int d0_ = lastp_ ? 0 : (CH) + 2, d1_ = lastp_ ? 1 : (CH) + 3;  \
-    W4_CHUNK(CH, 0, d0_, P05)                                            \
-    W4_CHUNK((CH) + 1, 1, d1_, P05)                                      \
+    const int d0_ = (CH) + 3 < nchunks ? (CH) + 3 : (CH) + 3 - nchunks;  \
+    const int f0_ = (CH) + 2 < nchunks ? (CH) + 2 : (CH) + 2 - nchunks;  \
+    W4_CHUNK(CH, 0, d0_, f0_, P05)                                       \
+    if ((CH) + 4 == nchunks && has_next) W4_SETUP(next)                  \
+    const int d1_ = (CH) + 4 < nchunks ? (CH) + 4 : (CH) + 4 - nchunks;  \
+    const int f1_ = (CH) + 3 < nchunks ? (CH) + 3 : (CH) + 3 - nchunks;  \
+    W4_CHUNK((CH) + 1, 1, d1_, f1_, P05)                                 \
   }
 
   if (PRO) {
@@ -371,12 +387,16 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
   W4_LOAD_A(ua_cur, 1, 1)
   __builtin_amdgcn_s_waitcnt(0x0F70);
   if (PRO) {
-    W4_FIXUP(0, 0)
-    W4_FIXUP(1, 1)
+    W4_FIXUP(0, 0, xo, pseg)
+    W4_FIXUP(1, 1, xo, pseg)
   }
   __syncthreads();
   if (pair05) W4_TRANSFORM_ALL(0, 0, true) else W4_TRANSFORM_ALL(0, 0, false)
   __syncthreads();
+  W4_DMA1(2, 0, 0)  // chunk 2 into the raw buffer the first transform freed
+  W4_DMA1(2, 0, 1)
+  unsigned xo_f = xo;  // offsets / segment the halo pieces awaiting their fix-up were requested with
+  int pseg_f = pseg;
   for (;;) {
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -478,6 +498,7 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
 #undef W4_TCOL
 #undef W4_MF
 #undef W4_FENCE
+#undef W4_LDS_BARRIER
 #undef W4_CHUNK
 #undef W4_TRANSFORM_ALL
 #undef W4_PAIR
