@@ -437,6 +437,70 @@ def test_bootstrap_6level_topology_vs_oracle():
     assert not _oracle_vs_hip(3, 64, [8, 16, 32, 64, 64, 64], 256, 2, hp, boot=True, seed=4, referee=False)
 
 
+def test_bootstrap256_full_config_vs_oracle():
+    """config 5's network exactly (soft_intro_vae_bootstrap, 256x256, [64,128,256,512,512,512], z 512, gamma_r 1) at B = 2
+    vs the live oracle — the full-width counterpart of test_bootstrap_6level_topology_vs_oracle"""
+    hp = dict(beta_rec=0.5, beta_kl=1.0, beta_neg=1024.0, gamma_r=1.0)
+    assert not _oracle_vs_hip(3, 512, [64, 128, 256, 512, 512, 512], 256, 2, hp, boot=True, seed=5, referee=False)
+
+
+def test_celeb1024_topology_reduced_width_vs_oracle():
+    """the reference's eight-level celeb1024 topology (soft_intro_vae/train_soft_intro_vae.py:405-417: channels
+    [16,32,64,128,256,512,512,512] at 1024x1024) at reduced width, one iteration vs the live oracle (1024x1024 maps
+    through every kernel's 32-bit addressing)"""
+    hp = dict(beta_rec=0.5, beta_kl=1.0, beta_neg=1024.0, gamma_r=1e-8)
+    assert not _oracle_vs_hip(3, 32, [4, 8, 8, 16, 16, 32, 32, 32], 1024, 2, hp, seed=6, referee=False)
+
+
+def test_dominant_kernels_at_headline_shapes_and_batch_128():
+    """The kernels that dominate the headline iteration, at the headline's OWN shapes and batch (256x256 / 128x128 maps,
+    batch 128), against torch-CPU fp64 on slabs: a convolution is per image, so three images of the batch are refereed
+    in full; a weight gradient sums over the batch, so it is refereed for a subset of output channels."""
+    import torch.nn.functional as F
+    from sivae_hip import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    B = 128
+    for (Ci, Co, H, pro) in [(64, 64, 256, False), (128, 128, 128, True), (64, 128, 128, False)]:
+        x = torch.randn(B, Ci, H, H, generator=g)
+        w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
+        xd, wd = x.to(dev), w.to(dev)
+        wp = ops.PackedW(wd, 0)
+        prm = None
+        if pro:
+            mean, invstd = 0.2 * torch.randn(Ci, generator=g), torch.rand(Ci, generator=g) + 0.5
+            gamma, beta = torch.rand(Ci, generator=g) + 0.5, 0.1 * torch.randn(Ci, generator=g)
+            prm = tuple(t.to(dev) for t in (mean, invstd, gamma, beta)) + (0.2,)
+        assert ops._lib.load().sivae_conv2d_wino4_pays(B, Ci, Co, H, H) == 1  # (the F(4x4,3x3) kernel is what runs)
+        y, part = ops.conv2d_fwd(xd, wp, Co, 3, pro=prm, want_stats=True)
+        for b in (0, 77, 127):
+            xb = x[b:b + 1].double()
+            if pro:
+                v = (xb - mean.double().view(1, -1, 1, 1)) * (invstd * gamma).double().view(1, -1, 1, 1) \
+                    + beta.double().view(1, -1, 1, 1)
+                xb = torch.where(v > 0, v, 0.2 * v)
+            ref = F.conv2d(xb, w.double(), padding=1)
+            assert _rel(y[b:b + 1], ref) <= 4e-5, (Ci, Co, H, b, _rel(y[b:b + 1], ref))
+        # the fused statistics of the whole batch against the GPU output itself in fp64
+        s = part.double().sum(0).cpu()
+        assert _rel(s[:, 0], y.double().sum((0, 2, 3)).cpu()) <= 1e-5
+        assert _rel(s[:, 1], (y.double() ** 2).sum((0, 2, 3)).cpu()) <= 1e-5
+        # data gradient (the same kernel with the mode-1 operand): adjoint identity over the whole batch
+        if not pro:
+            dy = torch.randn(B, Co, H, H, generator=g).to(dev)
+            dx = ops.conv2d_fwd(dy, ops.PackedW(wd, 1), Ci, 3)
+            lhs, rhs = float((y.double() * dy.double()).sum()), float((xd.double() * dx.double()).sum())
+            assert abs(lhs - rhs) <= 2e-6 * float(y.double().norm() * dy.double().norm()), (lhs, rhs)
+            # weight gradient at batch 128, refereed for two output channels
+            dw = ops.conv2d_wgrad(xd, dy, 3)
+            sub = [3, Co - 2]
+            xr = x.double().requires_grad_(False)
+            wr = w[sub].double().requires_grad_()
+            F.conv2d(xr, wr, padding=1).backward(dy[:, sub].double().cpu())
+            assert _rel(dw[sub], wr.grad) <= 2e-5, (Ci, Co, H, _rel(dw[sub], wr.grad))
+        del x, xd, y
+
+
 def test_size_independent_properties_at_full_batch_shapes():
     """Properties that need no oracle, at the headline layer shapes: dgrad is the adjoint of fwd
     (<conv(x), y> == <x, conv^T(y)>), <wgrad(x, y), w> equals the same inner product, and the fused
