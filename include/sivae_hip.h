@@ -528,6 +528,18 @@ int sivae_conv2d_wino4_fwd_pro(const float* x, const float* up, float* y, const 
                                int B, int Ci, int Co, int H, int W, int accumulate, int seg_images,
                                sivae_stream_t stream);
 
+/* Winograd F(4x4,3x3) weight gradient (conv_wino4_wgrad.hip) — the weight half of aten::convolution_backward of the
+ * nn.Conv2d(k=3) layers (soft_intro_vae/train_soft_intro_vae.py:56-61) on maps with H % 4 == 0, W % 16 == 0:
+ * dw[Co][Ci][3][3] from x [B][Ci][H][W] (or, pro_mean != NULL, LeakyReLU(BatchNorm(x)) recomputed on load; per-segment
+ * statistics [nseg][Ci] when seg_images > 0, nseg = B / seg_images <= 2) and dy [B][Co][H][W]; x / dy 16-byte aligned.
+ * `pays`: supported AND enough stages for one block per CU. */
+int sivae_conv2d_wino4_wgrad_supported(int H, int W);
+int sivae_conv2d_wino4_wgrad_pays(int B, int Ci, int Co, int H, int W);
+size_t sivae_conv2d_wino4_wgrad_workspace_bytes(int B, int Ci, int Co, int H, int W);
+int sivae_conv2d_wino4_wgrad(const float* x, const float* dy, float* dw, const float* pro_mean, const float* pro_invstd,
+                             const float* pro_gamma, const float* pro_beta, float pro_slope, int B, int Ci, int Co, int H,
+                             int W, int seg_images, void* workspace, size_t workspace_bytes, sivae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -201,6 +201,8 @@ WINO_UP = os.environ.get("SIVAE_WINO_UP", "1") != "0"  # phase-decomposed F(2x2,
 # SIVAE_WINO4_MAXC: largest channel count it takes (its U slab per 64-channel tile is 2.25x the F(2x2,3x3) one)
 WINO4 = os.environ.get("SIVAE_WINO4", "1") != "0"
 WINO4_MAXC = int(os.environ.get("SIVAE_WINO4_MAXC", "512"))
+# F(4x4,3x3) weight gradient (conv_wino4_wgrad.hip); SIVAE_WINO4_WGRAD=0: the F(2x2,3x3) one everywhere
+WINO4_WGRAD = WINO4 and os.environ.get("SIVAE_WINO4_WGRAD", "1") != "0"
 WINO4_PRO = os.environ.get("SIVAE_WINO4_PRO", "1") != "0"  # ... also with a fused BatchNorm prologue (conv2 forward)
 # SIVAE_FUSE_BN_BWD=1: reduce BatchNorm-1's backward sums in the epilogue of conv2's data gradient.  Measured a LOSS at
 # 256x256 bs128 (593 vs 585 ms per iteration: the extra tensor read sits on the kernel's critical path and disables its
@@ -499,6 +501,24 @@ def conv2d_wgrad(x, dy, ks, pro=None, upsample=False, out=None, nseg=1):
         if t0 is not None:
             flops = 2.0 * B * H * W * Co * Ci * 9
             TIMER.end("wino_up_wgrad_kernel", flops, t0, executed=flops * 9.0 / 36.0)
+        return dw
+    if (WINO4_WGRAD and WINO_WGRAD and ks == 3 and not upsample and (pro is None or nseg <= 2)
+            and max(Ci, Co) <= WINO4_MAXC and L.sivae_conv2d_wino4_wgrad_pays(B, Ci, Co, H, W) == 1):
+        # Winograd F(4x4,3x3) weight gradient (conv_wino4_wgrad.hip): 36 instead of 64 multiplies per tile, co, ci
+        ws = workspace(L.sivae_conv2d_wino4_wgrad_workspace_bytes(B, Ci, Co, H, W), x.device)
+        dw = _out(out, (Co, Ci, 3, 3), x.device)
+        pm = pi = pg = pb = None
+        slope = 1.0
+        if pro is not None:
+            pm, pi, pg, pb, slope = pro
+            _require(pm, pi, pg, pb)
+        t0 = TIMER.begin() if TIMER is not None else None
+        _lib.call("sivae_conv2d_wino4_wgrad", _p(x), _p(dy), _p(dw), _p(pm), _p(pi), _p(pg), _p(pb), float(slope), B, Ci,
+                  Co, H, W, (B // nseg) if (nseg > 1 and pro is not None) else 0, _p(ws), ws.numel(), _s())
+        if t0 is not None:
+            flops = 2.0 * B * H * W * Co * Ci * 9
+            TIMER.end("wino4_wgrad_kernel<%s>" % ("true" if pro is not None else "false"), flops, t0,
+                      executed=flops * 36.0 / 144.0)
         return dw
     wino = WINO_WGRAD and ks == 3 and L.sivae_conv2d_wino_wgrad_supported(H, W) == 1
     nbytes = (L.sivae_conv2d_wino_wgrad_workspace_bytes(B, Ci, Co, H, W) if wino

@@ -672,6 +672,42 @@ def check_wino4_pro(shape, nseg=1):
     return [(tag, _err(y, ref), WINO4_TOL), (tag + "_stats_sum", _err(s_[:, 0], ref.sum((0, 2, 3))), 4e-5)]
 
 
+def check_wino4_wgrad(shape, pro=False, nseg=1):
+    """F(4x4,3x3) weight gradient (conv_wino4_wgrad.hip) vs the fp64 one, straight through the C ABI: plain, with the fused
+    BatchNorm + LeakyReLU prologue, and with per-segment statistics"""
+    from sivae_hip import lib, ops
+    B, Ci, Co, H, W = shape
+    L = lib.load()
+    assert L.sivae_conv2d_wino4_wgrad_supported(H, W) == 1
+    x = _rand(B, Ci, H, W, seed=1)
+    w = _rand(Co, Ci, 3, 3, seed=2).requires_grad_()
+    dy = _rand(B, Co, H, W, seed=4)
+    xin = x
+    pm = pi = pg = pb = None
+    if pro:
+        mean = _rand(nseg, Ci, seed=3, scale=0.3)
+        invstd = (_rand(nseg, Ci, seed=5).abs() + 0.5)
+        gamma = _rand(Ci, seed=6) + 1.0
+        beta = _rand(Ci, seed=7, scale=0.2)
+        Bs = B // nseg
+        xs = []
+        for g in range(nseg):
+            v = (x[g * Bs:(g + 1) * Bs] - mean[g].view(1, -1, 1, 1)) * (invstd[g] * gamma).view(1, -1, 1, 1) \
+                + beta.view(1, -1, 1, 1)
+            xs.append(torch.where(v > 0, v, 0.2 * v))
+        xin = torch.cat(xs)
+        pm, pi, pg, pb = _d(mean.reshape(-1)), _d(invstd.reshape(-1)), _d(gamma), _d(beta)
+    _conv_ref(xin, w).backward(dy)
+    xd, dyd = _d(x), _d(dy)
+    ws = ops.workspace(L.sivae_conv2d_wino4_wgrad_workspace_bytes(B, Ci, Co, H, W), xd.device)
+    dw = torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=DEV)
+    lib.call("sivae_conv2d_wino4_wgrad", ops._p(xd), ops._p(dyd), ops._p(dw), ops._p(pm), ops._p(pi), ops._p(pg),
+             ops._p(pb), 0.2, B, Ci, Co, H, W, (B // nseg) if nseg > 1 else 0, ops._p(ws), ws.numel(), ops._s())
+    torch.cuda.synchronize()
+    tag = "wino4_wgrad%s%s%s" % ("_pro" if pro else "", "_seg%d" % nseg if nseg > 1 else "", shape)
+    return [(tag, _err(dw, w.grad), WINO4_TOL)]
+
+
 def check_conv5_k75():
     """merged-contraction 5x5 kernel (<= 3 -> <= 64 channels): forward with BatchNorm partials / bias, ragged tiles,
     1-3 input channels, fewer than 64 outputs; and as the data gradient of a 64 -> 3 conv (flipped pack)"""
@@ -1035,6 +1071,11 @@ def all_checks():
                        + check_wino4(s, mode=1)))
     for s in [(2, 64, 64, 32, 32), (4, 128, 64, 16, 32), (2, 100, 72, 48, 64), (2, 512, 64, 16, 32)]:
         checks.append(("wino4_pro%s" % (s,), lambda s=s: check_wino4_pro(s) + check_wino4_pro(s, nseg=2)))
+    for s in [(2, 64, 64, 32, 32), (1, 32, 64, 16, 16), (4, 128, 64, 16, 32), (3, 100, 72, 48, 64), (2, 96, 160, 8, 48),
+              (7, 64, 128, 4, 16)]:
+        checks.append(("wino4_wgrad%s" % (s,), lambda s=s: check_wino4_wgrad(s) + check_wino4_wgrad(s, pro=True)))
+    checks.append(("wino4_wgrad_seg", lambda: check_wino4_wgrad((4, 64, 64, 32, 32), pro=True, nseg=2)
+                   + check_wino4_wgrad((6, 40, 72, 16, 48), pro=True, nseg=2)))
     checks.append(("conv1x1_stream", check_conv1x1_stream))
     checks.append(("conv5_edge", check_conv5_edge))
     checks.append(("linear", check_linear))

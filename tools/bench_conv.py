@@ -90,6 +90,11 @@ for (Ci, Co, H, ks) in SHAPES:
                     torch.zeros(Ci, device="cuda"), 0.2)
         t = timeit(lambda: ops.conv2d_wgrad(x, dy, ks, pro=prow))
         out += "  wgrad %7.3f ms %6.1f TF" % (t, fl / t / 1e9)
+        if ks == 3 and ops.WINO4_WGRAD and WINO_ONLY:
+            ops.WINO4_WGRAD = False
+            t2 = timeit(lambda: ops.conv2d_wgrad(x, dy, ks, pro=prow))
+            ops.WINO4_WGRAD = True
+            out += " (%5.1f TF exec) | F(2,3) %7.3f ms (x%.2f)" % (fl / 4 / t / 1e9, t2, t2 / t)
         if ks == 3 and H >= 16 and ops.WINO_WGRAD and not WINO_ONLY:
             ops.WINO_WGRAD = False
             t = timeit(lambda: ops.conv2d_wgrad(x, dy, ks))
