@@ -11,18 +11,28 @@
 // (9 taps x 16 pixels) and the 64 of the F(2x2,3x3) form (conv_wino_wgrad.hip).
 //
 // fp32 "MFMA" time and ordinary VALU time ADD on a gfx950 SIMD (conv_wino4.hip), so both operands are transformed ONCE
-// per block into LDS and the MFMA loop is nothing but ds_read_b32 + MFMA:
+// per block into LDS and the MFMA lanes read them with plain ds_read_b32:
 //   * a block = 12 waves = 64 output channels x 32 input channels x 36 frequencies; wave (j, s) owns frequency column j
 //     of output-channel subtile s: 6 accumulators = 96 registers, three waves per SIMD, one block per CU;
 //   * a stage = a 4 x 16 pixel strip = 4 tiles = two k-steps (a k-step is a pair of tiles).  Its raw operands — the
 //     6 x 24 input halo of 32 channels (18 KB) and the 4 x 16 dY strip of 64 channels (16 KB) — arrive by LDS-direct
-//     16-byte loads (three per wave and stage) into a ring of three slots, requested three stages ahead;
-//   * transform phase: dY -> Mg by threads (tile, co) (waves 0-3), x -> V by threads (tile, ci, column pair) (waves 4-9,
-//     the pairing of conv_wino4.hip) into Mg[f][s][tile][32] / V[f][tile][32], which the MFMA lanes read linearly;
-//   * MFMA phase: 2 x 6 MFMAs per wave; under it the requests of stage s+3 and — with the fused BatchNorm + LeakyReLU
-//     prologue — the in-place rewrite of stage s+1's raw halo (zero padding restored through the table select).
-// Two LDS-only barriers per stage.  The sum over tiles is split across blocks ("slices") of whole stage triples; every
-// slice writes its partial dU and a second kernel adds the slices in a fixed order and applies G^T . G (no atomics).
+//     16-byte loads (three per wave and stage) into a ring of three slots, requested three stages ahead.  The slot
+//     layouts are chosen for the 16-byte reads of the transform: dY [row][co][group ^ ((co >> 2) & 3)], x [row][ci][(group +
+//     ((ci >> 3) & 1)) % 6] — conflict-free for the lane groups a ds_read_b128 serves per cycle, and the four / six
+//     groups of a row segment still come from adjacent lanes of a request;
+//   * every k-step transforms the two tiles of the NEXT k-step into the other half of the double-buffered V[36][2][32] /
+//     Mg[36][2][64]: nine wave-tasks of a third of an item each (thread = tile x channel x frequency-column pair, the
+//     pairing of conv_wino4.hip), spread over the SIMDs and sliced between the wave's own six MFMAs.  A long task on
+//     one wave does not overlap anything: the other waves' MFMAs starve its VALU issue, then it runs alone (first form:
+//     phase-serial, 0.85-1.09x the F(2x2,3x3) kernel; this form 1.35-1.55x);
+//   * the MFMA schedule is rotated by one pair across the barrier, so that a k-step opens with MFMAs whose operands are
+//     already in registers (its own LDS reads in flight) and closes with MFMAs under which its LDS stores drain;
+//   * with the fused BatchNorm + LeakyReLU prologue, k-step A rewrites groups 0-3 and k-step B groups 4-5 of the NEXT
+//     stage's raw halo in place (zero padding restored through the table select).
+// Two LDS-only barriers per stage.  The three task roles (x, x pair (0,5), dY) and the task-less waves run separate copies
+// of the loop.  The sum over tiles is split across blocks ("slices") of whole stage triples; every slice writes its
+// partial dU, the slices are added in a fixed order (wide split-K reducer from 8 slices up) and a last kernel applies
+// G^T . G (no atomics, run-to-run reproducible).
 #include "common.h"
 #include <stdlib.h>
 
@@ -46,8 +56,8 @@ struct Wino4WgArgs {
 #define G4_NT 768
 #define G4_XS 4608  // raw x slot: [6 rows][32 ci][6 groups of 4 floats]
 #define G4_YS 4096  // raw dY slot: [4 rows][64 co][4 groups, swizzled by (co >> 2) & 3]
-#define G4_VS 4608  // V[36][4 tiles][32 ci]
-#define G4_MS 9216  // Mg[36][2 subtiles][4 tiles][32 co]
+#define G4_VS 2304  // V of a k-step: [36][2 tiles][32 ci]
+#define G4_MS 4608  // Mg of a k-step: [36][2 tiles][64 co]
 
 // Timing ablations (results WRONG with any bit set): 1 no LDS-direct loads, 2 no transform phase, 4 no MFMAs
 #ifndef G4_ABLATE
@@ -64,11 +74,15 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
   __shared__ __attribute__((aligned(16))) float ry0[G4_YS];
   __shared__ __attribute__((aligned(16))) float ry1[G4_YS];
   __shared__ __attribute__((aligned(16))) float ry2[G4_YS];
-  __shared__ __attribute__((aligned(16))) float vs[G4_VS];
-  __shared__ __attribute__((aligned(16))) float ms[G4_MS];
+  __shared__ __attribute__((aligned(16))) float vs0[G4_VS];  // V / Mg of a k-step (two tiles), double-buffered
+  __shared__ __attribute__((aligned(16))) float vs1[G4_VS];
+  __shared__ __attribute__((aligned(16))) float ms0[G4_MS];
+  __shared__ __attribute__((aligned(16))) float ms1[G4_MS];
   __shared__ float4 pro4[PRO ? 64 : 1];  // {mean, invstd*gamma, beta, -} per (segment, channel of the tile)
 #define G4_RX(K) ((K) == 0 ? rx0 : ((K) == 1 ? rx1 : rx2))
 #define G4_RY(K) ((K) == 0 ? ry0 : ((K) == 1 ? ry1 : ry2))
+#define G4_VB(HB) ((HB) ? vs1 : vs0)
+#define G4_MB(HB) ((HB) ? ms1 : ms0)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -91,55 +105,66 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
   // ---- request role: wave w issues pieces 3w .. 3w+2 of a stage; pieces 0..17 are the x slot (waves 0-5), 18..33 the dY
   // slot (waves 6-11; the last two repeat piece 33).  A piece = 64 lanes x 16 bytes = 1 KB of consecutive LDS.
   const bool req_x = wave < 6;
-  unsigned rq_off[3], rq_bits[3];
+  // (an x wave's three pieces are exactly halo row `wave`: the row bits are scalar; per lane only "group 0" / "group 5")
+  const unsigned rq_sbits = 16u | (wave == 0 ? 1u : 0u) | (wave == 5 ? 2u : 0u);
+  unsigned rq_off[3], rq_lbits = 0;  // rq_lbits: bits 4 / 8 of piece i at byte i
   int rq_lds[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int d = wave * 3 + i;
     if (d < 18) {
-      const int pos = d * 64 + lane, row = pos / 192, rem = pos - row * 192, ci = rem / 6, p = rem - ci * 6;
+      const int pos = d * 64 + lane, row = pos / 192, rem = pos - row * 192, ci = rem / 6;
+      const int p = (rem - ci * 6 + 6 - ((ci >> 3) & 1)) % 6;  // (the slot holds group p rotated by r(ci), below)
       rq_off[i] = (ci0 + ci < a.Ci) ? (unsigned)((ci0 + ci) * HW + row * W + 4 * p) * 4u : SIVAE_OOB;
-      rq_bits[i] = (row == 0 ? 1u : 0u) | (row == 5 ? 2u : 0u) | (p == 0 ? 4u : 0u) | (p == 5 ? 8u : 0u) | 16u;
+      rq_lbits |= ((p == 0 ? 4u : 0u) | (p == 5 ? 8u : 0u)) << (8 * i);
       rq_lds[i] = d * 256;
     } else {
       const int dd = d - 18 < 15 ? d - 18 : 15;
       const int pos = dd * 64 + lane, row = pos >> 8, co = (pos & 255) >> 2, p = (pos & 3) ^ ((co >> 2) & 3);
       rq_off[i] = (co0 + co < a.Co) ? (unsigned)((co0 + co) * HW + row * W + 4 * p) * 4u : SIVAE_OOB;
-      rq_bits[i] = 16u;
       rq_lds[i] = dd * 256;
     }
   }
-  // ---- prologue role: 16-byte group tid of the x slot, and group 768 + (tid - 384) for the upper half of the block
-  const int fq1 = 768 + (tid >= 384 ? tid - 384 : 0);
-  const bool f_two = __builtin_amdgcn_readfirstlane(tid >= 384 ? 1 : 0) != 0;
-  int f_ci0, f_ci1;
-  unsigned f_bits0, f_bits1;
-  {
-    const int row = tid / 192, rem = tid - row * 192, ci = rem / 6, p = rem - ci * 6;
-    f_ci0 = ci;
-    f_bits0 = (row == 0 ? 1u : 0u) | (row == 5 ? 2u : 0u) | (p == 0 ? 4u : 0u) | (p == 5 ? 8u : 0u) | 16u;
-  }
-  {
-    const int row = fq1 / 192, rem = fq1 - row * 192, ci = rem / 6, p = rem - ci * 6;
-    f_ci1 = ci;
-    f_bits1 = (row == 0 ? 1u : 0u) | (row == 5 ? 2u : 0u) | (p == 0 ? 4u : 0u) | (p == 5 ? 8u : 0u) | 16u;
-  }
-  // ---- transform roles
-  // dY (waves 0-3): tile = wave, co = lane
-  const int ty_rd = (lane * 4 + ((wave & 3) ^ ((lane >> 2) & 3))) * 4;
-  const int ty_wr = (lane >> 5) * 128 + (wave & 3) * 32 + (lane & 31);
-  // x (waves 4-9): column pair tp = (wave - 4) >> 1 ((1,2), (3,4), (0,5)), tile = 2 * ((wave - 4) & 1) + hh, ci = l31
-  const int xw = wave >= 4 ? wave - 4 : 0;
-  const int tp = xw >> 1, xt = 2 * (xw & 1) + hh;
-  const int tx_rd = (l31 * 6 + xt + 1) * 4;  // patch columns 1..4 = group tile + 1
-  const int tx_wr = xt * 32 + l31;
+  // ---- prologue role: k-step A rewrites the 16-byte groups p = 0..3 of the NEXT stage's x slot (one per thread: row =
+  // tid / 128, channel (tid % 128) / 4, p = tid % 4), k-step B its groups p = 4, 5 (the first six waves: row = wave,
+  // channel lane / 2, p = 4 + lane % 2).  Row and channel-base are wave-uniform; per lane only the group offset is kept.
+  const int fa_s = ((wave >> 1) * 192 + (wave & 1) * 96) * 4, fa_cs = (wave & 1) * 16;
+  // (group of lane: (lane / 4) * 6 + lane % 4 + r(ci), ci = 16 (wave & 1) + lane / 4)
+  const unsigned fa_sbits = 16u | (wave < 2 ? 1u : 0u) | (wave >= 10 ? 2u : 0u);
+  const int fb_s = (wave * 192 + 4) * 4;
+  // (group of lane: (lane / 2) * 6 + (4 + lane % 2 + r(ci)) % 6, ci = lane / 2)
+  const unsigned fb_sbits = 16u | (wave == 0 ? 1u : 0u) | (wave == 5 ? 2u : 0u);
+  // ---- transform roles.  Every k-step transforms the two tiles of the NEXT k-step (k-step A, MFMAs on tiles 0,1: tiles
+  // 2,3 of the same stage; k-step B, MFMAs on tiles 2,3: tiles 0,1 of the next stage) in nine wave-tasks, each a THIRD of an
+  // item — the frequency columns come in pairs that share their partial sums ((1,2), (3,4); (0,5) stand alone):
+  //   x  -> V : thread (tile = hh, ci = l31, pair): waves 0, 1, 2                     (48 VALU, 12 ds_write_b32 per thread)
+  //   dY -> Mg: thread (tile tl, co = lane, pair): waves 4,5 (1,2); 3,7 (3,4); 6,10 (0,5)   (32 / 32 / 16 VALU, 12 writes)
+  // spread so that the three waves of a SIMD (w, w+4, w+8) carry ~80 VALU together; a wave slices its task between its
+  // own six MFMAs (a long task on one wave would run alone after the other waves' MFMAs: the first form of this loop).
+  const bool r_x = wave < 3;
+  const bool r_y = wave == 4 || wave == 5 || wave == 3 || wave == 7 || wave == 6 || wave == 10;
+  const int tp = r_x ? wave : ((wave == 4 || wave == 5) ? 0 : ((wave == 3 || wave == 7) ? 1 : 2));
+  const int ytl = (wave == 5 || wave == 7 || wave == 10) ? 1 : 0;
   const int jA = tp == 0 ? 1 : (tp == 1 ? 3 : 0), jB = tp == 0 ? 2 : (tp == 1 ? 4 : 5);
+  // x: patch columns 1..4 = 16-byte group tile + 1 (k-step B: tiles 0,1; k-step A: tiles 2,3 = + 8 floats)
+  // The 16-byte groups of a (row, channel) are stored ROTATED by r(ci) = (ci >> 3) & 1 (slot ci*6 + (p + r) % 6): with the
+  // plain stride of 6 slots the 16 lanes a ds_read_b128 serves per cycle hit 8 bank groups twice each
+  const int x_rot = (l31 >> 3) & 1;
+  const int tx_rd4 = l31 * 6 + hh + 1 + x_rot;
+  // patch columns 0 / 5 of tile t: last float of group t, first float of group t + 2 (k-step B: t = hh; A: t = hh + 2)
+  const int tx_e0B = l31 * 6 + hh + x_rot, tx_e5B = l31 * 6 + (hh + 2 + x_rot) % 6;
+  const int tx_e0A = l31 * 6 + hh + 2 + x_rot, tx_e5A = l31 * 6 + (hh + 4 + x_rot) % 6;
   const float t_al = tp == 0 ? -4.f : -1.f;  // a = d4 + al*d2
   const float t_be = tp == 0 ? 1.f : 2.f;    // b = be*d3 + ga*d1
   const float t_ga = tp == 0 ? -4.f : -2.f;
-  // ---- MFMA role: A = Mg[(i*6 + wj)][wsb][2kk + hh][l31], B = V[(i*6 + wj)][2kk + hh][l31]
-  const int m_rd = wj * 256 + wsb * 128 + lane;
-  const int v_rd = wj * 128 + lane;
+  // dY: group (tile ^ swizzle) of channel row lane (k-step A: tile + 2 = the group index ^ 2 = + / - 8 floats)
+  const int ty_rd4 = lane * 4 + (ytl ^ ((lane >> 2) & 3));
+  const float y_al = tp == 0 ? 1.f : 4.f;  // e = c0 + al*c2, o = c1 + al*c3; outputs e +- be*o
+  const float y_be = tp == 0 ? 1.f : 2.f;
+  const int t_wr = r_x ? lane : ytl * 64 + lane;
+  // ---- MFMA role: A = Mg[(i*6 + wj)][hh][wsb*32 + l31], B = V[(i*6 + wj)][hh][l31] of the k-step's half buffers
+  const int m_rd = wj * 128 + hh * 64 + wsb * 32 + l31;
+  const int v_rd = wj * 64 + lane;
 
   // ---- stage to request next (scalar): image db, strip row dry, strip column drx
   int sd = s_begin;
@@ -150,6 +175,9 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
     dry = rem / a.nrw;
     drx = rem - dry * a.nrw;
   }
+  // this wave's operand (x for the first six waves, dY for the others) at image db
+  const long long rq_img_step = (long long)(req_x ? a.Ci : a.Co) * HW;
+  const float* rq_img = (req_x ? a.x : a.dy) + (long long)db * rq_img_step;
   unsigned inf0 = 0, inf1 = 0, inf2 = 0;  // per ring slot: border / tail bits and the segment's table offset << 8
 #define G4_INF(K) ((K) == 0 ? inf0 : ((K) == 1 ? inf1 : inf2))
 #define G4_SETINF(K, V) { if ((K) == 0) inf0 = (V); else if ((K) == 1) inf1 = (V); else inf2 = (V); }
@@ -159,15 +187,19 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
   {                                                                                                 \
     const unsigned fl_ = (dry == 0 ? 1u : 0u) | (dry == a.nrh - 1 ? 2u : 0u) | (drx == 0 ? 4u : 0u) |  \
                          (drx == a.nrw - 1 ? 8u : 0u) | (sd >= s_end ? 16u : 0u);                   \
-    const float* base_ = req_x ? a.x + ((long long)db * a.Ci * HW + (long long)(dry * 4 - 1) * W + (drx * 16 - 4)) \
-                               : a.dy + ((long long)db * a.Co * HW + (long long)(dry * 4) * W + drx * 16); \
+    const float* base_ = rq_img + (req_x ? (dry * 4 - 1) * W + (drx * 16 - 4) : dry * 4 * W + drx * 16); \
     const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(base_, 0xFFFFFFFEull);                             \
     float* lds_ = req_x ? G4_RX(K) : G4_RY(K);                                                      \
     unsigned o0_ = rq_off[0], o1_ = rq_off[1], o2_ = rq_off[2];                                     \
     if (fl_) {                                                                                      \
-      o0_ = (rq_bits[0] & fl_) ? SIVAE_OOB : o0_;                                                   \
-      o1_ = (rq_bits[1] & fl_) ? SIVAE_OOB : o1_;                                                   \
-      o2_ = (rq_bits[2] & fl_) ? SIVAE_OOB : o2_;                                                   \
+      if ((req_x ? rq_sbits : 16u) & fl_) {                                                         \
+        o0_ = o1_ = o2_ = SIVAE_OOB;                                                                \
+      } else if (req_x) {                                                                           \
+        const unsigned lm_ = fl_ & 12u;                                                             \
+        o0_ = (rq_lbits & lm_) ? SIVAE_OOB : o0_;                                                   \
+        o1_ = (rq_lbits & (lm_ << 8)) ? SIVAE_OOB : o1_;                                            \
+        o2_ = (rq_lbits & (lm_ << 16)) ? SIVAE_OOB : o2_;                                           \
+      }                                                                                             \
     }                                                                                               \
     if (!(G4_ABLATE & 1)) {                                                                         \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (float __attribute__((address_space(3)))*)(lds_ + rq_lds[0]), 16, o0_, 0, 0, 0); \
@@ -181,17 +213,18 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
       if (++dry == a.nrh) {                                                                         \
         dry = 0;                                                                                    \
         ++db;                                                                                       \
+        rq_img += rq_img_step;                                                                      \
       }                                                                                             \
     }                                                                                               \
   }
   // fused BatchNorm + LeakyReLU prologue, in place on the raw x slot K: x' = max(v, slope v), v = (x - mean) scale + beta;
   // groups outside the image (and channels beyond Ci: zero table rows) stay zero
-#define G4_FIX1(K, Q, CI, BITS)                                                                     \
+#define G4_FIX1(K, FOFF, CIDX, SBITS, LCOND)                                                        \
   {                                                                                                 \
     const unsigned in_ = G4_INF(K);                                                                 \
-    float4 p_ = pro4[(in_ >> 8) + (CI)];                                                            \
-    if ((BITS) & in_ & 31u) p_ = make_float4(0.f, 0.f, 0.f, 0.f);                                   \
-    float4* q_ = reinterpret_cast<float4*>(G4_RX(K) + (Q) * 4);                                     \
+    float4 p_ = pro4[(in_ >> 8) + (CIDX)];                                                          \
+    if (((SBITS) & in_ & 31u) || (LCOND)) p_ = make_float4(0.f, 0.f, 0.f, 0.f);                     \
+    float4* q_ = reinterpret_cast<float4*>(G4_RX(K) + (FOFF));                                      \
     float4 v_ = *q_;                                                                                \
     v_.x = fmaf(v_.x - p_.x, p_.y, p_.z);                                                           \
     v_.y = fmaf(v_.y - p_.x, p_.y, p_.z);                                                           \
@@ -203,10 +236,21 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
     v_.w = fmaxf(v_.w, v_.w * a.pro_slope);                                                         \
     *q_ = v_;                                                                                       \
   }
-#define G4_FIX(K)                                                                                   \
+  // (the lane-dependent offsets are recomputed from a LAUNDERED lane index at every use: hoisted out of the loop they are
+  // spilled, and a spill reload inside the loop carries an s_waitcnt vmcnt(0) — it would wait out the requests in flight)
+#define G4_FIXA(K)                                                                                  \
   {                                                                                                 \
-    G4_FIX1(K, tid, f_ci0, f_bits0)                                                                 \
-    if (f_two) G4_FIX1(K, fq1, f_ci1, f_bits1)                                                      \
+    int ln_ = lane;                                                                                 \
+    asm volatile("" : "+v"(ln_));                                                                   \
+    G4_FIX1(K, fa_s + ((ln_ >> 2) * 6 + (ln_ & 3) + ((ln_ >> 5) & 1)) * 4, fa_cs + (ln_ >> 2), fa_sbits, \
+            (in_ & 4u) && (ln_ & 3) == 0)                                                           \
+  }
+#define G4_FIXB(K)                                                                                  \
+  {                                                                                                 \
+    int ln_ = lane;                                                                                 \
+    asm volatile("" : "+v"(ln_));                                                                   \
+    G4_FIX1(K, fb_s + ((ln_ >> 1) * 6 + (4 + (ln_ & 1) + ((ln_ >> 4) & 1)) % 6 - 4) * 4, ln_ >> 1, fb_sbits, \
+            (in_ & 8u) && (ln_ & 1) == 1)                                                           \
   }
 #define G4_FENCE __builtin_amdgcn_sched_barrier(0);
   // workgroup barrier that orders LDS traffic only (a __syncthreads() with LDS-direct loads in flight waits vmcnt(0))
@@ -224,96 +268,160 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
     M[4] = fmaf(-2.f, ao2_, ae2_);                                                                  \
     M[5] = (D3);                                                                                    \
   }
-  // transform phase of the stage in ring slot K
-#define G4_TRANSFORM(K)                                                                             \
+  // ---- task slices; ROLE (compile-time): 0 no task, 1 x -> V, 2 dY -> Mg.  The three roles run three COPIES of the whole
+  // loop (branching once per wave): with role branches inside a k-step the compiler carries the other roles' undefined
+  // registers through every join and spills hundreds of them.
+  // Registers: rd_ raw rows, ex_ patch columns 0 / 5 (x), tA_ / tB_ the pair's column-direction results per row.
+  // slice R: raw reads of this wave's task out of ring slot K (XOFF: + 8 floats, YXOR: ^ 8 floats for tiles 2,3)
+#define G4_T_READ(ROLE, K, XOFF, YXOR, HALF, RD, EX)                                                \
   if (!(G4_ABLATE & 2)) {                                                                           \
-    if (wave < 4) {                                                                                 \
-      const float* p_ = G4_RY(K) + ty_rd;                                                           \
-      float4 d_[4];                                                                                 \
-      _Pragma("unroll") for (int r = 0; r < 4; ++r) d_[r] = *reinterpret_cast<const float4*>(p_ + r * 1024); \
-      float m_[4][6];                                                                               \
-      G4_A4(d_[0].x, d_[1].x, d_[2].x, d_[3].x, m_[0])                                              \
-      G4_A4(d_[0].y, d_[1].y, d_[2].y, d_[3].y, m_[1])                                              \
-      G4_A4(d_[0].z, d_[1].z, d_[2].z, d_[3].z, m_[2])                                              \
-      G4_A4(d_[0].w, d_[1].w, d_[2].w, d_[3].w, m_[3])                                              \
-      float* q_ = ms + ty_wr;                                                                       \
-      _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                               \
-        float o_[6];                                                                                \
-        G4_A4(m_[0][i], m_[1][i], m_[2][i], m_[3][i], o_)                                           \
-        _Pragma("unroll") for (int j = 0; j < 6; ++j) q_[(i * 6 + j) * 256] = o_[j];                \
+    if ((ROLE) == 1 || (ROLE) == 3) { /* three patch rows per call; 16-byte reads (float4-typed: ds_read_b128) */ \
+      const float4* p4_ = reinterpret_cast<const float4*>(G4_RX(K)) + (tx_rd4 + (XOFF) / 4 + (HALF) * 3 * 192); \
+      _Pragma("unroll") for (int r = 0; r < 3; ++r) RD[r] = p4_[r * 192];                           \
+      if ((ROLE) == 3) { /* whole neighbour groups (conflict-free 16-byte reads; a dword read here is 8-way) */ \
+        const float4* e0_ = reinterpret_cast<const float4*>(G4_RX(K)) + ((XOFF) ? tx_e0A : tx_e0B) + (HALF) * 3 * 192; \
+        const float4* e5_ = reinterpret_cast<const float4*>(G4_RX(K)) + ((XOFF) ? tx_e5A : tx_e5B) + (HALF) * 3 * 192; \
+        _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                             \
+          EX[r] = e0_[r * 192].w;                                                                   \
+          EX[3 + r] = e5_[r * 192].x;                                                               \
+        }                                                                                           \
       }                                                                                             \
-    } else if (wave < 10) {                                                                         \
-      const float* p_ = G4_RX(K) + tx_rd;                                                           \
-      float tA_[6], tB_[6];                                                                         \
+    } else if ((ROLE) == 2 && (HALF) == 0) {                                                        \
+      const float4* p4_ = reinterpret_cast<const float4*>(G4_RY(K)) + (ty_rd4 ^ ((YXOR) / 4));      \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) RD[r] = p4_[r * 256];                           \
+    }                                                                                               \
+  }
+  // slice 0: the column direction (per raw row, the pair's two results); x: rows 3*HALF .. 3*HALF+2
+#define G4_T_COL(ROLE, HALF, RD, EX)                                                                \
+  if (!(G4_ABLATE & 2)) {                                                                           \
+    if ((ROLE) == 3) {                                                                              \
+      _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                               \
+        tA_[3 * (HALF) + r] = fmaf(4.f, EX[r], fmaf(-5.f, RD[r].y, RD[r].w));                       \
+        tB_[3 * (HALF) + r] = fmaf(4.f, RD[r].x, fmaf(-5.f, RD[r].z, EX[3 + r]));                   \
+      }                                                                                             \
+    } else if ((ROLE) == 1) {                                                                       \
+      _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                               \
+        const float a_ = fmaf(t_al, RD[r].y, RD[r].w);                                              \
+        const float b_ = fmaf(t_ga, RD[r].x, t_be * RD[r].z);                                       \
+        tA_[3 * (HALF) + r] = a_ + b_;                                                              \
+        tB_[3 * (HALF) + r] = a_ - b_;                                                              \
+      }                                                                                             \
+    } else if ((ROLE) == 2 && (HALF) == 0) {                                                        \
       if (tp == 2) {                                                                                \
-        _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                             \
-          const float4 d_ = *reinterpret_cast<const float4*>(p_ + r * 768);                         \
-          const float e0_ = p_[r * 768 - 1], e5_ = p_[r * 768 + 4];                                 \
-          tA_[r] = fmaf(4.f, e0_, fmaf(-5.f, d_.y, d_.w));                                          \
-          tB_[r] = fmaf(4.f, d_.x, fmaf(-5.f, d_.z, e5_));                                          \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                             \
+          tA_[r] = RD[r].x;                                                                         \
+          tB_[r] = RD[r].w;                                                                         \
         }                                                                                           \
       } else {                                                                                      \
-        _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                             \
-          const float4 d_ = *reinterpret_cast<const float4*>(p_ + r * 768);                         \
-          const float a_ = fmaf(t_al, d_.y, d_.w);                                                  \
-          const float b_ = fmaf(t_ga, d_.x, t_be * d_.z);                                           \
-          tA_[r] = a_ + b_;                                                                         \
-          tB_[r] = a_ - b_;                                                                         \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                             \
+          const float e_ = fmaf(y_al, RD[r].z, RD[r].x), o_ = fmaf(y_al, RD[r].w, RD[r].y);         \
+          tA_[r] = fmaf(y_be, o_, e_);                                                              \
+          tB_[r] = fmaf(-y_be, o_, e_);                                                             \
         }                                                                                           \
       }                                                                                             \
-      G4_TCOL(tA_, jA)                                                                              \
-      G4_TCOL(tB_, jB)                                                                              \
     }                                                                                               \
   }
-  // V[.][J] = B^T t (the row direction) for one column of the pair
-#define G4_TCOL(T, J)                                                                               \
-  {                                                                                                 \
-    const float A_ = fmaf(-4.f, T[2], T[4]), B_ = fmaf(-4.f, T[1], T[3]);                           \
-    const float C_ = T[4] - T[2], D_ = T[3] - T[1];                                                 \
-    float* q_ = vs + (J) * 128 + tx_wr;                                                             \
-    q_[0 * 768] = fmaf(4.f, T[0], fmaf(-5.f, T[2], T[4]));                                          \
-    q_[1 * 768] = A_ + B_;                                                                          \
-    q_[2 * 768] = A_ - B_;                                                                          \
-    q_[3 * 768] = fmaf(2.f, D_, C_);                                                                \
-    q_[4 * 768] = fmaf(-2.f, D_, C_);                                                               \
-    q_[5 * 768] = fmaf(4.f, T[1], fmaf(-5.f, T[3], T[5]));                                          \
-  }
-#define G4_READ(KK, AV, BV)                                                                         \
-  {                                                                                                 \
-    const float* pa_ = ms + m_rd + (KK) * 64;                                                       \
-    const float* pb_ = vs + v_rd + (KK) * 64;                                                       \
-    _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                                 \
-      AV[i] = pa_[i * 1536];                                                                        \
-      BV[i] = pb_[i * 768];                                                                         \
+  // slices 1, 2: the row direction of one column of the pair -> half buffer HB
+#define G4_T_ROW(ROLE, HB, T, J)                                                                    \
+  if (!(G4_ABLATE & 2)) {                                                                           \
+    if ((ROLE) == 1 || (ROLE) == 3) {                                                               \
+      const float A_ = fmaf(-4.f, T[2], T[4]), B_ = fmaf(-4.f, T[1], T[3]);                         \
+      const float C_ = T[4] - T[2], D_ = T[3] - T[1];                                               \
+      float* q_ = G4_VB(HB) + (J) * 64 + t_wr;                                                      \
+      q_[0 * 384] = fmaf(4.f, T[0], fmaf(-5.f, T[2], T[4]));                                        \
+      q_[1 * 384] = A_ + B_;                                                                        \
+      q_[2 * 384] = A_ - B_;                                                                        \
+      q_[3 * 384] = fmaf(2.f, D_, C_);                                                              \
+      q_[4 * 384] = fmaf(-2.f, D_, C_);                                                             \
+      q_[5 * 384] = fmaf(4.f, T[1], fmaf(-5.f, T[3], T[5]));                                        \
+    } else if ((ROLE) == 2) {                                                                       \
+      float o_[6];                                                                                  \
+      G4_A4(T[0], T[1], T[2], T[3], o_)                                                             \
+      float* q_ = G4_MB(HB) + (J) * 128 + t_wr;                                                     \
+      _Pragma("unroll") for (int i = 0; i < 6; ++i) q_[i * 768] = o_[i];                            \
     }                                                                                               \
   }
-#define G4_MMA(AV, BV)                                                                              \
+#define G4_READ2(HB, I0, AV, BV)                                                                    \
+  {                                                                                                 \
+    const float* pa_ = G4_MB(HB) + m_rd;                                                            \
+    const float* pb_ = G4_VB(HB) + v_rd;                                                            \
+    AV[0] = pa_[(I0) * 768];                                                                        \
+    AV[1] = pa_[((I0) + 1) * 768];                                                                  \
+    BV[0] = pb_[(I0) * 384];                                                                        \
+    BV[1] = pb_[((I0) + 1) * 384];                                                                  \
+  }
+#define G4_MMA2(I0, AV, BV)                                                                         \
   if (!(G4_ABLATE & 4)) {                                                                           \
-    _Pragma("unroll") for (int i = 0; i < 6; ++i)                                                   \
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i], BV[i], acc[i], 0, 0, 0);               \
+    acc[I0] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[0], BV[0], acc[I0], 0, 0, 0);                 \
+    acc[(I0) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[1], BV[1], acc[(I0) + 1], 0, 0, 0);     \
   }
-  // One stage s in ring slot K.  On entry: the raw operands of stages s and s+1 have landed and are visible, slot K is
-  // already rewritten by the prologue, stage s+2 is in flight, V / Mg are free.
-#define G4_STAGE(K)                                                                                 \
+  // One k-step on half buffer HB; this wave's task (raw slot TK, tile offsets XOFF / YXOR) fills half buffer HB ^ 1.
+  // The MFMA schedule is ROTATED by one pair: the k-step opens — right behind the barrier, while its own LDS reads are in
+  // flight — with the previous k-step's last pair (operands a2_/b2_ carried in registers), and ends with its pair (2,3),
+  // under which the task's LDS stores drain before the closing barrier.
+#define G4_KSTEP(ROLE, HB, TK, XOFF, YXOR, REQCODE, FIXCODE)                                        \
   {                                                                                                 \
-    G4_TRANSFORM(K)                                                                                 \
+    float4 rd_[4], rd2_[3];                                                                         \
+    float ex_[6], ex2_[6], tA_[6], tB_[6];                                                          \
+    float a0_[2], b0_[2], a1_[2], b1_[2];                                                           \
+    G4_T_READ(ROLE, TK, XOFF, YXOR, 0, rd_, ex_)                                                    \
+    G4_T_READ(ROLE, TK, XOFF, YXOR, 1, rd2_, ex2_)                                                  \
+    G4_READ2(HB, 0, a0_, b0_)                                                                       \
     G4_FENCE                                                                                        \
+    REQCODE                                                                                         \
+    G4_FENCE                                                                                        \
+    G4_MMA2(4, a2_, b2_)                                                                            \
+    G4_FENCE                                                                                        \
+    G4_READ2(HB, 2, a1_, b1_)                                                                       \
+    G4_T_COL(ROLE, 0, rd_, ex_)                                                                     \
+    G4_FENCE                                                                                        \
+    G4_MMA2(0, a0_, b0_)                                                                            \
+    G4_FENCE                                                                                        \
+    G4_READ2(HB, 4, a2_, b2_)                                                                       \
+    G4_T_COL(ROLE, 1, rd2_, ex2_)                                                                   \
+    G4_T_ROW(ROLE, (HB) ^ 1, tA_, jA)                                                               \
+    G4_T_ROW(ROLE, (HB) ^ 1, tB_, jB)                                                               \
+    FIXCODE                                                                                         \
+    G4_FENCE                                                                                        \
+    G4_MMA2(2, a1_, b1_)                                                                            \
+    G4_FENCE                                                                                        \
+  }
+  // One stage s in ring slot K = two k-steps.  On entry: half buffer 0 holds the transformed tiles 0,1 of stage s; slot K
+  // has landed and is already rewritten by the prologue; slot K+1 (stage s+1) has landed; stage s+2 is in flight.
+  //   k-step A: MFMAs on half 0  ||  tiles 2,3 of slot K -> half 1  ||  prologue on groups 0-3 of slot K+1
+  //   k-step B: request stage s+3 into slot K  ||  MFMAs on half 1  ||  tiles 0,1 of slot K+1 -> half 0  ||  prologue on
+  //             groups 4,5 of slot K+1 (tiles 0,1 read groups 0-3 only)
+#define G4_STAGE(ROLE, K)                                                                           \
+  {                                                                                                 \
+    G4_KSTEP(ROLE, 0, K, 8, 8, , if (PRO) G4_FIXA(((K) + 1) % 3))                                   \
     G4_LDS_BARRIER                                                                                  \
     G4_FENCE                                                                                        \
-    G4_REQ(K)                                                                                       \
-    float a0_[6], b0_[6], a1_[6], b1_[6];                                                           \
-    G4_READ(0, a0_, b0_)                                                                            \
-    G4_READ(1, a1_, b1_)                                                                            \
-    G4_FENCE                                                                                        \
-    G4_MMA(a0_, b0_)                                                                                \
-    G4_FENCE                                                                                        \
-    if (PRO) G4_FIX(((K) + 1) % 3)                                                                  \
-    G4_FENCE                                                                                        \
-    G4_MMA(a1_, b1_)                                                                                \
-    G4_FENCE                                                                                        \
+    G4_KSTEP(ROLE, 1, ((K) + 1) % 3, 0, 0, G4_REQ(K), if (PRO && wave < 6) G4_FIXB(((K) + 1) % 3))  \
     asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                                \
     G4_LDS_BARRIER                                                                                  \
     G4_FENCE                                                                                        \
+  }
+  // the whole K loop of one role (every copy executes the same barriers)
+#define G4_LOOP(ROLE)                                                                               \
+  {                                                                                                 \
+    { /* tiles 0,1 of the first stage -> half buffer 0 */                                           \
+      float4 rd_[4], rd2_[3];                                                                       \
+      float ex_[6], ex2_[6], tA_[6], tB_[6];                                                        \
+      G4_T_READ(ROLE, 0, 0, 0, 0, rd_, ex_)                                                         \
+      G4_T_READ(ROLE, 0, 0, 0, 1, rd2_, ex2_)                                                       \
+      G4_T_COL(ROLE, 0, rd_, ex_)                                                                   \
+      G4_T_COL(ROLE, 1, rd2_, ex2_)                                                                 \
+      G4_T_ROW(ROLE, 0, tA_, jA)                                                                    \
+      G4_T_ROW(ROLE, 0, tB_, jB)                                                                    \
+    }                                                                                               \
+    __syncthreads();                                                                                \
+    float a2_[2] = {0.f, 0.f}, b2_[2] = {0.f, 0.f}; /* the rotated pair of the k-step before */      \
+    for (int s = s_begin; s < s_end; s += 3) { /* whole triples: stages beyond s_end are all-zero operands */ \
+      G4_STAGE(ROLE, 0)                                                                             \
+      G4_STAGE(ROLE, 1)                                                                             \
+      G4_STAGE(ROLE, 2)                                                                             \
+    }                                                                                               \
+    G4_MMA2(4, a2_, b2_)                                                                            \
   }
 
   f32x16 acc[6];
@@ -336,14 +444,14 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
     asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     __syncthreads();
     if (PRO) {
-      G4_FIX(0)
+      G4_FIXA(0)
+      if (wave < 6) G4_FIXB(0)
       __syncthreads();
     }
-    for (int s = s_begin; s < s_end; s += 3) {  // (whole triples: stages beyond s_end are all-zero operands)
-      G4_STAGE(0)
-      G4_STAGE(1)
-      G4_STAGE(2)
-    }
+    if (r_x && tp == 2) G4_LOOP(3)
+    else if (r_x) G4_LOOP(1)
+    else if (r_y) G4_LOOP(2)
+    else G4_LOOP(0)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -457,7 +565,8 @@ extern "C" size_t sivae_conv2d_wino4_wgrad_workspace_bytes(int B, int Ci, int Co
   Wino4WgPlan p;
   if (B <= 0 || Ci <= 0 || Co <= 0 || !sivae_conv2d_wino4_wgrad_supported(H, W)) return 0;
   if (wino4_wg_plan(B, Ci, Co, H, W, &p) != SIVAE_OK) return 0;
-  return (size_t)p.n_slices * 36 * p.Co_pad * p.Ci_pad * sizeof(float);
+  // (+ one slice-sized slot: from 8 slices up the slices are summed by the wide split-K reducer first)
+  return (size_t)(p.n_slices + 1) * 36 * p.Co_pad * p.Ci_pad * sizeof(float);
 }
 
 // dw[Co][Ci][3][3] = weight gradient of y = conv3x3(x', w) given dy, x' = x or (pro_mean != NULL) LeakyReLU(BatchNorm(x))
@@ -478,7 +587,8 @@ extern "C" int sivae_conv2d_wino4_wgrad(const float* x, const float* dy, float* 
   Wino4WgPlan p;
   int rc = wino4_wg_plan(B, Ci, Co, H, W, &p);
   if (rc != SIVAE_OK) return rc;
-  const size_t need = (size_t)p.n_slices * 36 * p.Co_pad * p.Ci_pad * sizeof(float);
+  const size_t slice_elems = (size_t)36 * p.Co_pad * p.Ci_pad;
+  const size_t need = (size_t)(p.n_slices + 1) * slice_elems * sizeof(float);
   if (workspace_bytes < need) return SIVAE_ERR_WORKSPACE;
   Wino4WgArgs a;
   a.x = x;
@@ -513,8 +623,20 @@ extern "C" int sivae_conv2d_wino4_wgrad(const float* x, const float* dy, float* 
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.xcd_remap ? (nblk + 7) / 8 * 8 : nblk)), dim3(G4_NT), 0, stream, a);
   rc = sivae_launch_status();
   if (rc != SIVAE_OK) return rc;
+  // G^T . G runs on Co x Ci / 64 blocks: with many slices (few channel tiles) that is a handful of blocks each walking
+  // hundreds of strided rows — sum the slices with the wide reducer first (2 304+ blocks, fixed order: deterministic)
+  const float* red_src = static_cast<const float*>(workspace);
+  int red_slices = p.n_slices;
+  if (p.n_slices >= 8) {
+    float* sum = static_cast<float*>(workspace) + (size_t)p.n_slices * slice_elems;
+    sivae_launch_slice_reduce(red_src, sum, p.n_slices, slice_elems, stream);
+    rc = sivae_launch_status();
+    if (rc != SIVAE_OK) return rc;
+    red_src = sum;
+    red_slices = 1;
+  }
   const int n_cic = (Ci + 63) / 64;
-  hipLaunchKernelGGL(wino4_wgrad_reduce_kernel, dim3((unsigned)(Co * n_cic)), dim3(256), 0, stream,
-                     static_cast<const float*>(workspace), dw, Co, Ci, p.Co_pad, p.Ci_pad, p.n_slices);
+  hipLaunchKernelGGL(wino4_wgrad_reduce_kernel, dim3((unsigned)(Co * n_cic)), dim3(256), 0, stream, red_src, dw, Co, Ci,
+                     p.Co_pad, p.Ci_pad, red_slices);
   return sivae_launch_status();
 }
