@@ -170,7 +170,8 @@ def _pmc_busy(kernel_key, config="celeb256", dtype="fp32"):
     """matrix-pipe busy fraction of `kernel_key` from the committed rocprofv3 --pmc pass of the workload
     (tools/pmc_mfma_busy.py over SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE; counters cannot be read from inside the
     bench)"""
-    names = {("celeb256", "fp32"): ("r2_pmc_mfma_busy_bs128_final.json", "r2_pmc_mfma_busy_bs128.json"),
+    names = {("celeb256", "fp32"): ("r3_pmc_mfma_busy_celeb256_bs128_fp32.json", "r2_pmc_mfma_busy_bs128_final.json",
+                                    "r2_pmc_mfma_busy_bs128.json"),
              ("celeb128", "bf16"): ("r2_pmc_mfma_busy_celeb128_bf16.json",)}.get((config, dtype), ())
     for name in names:
         path = os.path.join(PROFILES, name)
@@ -183,7 +184,8 @@ def _pmc_busy(kernel_key, config="celeb256", dtype="fp32"):
 
 def _pmc_traffic(kernel_key, config, dtype):
     """HBM bytes per launch of `kernel_key` + whole-step bytes from the committed FETCH_SIZE / WRITE_SIZE passes"""
-    names = {("celeb256", "fp32"): ("r2_pmc_traffic_final.json", "r1_pmc_traffic.json"),
+    names = {("celeb256", "fp32"): ("r3_pmc_traffic_celeb256_bs128_fp32.json", "r2_pmc_traffic_final.json",
+                                    "r1_pmc_traffic.json"),
              ("celeb128", "bf16"): ("r2_pmc_traffic_celeb128_bf16.json",)}.get((config, dtype), ())
     for name in names:
         path = os.path.join(PROFILES, name)
