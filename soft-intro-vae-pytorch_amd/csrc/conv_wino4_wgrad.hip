@@ -78,7 +78,8 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
   __shared__ __attribute__((aligned(16))) float vs1[G4_VS];
   __shared__ __attribute__((aligned(16))) float ms0[G4_MS];
   __shared__ __attribute__((aligned(16))) float ms1[G4_MS];
-  __shared__ float4 pro4[PRO ? 64 : 1];  // {mean, invstd*gamma, beta, -} per (segment, channel of the tile)
+  // {scale, shift} = {invstd*gamma, beta - mean*scale} per (segment, channel of the tile): x' = lrelu(x*scale + shift)
+  __shared__ float2 pro2[PRO ? 64 : 1];
 #define G4_RX(K) ((K) == 0 ? rx0 : ((K) == 1 ? rx1 : rx2))
 #define G4_RY(K) ((K) == 0 ? ry0 : ((K) == 1 ? ry1 : ry2))
 #define G4_VB(HB) ((HB) ? vs1 : vs0)
@@ -222,19 +223,17 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
 #define G4_FIX1(K, FOFF, CIDX, SBITS, LCOND)                                                        \
   {                                                                                                 \
     const unsigned in_ = G4_INF(K);                                                                 \
-    float4 p_ = pro4[(in_ >> 8) + (CIDX)];                                                          \
-    if (((SBITS) & in_ & 31u) || (LCOND)) p_ = make_float4(0.f, 0.f, 0.f, 0.f);                     \
+    float2 p_ = pro2[(in_ >> 8) + (CIDX)];                                                          \
+    if (((SBITS) & in_ & 31u) || (LCOND)) p_ = make_float2(0.f, 0.f);                               \
     float4* q_ = reinterpret_cast<float4*>(G4_RX(K) + (FOFF));                                      \
-    float4 v_ = *q_;                                                                                \
-    v_.x = fmaf(v_.x - p_.x, p_.y, p_.z);                                                           \
-    v_.y = fmaf(v_.y - p_.x, p_.y, p_.z);                                                           \
-    v_.z = fmaf(v_.z - p_.x, p_.y, p_.z);                                                           \
-    v_.w = fmaf(v_.w - p_.x, p_.y, p_.z);                                                           \
-    v_.x = fmaxf(v_.x, v_.x * a.pro_slope);                                                         \
-    v_.y = fmaxf(v_.y, v_.y * a.pro_slope);                                                         \
-    v_.z = fmaxf(v_.z, v_.z * a.pro_slope);                                                         \
-    v_.w = fmaxf(v_.w, v_.w * a.pro_slope);                                                         \
-    *q_ = v_;                                                                                       \
+    const float4 v_ = *q_;                                                                          \
+    /* two pixels per packed-fp32 instruction */                                                    \
+    const f32x2 sc_ = {p_.x, p_.x}, sh_ = {p_.y, p_.y}, sl_ = {a.pro_slope, a.pro_slope};           \
+    f32x2 lo_ = {v_.x, v_.y}, hi_ = {v_.z, v_.w};                                                   \
+    lo_ = __builtin_elementwise_fma(lo_, sc_, sh_);                                                 \
+    hi_ = __builtin_elementwise_fma(hi_, sc_, sh_);                                                 \
+    const f32x2 ls_ = lo_ * sl_, hs_ = hi_ * sl_;                                                   \
+    *q_ = make_float4(fmaxf(lo_[0], ls_[0]), fmaxf(lo_[1], ls_[1]), fmaxf(hi_[0], hs_[0]), fmaxf(hi_[1], hs_[1])); \
   }
   // (the lane-dependent offsets are recomputed from a LAUNDERED lane index at every use: hoisted out of the loop they are
   // spilled, and a spill reload inside the loop carries an s_waitcnt vmcnt(0) — it would wait out the requests in flight)
@@ -368,10 +367,9 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
     G4_T_READ(ROLE, TK, XOFF, YXOR, 1, rd2_, ex2_)                                                  \
     G4_READ2(HB, 0, a0_, b0_)                                                                       \
     G4_FENCE                                                                                        \
-    REQCODE                                                                                         \
-    G4_FENCE                                                                                        \
     G4_MMA2(4, a2_, b2_)                                                                            \
     G4_FENCE                                                                                        \
+    REQCODE /* (scalar address arithmetic: under the two MFMAs just issued, not in front of them) */ \
     G4_READ2(HB, 2, a1_, b1_)                                                                       \
     G4_T_COL(ROLE, 0, rd_, ex_)                                                                     \
     G4_FENCE                                                                                        \
@@ -433,8 +431,12 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
   if (PRO) {
     for (int idx = tid; idx < a.pro_nseg * 32; idx += G4_NT) {
       const int c = ci0 + (idx & 31), so = (idx >> 5) * a.Ci;
-      pro4[idx] = c < a.Ci ? make_float4(a.pro_mean[so + c], a.pro_invstd[so + c] * a.pro_gamma[c], a.pro_beta[c], 0.f)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      float sc = 0.f, sh = 0.f;
+      if (c < a.Ci) {
+        sc = a.pro_invstd[so + c] * a.pro_gamma[c];
+        sh = fmaf(-a.pro_mean[so + c], sc, a.pro_beta[c]);
+      }
+      pro2[idx] = make_float2(sc, sh);
     }
   }
   if (s_begin < s_end) {
