@@ -203,6 +203,9 @@ WINO4 = os.environ.get("SIVAE_WINO4", "1") != "0"
 WINO4_MAXC = int(os.environ.get("SIVAE_WINO4_MAXC", "512"))
 # F(4x4,3x3) weight gradient (conv_wino4_wgrad.hip); SIVAE_WINO4_WGRAD=0: the F(2x2,3x3) one everywhere
 WINO4_WGRAD = WINO4 and os.environ.get("SIVAE_WINO4_WGRAD", "1") != "0"
+# SIVAE_WINO4_FORCE=1: take the F(4x4,3x3) kernels wherever they are SUPPORTED, not only where they pay (tests: the
+# oracle comparisons run at batch 2-4, below the work-item thresholds)
+WINO4_FORCE = os.environ.get("SIVAE_WINO4_FORCE", "0") == "1"
 WINO4_PRO = os.environ.get("SIVAE_WINO4_PRO", "1") != "0"  # ... also with a fused BatchNorm prologue (conv2 forward)
 # SIVAE_FUSE_BN_BWD=1: reduce BatchNorm-1's backward sums in the epilogue of conv2's data gradient.  Measured a LOSS at
 # 256x256 bs128 (593 vs 585 ms per iteration: the extra tensor read sits on the kernel's critical path and disables its
@@ -398,7 +401,9 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
             TIMER.end("conv1x1_stream_kernel", 2.0 * B * H * W * Co * Ci, t0)
         return y
     if (WINO and WINO4 and ks == 3 and bias is None and not upsample and isinstance(wp, PackedW)
-            and max(Ci, Co) <= WINO4_MAXC and L.sivae_conv2d_wino4_pays(B, Ci, Co, H, W) == 1
+            and max(Ci, Co) <= WINO4_MAXC
+            and (L.sivae_conv2d_wino4_pays(B, Ci, Co, H, W) == 1
+                 or (WINO4_FORCE and Ci >= 16 and L.sivae_conv2d_wino4_supported(H, W) == 1))
             and (pro is None or (WINO4_PRO and nseg * ((Ci + 31) // 32) * 32 <= 1024))):
         # large maps: F(4x4,3x3) — 2.25 multiplies per output pixel instead of 4
         _require(x, out)
@@ -503,7 +508,9 @@ def conv2d_wgrad(x, dy, ks, pro=None, upsample=False, out=None, nseg=1):
             TIMER.end("wino_up_wgrad_kernel", flops, t0, executed=flops * 9.0 / 36.0)
         return dw
     if (WINO4_WGRAD and WINO_WGRAD and ks == 3 and not upsample and (pro is None or nseg <= 2)
-            and max(Ci, Co) <= WINO4_MAXC and L.sivae_conv2d_wino4_wgrad_pays(B, Ci, Co, H, W) == 1):
+            and max(Ci, Co) <= WINO4_MAXC
+            and (L.sivae_conv2d_wino4_wgrad_pays(B, Ci, Co, H, W) == 1
+                 or (WINO4_FORCE and min(Ci, Co) >= 16 and L.sivae_conv2d_wino4_wgrad_supported(H, W) == 1))):
         # Winograd F(4x4,3x3) weight gradient (conv_wino4_wgrad.hip): 36 instead of 64 multiplies per tile, co, ci
         ws = workspace(L.sivae_conv2d_wino4_wgrad_workspace_bytes(B, Ci, Co, H, W), x.device)
         dw = _out(out, (Co, Ci, 3, 3), x.device)

@@ -437,6 +437,18 @@ def test_bootstrap_6level_topology_vs_oracle():
     assert not _oracle_vs_hip(3, 64, [8, 16, 32, 64, 64, 64], 256, 2, hp, boot=True, seed=4, referee=False)
 
 
+def test_forced_wino4_kernels_vs_oracle(monkeypatch):
+    """Both F(4x4,3x3) kernels (forward / data gradient AND the weight gradient) on every layer they support — at the
+    oracle comparisons' batch sizes the dispatch would keep most layers on F(2x2,3x3) — one iteration vs the live oracle
+    with the fp64 gradient referee, plain and bootstrap"""
+    from sivae_hip import ops
+    monkeypatch.setattr(ops, "WINO4_FORCE", True)
+    hp = dict(beta_rec=0.5, beta_kl=1.0, beta_neg=256.0, gamma_r=1e-8)
+    assert not _oracle_vs_hip(3, 64, [32, 64, 64, 96], 128, 4, hp, seed=21)
+    hp = dict(beta_rec=0.5, beta_kl=1.0, beta_neg=256.0, gamma_r=1.0)
+    assert not _oracle_vs_hip(3, 48, [32, 48, 64], 64, 4, hp, boot=True, seed=22, referee=False)
+
+
 def test_bootstrap256_full_config_vs_oracle():
     """config 5's network exactly (soft_intro_vae_bootstrap, 256x256, [64,128,256,512,512,512], z 512, gamma_r 1) at B = 2
     vs the live oracle — the full-width counterpart of test_bootstrap_6level_topology_vs_oracle"""
