@@ -59,7 +59,8 @@ struct Wino4WgArgs {
 #define G4_VS 2304  // V of a k-step: [36][2 tiles][32 ci]
 #define G4_MS 4608  // Mg of a k-step: [36][2 tiles][64 co]
 
-// Timing ablations (results WRONG with any bit set): 1 no LDS-direct loads, 2 no transform phase, 4 no MFMAs
+// Timing ablations (results WRONG with any bit set): 1 no LDS-direct loads, 2 no transform phase, 4 no MFMAs, 8 no prologue
+// store, 16 no prologue at all
 #ifndef G4_ABLATE
 #define G4_ABLATE 0
 #endif
@@ -132,9 +133,9 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
   const int fa_s = ((wave >> 1) * 192 + (wave & 1) * 96) * 4, fa_cs = (wave & 1) * 16;
   // (group of lane: (lane / 4) * 6 + lane % 4 + r(ci), ci = 16 (wave & 1) + lane / 4)
   const unsigned fa_sbits = 16u | (wave < 2 ? 1u : 0u) | (wave >= 10 ? 2u : 0u);
-  const int fb_s = (wave * 192 + 4) * 4;
+  const int fb_s = ((wave % 6) * 192 + 4) * 4;  // (waves 6-11 read the same groups as 0-5, unconditionally, and do not write)
   // (group of lane: (lane / 2) * 6 + (4 + lane % 2 + r(ci)) % 6, ci = lane / 2)
-  const unsigned fb_sbits = 16u | (wave == 0 ? 1u : 0u) | (wave == 5 ? 2u : 0u);
+  const unsigned fb_sbits = 16u | (wave % 6 == 0 ? 1u : 0u) | (wave % 6 == 5 ? 2u : 0u);
   // ---- transform roles.  Every k-step transforms the two tiles of the NEXT k-step (k-step A, MFMAs on tiles 0,1: tiles
   // 2,3 of the same stage; k-step B, MFMAs on tiles 2,3: tiles 0,1 of the next stage) in nine wave-tasks, each a THIRD of an
   // item — the frequency columns come in pairs that share their partial sums ((1,2), (3,4); (0,5) stand alone):
@@ -220,20 +221,34 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
   }
   // fused BatchNorm + LeakyReLU prologue, in place on the raw x slot K: x' = max(v, slope v), v = (x - mean) scale + beta;
   // groups outside the image (and channels beyond Ci: zero table rows) stay zero
-#define G4_FIX1(K, FOFF, CIDX, SBITS, LCOND)                                                        \
+  // read part (issued at the top of the k-step, so that the LDS latency hides under the MFMAs) ...
+#define G4_FIX_RD(K, FOFF, CIDX, SBITS, LCOND)                                                      \
   {                                                                                                 \
     const unsigned in_ = G4_INF(K);                                                                 \
-    float2 p_ = pro2[(in_ >> 8) + (CIDX)];                                                          \
-    if (((SBITS) & in_ & 31u) || (LCOND)) p_ = make_float2(0.f, 0.f);                               \
-    float4* q_ = reinterpret_cast<float4*>(G4_RX(K) + (FOFF));                                      \
-    const float4 v_ = *q_;                                                                          \
-    /* two pixels per packed-fp32 instruction */                                                    \
-    const f32x2 sc_ = {p_.x, p_.x}, sh_ = {p_.y, p_.y}, sl_ = {a.pro_slope, a.pro_slope};           \
-    f32x2 lo_ = {v_.x, v_.y}, hi_ = {v_.z, v_.w};                                                   \
+    fxp_ = pro2[(in_ >> 8) + (CIDX)];                                                               \
+    if (((SBITS) & in_ & 31u) || (LCOND)) fxp_ = make_float2(0.f, 0.f);                             \
+    fxq_ = reinterpret_cast<float4*>(G4_RX(K) + (FOFF));                                            \
+    fxv_ = *fxq_;                                                                                   \
+  }
+  // ... and the rewrite (two pixels per packed-fp32 instruction)
+#define G4_FIX_WR                                                                                   \
+  {                                                                                                 \
+    const f32x2 sc_ = {fxp_.x, fxp_.x}, sh_ = {fxp_.y, fxp_.y}, sl_ = {a.pro_slope, a.pro_slope};   \
+    f32x2 lo_ = {fxv_.x, fxv_.y}, hi_ = {fxv_.z, fxv_.w};                                           \
     lo_ = __builtin_elementwise_fma(lo_, sc_, sh_);                                                 \
     hi_ = __builtin_elementwise_fma(hi_, sc_, sh_);                                                 \
     const f32x2 ls_ = lo_ * sl_, hs_ = hi_ * sl_;                                                   \
-    *q_ = make_float4(fmaxf(lo_[0], ls_[0]), fmaxf(lo_[1], ls_[1]), fmaxf(hi_[0], hs_[0]), fmaxf(hi_[1], hs_[1])); \
+    const float4 fo_ = make_float4(fmaxf(lo_[0], ls_[0]), fmaxf(lo_[1], ls_[1]), fmaxf(hi_[0], hs_[0]), fmaxf(hi_[1], hs_[1])); \
+    if (!(G4_ABLATE & 8)) *fxq_ = fo_;                                                              \
+    else if (fo_.x == 12345.f) fxq_[1] = fo_; /* (keeps the arithmetic alive) */                    \
+  }
+#define G4_FIX1(K, FOFF, CIDX, SBITS, LCOND)                                                        \
+  {                                                                                                 \
+    float2 fxp_;                                                                                    \
+    float4 fxv_;                                                                                    \
+    float4* fxq_;                                                                                   \
+    G4_FIX_RD(K, FOFF, CIDX, SBITS, LCOND)                                                          \
+    G4_FIX_WR                                                                                       \
   }
   // (the lane-dependent offsets are recomputed from a LAUNDERED lane index at every use: hoisted out of the loop they are
   // spilled, and a spill reload inside the loop carries an s_waitcnt vmcnt(0) — it would wait out the requests in flight)
@@ -243,6 +258,20 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
     asm volatile("" : "+v"(ln_));                                                                   \
     G4_FIX1(K, fa_s + ((ln_ >> 2) * 6 + (ln_ & 3) + ((ln_ >> 5) & 1)) * 4, fa_cs + (ln_ >> 2), fa_sbits, \
             (in_ & 4u) && (ln_ & 3) == 0)                                                           \
+  }
+#define G4_FIXA_RD(K)                                                                               \
+  {                                                                                                 \
+    int ln_ = lane;                                                                                 \
+    asm volatile("" : "+v"(ln_));                                                                   \
+    G4_FIX_RD(K, fa_s + ((ln_ >> 2) * 6 + (ln_ & 3) + ((ln_ >> 5) & 1)) * 4, fa_cs + (ln_ >> 2), fa_sbits, \
+              (in_ & 4u) && (ln_ & 3) == 0)                                                         \
+  }
+#define G4_FIXB_RD(K)                                                                               \
+  {                                                                                                 \
+    int ln_ = lane;                                                                                 \
+    asm volatile("" : "+v"(ln_));                                                                   \
+    G4_FIX_RD(K, fb_s + ((ln_ >> 1) * 6 + (4 + (ln_ & 1) + ((ln_ >> 4) & 1)) % 6 - 4) * 4, ln_ >> 1, fb_sbits, \
+              (in_ & 8u) && (ln_ & 1) == 1)                                                         \
   }
 #define G4_FIXB(K)                                                                                  \
   {                                                                                                 \
@@ -358,8 +387,12 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
   // The MFMA schedule is ROTATED by one pair: the k-step opens — right behind the barrier, while its own LDS reads are in
   // flight — with the previous k-step's last pair (operands a2_/b2_ carried in registers), and ends with its pair (2,3),
   // under which the task's LDS stores drain before the closing barrier.
-#define G4_KSTEP(ROLE, HB, TK, XOFF, YXOR, REQCODE, FIXCODE)                                        \
+#define G4_KSTEP(ROLE, HB, TK, XOFF, YXOR, REQCODE, FIXRD, FIXCODE)                                 \
   {                                                                                                 \
+    float2 fxp_;                                                                                    \
+    float4 fxv_;                                                                                    \
+    float4* fxq_;                                                                                   \
+    if ((ROLE) != 3) { FIXRD } /* (the (0,5) x role has no registers to spare: it reads late) */     \
     float4 rd_[4], rd2_[3];                                                                         \
     float ex_[6], ex2_[6], tA_[6], tB_[6];                                                          \
     float a0_[2], b0_[2], a1_[2], b1_[2];                                                           \
@@ -379,6 +412,7 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
     G4_T_COL(ROLE, 1, rd2_, ex2_)                                                                   \
     G4_T_ROW(ROLE, (HB) ^ 1, tA_, jA)                                                               \
     G4_T_ROW(ROLE, (HB) ^ 1, tB_, jB)                                                               \
+    if ((ROLE) == 3) { FIXRD }                                                                      \
     FIXCODE                                                                                         \
     G4_FENCE                                                                                        \
     G4_MMA2(2, a1_, b1_)                                                                            \
@@ -391,10 +425,11 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
   //             groups 4,5 of slot K+1 (tiles 0,1 read groups 0-3 only)
 #define G4_STAGE(ROLE, K)                                                                           \
   {                                                                                                 \
-    G4_KSTEP(ROLE, 0, K, 8, 8, , if (PRO) G4_FIXA(((K) + 1) % 3))                                   \
+    G4_KSTEP(ROLE, 0, K, 8, 8, , if (PRO && !(G4_ABLATE & 16)) G4_FIXA_RD(((K) + 1) % 3), if (PRO && !(G4_ABLATE & 16)) G4_FIX_WR)            \
     G4_LDS_BARRIER                                                                                  \
     G4_FENCE                                                                                        \
-    G4_KSTEP(ROLE, 1, ((K) + 1) % 3, 0, 0, G4_REQ(K), if (PRO && wave < 6) G4_FIXB(((K) + 1) % 3))  \
+    G4_KSTEP(ROLE, 1, ((K) + 1) % 3, 0, 0, G4_REQ(K), if (PRO && !(G4_ABLATE & 16)) G4_FIXB_RD(((K) + 1) % 3), \
+             if (PRO && !(G4_ABLATE & 16) && wave < 6) G4_FIX_WR)                                                        \
     asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                                \
     G4_LDS_BARRIER                                                                                  \
     G4_FENCE                                                                                        \
