@@ -59,8 +59,7 @@ struct Wino4WgArgs {
 #define G4_VS 2304  // V of a k-step: [36][2 tiles][32 ci]
 #define G4_MS 4608  // Mg of a k-step: [36][2 tiles][64 co]
 
-// Timing ablations (results WRONG with any bit set): 1 no LDS-direct loads, 2 no transform phase, 4 no MFMAs, 8 no prologue
-// store, 16 no prologue at all
+// Timing ablations (results WRONG with any bit set): 1 no LDS-direct loads, 2 no transform phase, 4 no MFMAs, 16 no prologue
 #ifndef G4_ABLATE
 #define G4_ABLATE 0
 #endif
@@ -127,15 +126,18 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
       rq_lds[i] = dd * 256;
     }
   }
-  // ---- prologue role: k-step A rewrites the 16-byte groups p = 0..3 of the NEXT stage's x slot (one per thread: row =
-  // tid / 128, channel (tid % 128) / 4, p = tid % 4), k-step B its groups p = 4, 5 (the first six waves: row = wave,
-  // channel lane / 2, p = 4 + lane % 2).  Row and channel-base are wave-uniform; per lane only the group offset is kept.
-  const int fa_s = ((wave >> 1) * 192 + (wave & 1) * 96) * 4, fa_cs = (wave & 1) * 16;
-  // (group of lane: (lane / 4) * 6 + lane % 4 + r(ci), ci = 16 (wave & 1) + lane / 4)
-  const unsigned fa_sbits = 16u | (wave < 2 ? 1u : 0u) | (wave >= 10 ? 2u : 0u);
-  const int fb_s = ((wave % 6) * 192 + 4) * 4;  // (waves 6-11 read the same groups as 0-5, unconditionally, and do not write)
-  // (group of lane: (lane / 2) * 6 + (4 + lane % 2 + r(ci)) % 6, ci = lane / 2)
-  const unsigned fb_sbits = 16u | (wave % 6 == 0 ? 1u : 0u) | (wave % 6 == 5 ? 2u : 0u);
+  // ---- prologue role: k-step A of stage s rewrites the whole raw x slot of stage s+1 in place — 16-byte group tid (rows 0-3;
+  // a wave covers 64 consecutive groups of ONE row: row = wave / 3) and, for the first six waves, group 768 + tid (rows 4, 5:
+  // the same channel / group-of-the-row, so the table entry and the left / right test are shared).  Per lane one register:
+  // channel << 3 | (true group == 0) | (true group == 5) << 1; the row part of everything is wave-uniform.
+  unsigned fx_lc;
+  {
+    const int rem = (wave % 3) * 64 + lane, ci = rem / 6, pp = rem - ci * 6, p = (pp + 6 - ((ci >> 3) & 1)) % 6;
+    fx_lc = ((unsigned)ci << 3) | (p == 0 ? 1u : 0u) | (p == 5 ? 2u : 0u);
+  }
+  const int fx_s0 = ((wave / 3) * 192 + (wave % 3) * 64) * 4;  // floats; the second group: + 768 * 4
+  const unsigned fx_sb0 = 16u | (wave < 3 ? 1u : 0u);           // row 0 <-> top border
+  const unsigned fx_sb1 = 16u | (wave >= 3 ? 2u : 0u);          // (waves 0-5) row 4 + wave / 3 == 5 <-> bottom border
   // ---- transform roles.  Every k-step transforms the two tiles of the NEXT k-step (k-step A, MFMAs on tiles 0,1: tiles
   // 2,3 of the same stage; k-step B, MFMAs on tiles 2,3: tiles 0,1 of the next stage) in nine wave-tasks, each a THIRD of an
   // item — the frequency columns come in pairs that share their partial sums ((1,2), (3,4); (0,5) stand alone):
@@ -221,64 +223,36 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
   }
   // fused BatchNorm + LeakyReLU prologue, in place on the raw x slot K: x' = max(v, slope v), v = (x - mean) scale + beta;
   // groups outside the image (and channels beyond Ci: zero table rows) stay zero
-  // read part (issued at the top of the k-step, so that the LDS latency hides under the MFMAs) ...
-#define G4_FIX_RD(K, FOFF, CIDX, SBITS, LCOND)                                                      \
+  // x' = max(v, slope v), v = x scale + shift (two pixels per packed-fp32 instruction); groups outside the image and
+  // channels beyond Ci (zero table rows) stay zero
+#define G4_FIX_ONE(QP, SC, SH)                                                                      \
   {                                                                                                 \
-    const unsigned in_ = G4_INF(K);                                                                 \
-    fxp_ = pro2[(in_ >> 8) + (CIDX)];                                                               \
-    if (((SBITS) & in_ & 31u) || (LCOND)) fxp_ = make_float2(0.f, 0.f);                             \
-    fxq_ = reinterpret_cast<float4*>(G4_RX(K) + (FOFF));                                            \
-    fxv_ = *fxq_;                                                                                   \
-  }
-  // ... and the rewrite (two pixels per packed-fp32 instruction)
-#define G4_FIX_WR                                                                                   \
-  {                                                                                                 \
-    const f32x2 sc_ = {fxp_.x, fxp_.x}, sh_ = {fxp_.y, fxp_.y}, sl_ = {a.pro_slope, a.pro_slope};   \
-    f32x2 lo_ = {fxv_.x, fxv_.y}, hi_ = {fxv_.z, fxv_.w};                                           \
+    const float4 v_ = *(QP);                                                                        \
+    const f32x2 sc_ = {SC, SC}, sh_ = {SH, SH}, sl_ = {a.pro_slope, a.pro_slope};                   \
+    f32x2 lo_ = {v_.x, v_.y}, hi_ = {v_.z, v_.w};                                                   \
     lo_ = __builtin_elementwise_fma(lo_, sc_, sh_);                                                 \
     hi_ = __builtin_elementwise_fma(hi_, sc_, sh_);                                                 \
     const f32x2 ls_ = lo_ * sl_, hs_ = hi_ * sl_;                                                   \
-    const float4 fo_ = make_float4(fmaxf(lo_[0], ls_[0]), fmaxf(lo_[1], ls_[1]), fmaxf(hi_[0], hs_[0]), fmaxf(hi_[1], hs_[1])); \
-    if (!(G4_ABLATE & 8)) *fxq_ = fo_;                                                              \
-    else if (fo_.x == 12345.f) fxq_[1] = fo_; /* (keeps the arithmetic alive) */                    \
+    *(QP) = make_float4(fmaxf(lo_[0], ls_[0]), fmaxf(lo_[1], ls_[1]), fmaxf(hi_[0], hs_[0]), fmaxf(hi_[1], hs_[1])); \
   }
-#define G4_FIX1(K, FOFF, CIDX, SBITS, LCOND)                                                        \
-  {                                                                                                 \
-    float2 fxp_;                                                                                    \
-    float4 fxv_;                                                                                    \
-    float4* fxq_;                                                                                   \
-    G4_FIX_RD(K, FOFF, CIDX, SBITS, LCOND)                                                          \
-    G4_FIX_WR                                                                                       \
-  }
-  // (the lane-dependent offsets are recomputed from a LAUNDERED lane index at every use: hoisted out of the loop they are
+  // (the lane offset is recomputed from a LAUNDERED lane index at every use: hoisted out of the loop such constants are
   // spilled, and a spill reload inside the loop carries an s_waitcnt vmcnt(0) — it would wait out the requests in flight)
-#define G4_FIXA(K)                                                                                  \
-  {                                                                                                 \
+#define G4_FIX(K)                                                                                   \
+  if (!(G4_ABLATE & 16)) {                                                                          \
+    const unsigned in_ = G4_INF(K);                                                                 \
     int ln_ = lane;                                                                                 \
     asm volatile("" : "+v"(ln_));                                                                   \
-    G4_FIX1(K, fa_s + ((ln_ >> 2) * 6 + (ln_ & 3) + ((ln_ >> 5) & 1)) * 4, fa_cs + (ln_ >> 2), fa_sbits, \
-            (in_ & 4u) && (ln_ & 3) == 0)                                                           \
-  }
-#define G4_FIXA_RD(K)                                                                               \
-  {                                                                                                 \
-    int ln_ = lane;                                                                                 \
-    asm volatile("" : "+v"(ln_));                                                                   \
-    G4_FIX_RD(K, fa_s + ((ln_ >> 2) * 6 + (ln_ & 3) + ((ln_ >> 5) & 1)) * 4, fa_cs + (ln_ >> 2), fa_sbits, \
-              (in_ & 4u) && (ln_ & 3) == 0)                                                         \
-  }
-#define G4_FIXB_RD(K)                                                                               \
-  {                                                                                                 \
-    int ln_ = lane;                                                                                 \
-    asm volatile("" : "+v"(ln_));                                                                   \
-    G4_FIX_RD(K, fb_s + ((ln_ >> 1) * 6 + (4 + (ln_ & 1) + ((ln_ >> 4) & 1)) % 6 - 4) * 4, ln_ >> 1, fb_sbits, \
-              (in_ & 8u) && (ln_ & 1) == 1)                                                         \
-  }
-#define G4_FIXB(K)                                                                                  \
-  {                                                                                                 \
-    int ln_ = lane;                                                                                 \
-    asm volatile("" : "+v"(ln_));                                                                   \
-    G4_FIX1(K, fb_s + ((ln_ >> 1) * 6 + (4 + (ln_ & 1) + ((ln_ >> 4) & 1)) % 6 - 4) * 4, ln_ >> 1, fb_sbits, \
-            (in_ & 8u) && (ln_ & 1) == 1)                                                           \
+    const float2 p_ = pro2[(in_ >> 8) + (fx_lc >> 3)];                                              \
+    const bool lout_ = (fx_lc & (in_ >> 2) & 3u) != 0u;                                             \
+    float4* q_ = reinterpret_cast<float4*>(G4_RX(K) + fx_s0) + ln_;                                 \
+    {                                                                                               \
+      const bool out_ = lout_ || (fx_sb0 & in_ & 31u) != 0u;                                        \
+      G4_FIX_ONE(q_, out_ ? 0.f : p_.x, out_ ? 0.f : p_.y)                                          \
+    }                                                                                               \
+    if (wave < 6) {                                                                                 \
+      const bool out_ = lout_ || (fx_sb1 & in_ & 31u) != 0u;                                        \
+      G4_FIX_ONE(q_ + 768, out_ ? 0.f : p_.x, out_ ? 0.f : p_.y)                                    \
+    }                                                                                               \
   }
 #define G4_FENCE __builtin_amdgcn_sched_barrier(0);
   // workgroup barrier that orders LDS traffic only (a __syncthreads() with LDS-direct loads in flight waits vmcnt(0))
@@ -387,12 +361,8 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
   // The MFMA schedule is ROTATED by one pair: the k-step opens — right behind the barrier, while its own LDS reads are in
   // flight — with the previous k-step's last pair (operands a2_/b2_ carried in registers), and ends with its pair (2,3),
   // under which the task's LDS stores drain before the closing barrier.
-#define G4_KSTEP(ROLE, HB, TK, XOFF, YXOR, REQCODE, FIXRD, FIXCODE)                                 \
+#define G4_KSTEP(ROLE, HB, TK, XOFF, YXOR, REQCODE, FIXCODE)                                        \
   {                                                                                                 \
-    float2 fxp_;                                                                                    \
-    float4 fxv_;                                                                                    \
-    float4* fxq_;                                                                                   \
-    if ((ROLE) != 3) { FIXRD } /* (the (0,5) x role has no registers to spare: it reads late) */     \
     float4 rd_[4], rd2_[3];                                                                         \
     float ex_[6], ex2_[6], tA_[6], tB_[6];                                                          \
     float a0_[2], b0_[2], a1_[2], b1_[2];                                                           \
@@ -412,7 +382,6 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
     G4_T_COL(ROLE, 1, rd2_, ex2_)                                                                   \
     G4_T_ROW(ROLE, (HB) ^ 1, tA_, jA)                                                               \
     G4_T_ROW(ROLE, (HB) ^ 1, tB_, jB)                                                               \
-    if ((ROLE) == 3) { FIXRD }                                                                      \
     FIXCODE                                                                                         \
     G4_FENCE                                                                                        \
     G4_MMA2(2, a1_, b1_)                                                                            \
@@ -420,16 +389,14 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
   }
   // One stage s in ring slot K = two k-steps.  On entry: half buffer 0 holds the transformed tiles 0,1 of stage s; slot K
   // has landed and is already rewritten by the prologue; slot K+1 (stage s+1) has landed; stage s+2 is in flight.
-  //   k-step A: MFMAs on half 0  ||  tiles 2,3 of slot K -> half 1  ||  prologue on groups 0-3 of slot K+1
-  //   k-step B: request stage s+3 into slot K  ||  MFMAs on half 1  ||  tiles 0,1 of slot K+1 -> half 0  ||  prologue on
-  //             groups 4,5 of slot K+1 (tiles 0,1 read groups 0-3 only)
+  //   k-step A: MFMAs on half 0  ||  tiles 2,3 of slot K -> half 1  ||  prologue on the whole slot K+1
+  //   k-step B: request stage s+3 into slot K  ||  MFMAs on half 1  ||  tiles 0,1 of slot K+1 -> half 0
 #define G4_STAGE(ROLE, K)                                                                           \
   {                                                                                                 \
-    G4_KSTEP(ROLE, 0, K, 8, 8, , if (PRO && !(G4_ABLATE & 16)) G4_FIXA_RD(((K) + 1) % 3), if (PRO && !(G4_ABLATE & 16)) G4_FIX_WR)            \
+    G4_KSTEP(ROLE, 0, K, 8, 8, , if (PRO) G4_FIX(((K) + 1) % 3))                                    \
     G4_LDS_BARRIER                                                                                  \
     G4_FENCE                                                                                        \
-    G4_KSTEP(ROLE, 1, ((K) + 1) % 3, 0, 0, G4_REQ(K), if (PRO && !(G4_ABLATE & 16)) G4_FIXB_RD(((K) + 1) % 3), \
-             if (PRO && !(G4_ABLATE & 16) && wave < 6) G4_FIX_WR)                                                        \
+    G4_KSTEP(ROLE, 1, ((K) + 1) % 3, 0, 0, G4_REQ(K), )                                             \
     asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                                \
     G4_LDS_BARRIER                                                                                  \
     G4_FENCE                                                                                        \
@@ -481,8 +448,7 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
     asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     __syncthreads();
     if (PRO) {
-      G4_FIXA(0)
-      if (wave < 6) G4_FIXB(0)
+      G4_FIX(0)
       __syncthreads();
     }
     if (r_x && tp == 2) G4_LOOP(3)
