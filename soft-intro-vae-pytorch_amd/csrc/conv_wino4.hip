@@ -54,6 +54,7 @@ struct Wino4Args {
   int accumulate;
   int n_items;
   int xcd_group;
+  int two;  // 16 x 16 maps: a work item is a PAIR of images side by side (32 x 16 pixels)
 };
 
 #define W4_CK 8
@@ -127,6 +128,10 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
   const float t_be = tp == 0 ? 1.f : 2.f;    // b = be*d3 + ga*d1
   const float t_ga = tp == 0 ? -4.f : -2.f;
   const bool pair05 = tp == 2;
+  // pair mode: lanes whose tile column is 4 (patch column 0 = the other image's last column) / 3 (patch column 5 = the
+  // other image's first column) — as 64-bit lane masks for v_cndmask (tile = lane & 31, column = tile & 7)
+  const unsigned long long seam_m0 = 0x1010101010101010ull, seam_m5 = 0x0808080808080808ull;
+  const int two_w = a.two ? 32 : a.W, two_mask = a.two ? 15 : -1, two_img = a.two ? a.Ci * a.H * a.W : 0;
   // ---- MFMA role: B operand V[(i*6 + wj)][2*kk + hh][l31]
   const int vrb = (wj * CK + hh) * 32 + l31;
 
@@ -164,9 +169,13 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
     r0 = tby * W4_PXH;                                                   \
     c0 = tbx * W4_PXW;                                                   \
     co0 = co_tile * W4_TCO;                                              \
-    xrsrc = make_rsrc(a.x + (size_t)b * a.Ci * HW, (unsigned long long)a.Ci * HW * 4ull); \
+    /* pair mode (16 x 16 maps): images 2 pt, 2 pt + 1 side by side — halo groups 1-4 of a row = image 0, 5-8 = image 1, */ \
+    /* 0 and 9 = zero padding (branch-free: two_w = 32, two_mask = 15, two_img = Ci*HW; otherwise W, ~0, 0) */ \
+    b = a.two ? 2 * pt : b;                                              \
+    xrsrc = make_rsrc(a.x + (size_t)b * a.Ci * HW, (unsigned long long)(a.two ? 2 : 1) * a.Ci * HW * 4ull); \
     const int r = r0 - 1 + prow, c = c0 - 4 + 4 * pk;                    \
-    xo = (pvalid && r >= 0 && r < H && c >= 0 && c < W) ? (unsigned)(r * W + c) * 4u : SIVAE_OOB; \
+    xo = (pvalid && r >= 0 && r < H && c >= 0 && c < two_w)              \
+             ? (unsigned)((c >> 4) * two_img + r * W + (c & two_mask)) * 4u : SIVAE_OOB; \
     ua_base = (unsigned)((wj * a.Ci_pad) * a.Co_pad + co0) * 24u;        \
     if (PRO) pseg = (b / a.pro_seg_images) * a.Ci_pad;                   \
   }
@@ -249,6 +258,10 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
       if (P05) {                                                         \
         te0_[r] = p_[r * RS - 1];                                        \
         te5_[r] = p_[r * RS + 4];                                        \
+        if (a.two) { /* the seam between the two images is zero padding for both (tile columns 3 | 4) */ \
+          asm volatile("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(te0_[r]) : "s"(seam_m0));                \
+          asm volatile("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(te5_[r]) : "s"(seam_m5));                \
+        }                                                                \
       }                                                                  \
     }                                                                    \
   }
@@ -419,14 +432,17 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
     {
       float* ex = vx + VBUF;
       const __amdgpu_buffer_rsrc_t yrsrc =
-          make_rsrc(a.y + (size_t)e_b * a.Co * HW, (unsigned long long)a.Co * HW * 4ull);
+          make_rsrc(a.y + (size_t)e_b * a.Co * HW, (unsigned long long)(a.two ? 2 : 1) * a.Co * HW * 4ull);
       float ssum[3] = {0.f, 0.f, 0.f}, ssq[3] = {0.f, 0.f, 0.f};
       // The lane index is laundered once per item: otherwise hipcc hoists the lane-dependent LDS / global offsets of this
       // epilogue out of the persistent item loop, spills them, and reloads each one behind an s_waitcnt vmcnt(0) — which
       // also waits for every output store issued so far (stores share vmcnt on gfx9): ~25 K cycles per item.
       int lane_ = lane;
       asm volatile("" : "+v"(lane_));
-      const int tx_ = lane_ & 7, ty_ = (lane_ >> 3) & 3, hh_ = lane_ >> 5;
+      const int ty_ = (lane_ >> 3) & 3, hh_ = lane_ >> 5;
+      // pair mode: tile columns 4-7 are image e_b + 1
+      const int tx_ = a.two ? (lane_ & 3) : (lane_ & 7);
+      const unsigned img_off = a.two ? (unsigned)((lane_ >> 2) & 1) * (unsigned)(a.Co * HW) * 4u : 0u;
 #pragma unroll
       for (int ar = 0; ar < 4; ++ar) {
 #pragma unroll
@@ -454,7 +470,7 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
             o.z = (z[1] + z[2]) + 4.f * (z[3] + z[4]);
             o.w = (z[1] - z[2]) + 8.f * (z[3] - z[4]) + z[5];
             const int chn = e_co0 + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh_;
-            const unsigned off = chn < a.Co ? (unsigned)((chn * H + e_r0 + 4 * ty_ + ar) * W + e_c0 + 4 * tx_) * 4u : SIVAE_OOB;
+            const unsigned off = chn < a.Co ? (unsigned)((chn * H + e_r0 + 4 * ty_ + ar) * W + e_c0 + 4 * tx_) * 4u + img_off : SIVAE_OOB;
             if (a.accumulate) {
               const float4 old = buf_load_f32x4(yrsrc, off, 0u);
               o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
@@ -565,8 +581,14 @@ extern "C" int sivae_pack_wino4_weight(const float* w, float* up, int Co, int Ci
 }
 
 // maps the F(4x4,3x3) kernel takes: whole 32 x 16 pixel tile blocks
+// 1: whole 32 x 16 pixel tile blocks; 2: 16 x 16 maps — a work item is a pair of images (B and, with segments, the images
+// per segment must be even)
 extern "C" int sivae_conv2d_wino4_supported(int H, int W) {
+  if (H == 16 && W == 16) return 2;
   return (H >= 16 && W >= 32 && (H % W4_PXH) == 0 && (W % W4_PXW) == 0) ? 1 : 0;
+}
+static inline long long w4_px_tiles(int B, int H, int W) {
+  return (H == 16 && W == 16) ? B / 2 : (long long)B * (H / W4_PXH) * (W / W4_PXW);
 }
 
 // does the F(4x4,3x3) kernel beat F(2x2,3x3) for this launch?  Its work item is 64 channels x 512 pixels and a CU holds
@@ -574,14 +596,16 @@ extern "C" int sivae_conv2d_wino4_supported(int H, int W) {
 // the F(2x2,3x3) kernel with its 4x smaller items and split-K wins (measured 0.78x); from one item per CU up it is
 // 1.27-1.57x (256x256 shard sizes 8 / 16 / 32 / 128 images).
 extern "C" int sivae_conv2d_wino4_pays(int B, int Ci, int Co, int H, int W) {
-  if (B <= 0 || Ci < 16 || Co <= 0 || !sivae_conv2d_wino4_supported(H, W)) return 0;
-  const long long items = (long long)B * (H / W4_PXH) * (W / W4_PXW) * ((Co + W4_TCO - 1) / W4_TCO);
+  const int sup = sivae_conv2d_wino4_supported(H, W);
+  if (B <= 0 || Ci < 16 || Co <= 0 || !sup || (sup == 2 && (B & 1))) return 0;
+  const long long items = w4_px_tiles(B, H, W) * ((Co + W4_TCO - 1) / W4_TCO);
   return items >= sivae_num_cus() ? 1 : 0;
 }
 
 extern "C" int sivae_conv2d_wino4_num_px_tiles(int B, int H, int W) {
-  if (B <= 0 || !sivae_conv2d_wino4_supported(H, W)) return SIVAE_ERR_SHAPE;
-  return B * (H / W4_PXH) * (W / W4_PXW);
+  const int sup = sivae_conv2d_wino4_supported(H, W);
+  if (B <= 0 || !sup || (sup == 2 && (B & 1))) return SIVAE_ERR_SHAPE;
+  return (int)w4_px_tiles(B, H, W);
 }
 
 // y[B][Co][H][W] (+)= conv3x3(x, U);  stats_partial (optional): [sivae_conv2d_wino4_num_px_tiles][Co][2] per-tile {sum, sumsq}
@@ -594,7 +618,9 @@ static int wino4_impl(const float* x, const float* up, float* y, const float* pr
   if (pro_mean && !(pro_slope >= 0.f && pro_slope <= 1.f)) return SIVAE_ERR_MODE;  // prologue uses max(v, v*slope)
   if (seg_images < 0 || (seg_images > 0 && B % seg_images != 0)) return SIVAE_ERR_SHAPE;
   if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
-  if (!sivae_conv2d_wino4_supported(H, W)) return SIVAE_ERR_SHAPE;
+  const int sup = sivae_conv2d_wino4_supported(H, W);
+  if (!sup) return SIVAE_ERR_SHAPE;
+  if (sup == 2 && ((B & 1) || (seg_images & 1))) return SIVAE_ERR_SHAPE;  // image pairs inside one segment
   if (((uintptr_t)y & 15u) != 0) return SIVAE_ERR_SHAPE;  // 16-byte stores
   const long long hw = (long long)H * W;
   if ((long long)Ci * hw * 4 >= 0x7fffffffLL || (long long)Co * hw * 4 >= 0x7fffffffLL) return SIVAE_ERR_RANGE;
@@ -619,11 +645,12 @@ static int wino4_impl(const float* x, const float* up, float* y, const float* pr
   a.Co_pad = w4_npad(Co);
   if (pro_mean && a.pro_nseg * a.Ci_pad > W4_PRO_MAX) return SIVAE_ERR_SHAPE;
   if (36ull * a.Ci_pad * a.Co_pad * 4ull >= 0xffffffffull) return SIVAE_ERR_RANGE;
-  a.nbh = H / W4_PXH;
-  a.nbw = W / W4_PXW;
+  a.two = sup == 2 ? 1 : 0;
+  a.nbh = a.two ? 1 : H / W4_PXH;
+  a.nbw = a.two ? 1 : W / W4_PXW;
   a.n_co_tiles = a.Co_pad / W4_TCO;
   a.accumulate = accumulate;
-  const long long nitems = (long long)B * a.nbh * a.nbw * a.n_co_tiles;
+  const long long nitems = w4_px_tiles(B, H, W) * a.n_co_tiles;
   if (nitems > 0x7fffffffLL) return SIVAE_ERR_RANGE;
   a.n_items = (int)nitems;
   // (96 KB of static LDS: one block per CU)

@@ -402,8 +402,10 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
         return y
     if (WINO and WINO4 and ks == 3 and bias is None and not upsample and isinstance(wp, PackedW)
             and max(Ci, Co) <= WINO4_MAXC
+            and (nseg == 1 or W != 16 or (B // nseg) % 2 == 0)  # (16x16 maps: image pairs inside one segment)
             and (L.sivae_conv2d_wino4_pays(B, Ci, Co, H, W) == 1
-                 or (WINO4_FORCE and Ci >= 16 and L.sivae_conv2d_wino4_supported(H, W) == 1))
+                 or (WINO4_FORCE and Ci >= 16 and (L.sivae_conv2d_wino4_supported(H, W) == 1 or
+                                                   (L.sivae_conv2d_wino4_supported(H, W) == 2 and B % 2 == 0))))
             and (pro is None or (WINO4_PRO and nseg * ((Ci + 31) // 32) * 32 <= 1024))):
         # large maps: F(4x4,3x3) — 2.25 multiplies per output pixel instead of 4
         _require(x, out)

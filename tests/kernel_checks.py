@@ -605,7 +605,7 @@ def check_wino4(shape, accumulate=False, stats=False, mode=0):
     from sivae_hip import lib, ops
     B, Ci, Co, H, W = shape
     L = lib.load()
-    assert L.sivae_conv2d_wino4_supported(H, W) == 1
+    assert L.sivae_conv2d_wino4_supported(H, W) in (1, 2)  # (2: 16 x 16 maps, a work item is a pair of images)
     x = _rand(B, Ci, H, W, seed=1)
     res = []
     if mode == 0:
@@ -635,8 +635,13 @@ def check_wino4(shape, accumulate=False, stats=False, mode=0):
         res.append((tag + "_stats_sum", _err(s[:, 0], ref.sum((0, 2, 3))), 4e-5))
         res.append((tag + "_stats_sq", _err(s[:, 1], (ref * ref).sum((0, 2, 3))), 4e-5))
         # rows are in image order (segmented BatchNorm statistics rely on it)
-        per_img = part.double().view(B, -1, Co, 2).sum(1).cpu()
-        res.append((tag + "_stats_rows", _err(per_img[..., 0], ref.sum((2, 3))), 4e-5))
+        nrow = part.shape[0]
+        if nrow >= B:
+            per_img = part.double().view(B, -1, Co, 2).sum(1).cpu()
+            res.append((tag + "_stats_rows", _err(per_img[..., 0], ref.sum((2, 3))), 4e-5))
+        else:  # 16 x 16 maps: one row per image pair
+            ref_rows = ref.view(nrow, B // nrow, Co, H, W).sum((1, 3, 4))
+            res.append((tag + "_stats_rows", _err(part.double().cpu()[..., 0], ref_rows), 4e-5))
     return res
 
 
@@ -1071,6 +1076,11 @@ def all_checks():
                        + check_wino4(s, mode=1)))
     for s in [(2, 64, 64, 32, 32), (4, 128, 64, 16, 32), (2, 100, 72, 48, 64), (2, 512, 64, 16, 32)]:
         checks.append(("wino4_pro%s" % (s,), lambda s=s: check_wino4_pro(s) + check_wino4_pro(s, nseg=2)))
+    for s in [(2, 64, 64, 16, 16), (6, 40, 72, 16, 16), (4, 512, 128, 16, 16)]:  # 16 x 16 maps: image pairs
+        checks.append(("wino4_pair%s" % (s,), lambda s=s: check_wino4(s, stats=True) + check_wino4(s, accumulate=True)
+                       + check_wino4(s, mode=1)))
+    for s in [(4, 64, 64, 16, 16), (8, 96, 40, 16, 16)]:
+        checks.append(("wino4_pair_pro%s" % (s,), lambda s=s: check_wino4_pro(s) + check_wino4_pro(s, nseg=2)))
     for s in [(2, 64, 64, 32, 32), (1, 32, 64, 16, 16), (4, 128, 64, 16, 32), (3, 100, 72, 48, 64), (2, 96, 160, 8, 48),
               (7, 64, 128, 4, 16)]:
         checks.append(("wino4_wgrad%s" % (s,), lambda s=s: check_wino4_wgrad(s) + check_wino4_wgrad(s, pro=True)))

@@ -51,7 +51,7 @@ for (Ci, Co, H, ks) in SHAPES:
                 pro = (torch.zeros(Ci, device="cuda"), torch.ones(Ci, device="cuda"), torch.ones(Ci, device="cuda"),
                        torch.zeros(Ci, device="cuda"), 0.2)
             t = timeit(lambda: ops.conv2d_fwd(x, wq, Co, ks, want_stats=True, pro=pro))
-            if ops.WINO4 and max(Ci, Co) <= ops.WINO4_MAXC and H % 32 == 0:
+            if ops.WINO4 and max(Ci, Co) <= ops.WINO4_MAXC and (H % 32 == 0 or H == 16):
                 ops.WINO4 = False
                 t2 = timeit(lambda: ops.conv2d_fwd(x, wq, Co, ks, want_stats=True, pro=pro))
                 ops.WINO4 = True
