@@ -516,7 +516,8 @@ int sivae_conv2d_wino_wgrad_seg(const float* x, const float* dy, float* dw, cons
  * stats_partial: [sivae_conv2d_wino4_num_px_tiles][Co][2] rows in image order (sivae_bn_stats_from_conv[_seg]). */
 size_t sivae_pack_wino4_weight_bytes(int Co, int Ci, int mode);
 int sivae_pack_wino4_weight(const float* w, float* up, int Co, int Ci, int mode, sivae_stream_t stream);
-int sivae_conv2d_wino4_supported(int H, int W);
+int sivae_conv2d_wino4_supported(int H, int W); /* 1: H % 16 == 0, W % 32 == 0; 2: 16 x 16 maps, run as image pairs (B even,
+                                                     seg_images even; stats rows per pair); 0 otherwise */
 int sivae_conv2d_wino4_pays(int B, int Ci, int Co, int H, int W); /* supported AND >= one work item per CU */
 int sivae_conv2d_wino4_num_px_tiles(int B, int H, int W);
 int sivae_conv2d_wino4_fwd(const float* x, const float* up, float* y, float* stats_partial, int B, int Ci, int Co, int H,
