@@ -449,6 +449,40 @@ def test_forced_wino4_kernels_vs_oracle(monkeypatch):
     assert not _oracle_vs_hip(3, 48, [32, 48, 64], 64, 4, hp, boot=True, seed=22, referee=False)
 
 
+@pytest.mark.parametrize("B", [2, 3, 6, 8])
+def test_forced_wino4_kernels_any_batch(monkeypatch, B):
+    """dispatch robustness of the F(4x4,3x3) kernels: odd batches (no image pairs on the 16x16 maps), batches that are
+    not paired (B % 4 != 0) and paired ones — one iteration with the kernels forced wherever supported against the same
+    iteration on the F(2x2,3x3) kernels (losses and every gradient)"""
+    import train_soft_intro_vae as T
+    from sivae_hip import ops
+    dev = torch.device("cuda:0")
+    hp = dict(beta_rec=0.5, beta_kl=1.0, beta_neg=256.0, gamma_r=1e-8)
+    g = torch.Generator().manual_seed(100 + B)
+    real = torch.rand(B, 3, 64, 64, generator=g).to(dev)
+    noise = torch.randn(B, 32, generator=g).to(dev)
+    eps = [torch.randn(B, 32, generator=g).to(dev) for _ in range(5)]
+    out = {}
+    for forced in (False, True):
+        monkeypatch.setattr(ops, "WINO4_FORCE", forced)
+        monkeypatch.setattr(ops, "WINO4", forced)
+        monkeypatch.setattr(ops, "WINO4_WGRAD", forced)
+        torch.manual_seed(7)
+        model = T.SoftIntroVAE(cdim=3, zdim=32, channels=[32, 64, 64], image_size=64).to(dev).train()
+        eng, grads = _engine(model, False, hp, 2e-4)
+        es = eng.e_step(real, noise, eps[:3], keep=True)
+        ds = eng.d_step(real, noise, es["z"], eps[3:], keep=True)
+        out[forced] = (es, ds, {t: {k: v.clone() for k, v in gs.items()} for t, gs in grads.items()})
+    for t in ("E", "D"):
+        for k, v in out[True][2][t].items():
+            assert _rel2(v, out[False][2][t][k]) <= 5e-3, (B, t, k, _rel2(v, out[False][2][t][k]))
+    for step in (0, 1):
+        for k in ("lossE", "lossD"):
+            if k in out[True][step]:
+                a_, b_ = float(out[True][step][k]), float(out[False][step][k])
+                assert abs(a_ - b_) <= 1e-4 * max(1.0, abs(b_)), (B, k, a_, b_)
+
+
 def test_bootstrap256_full_config_vs_oracle():
     """config 5's network exactly (soft_intro_vae_bootstrap, 256x256, [64,128,256,512,512,512], z 512, gamma_r 1) at B = 2
     vs the live oracle — the full-width counterpart of test_bootstrap_6level_topology_vs_oracle"""
