@@ -529,6 +529,17 @@ int sivae_conv2d_wino4_fwd_pro(const float* x, const float* up, float* y, const 
                                int B, int Ci, int Co, int H, int W, int accumulate, int seg_images,
                                sivae_stream_t stream);
 
+/* split-K form of the F(4x4,3x3) forward / data gradient for launches with fewer work items than CUs (the deep layers of
+ * the per-GPU shards): sivae_conv2d_wino4_splitk -> number of K slices S (1 = the plain kernel); for S > 1 the partial
+ * outputs go through `workspace` ([S][B][Co][H][W]), are summed in a fixed order, and stats_partial is [B][Co][2] (per
+ * image) instead of per pixel tile.  pro_mean may be NULL (no prologue); seg_images as in sivae_conv2d_wino4_fwd_pro. */
+int sivae_conv2d_wino4_splitk(int B, int Ci, int Co, int H, int W);
+size_t sivae_conv2d_wino4_splitk_workspace_bytes(int B, int Ci, int Co, int H, int W);
+int sivae_conv2d_wino4_fwd_splitk(const float* x, const float* up, float* y, const float* pro_mean, const float* pro_invstd,
+                                  const float* pro_gamma, const float* pro_beta, float pro_slope, float* stats_partial, int B,
+                                  int Ci, int Co, int H, int W, int accumulate, int seg_images, void* workspace,
+                                  size_t workspace_bytes, sivae_stream_t stream);
+
 /* Winograd F(4x4,3x3) weight gradient (conv_wino4_wgrad.hip) — the weight half of aten::convolution_backward of the
  * nn.Conv2d(k=3) layers (soft_intro_vae/train_soft_intro_vae.py:56-61) on maps with H % 4 == 0, W % 16 == 0:
  * dw[Co][Ci][3][3] from x [B][Ci][H][W] (or, pro_mean != NULL, LeakyReLU(BatchNorm(x)) recomputed on load; per-segment

@@ -55,6 +55,10 @@ struct Wino4Args {
   int n_items;
   int xcd_group;
   int two;  // 16 x 16 maps: a work item is a PAIR of images side by side (32 x 16 pixels)
+  // split-K (launches with fewer work items than CUs): an item = (pixel tile, K slice, co tile); slice ks walks the cps
+  // chunks from ks * cps on and writes its partial outputs to y + ks * slice_stride (summed by wino4_splitk_reduce_kernel)
+  int ksl, cps;
+  long long slice_stride;
 };
 
 #define W4_CK 8
@@ -143,7 +147,7 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
   const bool pvalid = pg < 180;
 
   const int n_items = a.n_items;
-  const int nchunks = a.Ci_pad / CK;  // a multiple of 4 (Ci_pad is a multiple of 32)
+  const int nchunks = a.cps;  // chunks per work item: Ci_pad / CK (a multiple of 4), or an even share >= 4 of it per K slice
   const int ksteps = nchunks * (CK / 2);
   const __amdgpu_buffer_rsrc_t ursrc = make_rsrc(a.up, 36ull * a.Ci_pad * a.Co_pad * 4ull);
   const unsigned va0 = (unsigned)(hh * a.Co_pad + ws * 32 + l31) * 24u;
@@ -155,13 +159,17 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
   int item = blockIdx.x;
   if (a.xcd_group) item = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
   int b, r0, c0, co0, pt;
+  int cbase = 0, kslice = 0;  // first input channel / index of the item's K slice (split-K)
   __amdgpu_buffer_rsrc_t xrsrc;
   unsigned xo, ua_base;
   int pseg = 0;  // table offset of the segment of the item whose halo is being requested
 #define W4_SETUP(ITEM)                                                   \
   {                                                                      \
     const int co_tile = (ITEM) % a.n_co_tiles;                           \
-    pt = (ITEM) / a.n_co_tiles;                                          \
+    const int iq_ = (ITEM) / a.n_co_tiles;                               \
+    kslice = iq_ % a.ksl;                                                \
+    pt = iq_ / a.ksl;                                                    \
+    cbase = kslice * a.cps * CK;                                         \
     const int tbx = pt % a.nbw;                                          \
     const int t2 = pt / a.nbw;                                           \
     const int tby = t2 % a.nbh;                                          \
@@ -176,15 +184,15 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
     const int r = r0 - 1 + prow, c = c0 - 4 + 4 * pk;                    \
     xo = (pvalid && r >= 0 && r < H && c >= 0 && c < two_w)              \
              ? (unsigned)((c >> 4) * two_img + r * W + (c & two_mask)) * 4u : SIVAE_OOB; \
-    ua_base = (unsigned)((wj * a.Ci_pad) * a.Co_pad + co0) * 24u;        \
-    if (PRO) pseg = (b / a.pro_seg_images) * a.Ci_pad;                   \
+    ua_base = (unsigned)((wj * a.Ci_pad + cbase) * a.Co_pad + co0) * 24u; \
+    if (PRO) pseg = (b / a.pro_seg_images) * a.Ci_pad + cbase;           \
   }
   // piece N (0, 1) of halo chunk CH -> raw buffer BUF (out-of-image / padding groups receive 0; channels beyond Ci
   // re-read the last one: their U is zero)
 #define W4_DMA1(CH, BUF, N)                                              \
   if (!((W4_ABLATE & 1) && item >= 0)) {                                 \
     const int ck = dpl0 + 4 * (N);                                       \
-    const int ci = (CH)*CK + ck;                                         \
+    const int ci = cbase + (CH)*CK + ck;                                 \
     const int cic = ci < a.Ci ? ci : a.Ci - 1;                           \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(                            \
         xrsrc, (float __attribute__((address_space(3)))*)(RAWB(BUF) + ck * PLANE + dsub * 256), 16, xo, \
@@ -416,7 +424,7 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     // coordinates of the item being accumulated (W4_SETUP overwrites b, r0, ... for the next one in the last pair)
-    const int e_pt = pt, e_b = b, e_r0 = r0, e_c0 = c0, e_co0 = co0;
+    const int e_pt = pt, e_b = b, e_r0 = r0, e_c0 = c0, e_co0 = co0, e_ks = kslice;
     const int next = item + (int)gridDim.x;
     const bool has_next = next < n_items;
     if (pair05) {
@@ -432,7 +440,8 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
     {
       float* ex = vx + VBUF;
       const __amdgpu_buffer_rsrc_t yrsrc =
-          make_rsrc(a.y + (size_t)e_b * a.Co * HW, (unsigned long long)(a.two ? 2 : 1) * a.Co * HW * 4ull);
+          make_rsrc(a.y + (size_t)e_ks * a.slice_stride + (size_t)e_b * a.Co * HW,
+                    (unsigned long long)(a.two ? 2 : 1) * a.Co * HW * 4ull);
       float ssum[3] = {0.f, 0.f, 0.f}, ssq[3] = {0.f, 0.f, 0.f};
       // The lane index is laundered once per item: otherwise hipcc hoists the lane-dependent LDS / global offsets of this
       // epilogue out of the persistent item loop, spills them, and reloads each one behind an s_waitcnt vmcnt(0) — which
@@ -612,7 +621,7 @@ extern "C" int sivae_conv2d_wino4_num_px_tiles(int B, int H, int W) {
 // of y in image order (sivae_bn_stats_from_conv / _seg).  The data gradient is this function on dy with the mode-1 pack.
 static int wino4_impl(const float* x, const float* up, float* y, const float* pro_mean, const float* pro_invstd,
                       const float* pro_gamma, const float* pro_beta, float pro_slope, float* stats_partial, int B, int Ci,
-                      int Co, int H, int W, int accumulate, int seg_images, hipStream_t stream) {
+                      int Co, int H, int W, int accumulate, int seg_images, hipStream_t stream, int ksl = 1) {
   if (!x || !up || !y) return SIVAE_ERR_NULL;
   if (pro_mean && (!pro_invstd || !pro_gamma || !pro_beta)) return SIVAE_ERR_NULL;
   if (pro_mean && !(pro_slope >= 0.f && pro_slope <= 1.f)) return SIVAE_ERR_MODE;  // prologue uses max(v, v*slope)
@@ -650,7 +659,13 @@ static int wino4_impl(const float* x, const float* up, float* y, const float* pr
   a.nbw = a.two ? 1 : W / W4_PXW;
   a.n_co_tiles = a.Co_pad / W4_TCO;
   a.accumulate = accumulate;
-  const long long nitems = w4_px_tiles(B, H, W) * a.n_co_tiles;
+  const int nchunks_all = a.Ci_pad / W4_CK;
+  if (ksl < 1 || nchunks_all % ksl != 0 || (ksl > 1 && ((nchunks_all / ksl) < 4 || ((nchunks_all / ksl) & 1))))
+    return SIVAE_ERR_SHAPE;
+  a.ksl = ksl;
+  a.cps = nchunks_all / ksl;
+  a.slice_stride = ksl > 1 ? (long long)B * Co * hw : 0;  // (y is then the [ksl][B][Co][H][W] partial-sum workspace)
+  const long long nitems = w4_px_tiles(B, H, W) * a.n_co_tiles * ksl;
   if (nitems > 0x7fffffffLL) return SIVAE_ERR_RANGE;
   a.n_items = (int)nitems;
   // (96 KB of static LDS: one block per CU)
@@ -678,4 +693,83 @@ extern "C" int sivae_conv2d_wino4_fwd_pro(const float* x, const float* up, float
                                           int accumulate, int seg_images, hipStream_t stream) {
   return wino4_impl(x, up, y, pro_mean, pro_invstd, pro_gamma, pro_beta, pro_slope, stats_partial, B, Ci, Co, H, W,
                     accumulate, seg_images, stream);
+}
+
+// ---- split-K form for launches that would leave most of the chip idle (the 16-image shard of config 4 runs the
+// 512-channel 16x16 / 32x32 layers as 64..128 work items of one block per CU).  The K range is cut into S slices (S x
+// items ~ one block per CU), every (item, slice) writes its partial output tensor, and one small kernel sums the slices in
+// a fixed order (deterministic), adds the old y when accumulating, and leaves per-IMAGE {sum, sumsq} rows for the
+// consumer BatchNorm (as sivae_conv2d_wino_fwd_splitk does for the F(2x2,3x3) kernel).
+__global__ void __launch_bounds__(64) wino4_splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ y,
+                                                                 float* __restrict__ stats, int S, int HW,
+                                                                 size_t slice_stride, int accumulate) {
+  const int bc = blockIdx.x;  // b * C + c
+  const size_t base = (size_t)bc * HW;
+  float s = 0.f, q = 0.f;
+  for (int p = threadIdx.x; p < HW; p += 64) {
+    float v = accumulate ? y[base + p] : 0.f;
+    for (int k = 0; k < S; ++k) v += part[(size_t)k * slice_stride + base + p];
+    y[base + p] = v;
+    s += v;
+    q += v * v;
+  }
+  if (stats != nullptr) {
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (threadIdx.x == 0) {
+      stats[(size_t)bc * 2 + 0] = s;
+      stats[(size_t)bc * 2 + 1] = q;
+    }
+  }
+}
+
+// number of K slices sivae_conv2d_wino4_fwd_splitk will use (1: the plain kernel; its statistics rows are then per pixel
+// tile — sivae_conv2d_wino4_num_px_tiles —, otherwise per image: B rows)
+extern "C" int sivae_conv2d_wino4_splitk(int B, int Ci, int Co, int H, int W) {
+  const int sup = sivae_conv2d_wino4_supported(H, W);
+  if (B <= 0 || Ci <= 0 || Co <= 0 || !sup || (sup == 2 && (B & 1))) return SIVAE_ERR_SHAPE;
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* e = getenv("SIVAE_WINO4_SPLITK");
+    enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!enabled || Ci < 16) return 1;
+  const long long items = w4_px_tiles(B, H, W) * ((Co + W4_TCO - 1) / W4_TCO);
+  const int cus = sivae_num_cus();
+  if (items >= cus) return 1;
+  const int nchunks = w4_kpad(Ci) / W4_CK;
+  int S = 1;
+  // powers of two up to 8: S x items <= one block per CU, at least 8 chunks (64 input channels) per slice
+  while (S < 8 && (long long)(2 * S) * items <= cus && nchunks % (2 * S) == 0 && nchunks / (2 * S) >= 8) S *= 2;
+  return S;
+}
+
+extern "C" size_t sivae_conv2d_wino4_splitk_workspace_bytes(int B, int Ci, int Co, int H, int W) {
+  const int S = sivae_conv2d_wino4_splitk(B, Ci, Co, H, W);
+  if (S <= 1) return 0;
+  return (size_t)S * B * Co * H * W * sizeof(float);
+}
+
+// y (+)= conv3x3(x', U) as sivae_conv2d_wino4_fwd_pro (pro_mean may be NULL: no prologue), split over K when
+// sivae_conv2d_wino4_splitk(...) > 1: stats_partial is then [B][Co][2] (per image)
+extern "C" int sivae_conv2d_wino4_fwd_splitk(const float* x, const float* up, float* y, const float* pro_mean,
+                                             const float* pro_invstd, const float* pro_gamma, const float* pro_beta,
+                                             float pro_slope, float* stats_partial, int B, int Ci, int Co, int H, int W,
+                                             int accumulate, int seg_images, void* workspace, size_t workspace_bytes,
+                                             hipStream_t stream) {
+  const int S = sivae_conv2d_wino4_splitk(B, Ci, Co, H, W);
+  if (S < 0) return S;
+  if (S == 1)
+    return wino4_impl(x, up, y, pro_mean, pro_invstd, pro_gamma, pro_beta, pro_slope, stats_partial, B, Ci, Co, H, W,
+                      accumulate, seg_images, stream);
+  if (!y || !workspace) return SIVAE_ERR_NULL;
+  if (workspace_bytes < (size_t)S * B * Co * H * W * sizeof(float)) return SIVAE_ERR_WORKSPACE;
+  if (((uintptr_t)workspace & 15u) != 0) return SIVAE_ERR_SHAPE;
+  float* part = reinterpret_cast<float*>(workspace);
+  const int rc = wino4_impl(x, up, part, pro_mean, pro_invstd, pro_gamma, pro_beta, pro_slope, nullptr, B, Ci, Co, H, W, 0,
+                            seg_images, stream, S);
+  if (rc != SIVAE_OK) return rc;
+  hipLaunchKernelGGL(wino4_splitk_reduce_kernel, dim3((unsigned)(B * Co)), dim3(64), 0, stream, part, y, stats_partial, S,
+                     H * W, (size_t)B * Co * H * W, accumulate);
+  return sivae_launch_status();
 }

@@ -206,6 +206,8 @@ WINO4_WGRAD = WINO4 and os.environ.get("SIVAE_WINO4_WGRAD", "1") != "0"
 # SIVAE_WINO4_FORCE=1: take the F(4x4,3x3) kernels wherever they are SUPPORTED, not only where they pay (tests: the
 # oracle comparisons run at batch 2-4, below the work-item thresholds)
 WINO4_FORCE = os.environ.get("SIVAE_WINO4_FORCE", "0") == "1"
+# SIVAE_WINO4_SPLITK=0: no split-K form of the F(4x4,3x3) kernel (launches below one work item per CU stay on F(2x2,3x3))
+WINO4_SPLITK = os.environ.get("SIVAE_WINO4_SPLITK", "1") != "0"
 WINO4_PRO = os.environ.get("SIVAE_WINO4_PRO", "1") != "0"  # ... also with a fused BatchNorm prologue (conv2 forward)
 # SIVAE_FUSE_BN_BWD=1: reduce BatchNorm-1's backward sums in the epilogue of conv2's data gradient.  Measured a LOSS at
 # 256x256 bs128 (593 vs 585 ms per iteration: the extra tensor read sits on the kernel's critical path and disables its
@@ -400,13 +402,35 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
         if t0 is not None:
             TIMER.end("conv1x1_stream_kernel", 2.0 * B * H * W * Co * Ci, t0)
         return y
-    if (WINO and WINO4 and ks == 3 and bias is None and not upsample and isinstance(wp, PackedW)
-            and max(Ci, Co) <= WINO4_MAXC
-            and (nseg == 1 or W != 16 or (B // nseg) % 2 == 0)  # (16x16 maps: image pairs inside one segment)
-            and (L.sivae_conv2d_wino4_pays(B, Ci, Co, H, W) == 1
-                 or (WINO4_FORCE and Ci >= 16 and (L.sivae_conv2d_wino4_supported(H, W) == 1 or
-                                                   (L.sivae_conv2d_wino4_supported(H, W) == 2 and B % 2 == 0))))
-            and (pro is None or (WINO4_PRO and nseg * ((Ci + 31) // 32) * 32 <= 1024))):
+    w4_sup = L.sivae_conv2d_wino4_supported(H, W) if (WINO and WINO4) else 0
+    w4_ok = (w4_sup and ks == 3 and bias is None and not upsample and isinstance(wp, PackedW)
+             and 16 <= Ci and max(Ci, Co) <= WINO4_MAXC and (w4_sup == 1 or B % 2 == 0)
+             and (nseg == 1 or w4_sup == 1 or (B // nseg) % 2 == 0)  # (16x16 maps: image pairs inside one segment)
+             and (pro is None or (WINO4_PRO and nseg * ((Ci + 31) // 32) * 32 <= 1024)))
+    # fewer work items than CUs (the deep layers of a per-GPU shard): split over K when that fills the chip
+    w4_S = (L.sivae_conv2d_wino4_splitk(B, Ci, Co, H, W) if (w4_ok and WINO4_SPLITK
+                                                              and L.sivae_conv2d_wino4_pays(B, Ci, Co, H, W) != 1) else 1)
+    if w4_ok and w4_S > 1:
+        _require(x, out)
+        y = out if out is not None else torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
+        assert y.shape == (B, Co, H, W) and y.is_contiguous()
+        stats = torch.empty((B, Co, 2), dtype=torch.float32, device=x.device) if want_stats else None  # (rows per image)
+        ws = workspace(L.sivae_conv2d_wino4_splitk_workspace_bytes(B, Ci, Co, H, W), x.device)
+        pm = pi = pg = pb = None
+        slope = 1.0
+        if pro is not None:
+            pm, pi, pg, pb, slope = pro
+            _require(pm, pi, pg, pb)
+        t0 = TIMER.begin() if TIMER is not None else None
+        _lib.call("sivae_conv2d_wino4_fwd_splitk", _p(x), _p(wp.wino4()), _p(y), _p(pm), _p(pi), _p(pg), _p(pb),
+                  float(slope), _p(stats), B, Ci, Co, H, W, int(bool(accumulate)), (B // nseg) if nseg > 1 else 0,
+                  _p(ws), ws.numel(), _s(x))
+        if t0 is not None:
+            flops = 2.0 * B * H * W * Co * Ci * 9
+            TIMER.end("conv_wino4_kernel<%s>" % ("true" if pro is not None else "false"), flops, t0,
+                      executed=flops * 36.0 / 144.0)
+        return (y, stats) if want_stats else y
+    if w4_ok and (L.sivae_conv2d_wino4_pays(B, Ci, Co, H, W) == 1 or WINO4_FORCE):
         # large maps: F(4x4,3x3) — 2.25 multiplies per output pixel instead of 4
         _require(x, out)
         y = out if out is not None else torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)

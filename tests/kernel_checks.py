@@ -645,6 +645,51 @@ def check_wino4(shape, accumulate=False, stats=False, mode=0):
     return res
 
 
+def check_wino4_splitk(shape, pro=False, nseg=1, accumulate=False):
+    """split-K form of the F(4x4,3x3) kernel (few work items): output, accumulate, per-image statistics, prologue/segments"""
+    from sivae_hip import lib, ops
+    B, Ci, Co, H, W = shape
+    L = lib.load()
+    S = L.sivae_conv2d_wino4_splitk(B, Ci, Co, H, W)
+    res = [("wino4_splitk slices%s" % (shape,), float(S <= 1), 0.0)]  # (the shapes below are chosen to split)
+    x = _rand(B, Ci, H, W, seed=1)
+    w = _rand(Co, Ci, 3, 3, seed=2, scale=1.0 / math.sqrt(Ci * 9))
+    xin = x
+    pm = pi = pg = pb = None
+    if pro:
+        mean = _rand(nseg, Ci, seed=3, scale=0.3)
+        invstd = (_rand(nseg, Ci, seed=4).abs() + 0.5)
+        gamma = _rand(Ci, seed=5) + 1.0
+        beta = _rand(Ci, seed=6, scale=0.2)
+        Bs = B // nseg
+        xs = []
+        for g in range(nseg):
+            v = (x[g * Bs:(g + 1) * Bs] - mean[g].view(1, -1, 1, 1)) * (invstd[g] * gamma).view(1, -1, 1, 1) \
+                + beta.view(1, -1, 1, 1)
+            xs.append(torch.where(v > 0, v, 0.2 * v))
+        xin = torch.cat(xs)
+        pm, pi, pg, pb = _d(mean.reshape(-1)), _d(invstd.reshape(-1)), _d(gamma), _d(beta)
+    ref = _conv_ref(xin, w)
+    y0 = _rand(B, Co, H, W, seed=7) if accumulate else None
+    y = _d(y0) if accumulate else torch.empty((B, Co, H, W), dtype=torch.float32, device=DEV)
+    if accumulate:
+        ref = ref + y0
+    part = torch.empty((B, Co, 2), dtype=torch.float32, device=DEV)
+    wp = ops.PackedW(_d(w), 0)
+    xd, up = _d(x), wp.wino4()
+    ws = ops.workspace(L.sivae_conv2d_wino4_splitk_workspace_bytes(B, Ci, Co, H, W), xd.device)
+    lib.call("sivae_conv2d_wino4_fwd_splitk", ops._p(xd), ops._p(up), ops._p(y), ops._p(pm), ops._p(pi), ops._p(pg),
+             ops._p(pb), 0.2, ops._p(part), B, Ci, Co, H, W, int(accumulate), (B // nseg) if nseg > 1 else 0, ops._p(ws),
+             ws.numel(), ops._s())
+    torch.cuda.synchronize()
+    tag = "wino4_splitk%s%s%s%s" % ("_pro" if pro else "", "_seg%d" % nseg if nseg > 1 else "", "_acc" if accumulate else "",
+                                   shape)
+    res.append((tag, _err(y, ref), WINO4_TOL))
+    res.append((tag + "_stats_rows", _err(part.double().cpu()[..., 0], ref.sum((2, 3))), 4e-5))
+    res.append((tag + "_stats_sq", _err(part.double().cpu()[..., 1], (ref * ref).sum((2, 3))), 4e-5))
+    return res
+
+
 def check_wino4_pro(shape, nseg=1):
     """F(4x4,3x3) with the fused BatchNorm + LeakyReLU prologue (and per-segment statistics) vs fp64"""
     from sivae_hip import ops
@@ -1081,6 +1126,11 @@ def all_checks():
                        + check_wino4(s, mode=1)))
     for s in [(4, 64, 64, 16, 16), (8, 96, 40, 16, 16)]:
         checks.append(("wino4_pair_pro%s" % (s,), lambda s=s: check_wino4_pro(s) + check_wino4_pro(s, nseg=2)))
+    for s in [(2, 256, 64, 32, 32), (4, 512, 128, 16, 16), (1, 128, 100, 16, 32)]:
+        checks.append(("wino4_splitk%s" % (s,), lambda s=s: check_wino4_splitk(s) + check_wino4_splitk(s, accumulate=True)
+                       + check_wino4_splitk(s, pro=True)))
+    checks.append(("wino4_splitk_seg", lambda: check_wino4_splitk((4, 256, 64, 32, 32), pro=True, nseg=2)
+                   + check_wino4_splitk((8, 512, 64, 16, 16), pro=True, nseg=2)))
     for s in [(2, 64, 64, 32, 32), (1, 32, 64, 16, 16), (4, 128, 64, 16, 32), (3, 100, 72, 48, 64), (2, 96, 160, 8, 48),
               (7, 64, 128, 4, 16)]:
         checks.append(("wino4_wgrad%s" % (s,), lambda s=s: check_wino4_wgrad(s) + check_wino4_wgrad(s, pro=True)))
