@@ -128,6 +128,58 @@ def test_round2_entry_points_validate_arguments():
     assert L.sivae_kl_bwd_t(one, 0, 1.0, one, one, 4, one, 0, 0, one, 0, 0, one, one, 8, 2, 8, null) == -2  # ld < Z
 
 
+def test_round3_entry_points_validate_arguments():
+    """Winograd F(4x4,3x3) forward / weight gradient, its image-pair and split-K forms, and the segmented-batch entry
+    points: host-side validation and the shape / plan queries (every call returns before any kernel launch)"""
+    L = lib.load()
+    null = None
+    one = ctypes.c_void_p(16)
+    # domains: 1 = whole 32 x 16 pixel blocks, 2 = 16 x 16 maps as image pairs, 0 = unsupported
+    assert [L.sivae_conv2d_wino4_supported(h, w) for h, w in ((256, 256), (32, 32), (16, 32), (16, 16), (8, 8), (24, 32))] \
+        == [1, 1, 1, 2, 0, 0]
+    assert L.sivae_conv2d_wino4_num_px_tiles(4, 32, 64) == 4 * 2 * 2 and L.sivae_conv2d_wino4_num_px_tiles(6, 16, 16) == 3
+    assert L.sivae_conv2d_wino4_num_px_tiles(5, 16, 16) == -2  # (an odd batch has no image pairs)
+    assert L.sivae_conv2d_wino4_pays(5, 64, 64, 16, 16) == 0 and L.sivae_conv2d_wino4_pays(2, 8, 64, 256, 256) == 0
+    # packed U: [6][Ci_pad32][Co_pad64][6] floats
+    assert L.sivae_pack_wino4_weight_bytes(64, 40, 0) == 36 * 64 * 64 * 4 and L.sivae_pack_wino4_weight_bytes(64, 40, 1) == 36 * 64 * 64 * 4
+    assert L.sivae_pack_wino4_weight_bytes(64, 40, 2) == 0
+    assert L.sivae_pack_wino4_weight(null, one, 4, 4, 0, null) == -1 and L.sivae_pack_wino4_weight(one, one, 4, 4, 3, null) == -6
+    # forward: null / unsupported map / odd pair batch / pairs straddling a segment / prologue slope / alignment of y
+    assert L.sivae_conv2d_wino4_fwd(null, one, one, null, 2, 32, 32, 32, 32, 0, null) == -1
+    assert L.sivae_conv2d_wino4_fwd(one, one, one, null, 2, 32, 32, 8, 8, 0, null) == -2
+    assert L.sivae_conv2d_wino4_fwd(one, one, one, null, 3, 32, 32, 16, 16, 0, null) == -2
+    assert L.sivae_conv2d_wino4_fwd_pro(one, one, one, one, one, one, one, 0.2, null, 6, 32, 32, 16, 16, 0, 3, null) == -2
+    assert L.sivae_conv2d_wino4_fwd_pro(one, one, one, one, one, one, one, 1.5, null, 2, 32, 32, 32, 32, 0, 0, null) == -6
+    assert L.sivae_conv2d_wino4_fwd_pro(one, one, one, one, null, one, one, 0.2, null, 2, 32, 32, 32, 32, 0, 0, null) == -1
+    assert L.sivae_conv2d_wino4_fwd(one, one, ctypes.c_void_p(20), null, 2, 32, 32, 32, 32, 0, null) == -2
+    # split-K plan: only below one work item per CU, powers of two, >= 8 chunks of 8 channels per slice
+    assert L.sivae_conv2d_wino4_splitk(128, 512, 512, 32, 32) == 1
+    S = L.sivae_conv2d_wino4_splitk(16, 512, 512, 16, 16)
+    assert S in (1, 2, 4, 8) and L.sivae_conv2d_wino4_splitk(16, 64, 512, 16, 16) == 1  # (64 channels: one slice)
+    assert L.sivae_conv2d_wino4_splitk_workspace_bytes(16, 512, 512, 16, 16) == (S * 16 * 512 * 256 * 4 if S > 1 else 0)
+    assert L.sivae_conv2d_wino4_splitk(3, 512, 512, 16, 16) == -2
+    if S > 1:
+        assert L.sivae_conv2d_wino4_fwd_splitk(one, one, one, null, null, null, null, 1.0, null, 16, 512, 512, 16, 16, 0,
+                                               0, null, 0, null) == -1
+        assert L.sivae_conv2d_wino4_fwd_splitk(one, one, one, null, null, null, null, 1.0, null, 16, 512, 512, 16, 16, 0,
+                                               0, one, 64, null) == -4
+    # weight gradient: strips of 4 x 16 pixels; at most two segments; 16-byte aligned operands
+    assert [L.sivae_conv2d_wino4_wgrad_supported(h, w) for h, w in ((16, 16), (4, 16), (8, 8), (6, 16), (256, 256))] \
+        == [1, 1, 0, 0, 1]
+    assert L.sivae_conv2d_wino4_wgrad_pays(128, 128, 128, 128, 128) == 1 and L.sivae_conv2d_wino4_wgrad_pays(1, 64, 64, 16, 16) == 0
+    nb = L.sivae_conv2d_wino4_wgrad_workspace_bytes(128, 128, 128, 128, 128)
+    assert nb > 0 and nb % (36 * 128 * 128 * 4) == 0
+    assert L.sivae_conv2d_wino4_wgrad(one, one, one, null, null, null, null, 0.2, 2, 32, 32, 8, 8, 0, one, 1 << 30, null) == -2
+    assert L.sivae_conv2d_wino4_wgrad(one, null, one, null, null, null, null, 0.2, 2, 32, 32, 16, 16, 0, one, 1 << 30, null) == -1
+    assert L.sivae_conv2d_wino4_wgrad(one, one, one, null, null, null, null, 0.2, 2, 32, 32, 16, 16, 0, one, 16, null) == -4
+    assert L.sivae_conv2d_wino4_wgrad(one, one, one, one, one, one, one, 0.2, 6, 32, 32, 16, 16, 2, one, 1 << 30, null) == -2
+    assert L.sivae_conv2d_wino4_wgrad(ctypes.c_void_p(20), one, one, null, null, null, null, 0.2, 2, 32, 32, 16, 16, 0, one,
+                                      1 << 30, null) == -2
+    # segmented batches: the images of a segment must divide the batch
+    assert L.sivae_conv2d_wino_fwd_seg(one, one, one, one, one, one, one, 0.2, null, 6, 16, 16, 16, 16, 0, 0, 4,
+                                       null) == -2
+
+
 def test_workspace_and_padding_queries():
     L = lib.load()
     assert L.sivae_conv_ck(3) == 8 and L.sivae_conv_ck(1) == 32 and L.sivae_conv_ck(5) == 4
