@@ -62,8 +62,10 @@ def decoder_plan(channels, conv_input_size):
     return plan
 
 
-def init_params(cdim, zdim, channels, image_size, seed=0, bootstrap=False, dtype=torch.float32):
-    """Random parameters with the reference's shapes and torch's default init distributions
+def init_params(cdim, zdim, channels, image_size, seed=0, bootstrap=False, dtype=torch.float32, cond_dim=0):
+    """cond_dim > 0: the conditional variant (Encoder.fc takes num_fc_features + cond_dim inputs, Decoder.fc zdim +
+    cond_dim: train_soft_intro_vae.py:106-107,138-143).
+    Random parameters with the reference's shapes and torch's default init distributions
     (kaiming-uniform(a=sqrt 5) == U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weights and biases).
     Encoder BatchNorm buffers carry the side effect of the constructor's dummy forward
     (train_soft_intro_vae.py:102,111-114): running_var = 0.9, num_batches_tracked = 1."""
@@ -102,11 +104,11 @@ def init_params(cdim, zdim, channels, image_size, seed=0, bootstrap=False, dtype
         elif item[0] == "res":
             res("encoder." + item[1], item[2], item[3], True)
     nfeat = feat[0] * feat[1] * feat[2]
-    P["encoder.fc.weight"] = uni((2 * zdim, nfeat), nfeat)
-    P["encoder.fc.bias"] = uni((2 * zdim,), nfeat)
+    P["encoder.fc.weight"] = uni((2 * zdim, nfeat + cond_dim), nfeat + cond_dim)
+    P["encoder.fc.bias"] = uni((2 * zdim,), nfeat + cond_dim)
     for dec in (["decoder", "target_decoder"] if bootstrap else ["decoder"]):
-        P[dec + ".fc.0.weight"] = uni((nfeat, zdim), zdim)
-        P[dec + ".fc.0.bias"] = uni((nfeat,), zdim)
+        P[dec + ".fc.0.weight"] = uni((nfeat, zdim + cond_dim), zdim + cond_dim)
+        P[dec + ".fc.0.bias"] = uni((nfeat,), zdim + cond_dim)
         for item in decoder_plan(channels, feat):
             if item[0] == "res":
                 res(dec + "." + item[1], item[2], item[3], False)
@@ -138,8 +140,9 @@ def residual_block(P, name, x, training=True):
     return F.leaky_relu(c + identity, SLOPE)
 
 
-def encode(P, x, channels, image_size, training=True, prefix="encoder."):
-    """Encoder.forward :116-122 -> (mu, logvar)"""
+def encode(P, x, channels, image_size, training=True, prefix="encoder.", o_cond=None):
+    """Encoder.forward :116-122 -> (mu, logvar); o_cond [B, cond_dim] (conditional model, :118-119): concatenated to the
+    flattened features in front of fc"""
     plan, _ = encoder_plan(channels, image_size)
     h = x
     for item in plan:
@@ -150,15 +153,21 @@ def encode(P, x, channels, image_size, training=True, prefix="encoder."):
             h = residual_block(P, prefix + item[1], h, training)
         else:
             h = F.avg_pool2d(h, 2)
-    y = F.linear(h.reshape(h.shape[0], -1), P[prefix + "fc.weight"], P[prefix + "fc.bias"])
+    h = h.reshape(h.shape[0], -1)
+    if o_cond is not None:
+        h = torch.cat([h, o_cond], dim=1)
+    y = F.linear(h, P[prefix + "fc.weight"], P[prefix + "fc.bias"])
     zdim = y.shape[1] // 2
     return y[:, :zdim], y[:, zdim:]
 
 
-def decode(P, z, channels, image_size, training=True, prefix="decoder."):
-    """Decoder.forward :161-169"""
+def decode(P, z, channels, image_size, training=True, prefix="decoder.", y_cond=None):
+    """Decoder.forward :161-169; y_cond [B, cond_dim] (conditional model, :162-165): concatenated to z in front of fc"""
     _, feat = encoder_plan(channels, image_size)
-    h = F.relu(F.linear(z.reshape(z.shape[0], -1), P[prefix + "fc.0.weight"], P[prefix + "fc.0.bias"]))
+    z = z.reshape(z.shape[0], -1)
+    if y_cond is not None:
+        z = torch.cat([z, y_cond.reshape(y_cond.shape[0], -1)], dim=1)
+    h = F.relu(F.linear(z, P[prefix + "fc.0.weight"], P[prefix + "fc.0.bias"]))
     h = h.reshape(z.shape[0], *feat)
     for item in decoder_plan(channels, feat):
         if item[0] == "res":

@@ -739,8 +739,12 @@ extern "C" int sivae_conv2d_wino4_splitk(int B, int Ci, int Co, int H, int W) {
   if (items >= cus) return 1;
   const int nchunks = w4_kpad(Ci) / W4_CK;
   int S = 1;
-  // powers of two up to 8: S x items <= one block per CU, at least 8 chunks (64 input channels) per slice
-  while (S < 8 && (long long)(2 * S) * items <= cus && nchunks % (2 * S) == 0 && nchunks / (2 * S) >= 8) S *= 2;
+  // powers of two up to 8: S x items <= one block per CU, at least 8 chunks (64 input channels) per slice and an EVEN
+  // number of chunks per slice (the kernel's K loop is unrolled by chunk pairs; wino4_impl rejects odd counts — padded
+  // channel counts of 288 / 352 / 416 / 480 would otherwise pick S = 4 with 9 / 11 / 13 / 15 chunks per slice)
+  while (S < 8 && (long long)(2 * S) * items <= cus && nchunks % (2 * S) == 0 && nchunks / (2 * S) >= 8 &&
+         ((nchunks / (2 * S)) & 1) == 0)
+    S *= 2;
   return S;
 }
 

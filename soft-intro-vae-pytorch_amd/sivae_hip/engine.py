@@ -58,10 +58,14 @@ def calc_reconstruction_loss(x, recon_x, loss_type="mse", reduction="sum"):
     return SF.ReconFn.apply(x, recon_x, loss_type, "total", 1.0 if reduction == "sum" else 1.0 / (B * D))
 
 
-def _per_sample(v):
-    while v.dim() > 1:
-        v = v.sum(-1)
-    return v
+def _recon_rows(x, recon_x, loss_type):
+    """per-sample reconstruction sums [B] — what the reference builds for the exp-ELBO terms as
+    calc_reconstruction_loss(..., reduction='none') followed by `while len(shape) > 1: sum(-1)` (:574-579).  For l1 / bce
+    the 'none' result is the [B, D] element tensor; the engine goes straight to the row sums (one fused kernel, 2-stage
+    fp64) instead of materialising it."""
+    if loss_type not in ("mse", "l1", "bce"):
+        raise NotImplementedError
+    return SF.ReconFn.apply(x, recon_x, loss_type, "rows", 1.0)
 
 
 STAT_NAMES = ("lossE", "lossD", "loss_rec", "kl_real", "kl_fake", "kl_rec", "expelbo_rec", "expelbo_fake")
@@ -301,8 +305,8 @@ class SoftIntroEngine:
 
         kl_rec = calc_kl(rec_logvar, rec_mu, reduce="none")
         kl_fake = calc_kl(fake_logvar, fake_mu, reduce="none")
-        l_rec_rec = _per_sample(calc_reconstruction_loss(rec, rec_rec, lt, "none"))
-        l_rec_fake = _per_sample(calc_reconstruction_loss(fake, rec_fake, lt, "none"))
+        l_rec_rec = _recon_rows(rec, rec_rec, lt)
+        l_rec_fake = _recon_rows(fake, rec_fake, lt)
         expelbo_rec = SF.expelbo(l_rec_rec, kl_rec, scale, br, bn)
         expelbo_fake = SF.expelbo(l_rec_fake, kl_fake, scale, br, bn)
         lossE = scale * (br * loss_rec + bk * kl_real) + 0.25 * (expelbo_rec + expelbo_fake)

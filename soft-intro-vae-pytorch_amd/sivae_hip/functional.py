@@ -515,6 +515,11 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, relu):
         x = x.contiguous()
+        if x.dim() != 2 or w.dim() != 2 or x.shape[1] != w.shape[1]:
+            # nn.Linear's error (e.g. a conditional model called without its condition, reference :118-120): the raw
+            # kernels take pointers and would read past the end of x
+            raise RuntimeError("mat1 and mat2 shapes cannot be multiplied (%s and %dx%d)" % (
+                "x".join(str(d) for d in x.shape), w.shape[1] if w.dim() == 2 else -1, w.shape[0]))
         _claim(ctx, ((1, w), (2, bias)))
         B, K = x.shape
         N = w.shape[0]

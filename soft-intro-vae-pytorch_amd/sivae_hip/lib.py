@@ -13,7 +13,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _REPO = os.path.dirname(os.path.dirname(_HERE))
-LIB_PATH = os.path.join(_HERE, "libsivae_hip.so")
+# SIVAE_LIB: another build of the same ABI (A/B measurements inside one process launch — tools/profile.sh `ab`)
+LIB_PATH = os.environ.get("SIVAE_LIB") or os.path.join(_HERE, "libsivae_hip.so")
 HEADER_PATH = os.path.join(_REPO, "include", "sivae_hip.h")
 BUILD_SCRIPT = os.path.join(os.path.dirname(_HERE), "csrc", "build.sh")
 
@@ -109,6 +110,23 @@ def load():
 def prototypes():
     load()
     return dict(_protos)
+
+
+_sha = None
+
+
+def sha256():
+    """sha256 of the loaded library file: stamped into PMC summaries (tools/pmc_*.py --lib-sha) and compared by bench.py so
+    that counter figures taken with another build are marked stale"""
+    global _sha
+    if _sha is None:
+        import hashlib
+        h = hashlib.sha256()
+        with open(LIB_PATH, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 20), b""):
+                h.update(blk)
+        _sha = h.hexdigest()
+    return _sha
 
 
 def call(name, *args):

@@ -158,6 +158,17 @@ def test_round3_entry_points_validate_arguments():
     assert S in (1, 2, 4, 8) and L.sivae_conv2d_wino4_splitk(16, 64, 512, 16, 16) == 1  # (64 channels: one slice)
     assert L.sivae_conv2d_wino4_splitk_workspace_bytes(16, 512, 512, 16, 16) == (S * 16 * 512 * 256 * 4 if S > 1 else 0)
     assert L.sivae_conv2d_wino4_splitk(3, 512, 512, 16, 16) == -2
+    # every plan the query returns is one the kernel accepts: slices of an EVEN number (>= 8) of 8-channel chunks — the
+    # padded widths 288 / 352 / 416 / 480 once gave S = 4 with 9 / 11 / 13 / 15 chunks per slice (round-3 advisor finding)
+    for Ci in list(range(272, 289)) + [320, 352, 384, 416, 448, 480, 512]:
+        for B, H, W in ((2, 32, 32), (4, 32, 32), (2, 16, 16), (8, 16, 16), (16, 16, 16), (1, 32, 64)):
+            for Co in (64, 128, 512):
+                Sx = L.sivae_conv2d_wino4_splitk(B, Ci, Co, H, W)
+                assert Sx in (1, 2, 4, 8), (B, Ci, Co, H, W, Sx)
+                if Sx > 1:
+                    chunks = ((Ci + 31) // 32) * 32 // 8
+                    assert chunks % Sx == 0 and (chunks // Sx) % 2 == 0 and chunks // Sx >= 8, (Ci, Sx, chunks)
+    assert L.sivae_conv2d_wino4_splitk(2, 288, 64, 32, 32) in (1, 2)  # (the advisor's example: not 4)
     if S > 1:
         assert L.sivae_conv2d_wino4_fwd_splitk(one, one, one, null, null, null, null, 1.0, null, 16, 512, 512, 16, 16, 0,
                                                0, null, 0, null) == -1

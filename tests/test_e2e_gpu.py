@@ -96,12 +96,12 @@ def _build(fx, device):
     return model.to(device).train(), boot
 
 
-def _engine(model, boot, hp, lr):
+def _engine(model, boot, hp, lr, recon_loss_type="mse"):
     from sivae_hip.engine import SoftIntroEngine
     from sivae_hip.optim import FlatAdam
     oe, od = FlatAdam(model.encoder.parameters(), lr=lr), FlatAdam(model.decoder.parameters(), lr=lr)
     eng = SoftIntroEngine(model, oe, od, beta_kl=hp["beta_kl"], beta_rec=hp["beta_rec"], beta_neg=hp["beta_neg"],
-                          gamma_r=hp["gamma_r"], bootstrap=boot)
+                          gamma_r=hp["gamma_r"], bootstrap=boot, recon_loss_type=recon_loss_type)
     grads = {}
     for tag, opt, net in (("E", oe, model.encoder), ("D", od, model.decoder)):
         orig = opt.step
@@ -385,9 +385,11 @@ def _oracle_vs_hip(cdim, zdim, channels, image_size, B, hp, boot=False, seed=0, 
             # (the referee's yardstick is the reference's OWN fp32 error against fp64.  F(4x4,3x3) — the large-map 3x3
             # convs, round 3 — rounds ~10x coarser per layer than a direct fp32 conv (1e-5 vs 1e-6; forward outputs stay
             # 10x inside the 1e-4 gate), so ill-conditioned sums such as a BatchNorm-weight gradient at B = 4 come out up
-            # to ~6x the reference's own error where F(2x2,3x3) gave <= 5x: the bound is 8x / 8e-3 relative L2.
-            # SIVAE_WINO4=0 runs the round-2 arithmetic.)
-            if hip_err > max(8.0 * ref_err, 1e-5) and _rel2(hip, g64[k]) > 8e-3:
+            # to ~6x the reference's own error where F(2x2,3x3) gave <= 5x: the bound is 8x / 8e-3 relative L2 on that
+            # path only — SIVAE_WINO4=0 runs the round-2 arithmetic and keeps the round-2 gate of 5x / 5e-3.)
+            from sivae_hip import ops as _ops
+            mult, l2 = (8.0, 8e-3) if (_ops.WINO4 or _ops.WINO4_FORCE) else (5.0, 5e-3)
+            if hip_err > max(mult * ref_err, 1e-5) and _rel2(hip, g64[k]) > l2:
                 problems.append(("E/grad/" + k, hip_err, ref_err, _rel2(hip, g64[k])))
     dmax, dmed, dfrac = _drift(model.state_dict(), P, lr, "encoder.")
     if not (dmed <= 0.1 and dfrac <= 0.02):

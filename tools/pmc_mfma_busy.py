@@ -22,6 +22,11 @@ def short(name):
     return (m.group(1) if m else name[:60]).replace(" ", "")
 
 
+def _lib_sha():
+    """--lib-sha <first 16 hex digits of the sha256 of the libsivae_hip.so the pass ran with> (tools/profile.sh)"""
+    return sys.argv[sys.argv.index("--lib-sha") + 1] if "--lib-sha" in sys.argv else None
+
+
 def main():
     per = defaultdict(lambda: defaultdict(float))
     names = {}
@@ -52,7 +57,8 @@ def main():
                   "share_of_gpu_active": None}
     for k in out:
         out[k]["share_of_gpu_active"] = round(agg[k]["GRBM_GUI_ACTIVE"] / N_XCD / tot_act, 4)
-    res = {"formula": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE/8)",
+    res = {"lib_sha256_16": _lib_sha(),
+           "formula": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE/8)",
            "whole_step_mfma_busy_frac": round(tot_busy / (N_SIMD * tot_act), 4),
            "kernels": dict(sorted(out.items(), key=lambda kv: -kv[1]["share_of_gpu_active"]))}
     json.dump(res, sys.stdout, indent=1)

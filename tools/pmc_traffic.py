@@ -42,7 +42,8 @@ def main():
     cal_r = GIB / (fetch[1][2] * 1024.0)
     cal_w_fill = GIB / (write[0][2] * 1024.0)
     cal_w_copy = GIB / (write[1][2] * 1024.0)
-    out = {"unit": "bytes per launch", "calibration": {
+    out = {"lib_sha256_16": sys.argv[sys.argv.index("--lib-sha") + 1] if "--lib-sha" in sys.argv else None,
+           "unit": "bytes per launch", "calibration": {
         "copy_1GiB_FETCH_SIZE_KiB": fetch[1][2], "read_scale": round(cal_r, 4),
         "fill_1GiB_WRITE_SIZE_KiB": write[0][2], "copy_1GiB_WRITE_SIZE_KiB": write[1][2],
         "write_scale": round(0.5 * (cal_w_fill + cal_w_copy), 4),
