@@ -492,6 +492,22 @@ int sivae_bn_bwd_seg(const float* dy, const float* y, const unsigned char* mask,
                      float* dz_out, float* dgamma, float* dbeta, int B, int C, int H, int W, int dy_pooled, int dz_sum,
                      int seg_images, unsigned int* counters, void* workspace, size_t workspace_bytes,
                      sivae_stream_t stream);
+/* The same backward as ONE persistent launch that reads dy and x once and writes dx once (bn_fused.hip, round 4): the
+ * chip's register files hold the activations between the reduction phase and the dx phase, (segment, channel) plane sets are
+ * walked in groups separated by a grid barrier, per-channel sums are folded in a fixed order (deterministic).  Replaces
+ * the backward of nn.BatchNorm2d + nn.LeakyReLU (+ torch.add) of train_soft_intro_vae.py:57-63,71-74,90-91 like
+ * sivae_bn_bwd_seg, with the same argument meaning.  `state`: sivae_bn_bwd_fused_state_uints() unsigned ints, zeroed ONCE
+ * by the caller and then left consistent by every call (one buffer per stream).  Power-of-two maps only
+ * (sivae_bn_bwd_fused_supported); the grid (2 blocks per CU) must be fully resident: not to be run concurrently with
+ * another persistent kernel on the device. */
+int sivae_bn_bwd_fused_supported(int B, int C, int H, int W, int seg_images);
+size_t sivae_bn_bwd_fused_workspace_bytes(int B, int C, int H, int W, int seg_images);
+int sivae_bn_bwd_fused_state_uints(void);
+int sivae_bn_bwd_fused(const float* dy, const float* y, const unsigned char* mask, const float* x, const float* mean,
+                       const float* invstd, const float* gamma, const float* beta, int act_mode, float slope, float* dx,
+                       float* dz_out, float* dgamma, float* dbeta, int B, int C, int H, int W, int dy_pooled, int dz_sum,
+                       int seg_images, unsigned int* state, void* workspace, size_t workspace_bytes,
+                       sivae_stream_t stream);
 /* Winograd 3x3 forward / data gradient and weight gradient with a segmented BatchNorm prologue (pro_* may be NULL: then
  * only the row order of stats_partial matters — image order, so rows [g*n/nseg, (g+1)*n/nseg) are pass g).  On 8x8 /
  * 4x4 maps seg_images must be a multiple of 2 / 4 (a tile block holds that many images). */

@@ -144,6 +144,41 @@ def counters(device):
     return buf
 
 
+# SIVAE_BN_FUSED=0: the three-launch BatchNorm backward (reduce / finalize / dx: two reads of dy and x) instead of the
+# one-pass persistent kernel of bn_fused.hip (one read, activations held in registers across a grid barrier).  The
+# persistent kernel needs its whole grid resident — two PROCESSES sharing one GPU (the 2-rank same-device tests) must
+# switch it off; one process per GPU (the deployment) is fine.
+BN_FUSED = os.environ.get("SIVAE_BN_FUSED", "1") != "0"
+_bn_states = {}
+
+
+def bn_fused_state(device):
+    """barrier / counter state of sivae_bn_bwd_fused per (device, stream): zeroed once, left consistent by every call"""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _bn_states.get(key)
+    if buf is None:
+        buf = torch.zeros(_lib.load().sivae_bn_bwd_fused_state_uints(), dtype=torch.int32, device=device)
+        _bn_states[key] = buf
+    return buf
+
+
+def _bn_bwd_fused_ok(x, nseg):
+    if not BN_FUSED or SYNC_BN is not None or x.dim() != 4:
+        return False
+    B, C, H, W = x.shape
+    return _lib.load().sivae_bn_bwd_fused_supported(B, C, H, W, B // nseg) == 1
+
+
+def _bn_bwd_fused(dy, y, mask, x, mean, invstd, gamma, beta, act_mode, slope, dx, dz, dgamma, dbeta, dy_pooled, dz_sum,
+                  nseg):
+    B, C, H, W = x.shape
+    L = _lib.load()
+    ws = workspace(L.sivae_bn_bwd_fused_workspace_bytes(B, C, H, W, B // nseg), x.device)
+    _lib.call("sivae_bn_bwd_fused", _p(dy), _p(y), _p(mask), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta),
+              int(act_mode), float(slope), _p(dx), _p(dz), _p(dgamma), _p(dbeta), B, C, H, W, int(bool(dy_pooled)),
+              int(bool(dz_sum)), B // nseg, _p(bn_fused_state(x.device)), _p(ws), ws.numel(), _s(x))
+
+
 def _out(out, shape, device):
     """a caller-provided destination (a contiguous fp32 device tensor of exactly `shape`: the parameter-gradient slab
     views of optim.FlatAdam) or a fresh tensor"""
@@ -820,6 +855,10 @@ def bn_bwd_signmask(dy, mask, x, mean, invstd, gamma, slope=LRELU_SLOPE, dy_pool
     elif want_dz:
         dz = torch.empty_like(x)
     dgamma, dbeta = _pg(pg_out, C, x.device, want_param_grads)
+    if _bn_bwd_fused_ok(x, nseg):
+        _bn_bwd_fused(dy, None, mask, x, mean, invstd, gamma, None, 3, slope, dx, dz, dgamma, dbeta, dy_pooled, dz_sum,
+                      nseg)
+        return dx, dz, dgamma, dbeta
     if nseg > 1 or (BN_FUSED_FINALIZE and SYNC_BN is None):
         _bn_bwd_seg(dy, None, mask, x, mean, invstd, gamma, None, 3, slope, dx, dz, dgamma, dbeta, dy_pooled, dz_sum,
                     nseg)
@@ -843,6 +882,9 @@ def bn_bwd_dzsum(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_param_gr
     dx = torch.empty_like(x)
     dzh = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
     dgamma, dbeta = _pg(pg_out, C, x.device, want_param_grads)
+    if _bn_bwd_fused_ok(x, nseg):
+        _bn_bwd_fused(dy, y, None, x, mean, invstd, gamma, None, 1, slope, dx, dzh, dgamma, dbeta, False, True, nseg)
+        return dx, dzh, dgamma, dbeta
     if nseg > 1 or (BN_FUSED_FINALIZE and SYNC_BN is None):
         _bn_bwd_seg(dy, y, None, x, mean, invstd, gamma, None, 1, slope, dx, dzh, dgamma, dbeta, False, True, nseg)
         return dx, dzh, dgamma, dbeta
@@ -869,6 +911,10 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, slope=LRELU_SLOPE, want_dz=False, want
     dx = torch.empty_like(x)
     dz = torch.empty_like(x) if want_dz else None
     dgamma, dbeta = _pg(pg_out, C, x.device, want_param_grads)
+    if _bn_bwd_fused_ok(x, nseg):
+        _bn_bwd_fused(dy, y, None, x, mean, invstd, gamma, beta, act_mode, slope, dx, dz, dgamma, dbeta, dy_pooled, False,
+                      nseg)
+        return dx, dz, dgamma, dbeta
     if nseg > 1 or (BN_FUSED_FINALIZE and SYNC_BN is None and x.dim() == 4):
         _bn_bwd_seg(dy, y, None, x, mean, invstd, gamma, beta, act_mode, slope, dx, dz, dgamma, dbeta, dy_pooled, False,
                     nseg)

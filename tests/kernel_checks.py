@@ -1075,6 +1075,92 @@ def check_output_u8():
     return res
 
 
+def check_bn_bwd_fused():
+    """the one-pass persistent BatchNorm backward (bn_fused.hip) against the three-launch form (bn.hip) on the same inputs:
+    every sign source (none / saved output / recomputed from x / 1-bit mask), pooled dy, dz at full resolution and as 2x2
+    block sums, one and two segments, plane sets of one slab, several slabs and several groups per half-grid — and against
+    torch fp64 for the plain variant.  Summation orders differ, values must agree to fp32 rounding."""
+    from sivae_hip import ops
+    res = []
+    L = ops._lib.load()
+
+    def both(fn):
+        out = []
+        for fused in (False, True):
+            ops.BN_FUSED = fused
+            try:
+                out.append(fn())
+            finally:
+                ops.BN_FUSED = True
+        return out
+
+    shapes = [(4, 16, 4, 4, 1), (8, 8, 8, 16, 2), (6, 40, 16, 16, 1), (4, 24, 64, 64, 2), (2, 520, 8, 8, 1),
+              (16, 3, 128, 128, 1), (32, 2, 256, 256, 2), (2, 700, 32, 32, 2),
+              (128, 2, 256, 256, 1)]  # (the last: a plane set larger than a half-grid holds -> the one-grid form)
+    for (B, C, H, W, nseg) in shapes:
+        tag = "(%d,%d,%d,%d,seg%d)" % (B, C, H, W, nseg)
+        assert L.sivae_bn_bwd_fused_supported(B, C, H, W, B // nseg) == 1, tag
+        x = _d(_rand(B, C, H, W, seed=1) * 1.5 + 0.3)
+        r = _d(_rand(B, C, H, W, seed=2))
+        gamma, beta = _d(_rand(C, seed=8).abs() + 0.5), _d(_rand(C, seed=9))
+        dy = _d(_rand(B, C, H, W, seed=4))
+        dyh = _d(_rand(B, C, H // 2, W // 2, seed=5))
+        Bs = B // nseg
+        xs = x.view(nseg, Bs, C, H * W).double()
+        mean = xs.mean((1, 3)).float().reshape(-1).contiguous()
+        invstd = (1.0 / torch.sqrt(xs.var((1, 3), unbiased=False) + 1e-5)).float().reshape(-1).contiguous()
+        y = ops.bn_apply_act(x, r, mean, invstd, gamma, beta, 0.2, nseg=nseg)
+        # sign recomputed from x (BatchNorm-1 of a block), no dz
+        a, b = both(lambda: ops.bn_bwd(dy, None, x, mean, invstd, gamma, 0.2, beta=beta, act_mode=2, nseg=nseg))
+        for n_, i_ in (("dx", 0), ("dgamma", 2), ("dbeta", 3)):
+            res.append(("bn_fused_act2_%s%s" % (n_, tag), _err(b[i_], a[i_]), 3e-6))
+        # sign from the saved output, dz at full resolution; pooled dy
+        a, b = both(lambda: ops.bn_bwd(dy, y, x, mean, invstd, gamma, 0.2, want_dz=True, act_mode=1, nseg=nseg))
+        for n_, i_ in (("dx", 0), ("dz", 1), ("dgamma", 2), ("dbeta", 3)):
+            res.append(("bn_fused_act1_%s%s" % (n_, tag), _err(b[i_], a[i_]), 3e-6))
+        a, b = both(lambda: ops.bn_bwd(dyh, y, x, mean, invstd, gamma, 0.2, want_dz=True, act_mode=1, dy_pooled=True,
+                                       nseg=nseg))
+        for n_, i_ in (("dx", 0), ("dz", 1), ("dgamma", 2), ("dbeta", 3)):
+            res.append(("bn_fused_act1_pooled_%s%s" % (n_, tag), _err(b[i_], a[i_]), 3e-6))
+        a, b = both(lambda: ops.bn_bwd_dzsum(dy, y, x, mean, invstd, gamma, 0.2, nseg=nseg))
+        for n_, i_ in (("dx", 0), ("dzh", 1), ("dgamma", 2), ("dbeta", 3)):
+            res.append(("bn_fused_act1_dzsum_%s%s" % (n_, tag), _err(b[i_], a[i_]), 3e-6))
+        # no activation
+        a, b = both(lambda: ops.bn_bwd(dy, None, x, mean, invstd, gamma, 0.2, act_mode=0, nseg=nseg))
+        res.append(("bn_fused_act0_dx%s" % tag, _err(b[0], a[0]), 3e-6))
+        if W % 8 == 0:
+            _, _, mask = ops.bn_apply_act_signmask(x, r, mean, invstd, gamma, beta, 0.2, nseg=nseg)
+            a, b = both(lambda: ops.bn_bwd_signmask(dy, mask, x, mean, invstd, gamma, 0.2, nseg=nseg))
+            for n_, i_ in (("dx", 0), ("dz", 1), ("dgamma", 2), ("dbeta", 3)):
+                res.append(("bn_fused_mask_%s%s" % (n_, tag), _err(b[i_], a[i_]), 3e-6))
+            a, b = both(lambda: ops.bn_bwd_signmask(dy, mask, x, mean, invstd, gamma, 0.2, dz_sum=True, nseg=nseg))
+            for n_, i_ in (("dx", 0), ("dzh", 1), ("dgamma", 2), ("dbeta", 3)):
+                res.append(("bn_fused_mask_dzsum_%s%s" % (n_, tag), _err(b[i_], a[i_]), 3e-6))
+            a, b = both(lambda: ops.bn_bwd_signmask(dyh, mask, x, mean, invstd, gamma, 0.2, dy_pooled=True, nseg=nseg))
+            for n_, i_ in (("dx", 0), ("dz", 1), ("dgamma", 2), ("dbeta", 3)):
+                res.append(("bn_fused_mask_pooled_%s%s" % (n_, tag), _err(b[i_], a[i_]), 3e-6))
+            # no parameter gradients wanted (frozen network): dx only
+            a, b = both(lambda: ops.bn_bwd_signmask(dy, mask, x, mean, invstd, gamma, 0.2, want_param_grads=False,
+                                                    nseg=nseg))
+            res.append(("bn_fused_mask_nopg_dx%s" % tag, _err(b[0], a[0]), 3e-6))
+    # against torch fp64 (unsegmented, sign recomputed from x)
+    B, C, H, W = 8, 12, 32, 32
+    xt = (_rand(B, C, H, W, seed=1) * 2.0 + 0.7).requires_grad_()
+    gt, bt = (_rand(C, seed=3) * 0.5 + 1.0).requires_grad_(), _rand(C, seed=4).requires_grad_()
+    dyt = _rand(B, C, H, W, seed=7)
+    F.leaky_relu(F.batch_norm(xt, None, None, gt, bt, True, 0.1, 1e-5), 0.2).backward(dyt)
+    xd = _d(xt.detach())
+    mean, invstd = ops.bn_stats(xd)
+    dx, _, dg, db = ops.bn_bwd(_d(dyt), None, xd, mean, invstd, _d(gt.detach()), 0.2, beta=_d(bt.detach()), act_mode=2)
+    res.append(("bn_fused_vs_fp64_dx", _err(dx, xt.grad), 2e-5))
+    res.append(("bn_fused_vs_fp64_dgamma", _err(dg, gt.grad), 2e-5))
+    res.append(("bn_fused_vs_fp64_dbeta", _err(db, bt.grad), 2e-5))
+    # repeated calls leave the barrier / counter state consistent: same result, bit for bit
+    dx2, _, dg2, db2 = ops.bn_bwd(_d(dyt), None, xd, mean, invstd, _d(gt.detach()), 0.2, beta=_d(bt.detach()), act_mode=2)
+    res.append(("bn_fused_repeat_bitwise", float((dx2 - dx).abs().max() + (dg2 - dg).abs().max()), 0.0))
+    return res
+
+
 def all_checks():
     """-> list of (label, thunk) ; every thunk returns a list of (name, err, tol)"""
     checks = []
@@ -1151,6 +1237,7 @@ def all_checks():
     checks.append(("bn_apply_pool", check_bn_apply_pool))
     checks.append(("bn_bwd_dzsum", check_bn_bwd_dzsum))
     checks.append(("bn_signmask", check_bn_signmask))
+    checks.append(("bn_bwd_fused", check_bn_bwd_fused))
     checks.append(("output_u8", check_output_u8))
     checks.append(("space_to_depth", check_space_to_depth))
     checks.append(("bn_apply_resup", check_bn_apply_resup))
