@@ -362,6 +362,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the Soft-IntroVAE HIP engine has no CPU path)")
+    if args.same_device:
+        os.environ["SIVAE_DP_SAME_DEVICE"] = "1"  # (persistent kernels of several processes on one GPU: see ops.BN_FUSED)
     world, rank, local = dp.init(backend=args.backend)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"

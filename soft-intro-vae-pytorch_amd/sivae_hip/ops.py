@@ -165,6 +165,8 @@ def bn_fused_state(device):
 def _bn_bwd_fused_ok(x, nseg):
     if not BN_FUSED or SYNC_BN is not None or x.dim() != 4:
         return False
+    if os.environ.get("SIVAE_DP_SAME_DEVICE", "0") == "1":
+        return False  # several ranks share this GPU (tests only): their persistent grids could starve each other
     B, C, H, W = x.shape
     return _lib.load().sivae_bn_bwd_fused_supported(B, C, H, W, B // nseg) == 1
 

@@ -21,7 +21,7 @@ def _free_port():
 
 def _worker(rank, world, port, out_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0")
+                      LOCAL_RANK="0", SIVAE_DP_SAME_DEVICE="1")
     sys.path.insert(0, os.path.join(REPO, "soft-intro-vae-pytorch_amd"))
     import torch.distributed as dist
     import train_soft_intro_vae as T
