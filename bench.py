@@ -166,34 +166,62 @@ def _pmc_match(kernel_key, kernels):
     return None
 
 
+def _pmc_files(kind, config, dtype):
+    """committed PMC summaries of a workload, newest round first: profiles/r<N>_pmc_<kind>_<workload>*.json"""
+    import glob
+    import re
+    tag = {("celeb256", "fp32"): ("celeb256_bs128_fp32", "bs128", "final"), ("celeb128", "bf16"): ("celeb128_bf16",)}.get(
+        (config, dtype), ())
+    out = []
+    for path in glob.glob(os.path.join(PROFILES, "r*_pmc_%s*.json" % kind)):
+        name = os.path.basename(path)
+        m = re.match(r"r(\d+)_pmc_%s_?(.*)\.json" % kind, name)
+        if not m:
+            continue
+        rest = m.group(2)
+        if kind == "traffic" and rest in ("", "direct_kernels"):
+            rest = "bs128" if rest == "" else "skip"
+        if config == "celeb256" and "bf16" in rest:
+            continue
+        if any(rest == t or rest.startswith(t) for t in tag):
+            out.append((int(m.group(1)), name))
+    return [n for _, n in sorted(out, key=lambda rn: (-rn[0], rn[1]))]
+
+
+def _lib_sha16():
+    from sivae_hip import lib
+    return lib.sha256()[:16]
+
+
+def _stamp(d, source):
+    """provenance of a counter figure: the file it came from, the library build it was taken with, and whether that is
+    the build this run timed (`stale`: true when it is another build or the file carries no stamp — counters cannot be
+    read from inside the bench, so a kernel edit after the PMC pass must show)"""
+    sha = d.get("lib_sha256_16")
+    return dict(source="profiles/" + source, lib_sha256_16=sha, stale=(sha is None or sha != _lib_sha16()))
+
+
 def _pmc_busy(kernel_key, config="celeb256", dtype="fp32"):
-    """matrix-pipe busy fraction of `kernel_key` from the committed rocprofv3 --pmc pass of the workload
-    (tools/pmc_mfma_busy.py over SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE; counters cannot be read from inside the
-    bench)"""
-    names = {("celeb256", "fp32"): ("r3_pmc_mfma_busy_celeb256_bs128_fp32.json", "r2_pmc_mfma_busy_bs128_final.json",
-                                    "r2_pmc_mfma_busy_bs128.json"),
-             ("celeb128", "bf16"): ("r2_pmc_mfma_busy_celeb128_bf16.json",)}.get((config, dtype), ())
-    for name in names:
-        path = os.path.join(PROFILES, name)
-        if os.path.exists(path):
-            hit = _pmc_match(kernel_key, json.load(open(path))["kernels"])
-            if hit:
-                return dict(value=hit["mfma_busy_frac"], source="profiles/" + name)
+    """matrix-pipe busy fraction and MFMA op count of `kernel_key` from the newest committed rocprofv3 --pmc pass of the
+    workload (tools/pmc_mfma_busy.py over SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE / SQ_INSTS_VALU_MFMA_MOPS_F32)"""
+    for name in _pmc_files("mfma_busy", config, dtype):
+        d = json.load(open(os.path.join(PROFILES, name)))
+        hit = _pmc_match(kernel_key, d["kernels"])
+        if hit:
+            out = dict(value=hit["mfma_busy_frac"], mfma_mops_per_launch=hit.get("mfma_mops_f32_per_launch"))
+            out.update(_stamp(d, name))
+            return out
     return None
 
 
 def _pmc_traffic(kernel_key, config, dtype):
-    """HBM bytes per launch of `kernel_key` + whole-step bytes from the committed FETCH_SIZE / WRITE_SIZE passes"""
-    names = {("celeb256", "fp32"): ("r3_pmc_traffic_celeb256_bs128_fp32.json", "r2_pmc_traffic_final.json",
-                                    "r1_pmc_traffic.json"),
-             ("celeb128", "bf16"): ("r2_pmc_traffic_celeb128_bf16.json",)}.get((config, dtype), ())
-    for name in names:
-        path = os.path.join(PROFILES, name)
-        if os.path.exists(path):
-            d = json.load(open(path))
-            hit = _pmc_match(kernel_key, d["kernels"])
-            return dict(kernel_bytes=hit["hbm_bytes"] if hit else None, step_bytes=d.get("step_total_hbm_bytes"),
-                        source="profiles/" + name)
+    """HBM bytes per launch of `kernel_key` + whole-step bytes from the newest committed FETCH_SIZE / WRITE_SIZE passes"""
+    for name in _pmc_files("traffic", config, dtype):
+        d = json.load(open(os.path.join(PROFILES, name)))
+        hit = _pmc_match(kernel_key, d["kernels"])
+        out = dict(kernel_bytes=hit["hbm_bytes"] if hit else None, step_bytes=d.get("step_total_hbm_bytes"))
+        out.update(_stamp(d, name))
+        return out
     return None
 
 
@@ -317,7 +345,8 @@ def also_legs(args, world, rank, dev):
             if tr is not None and tr["step_bytes"]:
                 tbs = tr["step_bytes"] / (r["dt_untimed"] / n_untimed) / 1e12
                 leg["hbm"] = dict(step_bytes=tr["step_bytes"], achieved_tbs=round(tbs, 3), peak_tbs=PEAK_HBM_TBS,
-                                  frac=round(tbs / PEAK_HBM_TBS, 4), source=tr["source"])
+                                  frac=round(tbs / PEAK_HBM_TBS, 4), source=tr["source"],
+                                  lib_sha256_16=tr["lib_sha256_16"], stale=tr["stale"])
         out[name] = leg
     return out
 
@@ -425,10 +454,16 @@ def main():
                                         issued_tflops=round(v["executed_flops"] / (v["total_ms"] * 1e-3) / 1e12, 2),
                                         algorithmic_tflops=round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2))
                                 for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])})
+        pb = roof.get("mfma_busy_pmc")
+        if pb and pb.get("mfma_mops_per_launch") and args.dtype == "fp32":
+            # the counter twin of `frac`: MFMA ops the PMC pass counted per launch (x 512 FLOPs per v_mfma_f32_32x32x2 "mop")
+            # over THIS run's HIP-event time per launch
+            roof["frac_pmc"] = round(pb["mfma_mops_per_launch"] * 512.0 / (d["avg_ms"] * 1e-3) / 1e12 / peak, 4)
         tr = _pmc_traffic(key, args.config, args.dtype) if per == cfg_batch and not args.bootstrap else None
         if tr is not None:
             roof["traffic"] = tr["kernel_bytes"]
             roof["traffic_unit"] = "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, %s)" % tr["source"]
+            roof["traffic_provenance"] = {k: tr[k] for k in ("source", "lib_sha256_16", "stale")}
             if tr["step_bytes"]:
                 # the whole iteration against the HBM roofline: fabric bytes per iteration / measured iteration time
                 roof["hbm"] = dict(step_bytes=tr["step_bytes"], achieved_tbs=round(tr["step_bytes"] / (dt / args.steps) / 1e12, 3),

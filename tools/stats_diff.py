@@ -9,7 +9,7 @@ import sys
 def load(p):
     d = {}
     for r in csv.DictReader(open(p)):
-        n = re.sub(r"\(.*", "", r["Name"]).replace("void ", "")
+        n = re.sub(r"\(.*", "", r["Name"].replace("(anonymous namespace)::", "")).replace("void ", "")
         c, t = d.get(n, (0, 0.0))
         d[n] = (c + int(r["Calls"]), t + int(r["TotalDurationNs"]) / 1e6)
     return d
