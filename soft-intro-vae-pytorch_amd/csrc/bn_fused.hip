@@ -49,6 +49,7 @@ struct BnFusedArgs {
   int l2_qpp, l2_qw;  // log2(quads per plane), log2(quad columns per row); a quad = 2 rows x 4 columns
   int spc, cpg, ngroups, nx;
   int nsub;    // 2: two independent half-grids walking alternate groups; 1: one grid (plane sets too big for a half)
+  int local;   // 1: every (segment, channel) plane set fits ONE block (spc == 1): grid = VC ordinary blocks, no barrier
   int dzmode;  // 0: none, 1: dz at full resolution, 2: 2x2 block sums [.][H/2][W/2]
 };
 
@@ -124,28 +125,31 @@ template <int ACT, bool POOL, int NQ>
 __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
   __shared__ double red[4];
   const int t = threadIdx.x;
-  const int nb_sub = (int)gridDim.x / a.nsub;
-  const int sub = (int)blockIdx.x >= nb_sub ? 1 : 0;
+  const bool local = a.local != 0;
+  const int nb_sub = local ? (int)gridDim.x : (int)gridDim.x / a.nsub;
+  const int sub = (!local && (int)blockIdx.x >= nb_sub) ? 1 : 0;
   const int bid = (int)blockIdx.x - sub * nb_sub;
   unsigned* bar = a.bar + sub * BF_BAR_UINTS;
   unsigned* chcnt = a.bar + 2 * BF_BAR_UINTS;
   const int xcd = bid % a.nx;
   const unsigned bpx = (unsigned)(nb_sub / a.nx);
   unsigned target = 0;
-  if (t == 0) target = bf_load_u32(bar + (9 + xcd) * 32);
+  if (t == 0 && !local) target = bf_load_u32(bar + (9 + xcd) * 32);
   const int C = a.C, W = a.W, HW = a.H * a.W;
   const int VC = a.nseg * C;
   const int nq = a.Bs << a.l2_qpp;
   const unsigned qpp_m = (1u << a.l2_qpp) - 1u, qw_m = (1u << a.l2_qw) - 1u;
-  const int ci = bid / a.spc, slab = bid - ci * a.spc;
+  const int ci = local ? 0 : bid / a.spc, slab = local ? 0 : bid - ci * a.spc;
   const float slope = a.slope;
   const unsigned img_pitch = (unsigned)C * (unsigned)HW * 4u;  // bytes between two images of one channel
   const unsigned row_b = (unsigned)W * 4u;
   const unsigned long long win = ((unsigned long long)(a.Bs - 1) * C + 1ull) * HW * 4ull;  // bytes of a plane set's window
 
-  for (int grp = sub; grp < a.ngroups; grp += a.nsub) {
-    const int vc = grp * a.cpg + ci;
-    const bool active = ci < a.cpg && vc < VC;
+  // (local form: one pass of the loop body, vc = the block index)
+  for (int grp = sub; grp < (local ? 1 : a.ngroups); grp += a.nsub) {
+    const int vc = local ? bid : grp * a.cpg + ci;
+    const bool active = local ? true : (ci < a.cpg && vc < VC);
+    double t1 = 0.0, t2 = 0.0;
     float4 g0[NQ], g1[NQ], x0[NQ], x1[NQ];
     float m = 0.f, is = 0.f, gs = 0.f;
     int c = 0;
@@ -231,27 +235,31 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
       }
       s1 = block_sum<256>(s1, red);
       s2 = block_sum<256>(s2, red);
-      if (t == 0) {
+      if (local) {
+        t1 = s1;
+        t2 = s2;
+      } else if (t == 0) {
         __hip_atomic_store(a.part + ((size_t)vc * a.spc + slab) * 2 + 0, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(a.part + ((size_t)vc * a.spc + slab) * 2 + 1, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    // ---- barrier: every slab of every channel of this group is published
-    if (t == 0) {
-      ++target;
-      bf_grid_barrier(bar, xcd, a.nx, bpx, target);
+    if (!local) {
+      // ---- barrier: every slab of every channel of this group is published
+      if (t == 0) {
+        ++target;
+        bf_grid_barrier(bar, xcd, a.nx, bpx, target);
+      }
+      __syncthreads();
+      if (!active) continue;
+      // ---- phase 2: coefficients of this channel (fixed order: thread-strided slabs, then the block tree — the same
+      // in every block of the channel), then dx straight from the registers
+      for (int s = t; s < a.spc; s += 256) {
+        t1 += bf_load_f64(a.part + ((size_t)vc * a.spc + s) * 2 + 0);
+        t2 += bf_load_f64(a.part + ((size_t)vc * a.spc + s) * 2 + 1);
+      }
+      t1 = block_sum<256>(t1, red);
+      t2 = block_sum<256>(t2, red);
     }
-    __syncthreads();
-    if (!active) continue;
-    // ---- phase 2: coefficients of this channel (fixed order: thread-strided slabs, then the block tree — the same in
-    // every block of the channel), then dx straight from the registers
-    double t1 = 0.0, t2 = 0.0;
-    for (int s = t; s < a.spc; s += 256) {
-      t1 += bf_load_f64(a.part + ((size_t)vc * a.spc + s) * 2 + 0);
-      t2 += bf_load_f64(a.part + ((size_t)vc * a.spc + s) * 2 + 1);
-    }
-    t1 = block_sum<256>(t1, red);
-    t2 = block_sum<256>(t2, red);
     const float c1 = (float)(t1 / a.count), c2 = (float)(t2 / a.count);
     if (slab == 0 && t == 0 && (a.dgamma != nullptr || a.dbeta != nullptr)) {
       if (a.nseg == 1) {
@@ -312,12 +320,27 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
 struct BfPlan {
   int nq_per_thread;  // NQ
   int spc, cpg, ngroups, nb_sub, nsub;
+  int local;  // plane sets of one block each: an ordinary launch of VC blocks
 };
 
 // the NQ (quads per thread) of {10, 8, 4} with the smallest modelled time: groups per (half-)grid x (fixed barrier /
 // latency cost + streaming time of a group).  A channel plane set must fit one group (spc <= blocks of the (half-)grid).
 static bool bf_plan(int Bs, int VC, int HW, int max_nq, BfPlan* out) {
   const long long nq = (long long)Bs * HW / 8;
+  out->local = 0;
+  // small plane sets (the 4x4 / 8x8 / 16x16 maps, small shards): one block holds a whole (segment, channel) — no
+  // cross-block dependency, so no persistent grid and no barrier: VC ordinary blocks
+  for (int NQ : {4, 8, 10}) {
+    if (NQ > max_nq || nq > 256LL * NQ) continue;
+    out->nq_per_thread = NQ;
+    out->spc = 1;
+    out->cpg = 1;
+    out->ngroups = VC;
+    out->nb_sub = VC;
+    out->nsub = 1;
+    out->local = 1;
+    return true;
+  }
   // two half-grids (one block per CU each) when a plane set fits a half; otherwise one grid of two blocks per CU
   for (int nsub = 2; nsub >= 1; --nsub) {
     const int nb_sub = sivae_num_cus() * (nsub == 2 ? 1 : 2);
@@ -435,10 +458,11 @@ extern "C" int sivae_bn_bwd_fused(const float* dy, const float* y, const unsigne
   a.spc = p.spc;
   a.cpg = p.cpg;
   a.ngroups = p.ngroups;
-  a.nx = (p.nb_sub % 8 == 0) ? 8 : 1;
+  a.nx = (!p.local && p.nb_sub % 8 == 0) ? 8 : 1;
   a.nsub = p.nsub;
+  a.local = p.local;
   a.dzmode = !dz_out ? 0 : (dz_sum ? 2 : 1);
-  const dim3 grid((unsigned)(p.nsub * p.nb_sub)), block(256);
+  const dim3 grid((unsigned)(p.local ? VC : p.nsub * p.nb_sub)), block(256);
 #define BF_LAUNCH(A, P, Q) hipLaunchKernelGGL((bn_bwd_fused_kernel<A, P, Q>), grid, block, 0, stream, a)
 #define BF_NQ(A, P)                                 \
   {                                                 \
