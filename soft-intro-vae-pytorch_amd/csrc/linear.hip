@@ -233,7 +233,10 @@ int dispatch_rb(int B, F&& f) {
 }
 
 bool lin_ok(int B, int K, int N) {
-  return B > 0 && K > 0 && N > 0 && B <= 32 * MAX_RB && (K % 4) == 0 && (N % 4) == 0 &&
+  // (batches above 32 * MAX_RB = 256 rows run as row chunks of 256: forward / dgrad rows are independent, wgrad walks
+  // the whole batch anyway — the paired 2 x 256-image passes of the 32x32 configuration used to fall back to the 1x1-conv
+  // path: 187 us per call instead of ~20)
+  return B > 0 && K > 0 && N > 0 && B <= 16384 && (K % 4) == 0 && (N % 4) == 0 &&
          (long long)B * K * 4 < 0x7fffffffLL && (long long)N * K * 4 < 0xffffffffLL && (long long)B * N * 4 < 0x7fffffffLL;
 }
 
@@ -254,6 +257,15 @@ extern "C" int sivae_linear_fwd(const float* x, const float* w, const float* bia
                                 int N, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!x || !w || !y) return SIVAE_ERR_NULL;
   if (!lin_ok(B, K, N)) return SIVAE_ERR_SHAPE;
+  if (B > 32 * MAX_RB) {
+    for (int r0 = 0; r0 < B; r0 += 32 * MAX_RB) {
+      const int nb = B - r0 < 32 * MAX_RB ? B - r0 : 32 * MAX_RB;
+      const int rc = sivae_linear_fwd(x + (size_t)r0 * K, w, bias, y + (size_t)r0 * N, relu, nb, K, N, workspace,
+                                      workspace_bytes, stream);
+      if (rc != SIVAE_OK) return rc;
+    }
+    return SIVAE_OK;
+  }
   LinArgs a;
   a.a = x;
   a.w = w;
@@ -285,6 +297,15 @@ extern "C" int sivae_linear_dgrad(const float* dy, const float* w, float* dx, in
                                   size_t workspace_bytes, hipStream_t stream) {
   if (!dy || !w || !dx) return SIVAE_ERR_NULL;
   if (!lin_ok(B, K, N)) return SIVAE_ERR_SHAPE;
+  if (B > 32 * MAX_RB) {
+    for (int r0 = 0; r0 < B; r0 += 32 * MAX_RB) {
+      const int nb = B - r0 < 32 * MAX_RB ? B - r0 : 32 * MAX_RB;
+      const int rc = sivae_linear_dgrad(dy + (size_t)r0 * N, w, dx + (size_t)r0 * K, nb, K, N, workspace, workspace_bytes,
+                                        stream);
+      if (rc != SIVAE_OK) return rc;
+    }
+    return SIVAE_OK;
+  }
   LinArgs a;
   a.a = dy;
   a.w = w;

@@ -237,7 +237,7 @@ def check_linear_fast():
     from sivae_hip import ops
     res = []
     for (B, K, N) in [(128, 8192, 512), (16, 8192, 1024), (16, 512, 8192), (128, 256, 8192), (7, 100, 36), (33, 4100, 60),
-                      (1, 64, 128), (200, 72, 260)]:
+                      (1, 64, 128), (200, 72, 260), (512, 4096, 256), (512, 128, 4096), (300, 64, 64)]:  # (> 256 rows: chunks)
         assert ops.linear_supported(B, K, N)
         x = _rand(B, K, seed=1).requires_grad_()
         w = _rand(N, K, seed=2, scale=1.0 / math.sqrt(K)).requires_grad_()
@@ -252,7 +252,7 @@ def check_linear_fast():
         res.append(("linear_fast_fwd_relu" + tag, _err(yr, ref.detach().clamp(min=0)), 1e-5))
         res.append(("linear_fast_dgrad" + tag, _err(ops.linear_dgrad(_d(dy), _d(w.detach())), x.grad), 1e-5))
         res.append(("linear_fast_wgrad" + tag, _err(ops.linear_wgrad(_d(dy), _d(x.detach())), w.grad), 1e-5))
-    res.append(("linear_fast_unsupported", float(ops.linear_supported(300, 64, 64) or ops.linear_supported(8, 66, 64)), 0.0))
+    res.append(("linear_fast_unsupported", float(ops.linear_supported(20000, 64, 64) or ops.linear_supported(8, 66, 64)), 0.0))
     return res
 
 

@@ -114,11 +114,11 @@ def test_round2_entry_points_validate_arguments():
     assert L.sivae_bf16_to_f32_nchw(one, one, 1, 0, 4, 4, null) == -2
     assert L.sivae_bf16_add_inplace(one, null, 4, null) == -1 and L.sivae_bf16_add_inplace(one, one, 0, null) == 0
     # small-batch Linear: B <= 256, K % 4 == 0, N % 4 == 0
-    assert L.sivae_linear_supported(128, 8192, 1024) == 1 and L.sivae_linear_supported(257, 64, 64) == 0
+    assert L.sivae_linear_supported(128, 8192, 1024) == 1 and L.sivae_linear_supported(257, 64, 64) == 1 and L.sivae_linear_supported(16385, 64, 64) == 0
     assert L.sivae_linear_supported(8, 66, 64) == 0 and L.sivae_linear_supported(8, 64, 30) == 0
     assert L.sivae_linear_workspace_bytes(128, 8192, 512) >= 128 * 512 * 4
     assert L.sivae_linear_fwd(null, one, null, one, 0, 8, 64, 64, one, 1 << 20, null) == -1
-    assert L.sivae_linear_fwd(one, one, null, one, 0, 300, 64, 64, one, 1 << 20, null) == -2
+    assert L.sivae_linear_fwd(one, one, null, one, 0, 20000, 64, 64, one, 1 << 20, null) == -2  # (batches above 256 rows run as chunks; 16384 is the cap)
     assert L.sivae_linear_fwd(one, one, null, one, 0, 128, 8192, 512, one, 16, null) == -4
     assert L.sivae_linear_dgrad(one, one, one, 128, 256, 8192, one, 16, null) == -4
     assert L.sivae_linear_wgrad(one, null, one, 8, 64, 64, null) == -1
