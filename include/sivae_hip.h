@@ -476,6 +476,15 @@ int sivae_bn_stats_from_conv_seg(const float* partials, int n_tiles, int nseg, i
 int sivae_bn_update_running_seg(const float* mean, const float* invstd, int nseg, int seg_rev, int C, double count,
                                 float eps, float momentum, float* running_mean, float* running_var,
                                 long long* num_batches_tracked, sivae_stream_t stream);
+/* sivae_bn_stats_from_conv_seg with a scratch buffer: from 2048 partial rows per pass on (the 256x256 / 128x128 layers at
+ * batch 128) the rows are folded in two coalesced stages instead of one strided walk per channel; same statistics, same
+ * running-buffer updates (nn.BatchNorm2d training-mode forward, train_soft_intro_vae.py:57,62,90).  The workspace size is 0
+ * (and the pointer may be NULL) where the one-stage form is used. */
+size_t sivae_bn_stats_from_conv_workspace_bytes(int n_tiles, int nseg, int C);
+int sivae_bn_stats_from_conv_ws(const float* partials, int n_tiles, int nseg, int seg_rev, int B_seg, int C, int HW,
+                                float eps, float momentum, float* running_mean, float* running_var,
+                                long long* num_batches_tracked, float* mean_out, float* invstd_out, void* workspace,
+                                size_t workspace_bytes, sivae_stream_t stream);
 int sivae_bn_apply_act_seg(const float* x, const float* res, int res_up, const float* mean, const float* invstd,
                            const float* gamma, const float* beta, float slope, float* y, float* y_pooled, int B, int C,
                            int H, int W, int seg_images, sivae_stream_t stream);

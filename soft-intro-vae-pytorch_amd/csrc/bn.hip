@@ -208,6 +208,115 @@ static int bn_stats_from_conv_impl(const float* partials, int n_tiles, int nseg,
   return sivae_launch_status();
 }
 
+// ---- two-stage form for MANY partial rows (thousands of pixel tiles: the 256x256 / 128x128 layers at batch 128): the
+// one-block-per-channel walk above reads 8 of every 64 bytes it touches (a row holds all channels) and runs C blocks —
+// 81 us per call on [32768][64][2], 1.9 ms per headline iteration.  Stage 1 reads whole rows (consecutive threads =
+// consecutive channels) in chunks of BNC_ROWS rows, fp64 per thread, fixed-order fold over the row lanes through LDS ->
+// [nseg][C][nchunks][2] doubles; stage 2 is one thread per channel over the chunks (+ the running-buffer updates in
+// pass order, as above).
+#define BNC_ROWS 128
+__global__ void __launch_bounds__(256) bn_conv_rows_partial_kernel(const float* __restrict__ part, int S, int C,
+                                                                   int nchunks, double* __restrict__ out) {
+  __shared__ double red[2][256];
+  const int chunk = blockIdx.x, g = blockIdx.y, t = threadIdx.x;
+  int cw = 1;
+  while (cw < C && cw < 256) cw <<= 1;  // channel lanes (power of two <= 256), the other 256 / cw lanes walk rows
+  const int rp = 256 / cw, tx = t & (cw - 1), ty = t / cw;
+  const int r0 = chunk * BNC_ROWS;
+  const int r1 = r0 + BNC_ROWS < S ? r0 + BNC_ROWS : S;
+  for (int c0 = 0; c0 < C; c0 += cw) {
+    const int c = c0 + tx;
+    double sum = 0.0, sq = 0.0;
+    if (c < C)
+      for (int r = r0 + ty; r < r1; r += rp) {
+        const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)(g * S + r) * C + c) * 2);
+        sum += (double)v.x;
+        sq += (double)v.y;
+      }
+    red[0][t] = sum;
+    red[1][t] = sq;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+      double a = 0.0, b = 0.0;
+      for (int k = 0; k < rp; ++k) {
+        a += red[0][k * cw + tx];
+        b += red[1][k * cw + tx];
+      }
+      double* o = out + (((size_t)g * C + c) * nchunks + chunk) * 2;
+      o[0] = a;
+      o[1] = b;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(64) bn_conv_rows_finalize_kernel(const double* __restrict__ part2, int nchunks, int C,
+                                                                   double count, float eps, float momentum,
+                                                                   float* running_mean, float* running_var,
+                                                                   long long* num_batches_tracked,
+                                                                   float* __restrict__ mean_out,
+                                                                   float* __restrict__ invstd_out, int nseg,
+                                                                   int seg_rev) {
+  // one wave per channel: lanes stride over the chunks, then the fixed butterfly
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (c == 0 && lane == 0 && num_batches_tracked) *num_batches_tracked += nseg;
+  for (int gi = 0; gi < nseg; ++gi) {
+    const int g = seg_rev ? nseg - 1 - gi : gi;
+    const double* p = part2 + ((size_t)g * C + c) * nchunks * 2;
+    double sum = 0.0, sq = 0.0;
+    for (int k = lane; k < nchunks; k += 64) {
+      sum += p[2 * k];
+      sq += p[2 * k + 1];
+    }
+    sum = wave_sum(sum);
+    sq = wave_sum(sq);
+    if (lane == 0) {
+      const double mean = sum / count;
+      double var = sq / count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      mean_out[g * C + c] = (float)mean;
+      invstd_out[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+      if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+      }
+    }
+  }
+}
+
+// workspace of sivae_bn_stats_from_conv_ws (0: the call does not use one for this shape)
+extern "C" size_t sivae_bn_stats_from_conv_workspace_bytes(int n_tiles, int nseg, int C) {
+  if (n_tiles <= 0 || nseg <= 0 || C <= 0 || (n_tiles % nseg) != 0) return 0;
+  const int S = n_tiles / nseg;
+  if (S < 2048) return 0;
+  return (size_t)nseg * C * cdiv(S, BNC_ROWS) * 2 * sizeof(double);
+}
+
+// sivae_bn_stats_from_conv_seg with a scratch buffer: from 2048 partial rows per pass on, the statistics are folded in
+// two coalesced stages (above); below that this IS sivae_bn_stats_from_conv_seg (the workspace may then be NULL)
+extern "C" int sivae_bn_stats_from_conv_ws(const float* partials, int n_tiles, int nseg, int seg_rev, int B_seg, int C,
+                                           int HW, float eps, float momentum, float* running_mean, float* running_var,
+                                           long long* num_batches_tracked, float* mean_out, float* invstd_out,
+                                           void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  const size_t need = sivae_bn_stats_from_conv_workspace_bytes(n_tiles, nseg, C);
+  if (need == 0)
+    return bn_stats_from_conv_impl(partials, n_tiles, nseg, seg_rev, B_seg, C, HW, eps, momentum, running_mean,
+                                   running_var, num_batches_tracked, mean_out, invstd_out, stream);
+  if (!partials || !mean_out || !invstd_out) return SIVAE_ERR_NULL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return SIVAE_ERR_NULL;
+  if (B_seg <= 0 || HW <= 0) return SIVAE_ERR_SHAPE;
+  if (!workspace || workspace_bytes < need) return SIVAE_ERR_WORKSPACE;
+  const int S = n_tiles / nseg, nchunks = cdiv(S, BNC_ROWS);
+  double* part2 = (double*)workspace;
+  hipLaunchKernelGGL(bn_conv_rows_partial_kernel, dim3(nchunks, nseg), dim3(256), 0, stream, partials, S, C, nchunks,
+                     part2);
+  hipLaunchKernelGGL(bn_conv_rows_finalize_kernel, dim3(C), dim3(64), 0, stream, (const double*)part2, nchunks,
+                     C, (double)B_seg * HW, eps, momentum, running_mean, running_var, num_batches_tracked, mean_out,
+                     invstd_out, nseg, seg_rev);
+  return sivae_launch_status();
+}
+
 extern "C" int sivae_bn_stats_from_conv(const float* partials, int n_tiles, int B, int C, int HW, float eps,
                                         float momentum, float* running_mean, float* running_var,
                                         long long* num_batches_tracked, float* mean_out, float* invstd_out,

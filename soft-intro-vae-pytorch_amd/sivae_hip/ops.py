@@ -731,12 +731,16 @@ def bn_stats_from_conv(partials, B, C, HW, running_mean=None, running_var=None, 
     _require(partials, running_mean, running_var, num_batches_tracked)
     mean = torch.empty(nseg * C, dtype=torch.float32, device=partials.device)
     invstd = torch.empty(nseg * C, dtype=torch.float32, device=partials.device)
-    if nseg > 1:
-        if SYNC_BN is not None:
-            raise RuntimeError("sivae_hip: segmented batches and synchronised BatchNorm do not combine")
-        _lib.call("sivae_bn_stats_from_conv_seg", _p(partials), partials.shape[0], nseg, int(bool(seg_rev)), B // nseg,
+    if nseg > 1 and SYNC_BN is not None:
+        raise RuntimeError("sivae_hip: segmented batches and synchronised BatchNorm do not combine")
+    if SYNC_BN is None:
+        # (thousands of partial rows — the large-map layers at batch 128 — are folded in two coalesced stages through a
+        # scratch buffer; the call is the one-stage form below that)
+        nws = _lib.load().sivae_bn_stats_from_conv_workspace_bytes(partials.shape[0], nseg, C)
+        ws = workspace(nws, partials.device) if nws else None
+        _lib.call("sivae_bn_stats_from_conv_ws", _p(partials), partials.shape[0], nseg, int(bool(seg_rev)), B // nseg,
                   C, HW, float(eps), float(momentum), _p(running_mean), _p(running_var), _p(num_batches_tracked),
-                  _p(mean), _p(invstd), _s())
+                  _p(mean), _p(invstd), _p(ws), ws.numel() if ws is not None else 0, _s())
         return mean, invstd
     if SYNC_BN is not None:
         sums = torch.empty((C, 2), dtype=torch.float64, device=partials.device)

@@ -320,6 +320,36 @@ def check_bn_from_conv():
         res.append(("bn_from_conv_mean%s" % (shape,), _err(m1, ref.mean((0, 2, 3))), 1e-5))
         res.append(("bn_from_conv_invstd%s" % (shape,),
                     _err(i1, 1.0 / torch.sqrt(ref.var((0, 2, 3), unbiased=False) + 1e-5)), 1e-5))
+    # the two-stage form (>= 2048 partial rows per pass) against the one-stage form on synthetic partial rows: statistics,
+    # running buffers and the batch counter, one and two segments (seg_rev), ragged channel counts
+    L = ops._lib.load()
+    for (rows, nseg, C, rev) in [(4096, 1, 64, False), (2 * 3000, 2, 40, True), (2 * 2048, 2, 300, False), (5000, 1, 7, False)]:
+        S = rows // nseg
+        g = torch.Generator().manual_seed(rows + C)
+        part = torch.rand(rows, C, 2, generator=g)
+        part[:, :, 1] = part[:, :, 0] ** 2 + 0.5 + part[:, :, 1]  # (sumsq above sum^2 / n: positive variances)
+        pd = part.to(DEV)
+        assert L.sivae_bn_stats_from_conv_workspace_bytes(rows, nseg, C) > 0
+        outs = []
+        for two_stage in (False, True):
+            rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+            nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+            mean = torch.empty(nseg * C, device=DEV)
+            invstd = torch.empty(nseg * C, device=DEV)
+            if two_stage:
+                ws = ops.workspace(L.sivae_bn_stats_from_conv_workspace_bytes(rows, nseg, C), pd.device)
+                ops._lib.call("sivae_bn_stats_from_conv_ws", ops._p(pd), rows, nseg, int(rev), 4, C, 64, 1e-5, 0.1, ops._p(rm),
+                              ops._p(rv), ops._p(nbt), ops._p(mean), ops._p(invstd), ops._p(ws), ws.numel(), ops._s())
+            else:
+                ops._lib.call("sivae_bn_stats_from_conv_seg", ops._p(pd), rows, nseg, int(rev), 4, C, 64, 1e-5, 0.1,
+                              ops._p(rm), ops._p(rv), ops._p(nbt), ops._p(mean), ops._p(invstd), ops._s())
+            outs.append((mean, invstd, rm, rv, nbt))
+        tag = "(%d,%d,%d)" % (rows, nseg, C)
+        for n_, i_ in (("mean", 0), ("invstd", 1), ("running_mean", 2), ("running_var", 3)):
+            res.append(("bn_from_conv_2stage_%s%s" % (n_, tag), _err(outs[1][i_], outs[0][i_]), 1e-6))
+        res.append(("bn_from_conv_2stage_nbt" + tag, float(abs(int(outs[1][4]) - int(outs[0][4]))), 0.0))
+        ref_mean = part.view(nseg, S, C, 2)[..., 0].double().sum(1) / (4 * 64)
+        res.append(("bn_from_conv_2stage_mean_fp64" + tag, _err(outs[1][0].view(nseg, C), ref_mean), 1e-6))
     return res
 
 
