@@ -155,3 +155,30 @@ def test_train_entry_point_under_two_process_launch(tmp_path):
     assert int(a["encoder.main.1.num_batches_tracked"]) == 1 + 8 * 5 + 3 + 1
     ckpts = [f for f in os.listdir(tmp_path / "saves")]
     assert ckpts and all(f.endswith(".pth") for f in ckpts)  # written once (rank 0), not once per rank
+
+
+def test_bench_two_rank_launch_reports_strong_and_weak_lines(tmp_path):
+    """the driver's multi-GPU launch shape on one device: `torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`
+    (gloo, both ranks on cuda:0 — the box has one GPU) prints ONE JSON line whose headline is the BASELINE configuration
+    as stated (global batch 128 split over the ranks: 64 images per GPU, "strong") and which carries the
+    fixed-per-GPU-work variant beside it (128 images per GPU, "weak"); the two flat-gradient all-reduces per iteration
+    ran (finite losses on the all-reduced gradients)."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend",
+           "gloo", "--same-device", "--steps", "2", "--warmup", "1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 2 and d["warmup"] == 1
+    assert d["config"]["global_batch"] == 128 and d["config"]["per_gpu_batch"] == 64 and d["config"]["parallelism"] == "dp2"
+    assert d["metric"].endswith("256x256 bs128") and d["unit"] == "img/s" and d["value"] > 0
+    assert d["weak"]["scaling"] == "weak" and d["weak"]["global_batch"] == 256 and d["weak"]["per_gpu_batch"] == 128
+    assert d["weak"]["value"] > 0
+    import math
+    assert all(math.isfinite(v) for v in d["config"]["final_stats"].values())
+    assert "cpu_baseline" not in d  # (rank 0 of a multi-GPU launch does not time the CPU loop)
