@@ -46,6 +46,20 @@ int sivae_conv_co_pad(int co);
 size_t sivae_pack_conv_weight_bytes(int Co, int Ci, int ks, int mode);
 int sivae_pack_conv_weight(const float* w /*[Co][Ci][ks][ks]*/, float* wp, int Co, int Ci, int ks, int mode,
                            sivae_stream_t stream);
+/* Batched form (round 4): ONE launch rebuilds one operand form of EVERY weight of a network after its optimizer step
+ * (torch.optim.Adam.step of train_soft_intro_vae.py:588,622 changes all of them; 35 per-weight launches of 5-11 us became
+ * 5).  A job table lives in device memory and is reused from step to step (the packed buffers do not move):
+ *   sivae_pack_job_fill   writes job `index` of a HOST table (sivae_pack_job_bytes() bytes per job) for operand form
+ *                         0 direct (ks, mode) / 1 Winograd F(2x2,3x3) (mode) / 2 Winograd F(4x4,3x3) (mode) /
+ *                         3 upsample-phase forward / 4 upsample-phase data gradient; dst = the buffer the per-weight
+ *                         sivae_pack_* call of that form writes; returns the job's block count (its blocks are
+ *                         [first_block, first_block + count) of the launch) or an error code (< 0)
+ *   sivae_pack_batch      the launch: jobs_dev = the uploaded table, block_job_dev[b] = job index of block b (uint16) */
+int sivae_pack_job_bytes(void);
+int sivae_pack_job_fill(void* jobs_host, int index, int form, const float* w, float* dst, int Co, int Ci, int ks, int mode,
+                        int first_block);
+int sivae_pack_batch(int form, const void* jobs_dev, const unsigned short* block_job_dev, int n_blocks,
+                     sivae_stream_t stream);
 
 /* y[B][Co][H][W] (+)= conv(x', wp) + bias.
  *   x' = x, or LeakyReLU((x-pro_mean[c])*pro_invstd[c]*pro_gamma[c]+pro_beta[c], pro_slope) when

@@ -27,6 +27,7 @@
 // tiles of a half-wave hit 32 distinct banks (ds_read_b32 banks = dword address mod 32):
 // 4x8 tiles: RS = 20 (row pair = 40 = 8 mod 32), 2x16 tiles: RS = 40 (row pair = 80 = 16 mod 32).
 #include "common.h"
+#include "pack_batch.h"
 #include <stdlib.h>
 
 struct WinoArgs {
@@ -447,10 +448,10 @@ __global__ void __launch_bounds__(NG * 256, 2 * NG) conv_wino_kernel(WinoArgs a)
 // ---- weight transform U = G g G^T, packed [j][ci_pad][co_pad][i]; padding entries are zero
 //   mode 0 (forward): g = w[n][k]            (n = output channel, k = input channel)
 //   mode 1 (dgrad):   g = flip180(w[k][n])   (k = w's output channel is the GEMM's input channel)
-__global__ void __launch_bounds__(256) pack_wino_kernel(const float* __restrict__ w, float* __restrict__ up, int Co,
-                                                        int Ci, int mode, int kdim, int ndim, int kpad, int npad) {
+__device__ __forceinline__ void pack_wino_body(const float* __restrict__ w, float* __restrict__ up, int Co,
+                                                        int Ci, int mode, int kdim, int ndim, int kpad, int npad, size_t idx0_, const size_t stride_) {
   const size_t total = (size_t)kpad * npad;
-  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+  for (size_t idx = idx0_; idx < total; idx += stride_) {
     const int n = (int)(idx % npad), k = (int)(idx / npad);
     float g[3][3];
     const bool ok = k < kdim && n < ndim;
@@ -485,6 +486,18 @@ __global__ void __launch_bounds__(256) pack_wino_kernel(const float* __restrict_
     }
   }
 }
+
+__global__ void __launch_bounds__(256) pack_wino_kernel(const float* __restrict__ w, float* __restrict__ up, int Co,
+                                                        int Ci, int mode, int kdim, int ndim, int kpad, int npad) {
+  pack_wino_body(w, up, Co, Ci, mode, kdim, ndim, kpad, npad, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+}
+
+__global__ void __launch_bounds__(256) pack_wino_batch_kernel(const SivaePackJob* __restrict__ jobs,
+                                                               const unsigned short* __restrict__ block_job) {
+  const SivaePackJob j = jobs[block_job[blockIdx.x]];
+  pack_wino_body(j.w, j.dst, j.Co, j.Ci, j.mode, j.kdim, j.ndim, j.kpad, j.npad, (size_t)(blockIdx.x - j.blk0) * 256 + threadIdx.x, (size_t)j.nblk * 256);
+}
+
 
 static inline int wino_kpad(int k) { return ((k + WINO_CK - 1) / WINO_CK) * WINO_CK; }
 static inline int wino_npad(int n) { return ((n + WINO_TCO - 1) / WINO_TCO) * WINO_TCO; }
@@ -773,4 +786,17 @@ extern "C" int sivae_conv2d_wino_fwd_splitk_seg(const float* x, const float* up,
   if (seg_images <= 0) return SIVAE_ERR_SHAPE;
   return wino_fwd_splitk_impl(x, up, y, pro_mean, pro_invstd, pro_gamma, pro_beta, pro_slope, stats_partial, B, Ci, Co, H,
                               W, upsample, accumulate, workspace, workspace_bytes, stream, seg_images);
+}
+
+// ---- batched packing (pack_batch.h)
+int sivae_packjob_wino(SivaePackJob* j, int Co, int Ci, int mode) {
+  j->kdim = mode == 0 ? Ci : Co;
+  j->ndim = mode == 0 ? Co : Ci;
+  j->kpad = wino_kpad(j->kdim);
+  j->npad = wino_npad(j->ndim);
+  j->total = (unsigned long long)j->kpad * j->npad;
+  return SIVAE_OK;
+}
+void sivae_packbatch_wino(const SivaePackJob* jobs, const unsigned short* block_job, int nblocks, hipStream_t s) {
+  hipLaunchKernelGGL(pack_wino_batch_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, jobs, block_job);
 }

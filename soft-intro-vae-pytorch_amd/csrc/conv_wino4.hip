@@ -31,6 +31,7 @@
 // across the six frequency-column waves; outputs leave as 16-byte stores (four consecutive pixels of one channel per
 // lane) with the usual fused epilogues (accumulate, BatchNorm sum / sumsq partials).
 #include "common.h"
+#include "pack_batch.h"
 #include <stdlib.h>
 
 struct Wino4Args {
@@ -533,8 +534,8 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
 // ---- weight transform U = G g G^T (6x6), packed [j][ci_pad][co_pad][i]; padding entries are zero
 //   mode 0 (forward): g = w[n][k]            (n = output channel, k = input channel)
 //   mode 1 (dgrad):   g = flip180(w[k][n])   (k = w's output channel is the GEMM's input channel)
-__global__ void __launch_bounds__(256) pack_wino4_kernel(const float* __restrict__ w, float* __restrict__ up, int Co,
-                                                         int Ci, int mode, int kdim, int ndim, int kpad, int npad) {
+__device__ __forceinline__ void pack_wino4_body(const float* __restrict__ w, float* __restrict__ up, int Co,
+                                                         int Ci, int mode, int kdim, int ndim, int kpad, int npad, size_t idx0_, const size_t stride_) {
   const float G[6][3] = {{0.25f, 0.f, 0.f},
                          {-1.f / 6.f, -1.f / 6.f, -1.f / 6.f},
                          {-1.f / 6.f, 1.f / 6.f, -1.f / 6.f},
@@ -542,7 +543,7 @@ __global__ void __launch_bounds__(256) pack_wino4_kernel(const float* __restrict
                          {1.f / 24.f, -1.f / 12.f, 1.f / 6.f},
                          {0.f, 0.f, 1.f}};
   const size_t total = (size_t)kpad * npad;
-  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+  for (size_t idx = idx0_; idx < total; idx += stride_) {
     const int n = (int)(idx % npad), k = (int)(idx / npad);
     float g[3][3];
     const bool ok = k < kdim && n < ndim;
@@ -567,6 +568,18 @@ __global__ void __launch_bounds__(256) pack_wino4_kernel(const float* __restrict
     }
   }
 }
+
+__global__ void __launch_bounds__(256) pack_wino4_kernel(const float* __restrict__ w, float* __restrict__ up, int Co,
+                                                         int Ci, int mode, int kdim, int ndim, int kpad, int npad) {
+  pack_wino4_body(w, up, Co, Ci, mode, kdim, ndim, kpad, npad, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+}
+
+__global__ void __launch_bounds__(256) pack_wino4_batch_kernel(const SivaePackJob* __restrict__ jobs,
+                                                                const unsigned short* __restrict__ block_job) {
+  const SivaePackJob j = jobs[block_job[blockIdx.x]];
+  pack_wino4_body(j.w, j.dst, j.Co, j.Ci, j.mode, j.kdim, j.ndim, j.kpad, j.npad, (size_t)(blockIdx.x - j.blk0) * 256 + threadIdx.x, (size_t)j.nblk * 256);
+}
+
 
 static inline int w4_kpad(int k) { return ((k + 31) / 32) * 32; }  // an even number of 16-channel chunks
 static inline int w4_npad(int n) { return ((n + W4_TCO - 1) / W4_TCO) * W4_TCO; }
@@ -776,4 +789,17 @@ extern "C" int sivae_conv2d_wino4_fwd_splitk(const float* x, const float* up, fl
   hipLaunchKernelGGL(wino4_splitk_reduce_kernel, dim3((unsigned)(B * Co)), dim3(64), 0, stream, part, y, stats_partial, S,
                      H * W, (size_t)B * Co * H * W, accumulate);
   return sivae_launch_status();
+}
+
+// ---- batched packing (pack_batch.h)
+int sivae_packjob_wino4(SivaePackJob* j, int Co, int Ci, int mode) {
+  j->kdim = mode == 0 ? Ci : Co;
+  j->ndim = mode == 0 ? Co : Ci;
+  j->kpad = w4_kpad(j->kdim);
+  j->npad = w4_npad(j->ndim);
+  j->total = (unsigned long long)j->kpad * j->npad;
+  return SIVAE_OK;
+}
+void sivae_packbatch_wino4(const SivaePackJob* jobs, const unsigned short* block_job, int nblocks, hipStream_t s) {
+  hipLaunchKernelGGL(pack_wino4_batch_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, jobs, block_job);
 }

@@ -18,6 +18,7 @@
 // transform is entirely in registers — no LDS exchange, no barrier — and the wave stores its phase's pixels.
 // K loop, halo staging, persistent work items and fused BatchNorm+LeakyReLU prologue are those of conv_wino.hip.
 #include "common.h"
+#include "pack_batch.h"
 #include <stdlib.h>
 
 struct WinoUpArgs {
@@ -289,10 +290,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_kernel(WinoUpArgs a) {
 
 // ---- filter transform: g_pq = P_p w Q_q^T (3x3 -> 2x2 per phase), U_pq = G g_pq G^T (2x2 -> 3x3),
 // packed [phase][ci_pad][co_pad][12] (row-major 3x3 in the first 9 floats), padding entries zero
-__global__ void __launch_bounds__(256) pack_wino_up_kernel(const float* __restrict__ w, float* __restrict__ up, int Co,
-                                                           int Ci, int kpad, int npad) {
+__device__ __forceinline__ void pack_wino_up_body(const float* __restrict__ w, float* __restrict__ up, int Co,
+                                                           int Ci, int kpad, int npad, size_t idx0_, const size_t stride_) {
   const size_t total = (size_t)kpad * npad;
-  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+  for (size_t idx = idx0_; idx < total; idx += stride_) {
     const int n = (int)(idx % npad), k = (int)(idx / npad);
     float g[3][3];
     const bool ok = k < Ci && n < Co;
@@ -340,6 +341,18 @@ __global__ void __launch_bounds__(256) pack_wino_up_kernel(const float* __restri
       }
   }
 }
+
+__global__ void __launch_bounds__(256) pack_wino_up_kernel(const float* __restrict__ w, float* __restrict__ up, int Co,
+                                                           int Ci, int kpad, int npad) {
+  pack_wino_up_body(w, up, Co, Ci, kpad, npad, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+}
+
+__global__ void __launch_bounds__(256) pack_wino_up_batch_kernel(const SivaePackJob* __restrict__ jobs,
+                                                                  const unsigned short* __restrict__ block_job) {
+  const SivaePackJob j = jobs[block_job[blockIdx.x]];
+  pack_wino_up_body(j.w, j.dst, j.Co, j.Ci, j.kpad, j.npad, (size_t)(blockIdx.x - j.blk0) * 256 + threadIdx.x, (size_t)j.nblk * 256);
+}
+
 
 static inline int wup_kpad(int k) { return ((k + WUP_CK - 1) / WUP_CK) * WUP_CK; }
 static inline int wup_npad(int n) { return ((n + WUP_TCO - 1) / WUP_TCO) * WUP_TCO; }
@@ -438,4 +451,17 @@ extern "C" int sivae_conv2d_wino_up_fwd(const float* x_half, const float* up, fl
   a.Co_pad = wup_npad(Co);
   if (4ull * a.Ci_pad * a.Co_pad * 48ull >= 0xffffffffull) return SIVAE_ERR_RANGE;
   return wup_wide(W) ? wup_launch<1, 4>(a, stream) : wup_launch<2, 3>(a, stream);
+}
+
+// ---- batched packing (pack_batch.h)
+int sivae_packjob_wino_up(SivaePackJob* j, int Co, int Ci) {
+  j->kdim = Ci;
+  j->ndim = Co;
+  j->kpad = wup_kpad(Ci);
+  j->npad = wup_npad(Co);
+  j->total = (unsigned long long)j->kpad * j->npad;
+  return SIVAE_OK;
+}
+void sivae_packbatch_wino_up(const SivaePackJob* jobs, const unsigned short* block_job, int nblocks, hipStream_t s) {
+  hipLaunchKernelGGL(pack_wino_up_batch_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, jobs, block_job);
 }

@@ -14,6 +14,7 @@
 // LDS halo of the current 16-plane chunk.  Chunks never straddle phases (K index = phase * Cpad + c), so the patch
 // shift is uniform per chunk.  K loop, staging and persistent work items as in conv_wino.hip.
 #include "common.h"
+#include "pack_batch.h"
 #include <stdlib.h>
 
 struct WinoUpDgArgs {
@@ -352,10 +353,10 @@ extern "C" int sivae_space_to_depth2(const float* in, float* out, int B, int C, 
 
 // ---- filter transform for the data gradient: K index = phase * Cpad + k (k = w's OUTPUT channel = dy channel),
 // N index = w's input channel; U = G gf G^T with gf = 180-degree flip of the phase filter g_pq
-__global__ void __launch_bounds__(256) pack_wino_up_dgrad_kernel(const float* __restrict__ w, float* __restrict__ ud,
-                                                                 int Co, int Ci, int cpad, int npad) {
+__device__ __forceinline__ void pack_wino_up_dgrad_body(const float* __restrict__ w, float* __restrict__ ud,
+                                                                 int Co, int Ci, int cpad, int npad, size_t idx0_, const size_t stride_) {
   const size_t total = (size_t)cpad * npad;
-  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+  for (size_t idx = idx0_; idx < total; idx += stride_) {
     const int n = (int)(idx % npad), k = (int)(idx / npad);
     float g[3][3];
     const bool ok = k < Co && n < Ci;
@@ -401,6 +402,18 @@ __global__ void __launch_bounds__(256) pack_wino_up_dgrad_kernel(const float* __
       }
   }
 }
+
+__global__ void __launch_bounds__(256) pack_wino_up_dgrad_kernel(const float* __restrict__ w, float* __restrict__ ud,
+                                                                 int Co, int Ci, int cpad, int npad) {
+  pack_wino_up_dgrad_body(w, ud, Co, Ci, cpad, npad, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+}
+
+__global__ void __launch_bounds__(256) pack_wino_up_dgrad_batch_kernel(const SivaePackJob* __restrict__ jobs,
+                                                                        const unsigned short* __restrict__ block_job) {
+  const SivaePackJob j = jobs[block_job[blockIdx.x]];
+  pack_wino_up_dgrad_body(j.w, j.dst, j.Co, j.Ci, j.kpad, j.npad, (size_t)(blockIdx.x - j.blk0) * 256 + threadIdx.x, (size_t)j.nblk * 256);
+}
+
 
 static inline int wud_cpad(int c) { return ((c + WUD_CK - 1) / WUD_CK) * WUD_CK; }
 static inline int wud_npad(int n) { return ((n + WUD_TN - 1) / WUD_TN) * WUD_TN; }
@@ -559,4 +572,17 @@ extern "C" int sivae_conv2d_wino_up_dgrad_splitk_run(const float* dy, const floa
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(wud_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, part, dx, nsl, n, n, accumulate);
   return sivae_launch_status();
+}
+
+// ---- batched packing (pack_batch.h)
+int sivae_packjob_wino_up_dgrad(SivaePackJob* j, int Co, int Ci) {
+  j->kdim = Co;
+  j->ndim = Ci;
+  j->kpad = wud_cpad(Co);
+  j->npad = wud_npad(Ci);
+  j->total = (unsigned long long)j->kpad * j->npad;
+  return SIVAE_OK;
+}
+void sivae_packbatch_wino_up_dgrad(const SivaePackJob* jobs, const unsigned short* block_job, int nblocks, hipStream_t s) {
+  hipLaunchKernelGGL(pack_wino_up_dgrad_batch_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, jobs, block_job);
 }

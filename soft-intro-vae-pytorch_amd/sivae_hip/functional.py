@@ -68,6 +68,72 @@ def packed(w, mode):
     return _cached_pack(w, mode, lambda: ops.PackedW(w.detach(), mode))
 
 
+# SIVAE_PACK_BATCH=0: every cached operand form is rebuilt by its own launch on first use after an optimizer step
+# (35 launches of 5-11 us per network) instead of one launch per operand form (5 per network) right after the step.
+PACK_BATCH = os.environ.get("SIVAE_PACK_BATCH", "1") != "0"
+
+
+def repack(params, owner):
+    """After `params` were updated in place through raw pointers (FlatAdam.step, generation already bumped): rebuild every
+    operand form cached on them IN PLACE with one launch per form (sivae_pack_batch) and re-validate the caches.  The job
+    tables live on `owner` and are rebuilt only when the set of cached forms changes (the first iterations)."""
+    import ctypes
+    if not PACK_BATCH:
+        return
+    L = ops._lib.load()
+    entries, jobs = [], [[] for _ in range(5)]
+    for p in params:
+        store = p.__dict__.get("_sivae_pack")
+        if not store:
+            continue
+        for slot, (tag, obj) in list(store.items()):
+            if isinstance(obj, ops.PackedW):
+                forms = obj.batch_forms()
+                if forms:
+                    entries.append((p, store, slot, obj))
+                    for f, buf in forms:
+                        jobs[f].append((obj, buf))
+                else:
+                    del store[slot]
+            else:
+                del store[slot]  # (the small-channel 5x5 packs: rebuilt on demand)
+    if not entries:
+        return
+    key = tuple((f, obj.w.data_ptr(), buf.data_ptr()) for f in range(5) for obj, buf in jobs[f])
+    plan = owner.__dict__.get("_sivae_pack_plan")
+    if plan is None or plan["key"] != key:
+        jb = L.sivae_pack_job_bytes()
+        dev = entries[0][0].device
+        launches = []
+        for f in range(5):
+            if not jobs[f]:
+                continue
+            if len(jobs[f]) > 32767:
+                return  # (the block -> job map is 16 bits wide)
+            host = ctypes.create_string_buffer(jb * len(jobs[f]))
+            block_job, nblocks = [], 0
+            for i, (obj, buf) in enumerate(jobs[f]):
+                w = obj.w
+                Co, Ci = w.shape[0], w.shape[1]
+                ks = w.shape[2] if w.dim() == 4 else 1
+                nb = L.sivae_pack_job_fill(host, i, f, ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(buf.data_ptr()),
+                                           Co, Ci, ks, obj.mode, nblocks)
+                if nb <= 0:
+                    raise ops._lib.SivaeError("sivae_pack_job_fill", nb)
+                block_job.extend([i] * nb)
+                nblocks += nb
+            jt = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(dev)
+            bj = torch.tensor(block_job, dtype=torch.int16).to(dev)  # (indices < 32768: uint16 and int16 agree)
+            launches.append((f, jt, bj, nblocks))
+        plan = {"key": key, "launches": launches, "keep": [b for fl in jobs for _, b in fl]}
+        owner.__dict__["_sivae_pack_plan"] = plan
+    for f, jt, bj, nblocks in plan["launches"]:
+        ops._lib.call("sivae_pack_batch", f, ops._p(jt), ops._p(bj), nblocks, ops._s(jt))
+    for p, store, slot, obj in entries:
+        obj.refreshed()
+        store[slot] = (_wtag(p), obj)
+
+
 def packed5(w, mode):
     """pack for the small-channel 5x5 kernels (same invalidation rules as `packed`)"""
     return _cached_pack(w, 10 + mode, lambda: ops.pack5_smallco(w.detach(), mode))

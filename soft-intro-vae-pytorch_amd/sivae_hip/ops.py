@@ -273,6 +273,18 @@ class PackedW:
             self._direct = pack_weight(self.w, self.mode)
         return self._direct
 
+    # operand forms sivae_pack_batch rebuilds in place: (form id of include/sivae_hip.h, attribute holding the buffer)
+    _BATCH_FORMS = ((0, "_direct"), (1, "_wino"), (2, "_wino4"), (3, "_wino_up"), (4, "_wino_up_dgrad"))
+
+    def batch_forms(self):
+        """[(form id, buffer)] of the operand forms built so far that the batched repack can rebuild in place"""
+        return [(f, getattr(self, a)) for f, a in self._BATCH_FORMS if getattr(self, a, None) is not None]
+
+    def refreshed(self):
+        """the weight changed and the batched repack rebuilt the forms of batch_forms() in place: drop the others (they
+        are rebuilt on demand)"""
+        self._k75 = None
+
     def wino(self):
         if self._wino is None:
             self._wino = pack_wino(self.w, self.mode)

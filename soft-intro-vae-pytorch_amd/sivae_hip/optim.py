@@ -127,6 +127,7 @@ class FlatAdam:
                           self.betas[1], self.eps, grad_scale)
         self._reset_uses()
         SF.bump_generation(self.params)
+        SF.repack(self.params, self)  # every cached operand form of every weight, one launch per form
 
     def use_device_state(self):
         """Move the step counter and learning rate into a device tensor {t, lr, ., .} (float64).  Needed before the
