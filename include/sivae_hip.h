@@ -470,6 +470,16 @@ int sivae_bf16_bn_bwd(const void* dy, int dy_pooled, const void* y, const unsign
                       const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
                       void* dx, void* dz, int dz_sum, float* dgamma, float* dbeta, int B, int C, int H, int W,
                       void* workspace, size_t workspace_bytes, sivae_stream_t stream);
+/* The same backward as ONE launch that reads dy and x once (bf16_bn_fused.hip, round 4; the bf16 counterpart of
+ * sivae_bn_bwd_fused): raw vectors held in registers across a grid barrier, or a barrier-free launch where a channel
+ * block's plane set fits one block.  Power-of-two maps (sivae_bf16_bn_bwd_fused_supported); `state` = the barrier state
+ * of sivae_bn_bwd_fused (sivae_bn_bwd_fused_state_uints() unsigned ints, zeroed once, one buffer per stream). */
+int sivae_bf16_bn_bwd_fused_supported(int B, int C, int H, int W);
+size_t sivae_bf16_bn_bwd_fused_workspace_bytes(int B, int C, int H, int W);
+int sivae_bf16_bn_bwd_fused(const void* dy, int dy_pooled, const void* y, const unsigned char* sign_mask, const void* x,
+                            const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                            void* dx, void* dz, int dz_sum, float* dgamma, float* dbeta, int B, int C, int H, int W,
+                            unsigned int* state, void* workspace, size_t workspace_bytes, sivae_stream_t stream);
 int sivae_bf16_upsample2_fwd(const void* x, void* y, int B, int C, int Hs, int Ws, sivae_stream_t stream);
 int sivae_bf16_upsample2_bwd(const void* dy, void* dx, int B, int C, int Hs, int Ws, sivae_stream_t stream);
 int sivae_bf16_add_inplace(void* y, const void* x, size_t nvec, sivae_stream_t stream);

@@ -1,0 +1,415 @@
+// BatchNorm backward of the bf16 mode (blocked bf16 activations x[b][c/8][h][w][c%8], bf16_common.h) as ONE launch that
+// reads dy and x once and writes dx once — the bf16 counterpart of bn_fused.hip (same structure: a persistent grid of two
+// independent half-grids, plane sets walked in groups whose raw vectors stay in registers across a fence-free grid
+// barrier; or, for plane sets that fit one block, an ordinary barrier-free launch).  The three-launch form of
+// bf16_bn.hip (bf16_bn_bwd_partial_kernel -> finalize -> bf16_bn_bwd_apply_kernel) streams dy and x twice: 21 % of a
+// 128x128 bf16 iteration.
+//
+// Unit of work: an 8-channel block `cb` (one 16-byte vector per pixel), a thread's payload = NU 2x2-pixel quads of raw
+// dy and x vectors (32 registers per quad) + their 4 sign bytes; the per-channel sums are fp32 per thread (8 channels x
+// {sum g, sum g*xhat}), fp32 across the block, fp64 across slabs (fixed order).  Phase 2 recomputes g and xhat from the
+// raw vectors with the arithmetic of bf16_bn_bwd_apply_kernel.
+//
+// Reference op: backward of nn.BatchNorm2d + nn.LeakyReLU(0.2) (+ torch.add, nn.AvgPool2d(2) behind / nn.Upsample(2) in
+// front of the block), soft_intro_vae/train_soft_intro_vae.py:57-63,71-74,90-93,98,155 — in config 3's bf16 storage.
+#include "bf16_common.h"
+#include "bn_fused_common.h"
+
+namespace {
+
+struct Bf16BnFusedArgs {
+  const void* dy;
+  const void* y;
+  const void* x;
+  const unsigned char* mask;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  void* dx;
+  void* dz;
+  float* dgamma;
+  float* dbeta;
+  double* part;  // [Cb][spc][16]
+  unsigned* bar;
+  float inv_n;
+  float slope;
+  int C, Cb, H, W, B;
+  int l2_qpp, l2_qw;  // log2(quads per plane), log2(quads per row); a quad = 2 x 2 pixels
+  int spc, cpg, ngroups, nx, nsub, local;
+  int dzmode;  // 0 none, 1 full resolution, 2 2x2 block sums
+};
+
+// 16-byte buffer store + a guard.  Measured on gfx950 / ROCm 7.2 (this kernel, memory pipe saturated): when the VALU
+// instructions that follow a buffer_store_dwordx4 rewrite its data registers within a few issue slots, the store can
+// pick up the NEW values in lanes 12-15 of every 16-lane row (the last quad of each row is read last) — the two wait
+// states hipcc inserts for the store-data hazard are not enough under back-pressure.  Symptom here: isolated dwords of dx
+// in every fourth quad of a row wrong, only in blocks that start while the other half-grid streams, and only in some
+// runs.  The guard keeps the scheduler from moving anything across and leaves 16 idle cycles behind the store.
+__device__ __forceinline__ void bf_store_u32x4(__amdgpu_buffer_rsrc_t r, u32x4_t v, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// ACT: 1 sign from the saved output y, 2 recomputed from xhat * gamma + beta, 3 from the sign bytes
+template <int ACT, bool POOL, int NU>
+__global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedArgs a) {
+  __shared__ float red[4][16];
+  __shared__ double red2[16][16];
+  __shared__ float coef[16];  // c1[8] = sg / N, c2[8] = sgx / N of this block's channel block
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const bool local = a.local != 0;
+  const int nb_sub = local ? (int)gridDim.x : (int)gridDim.x / a.nsub;
+  const int sub = (!local && (int)blockIdx.x >= nb_sub) ? 1 : 0;
+  const int bid = (int)blockIdx.x - sub * nb_sub;
+  unsigned* bar = a.bar + sub * BF_BAR_UINTS;
+  const int xcd = bid % a.nx;
+  const unsigned bpx = (unsigned)(nb_sub / a.nx);
+  unsigned target = 0;
+  if (t == 0 && !local) target = bf_load_u32(bar + (9 + xcd) * 32);
+  const int W = a.W, HW = a.H * a.W, Cb = a.Cb;
+  const int nq = a.B << a.l2_qpp;
+  const unsigned qpp_m = (1u << a.l2_qpp) - 1u, qw_m = (1u << a.l2_qw) - 1u;
+  const int ci = local ? 0 : bid / a.spc, slab = local ? 0 : bid - ci * a.spc;
+  const float slope = a.slope;
+  const unsigned img_pitch = (unsigned)Cb * (unsigned)HW * 16u;  // bytes between two images of one channel block
+  const unsigned row_b = (unsigned)W * 16u;
+  const unsigned long long win = ((unsigned long long)(a.B - 1) * Cb + 1ull) * HW * 16ull;
+
+  for (int grp = sub; grp < (local ? 1 : a.ngroups); grp += a.nsub) {
+    const int cb = local ? bid : grp * a.cpg + ci;
+    const bool active = local ? true : (ci < a.cpg && cb < Cb);
+    u32x4_t dq[NU][POOL ? 1 : 4], xq[NU][4];
+    unsigned sg_bits[NU];  // sign bytes of the quad's 4 vectors (row 0: bytes 0, 1; row 1: bytes 2, 3)
+    float mu[8], is[8];
+    const unsigned qbase = (unsigned)(slab * (256 * NU) + t);
+    auto quad_off = [&](unsigned q) -> unsigned {  // byte offset of the quad's first vector (row 0) inside the window
+      const unsigned b = q >> a.l2_qpp, r = q & qpp_m, h2 = r >> a.l2_qw, w2 = r & qw_m;
+      return q < (unsigned)nq ? b * img_pitch + (2u * h2 * (unsigned)W + 2u * w2) * 16u : BF_OOB;
+    };
+    auto half_off = [&](unsigned q) -> unsigned {  // the quad's vector in a half-resolution tensor [.][H/2][W/2][8]
+      const unsigned b = q >> a.l2_qpp, r = q & qpp_m;
+      return q < (unsigned)nq ? b * (img_pitch >> 2) + r * 16u : BF_OOB;
+    };
+    double tsum = 0.0;  // (threads t < 256: value t & 15 of the channel block's 16 sums)
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = cb * 8 + e;
+        const bool ok = c < a.C;
+        mu[e] = ok ? a.mean[c] : 0.f;
+        is[e] = ok ? a.invstd[c] : 0.f;
+      }
+      const size_t base = (size_t)cb * HW;  // vector index of the channel block's plane in image 0
+      const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(a.x) + base * 16, win);
+      const __amdgpu_buffer_rsrc_t rdy =
+          POOL ? make_rsrc(reinterpret_cast<const char*>(a.dy) + (base >> 2) * 16, win >> 2)
+               : make_rsrc(reinterpret_cast<const char*>(a.dy) + base * 16, win);
+      // ---- phase 1: raw vectors into registers
+#pragma unroll
+      for (int j = 0; j < NU; ++j) {
+        const unsigned vo = quad_off(qbase + j * 256);
+        xq[j][0] = buf_load_u32x4(rx, vo, 0);
+        xq[j][1] = buf_load_u32x4(rx, vo == BF_OOB ? BF_OOB : vo + 16u, 0);
+        xq[j][2] = buf_load_u32x4(rx, vo, row_b);
+        xq[j][3] = buf_load_u32x4(rx, vo == BF_OOB ? BF_OOB : vo + 16u, row_b);
+        if (POOL) {
+          dq[j][0] = buf_load_u32x4(rdy, half_off(qbase + j * 256), 0);
+        } else {
+          dq[j][0] = buf_load_u32x4(rdy, vo, 0);
+          dq[j][1] = buf_load_u32x4(rdy, vo == BF_OOB ? BF_OOB : vo + 16u, 0);
+          dq[j][2] = buf_load_u32x4(rdy, vo, row_b);
+          dq[j][3] = buf_load_u32x4(rdy, vo == BF_OOB ? BF_OOB : vo + 16u, row_b);
+        }
+        if (ACT == 3) {
+          // one sign byte per vector: bytes vo/16, vo/16 + 1 (row 0) and + W (row 1): two 16-bit loads
+          const __amdgpu_buffer_rsrc_t rm = make_rsrc(a.mask + base, win >> 4);
+          const unsigned mo = vo == BF_OOB ? BF_OOB : (vo >> 4);
+          const unsigned m0 = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rm, (int)mo, 0, 0);
+          const unsigned m1 = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rm, (int)mo, (int)W, 0);
+          sg_bits[j] = m0 | (m1 << 16);
+        } else if (ACT == 1) {
+          const __amdgpu_buffer_rsrc_t ry = make_rsrc(reinterpret_cast<const char*>(a.y) + base * 16, win);
+          unsigned bits = 0;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const u32x4_t yv = buf_load_u32x4(ry, vo == BF_OOB ? BF_OOB : vo + (v & 1) * 16u, (v >> 1) ? row_b : 0u);
+            unsigned m = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              m |= (bf16_lo(yv[i]) > 0.f ? 1u : 0u) << (2 * i);
+              m |= (bf16_hi(yv[i]) > 0.f ? 1u : 0u) << (2 * i + 1);
+            }
+            bits |= m << (8 * v);
+          }
+          sg_bits[j] = bits;
+        } else {
+          sg_bits[j] = 0;
+        }
+      }
+      float gm[8], bt[8];
+      if (ACT == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = cb * 8 + e;
+          gm[e] = c < a.C ? a.gamma[c] : 0.f;
+          bt[e] = c < a.C ? a.beta[c] : 0.f;
+        }
+      }
+      float sg[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sgx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NU; ++j) {
+        float dp[8];
+        if (POOL) {
+          unpack8(dq[j][0], dp);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dp[e] *= 0.25f;
+        }
+        unsigned bits = sg_bits[j];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          float d[8], xv[8];
+          if (POOL) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] = dp[e];
+          } else {
+            unpack8(dq[j][v], d);
+          }
+          unpack8(xq[j][v], xv);
+          unsigned m = 0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xh = (xv[e] - mu[e]) * is[e];
+            bool pos;
+            if (ACT == 2) {
+              pos = xh * gm[e] + bt[e] > 0.f;
+              m |= (pos ? 1u : 0u) << e;
+            } else {
+              pos = (bits >> (8 * v + e)) & 1u;
+            }
+            const float g = d[e] * (pos ? 1.f : slope);
+            sg[e] += g;
+            sgx[e] += g * xh;
+          }
+          if (ACT == 2) bits |= m << (8 * v);
+        }
+        if (ACT == 2) sg_bits[j] = bits;  // (phase 2 reads the bits whatever their source)
+      }
+      // block fold of the 16 sums: wave butterflies, then the four waves through LDS
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float s1 = wave_sum(sg[e]), s2 = wave_sum(sgx[e]);
+        if (lane == 0) {
+          red[wave][e] = s1;
+          red[wave][8 + e] = s2;
+        }
+      }
+      __syncthreads();
+      if (t < 16) {
+        const float s = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+        if (local)
+          tsum = (double)s;
+        else
+          __hip_atomic_store(a.part + ((size_t)cb * a.spc + slab) * 16 + t, (double)s, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (!local) {
+      if (t == 0) {
+        ++target;
+        bf_grid_barrier(bar, xcd, a.nx, bpx, target);
+      }
+      __syncthreads();
+      if (!active) continue;
+      // the channel block's 16 sums over its slabs: thread (value v = t & 15, row r = t >> 4) strides over the slabs,
+      // rows folded in order through LDS — the same in every block of the channel block
+      const int v = t & 15, r = t >> 4;
+      double acc = 0.0;
+      for (int s = r; s < a.spc; s += 16) acc += bf_load_f64(a.part + ((size_t)cb * a.spc + s) * 16 + v);
+      red2[r][v] = acc;
+      __syncthreads();
+      if (t < 16) {
+        double u = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) u += red2[k][t];
+        tsum = u;
+      }
+    }
+    if (t < 16) {
+      coef[t] = (float)tsum * a.inv_n;
+      if (slab == 0) {
+        const int c = cb * 8 + (t & 7);
+        if (c < a.C) {
+          if (t < 8 && a.dbeta) a.dbeta[c] = (float)tsum;
+          if (t >= 8 && a.dgamma) a.dgamma[c] = (float)tsum;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase 2
+    float gi[8], c1[8], c2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = cb * 8 + e;
+      gi[e] = (c < a.C ? a.gamma[c] : 0.f) * is[e];
+      c1[e] = coef[e];
+      c2[e] = coef[8 + e];
+    }
+    const size_t base = (size_t)cb * HW;
+    const __amdgpu_buffer_rsrc_t rdx = make_rsrc(reinterpret_cast<char*>(a.dx) + base * 16, win);
+    const __amdgpu_buffer_rsrc_t rdz =
+        a.dzmode == 2 ? make_rsrc(reinterpret_cast<char*>(a.dz) + (base >> 2) * 16, win >> 2)
+                      : make_rsrc(reinterpret_cast<char*>(a.dzmode == 1 ? a.dz : a.dx) + base * 16, win);
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      const unsigned vo = quad_off(qbase + j * 256);
+      if (vo == BF_OOB) continue;
+      float dp[8];
+      if (POOL) {
+        unpack8(dq[j][0], dp);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dp[e] *= 0.25f;
+      }
+      float zs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const unsigned bits = sg_bits[j];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        float d[8], xv[8], g[8];
+        if (POOL) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d[e] = dp[e];
+        } else {
+          unpack8(dq[j][v], d);
+        }
+        unpack8(xq[j][v], xv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (xv[e] - mu[e]) * is[e];
+          const bool pos = (bits >> (8 * v + e)) & 1u;
+          g[e] = d[e] * (pos ? 1.f : slope);
+          zs[e] += g[e];
+          xv[e] = gi[e] * (g[e] - c1[e] - xh * c2[e]);
+        }
+        const unsigned vv = vo + (v & 1) * 16u, so = (v >> 1) ? row_b : 0u;
+        if (a.dzmode == 1) bf_store_u32x4(rdz, pack8(g), vv, so);
+        bf_store_u32x4(rdx, pack8(xv), vv, so);
+      }
+      if (a.dzmode == 2) bf_store_u32x4(rdz, pack8(zs), half_off(qbase + j * 256), 0);
+    }
+    __syncthreads();  // (coef / red are reused by the next group)
+  }
+}
+
+struct B16Plan {
+  int nu, spc, cpg, ngroups, nb_sub, nsub, local;
+};
+
+static bool b16_plan(int B, int Cb, int HW, B16Plan* out) {
+  const long long nq = (long long)B * HW / 4;
+  for (int NU : {1, 2, 4}) {
+    if (nq > 256LL * NU) continue;
+    *out = B16Plan{NU, 1, 1, Cb, Cb, 1, 1};
+    return true;
+  }
+  for (int nsub = 2; nsub >= 1; --nsub) {
+    const int nb_sub = sivae_num_cus() * (nsub == 2 ? 1 : 2);
+    const int NU = 4;
+    const long long slabq = 256LL * NU;
+    const long long spc = (nq + slabq - 1) / slabq;
+    if (spc > nb_sub) continue;
+    const int cpg = (int)(nb_sub / spc);
+    *out = B16Plan{NU, (int)spc, cpg, (Cb + cpg - 1) / cpg, nb_sub, nsub, 0};
+    return true;
+  }
+  return false;
+}
+
+static inline bool b16_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+}  // namespace
+
+// power-of-two maps from 2x2 up whose channel-block plane sets fit one group of the grid
+extern "C" int sivae_bf16_bn_bwd_fused_supported(int B, int C, int H, int W) {
+  if (B <= 0 || C <= 0 || !b16_pow2(H) || !b16_pow2(W) || H < 2 || W < 2) return 0;
+  const int Cb = bf16_cblocks(C);
+  if ((long long)B * Cb * H * W * 16 >= 0xfffffe00LL) return 0;
+  B16Plan p;
+  return b16_plan(B, Cb, H * W, &p) ? 1 : 0;
+}
+
+extern "C" size_t sivae_bf16_bn_bwd_fused_workspace_bytes(int B, int C, int H, int W) {
+  if (!sivae_bf16_bn_bwd_fused_supported(B, C, H, W)) return 0;
+  B16Plan p;
+  b16_plan(B, bf16_cblocks(C), H * W, &p);
+  return (size_t)bf16_cblocks(C) * p.spc * 16 * sizeof(double) + 16;
+}
+
+// sivae_bf16_bn_bwd (bf16_bn.hip) as one launch; same arguments + `state` (the zero-initialised-once barrier state of
+// sivae_bn_bwd_fused: sivae_bn_bwd_fused_state_uints() unsigned ints, one buffer per stream).  The persistent form needs
+// its whole grid (2 blocks per CU) resident.
+extern "C" int sivae_bf16_bn_bwd_fused(const void* dy, int dy_pooled, const void* y, const unsigned char* sign_mask,
+                                       const void* x, const float* mean, const float* invstd, const float* gamma,
+                                       const float* beta, float slope, void* dx, void* dz, int dz_sum, float* dgamma,
+                                       float* dbeta, int B, int C, int H, int W, unsigned int* state, void* workspace,
+                                       size_t workspace_bytes, hipStream_t stream) {
+  if (!dy || !x || !mean || !invstd || !gamma || !dx || !workspace || !state) return SIVAE_ERR_NULL;
+  if (!y && !sign_mask && !beta) return SIVAE_ERR_NULL;
+  if (dz_sum && !dz) return SIVAE_ERR_NULL;
+  if (dy_pooled && dz_sum) return SIVAE_ERR_MODE;
+  if (!sivae_bf16_bn_bwd_fused_supported(B, C, H, W)) return SIVAE_ERR_SHAPE;
+  if (workspace_bytes < sivae_bf16_bn_bwd_fused_workspace_bytes(B, C, H, W)) return SIVAE_ERR_WORKSPACE;
+  const int Cb = bf16_cblocks(C);
+  B16Plan p;
+  b16_plan(B, Cb, H * W, &p);
+  Bf16BnFusedArgs a;
+  a.dy = dy;
+  a.y = y;
+  a.x = x;
+  a.mask = sign_mask;
+  a.mean = mean;
+  a.invstd = invstd;
+  a.gamma = gamma;
+  a.beta = beta;
+  a.dx = dx;
+  a.dz = dz;
+  a.dgamma = dgamma;
+  a.dbeta = dbeta;
+  a.part = (double*)workspace;
+  a.bar = state;
+  a.inv_n = 1.0f / ((float)B * H * W);
+  a.slope = slope;
+  a.C = C;
+  a.Cb = Cb;
+  a.H = H;
+  a.W = W;
+  a.B = B;
+  a.l2_qpp = ilog2_exact(H * W / 4);
+  a.l2_qw = ilog2_exact(W / 2);
+  a.spc = p.spc;
+  a.cpg = p.cpg;
+  a.ngroups = p.ngroups;
+  a.nx = (!p.local && p.nb_sub % 8 == 0) ? 8 : 1;
+  a.nsub = p.nsub;
+  a.local = p.local;
+  a.dzmode = !dz ? 0 : (dz_sum ? 2 : 1);
+  const int act = sign_mask ? 3 : (y ? 1 : 2);
+  const dim3 grid((unsigned)(p.local ? Cb : p.nsub * p.nb_sub)), block(256);
+#define B16_LAUNCH(A, P, N) hipLaunchKernelGGL((bf16_bn_bwd_fused_kernel<A, P, N>), grid, block, 0, stream, a)
+#define B16_NU(A, P)                       \
+  {                                        \
+    if (p.nu == 4) B16_LAUNCH(A, P, 4);    \
+    else if (p.nu == 2) B16_LAUNCH(A, P, 2); \
+    else B16_LAUNCH(A, P, 1);              \
+  }
+#define B16_ACT(A)                               \
+  {                                              \
+    if (dy_pooled) B16_NU(A, true) else B16_NU(A, false) \
+  }
+  if (act == 3) B16_ACT(3) else if (act == 1) B16_ACT(1) else B16_ACT(2)
+#undef B16_ACT
+#undef B16_NU
+#undef B16_LAUNCH
+  return sivae_launch_status();
+}

@@ -6,6 +6,8 @@ vector, channel count padded to a multiple of 16 with zeros — bf16_common.h). 
 gradients, weights and weight gradients are float32.  Like `ops`, everything launches on torch's current stream of the
 tensor's device and there is no CPU path.
 """
+import os
+
 import torch
 
 from . import lib as _lib
@@ -207,6 +209,15 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, beta, C, slope=LRELU_SLOPE, dy_pooled=
     elif want_dz:
         dz = torch.empty_like(x)
     dgamma, dbeta = ops._pg(pg_out, C, x.device, want_param_grads)
+    L = _lib.load()
+    if (ops.BN_FUSED and ops.SYNC_BN is None and os.environ.get("SIVAE_DP_SAME_DEVICE", "0") != "1"
+            and L.sivae_bf16_bn_bwd_fused_supported(B, C, H, W) == 1):
+        # one launch, dy and x read once (bf16_bn_fused.hip)
+        ws = ops.workspace(L.sivae_bf16_bn_bwd_fused_workspace_bytes(B, C, H, W), x.device)
+        _lib.call("sivae_bf16_bn_bwd_fused", _p(dy), int(bool(dy_pooled)), _p(y), _p(mask), _p(x), _p(mean), _p(invstd),
+                  _p(gamma), _p(beta), float(slope), _p(dx), _p(dz), int(bool(dz_sum)), _p(dgamma), _p(dbeta), B, C, H, W,
+                  _p(ops.bn_fused_state(x.device)), _p(ws), ws.numel(), _s(x))
+        return dx, dz, dgamma, dbeta
     _lib.call("sivae_bf16_bn_bwd", _p(dy), int(bool(dy_pooled)), _p(y), _p(mask), _p(x), _p(mean), _p(invstd), _p(gamma),
               _p(beta), float(slope), _p(dx), _p(dz), int(bool(dz_sum)), _p(dgamma), _p(dbeta), B, C, H, W, _p(ws),
               ws.numel(), _s(x))

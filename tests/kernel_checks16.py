@@ -305,6 +305,51 @@ def check_bn(shape, res_mode, pool):
     return res
 
 
+def check_bn_fused16():
+    """the one-pass BatchNorm backward of the bf16 mode (bf16_bn_fused.hip) against the three-launch form on the same
+    inputs: barrier-free form (plane sets of one block), persistent half-grids, several groups, the one-grid form; every
+    sign source, pooled dy, dz at full resolution and as block sums.  The partial sums are fp32 in both forms but folded
+    in different orders: dgamma / dbeta to fp32 rounding of long sums, dx / dz to one bf16 rounding."""
+    from sivae_hip import ops, ops16
+    res = []
+    L = ops._lib.load()
+    for (B, C, H, W) in [(4, 64, 16, 16), (8, 520, 4, 4), (16, 64, 64, 64), (6, 300, 32, 32), (64, 16, 128, 128)]:
+        tag = "bn16_fused(%d,%d,%d,%d)" % (B, C, H, W)
+        assert L.sivae_bf16_bn_bwd_fused_supported(B, C, H, W) == 1, tag
+        x = _r16(_rand(B, C, H, W, seed=1))
+        r = _r16(_rand(B, C, H, W, seed=2))
+        mean, invstd, gamma, beta = _bn_params(C, x)
+        dev = [t.float().to(DEV) for t in (mean, invstd, gamma, beta)]
+        xb, rb = to_blocked(x).to(DEV), to_blocked(r).to(DEV)
+        y, _, mask = ops16.bn_apply_act(xb, rb, *dev, C, want_full=True, want_mask=True)
+        dy = to_blocked(_r16(_rand(B, C, H, W, seed=3))).to(DEV)
+        dyh = to_blocked(_r16(_rand(B, C, H // 2, W // 2, seed=4))).to(DEV)
+        cases = [("mask", lambda: ops16.bn_bwd(dy, mask, xb, *dev, C, want_dz=True)),
+                 ("mask dzsum", lambda: ops16.bn_bwd(dy, mask, xb, *dev, C, want_dz=True, dz_sum=True)),
+                 ("mask pooled", lambda: ops16.bn_bwd(dyh, mask, xb, *dev, C, dy_pooled=True, want_dz=True)),
+                 ("output", lambda: ops16.bn_bwd(dy, y, xb, *dev, C, want_dz=True)),
+                 ("recomputed", lambda: ops16.bn_bwd(dy, None, xb, *dev, C)),
+                 ("recomputed pooled", lambda: ops16.bn_bwd(dyh, None, xb, *dev, C, dy_pooled=True))]
+        for name, fn in cases:
+            outs = []
+            for fused in (False, True):
+                ops.BN_FUSED = fused
+                try:
+                    outs.append(fn())
+                finally:
+                    ops.BN_FUSED = True
+            a, b = outs
+            res.append(("%s %s dx" % (tag, name), _err(b[0].float(), a[0].float()), 1e-2))
+            if a[1] is not None:
+                res.append(("%s %s dz" % (tag, name), _err(b[1].float(), a[1].float()), 1e-2))
+            res.append(("%s %s dgamma" % (tag, name), _err(b[2], a[2]), 2e-4))
+            res.append(("%s %s dbeta" % (tag, name), _err(b[3], a[3]), 2e-4))
+            # most elements agree bit for bit (the coefficients differ in their last bits only)
+            same = float((b[0].float() == a[0].float()).float().mean())
+            res.append(("%s %s dx mostly identical" % (tag, name), 1.0 - same, 0.02))
+    return res
+
+
 def check_eltwise16():
     from sivae_hip import ops16
     res = []
@@ -424,6 +469,7 @@ def all_checks():
     for s in BN16_SHAPES:
         for rm in (0, 1, 2):
             checks.append(("bn16%s res%d" % (s, rm), lambda s=s, rm=rm: check_bn(s, rm, pool=rm != 2)))
+    checks.append(("bn16_fused", check_bn_fused16))
     checks.append(("eltwise16", check_eltwise16))
     checks.append(("splitk16", check_splitk16))
     return checks
