@@ -102,6 +102,10 @@ def repack(params, owner):
     key = tuple((f, obj.w.data_ptr(), buf.data_ptr()) for f in range(5) for obj, buf in jobs[f])
     plan = owner.__dict__.get("_sivae_pack_plan")
     if plan is None or plan["key"] != key:
+        if torch.cuda.is_current_stream_capturing():
+            # (building the job tables uploads them — not capturable; the forms stay invalid and are rebuilt one by one on
+            # their next use, inside the capture, as before round 4)
+            return
         jb = L.sivae_pack_job_bytes()
         dev = entries[0][0].device
         launches = []
