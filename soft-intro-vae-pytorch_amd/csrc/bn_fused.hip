@@ -19,6 +19,7 @@
 // Reference op: the backward of nn.BatchNorm2d + nn.LeakyReLU(0.2) (+ torch.add) in ResidualBlock / the encoder stem,
 // soft_intro_vae/train_soft_intro_vae.py:57-63,71-74,90-91.
 #include "bn_fused_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -308,8 +309,14 @@ static bool bf_plan(int Bs, int VC, int HW, int max_nq, BfPlan* out) {
     const int nb_sub = sivae_num_cus() * (nsub == 2 ? 1 : 2);
     double best = 0.0;
     bool found = false;
+    static int force_nq = -1;  // SIVAE_BN_FUSED_NQ=<10|8|4>: pin the quads per thread of the persistent form (A/B)
+    if (force_nq < 0) {
+      const char* e = getenv("SIVAE_BN_FUSED_NQ");
+      force_nq = e ? atoi(e) : 0;
+    }
     for (int NQ : {10, 8, 4}) {
       if (NQ > max_nq) continue;
+      if (force_nq > 0 && NQ != force_nq && NQ <= max_nq && force_nq <= max_nq) continue;
       const long long slabq = 256LL * NQ;
       const long long spc = (nq + slabq - 1) / slabq;
       if (spc > nb_sub) continue;
