@@ -116,23 +116,19 @@ _sha = None
 
 
 def sha256():
-    """sha256 of the loaded library file: stamped into PMC summaries (tools/pmc_*.py --lib-sha) and compared by bench.py so
-    that counter figures taken with another build are marked stale"""
+    """sha256 over the kernel SOURCES the library is built from (csrc/*.hip, *.h, build.sh, in name order) — what a PMC
+    summary is stamped with (tools/profile.sh -> tools/pmc_*.py --lib-sha) and what bench.py compares against, so that
+    counter figures taken with other kernels are marked stale.  (The sources, not the .so: a rebuild of the same sources
+    on another machine need not be byte-identical.)"""
     global _sha
     if _sha is None:
         import hashlib
         h = hashlib.sha256()
-        with open(LIB_PATH, "rb") as f:
-            for blk in iter(lambda: f.read(1 << 20), b""):
-                h.update(blk)
+        src = os.path.dirname(BUILD_SCRIPT)
+        for name in sorted(os.listdir(src)):
+            if name.endswith((".hip", ".h", ".sh")):
+                h.update(name.encode())
+                with open(os.path.join(src, name), "rb") as f:
+                    h.update(f.read())
         _sha = h.hexdigest()
     return _sha
-
-
-def call(name, *args):
-    """Call an int-returning entry point and raise SivaeError on a non-zero status."""
-    fn = getattr(load(), name)
-    rc = fn(*args)
-    if rc != 0:
-        raise SivaeError(name, rc)
-    return rc

@@ -15,9 +15,9 @@ cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
 tag="$1"; shift
 O="gpurun_out/$tag"; mkdir -p "$O"
-LIB=soft-intro-vae-pytorch_amd/sivae_hip/libsivae_hip.so
-sha=$(sha256sum $LIB | cut -c1-16)
-echo "lib sha256 $sha" | tee "$O/lib.txt"
+# provenance stamp of every PMC summary: sha256 over the kernel sources (sivae_hip.lib.sha256)
+sha=$(python -c "import sys; sys.path.insert(0, 'soft-intro-vae-pytorch_amd'); from sivae_hip import lib; print(lib.sha256()[:16])")
+echo "csrc sha256 $sha" | tee "$O/lib.txt"
 line() { python - "$1" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
