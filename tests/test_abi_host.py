@@ -293,3 +293,68 @@ def test_philox_offsets_and_multistep_lr():
     assert np.allclose(lrs, [2e-4, 2e-5, 2e-5, 2e-6, 2e-6])
     a, b = PhiloxStream(5, 0), PhiloxStream(5, 1)
     assert a.seed != b.seed and a.offset == 0
+
+
+def test_round4_entry_points_validate_arguments():
+    """the one-pass BatchNorm backward (fp32 + bf16), the two-stage statistics finalize and the batched weight packing:
+    plan / support queries and host-side validation (every call returns before any kernel launch)"""
+    L = lib.load()
+    null = None
+    one = ctypes.c_void_p(16)
+    # one-pass BatchNorm backward: power-of-two maps, plane sets within 32-bit byte offsets, <= 8192 channels
+    assert [L.sivae_bn_bwd_fused_supported(*a) for a in ((128, 64, 256, 256, 128), (256, 64, 256, 256, 128), (8, 512, 4, 4, 8),
+                                                        (2, 8, 28, 28, 2), (4, 16, 8, 12, 4), (4, 9000, 8, 8, 4),
+                                                        (6, 16, 8, 8, 4), (2, 16, 2, 4, 2))] == [1, 1, 1, 0, 0, 0, 0, 1]
+    assert L.sivae_bn_bwd_fused_supported(512, 64, 256, 256, 512) == 0  # (a plane set's window must stay below 4 GB)
+    assert L.sivae_bn_bwd_fused_state_uints() >= 2 * 17 * 32 + 8192
+    assert L.sivae_bn_bwd_fused_workspace_bytes(8, 512, 4, 4, 8) == (512 * 1 * 2 + 512 * 2) * 8   # one slab per channel
+    assert L.sivae_bn_bwd_fused_workspace_bytes(2, 8, 28, 28, 2) == 0
+    args = (one, null, null, one, one, one, one, one)
+    assert L.sivae_bn_bwd_fused(*args, 2, 0.2, one, null, null, null, 8, 16, 8, 8, 0, 0, 8, null, one, 1 << 20, null) == -1  # no state
+    assert L.sivae_bn_bwd_fused(*args, 2, 0.2, one, null, null, null, 8, 16, 8, 12, 0, 0, 8, one, one, 1 << 20, null) == -2
+    assert L.sivae_bn_bwd_fused(*args, 2, 0.2, one, null, null, null, 8, 16, 8, 8, 0, 0, 8, one, one, 8, null) == -4
+    assert L.sivae_bn_bwd_fused(*args, 7, 0.2, one, null, null, null, 8, 16, 8, 8, 0, 0, 8, one, one, 1 << 20, null) == -6
+    assert L.sivae_bn_bwd_fused(*args, 3, 0.2, one, null, null, null, 8, 16, 8, 8, 0, 0, 8, one, one, 1 << 20, null) == -1  # no mask
+    assert L.sivae_bn_bwd_fused(*args, 1, 0.2, one, one, null, null, 8, 16, 8, 8, 1, 1, 8, one, one, 1 << 20, null) == -1  # act 1: no y
+    assert L.sivae_bn_bwd_fused(one, one, null, one, one, one, one, one, 1, 0.2, one, one, null, null, 8, 16, 8, 8, 1, 1, 8,
+                                one, one, 1 << 20, null) == -6  # pooled dy and block-summed dz do not combine
+    assert L.sivae_bn_bwd_fused(one, null, null, one, one, one, one, one, 2, 0.2, ctypes.c_void_p(20), null, null, null, 8, 16,
+                                8, 8, 0, 0, 8, one, one, 1 << 20, null) == -2  # 16-byte aligned tensors
+    # bf16 form
+    assert [L.sivae_bf16_bn_bwd_fused_supported(*a) for a in ((128, 64, 128, 128), (8, 512, 4, 4), (2, 24, 8, 12),
+                                                             (128, 64, 256, 256))] == [1, 1, 0, 0]
+    assert L.sivae_bf16_bn_bwd_fused_workspace_bytes(8, 512, 4, 4) == 64 * 1 * 16 * 8 + 16
+    assert L.sivae_bf16_bn_bwd_fused(one, 0, null, null, one, one, one, one, one, 0.2, one, null, 0, null, null, 8, 16, 8, 8,
+                                     null, one, 1 << 20, null) == -1
+    assert L.sivae_bf16_bn_bwd_fused(one, 0, null, null, one, one, one, one, null, 0.2, one, null, 0, null, null, 8, 16, 8, 8,
+                                     one, one, 1 << 20, null) == -1  # no sign source at all
+    assert L.sivae_bf16_bn_bwd_fused(one, 0, null, null, one, one, one, one, one, 0.2, one, null, 0, null, null, 8, 16, 8, 12,
+                                     one, one, 1 << 20, null) == -2
+    assert L.sivae_bf16_bn_bwd_fused(one, 0, null, null, one, one, one, one, one, 0.2, one, null, 0, null, null, 8, 16, 8, 8,
+                                     one, one, 8, null) == -4
+    # two-stage statistics finalize: a workspace only from 2048 partial rows per pass on
+    assert L.sivae_bn_stats_from_conv_workspace_bytes(1024, 1, 64) == 0
+    assert L.sivae_bn_stats_from_conv_workspace_bytes(4096, 1, 64) == 1 * 64 * 32 * 2 * 8
+    assert L.sivae_bn_stats_from_conv_workspace_bytes(2 * 3000, 2, 40) == 2 * 40 * 24 * 2 * 8
+    assert L.sivae_bn_stats_from_conv_workspace_bytes(4097, 2, 64) == 0  # (rows must split evenly over the passes)
+    assert L.sivae_bn_stats_from_conv_ws(one, 4096, 1, 0, 4, 64, 64, 1e-5, 0.1, null, null, null, one, one, null, 0, null) == -4
+    assert L.sivae_bn_stats_from_conv_ws(null, 4096, 1, 0, 4, 64, 64, 1e-5, 0.1, null, null, null, one, one, one, 1 << 20,
+                                         null) == -1
+    assert L.sivae_bn_stats_from_conv_ws(one, 4096, 1, 0, 4, 64, 64, 1e-5, 0.1, one, null, null, one, one, one, 1 << 20,
+                                         null) == -1  # running mean without running var
+    # batched weight packing: the job table is filled on the host
+    jb = L.sivae_pack_job_bytes()
+    assert jb >= 64 and jb % 8 == 0
+    host = ctypes.create_string_buffer(jb * 4)
+    nb = L.sivae_pack_job_fill(host, 0, 2, one, one, 512, 512, 3, 0, 0)       # F(4x4,3x3): 512 x 512 weight pairs
+    assert nb == 512 * 512 // 512
+    nb2 = L.sivae_pack_job_fill(host, 1, 0, one, one, 64, 3, 5, 1, nb)        # direct 5x5, data-gradient mode
+    assert 1 <= nb2 <= 1024
+    assert L.sivae_pack_job_fill(host, 2, 1, one, one, 64, 64, 3, 0, nb + nb2) >= 1
+    assert L.sivae_pack_job_fill(host, 3, 3, one, one, 64, 64, 5, 0, 0) == -3  # the Winograd forms are 3x3 only
+    assert L.sivae_pack_job_fill(host, 3, 9, one, one, 64, 64, 3, 0, 0) == -6
+    assert L.sivae_pack_job_fill(host, 3, 0, one, one, 64, 64, 4, 0, 0) == -3
+    assert L.sivae_pack_job_fill(null, 0, 0, one, one, 64, 64, 3, 0, 0) == -1
+    assert L.sivae_pack_job_fill(host, 0, 0, one, one, 0, 64, 3, 0, 0) == -2
+    assert L.sivae_pack_batch(0, null, one, 4, null) == -1 and L.sivae_pack_batch(0, one, one, 0, null) == -2
+    assert L.sivae_pack_batch(7, one, one, 4, null) == -6
