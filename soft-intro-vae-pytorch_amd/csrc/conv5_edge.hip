@@ -284,12 +284,35 @@ __global__ void __launch_bounds__(256, 2) conv5_edge_wgrad_kernel(Conv5WgradArgs
     const __amdgpu_buffer_rsrc_t brs = make_rsrc(pbig + (size_t)b * Cbig * HW, (unsigned long long)Cbig * HW * 4ull);
     const __amdgpu_buffer_rsrc_t srs = make_rsrc(psml + (size_t)b * Csml * HW, (unsigned long long)Csml * HW * 4ull);
     // ---- large-side slab: positions = ROWS_BIG*32 (256 or 128); SMALL_CO: x rows r0-2.., else dy rows r0..
-    {
+    if (SMALL_CO) {
+      // The 8 staged x rows of a tile (r0 - 2 .. r0 + 5) live in a ROW RING (image row R at slot (R + 2) & 7): the next
+      // tile of the block is the row group below, whose first four rows are this tile's last four — they stay where they
+      // are and only the four new rows are fetched (round 4: the slab was re-staged whole, i.e. x was read twice:
+      // 8.8 GB per launch against 4.4 of tensors, and the kernel is bound by these dword loads: 0.40 matrix-pipe busy).
+      const bool cont = tile > tile_begin && rg != 0;  // (previous tile of this block = the row group above: rg is fastest)
+      const int rr0 = cont ? 4 : 0, npos = cont ? 128 : 256, cpt = cont ? 32 : 64;
+      const int pos = tid % npos, cgrp = tid / npos;
+      const int rr = rr0 + (pos >> 5), cc = pos & 31;
+      const int r = r0 - 2 + rr, c = c0 + cc;
+      const int slot = (r0 + rr) & 7;
+      const unsigned off = (r >= 0 && r < H && c < W) ? (unsigned)(r * W + c) * 4u : SIVAE_OOB;
+      for (int q0 = 0; q0 < cpt; q0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          int ch = cb0 + cgrp * cpt + q0 + q;
+          ch = ch < Cbig ? ch : Cbig - 1;
+          v[q] = buf_load_f32(brs, off, (unsigned)ch * (unsigned)HW * 4u);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) big[(cgrp * cpt + q0 + q) * BLD + slot * 32 + cc] = v[q];
+      }
+    } else {
       constexpr int NPOSB = ROWS_BIG * 32;
       const int pos = tid % NPOSB, cgrp = tid / NPOSB;       // cgrp in [0, 256/NPOSB)
       constexpr int CPT = 64 / (256 / NPOSB);                // channels per thread: 64 or 32
       const int rr = pos >> 5, cc = pos & 31;
-      const int r = r0 + rr - (SMALL_CO ? 2 : 0), c = c0 + cc;
+      const int r = r0 + rr, c = c0 + cc;
       const unsigned off = (r >= 0 && r < H && c < W) ? (unsigned)(r * W + c) * 4u : SIVAE_OOB;
 #pragma unroll
       for (int q0 = 0; q0 < CPT; q0 += 16) {
@@ -324,7 +347,7 @@ __global__ void __launch_bounds__(256, 2) conv5_edge_wgrad_kernel(Conv5WgradArgs
           // A[(co,kw)][c'] = dY[co][r][c'-kw+2]  (small tile col = c' - c0 - kw + 4) ; B[c'][ci] = X[ci][r+kh-2][c']
           const float av = sml[sc * SPL + r * SLD + cq - skw + 4];
 #pragma unroll
-          for (int kh = 0; kh < 5; ++kh) acc[kh] = mfma16(av, big[big_row + (r + kh) * 32 + cq], acc[kh]);
+          for (int kh = 0; kh < 5; ++kh) acc[kh] = mfma16(av, big[big_row + ((r0 + r + kh) & 7) * 32 + cq], acc[kh]);  // (row ring)
         } else {
           // A[co][c] = dY[co][r][c] ; B[c][(ci,kw)] = X[ci][r+kh-2][c+kw-2]  (small tile col = c - c0 + kw)
           const float av = big[big_row + r * 32 + cq];

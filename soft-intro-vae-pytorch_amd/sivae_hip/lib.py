@@ -132,3 +132,12 @@ def sha256():
                     h.update(f.read())
         _sha = h.hexdigest()
     return _sha
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise SivaeError on a non-zero status."""
+    fn = getattr(load(), name)
+    rc = fn(*args)
+    if rc != 0:
+        raise SivaeError(name, rc)
+    return rc

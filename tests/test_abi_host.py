@@ -358,3 +358,13 @@ def test_round4_entry_points_validate_arguments():
     assert L.sivae_pack_job_fill(host, 0, 0, one, one, 0, 64, 3, 0, 0) == -2
     assert L.sivae_pack_batch(0, null, one, 4, null) == -1 and L.sivae_pack_batch(0, one, one, 0, null) == -2
     assert L.sivae_pack_batch(7, one, one, 4, null) == -6
+
+
+def test_lib_call_raises_on_error_codes():
+    """sivae_hip.lib.call (what every wrapper in ops.py goes through) turns a non-zero status into SivaeError naming the
+    entry point and the code; sha256() stamps the kernel sources"""
+    import pytest
+    with pytest.raises(lib.SivaeError) as ei:
+        lib.call("sivae_pack_batch", 7, ctypes.c_void_p(16), ctypes.c_void_p(16), 4, None)
+    assert ei.value.code == -6 and "sivae_pack_batch" in str(ei.value) and "SIVAE_ERR_MODE" in str(ei.value)
+    assert len(lib.sha256()) == 64 and lib.sha256() == lib.sha256()
