@@ -31,7 +31,14 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(Conv1sArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, kk = lane >> 5;
   const int HW = a.HW, Ci = a.Ci;
-  const int cog = blockIdx.x % a.n_co_groups;  // consecutive blocks: the co groups of the same pixel range (x shared in L2)
+  // The co groups of one pixel range read the same x: keep them on ONE XCD so that the second group finds x in that L2
+  // (blocks go round-robin to the 8 XCDs by linear index: consecutive blockIdx.x are on DIFFERENT XCDs — round 4: the
+  // sibling groups each fetched x from HBM, 1.85 GB per launch against ~1.4 of tensors).  lb enumerates the blocks of an
+  // XCD consecutively when the grid is a multiple of 8 * groups.
+  const int nblk = (int)gridDim.x;
+  const bool remap = a.n_co_groups > 1 && (nblk % (8 * a.n_co_groups)) == 0;
+  const int lb = remap ? ((int)blockIdx.x & 7) * (nblk >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+  const int cog = lb % a.n_co_groups;
   const int co0 = cog * 64;
 
   for (int i = tid; i < Ci * 64; i += 256) {
@@ -46,7 +53,7 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(Conv1sArgs a) {
   const float* wl = wsm + kk * 64 + l31;
 
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-  for (int it = blockIdx.x / a.n_co_groups; it < a.n_pt_items; it += gridDim.x / a.n_co_groups) {
+  for (int it = lb / a.n_co_groups; it < a.n_pt_items; it += nblk / a.n_co_groups) {
     const int t = it * 4 + wave;  // this wave's pixel tile
     const int b = t / a.n_px_tiles, pt = t - b * a.n_px_tiles;
     const bool live = b < a.B;
