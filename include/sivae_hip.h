@@ -109,7 +109,9 @@ int sivae_conv2d_wino_fwd_splitk(const float* x, const float* up, float* y, cons
  * tensor: four output-parity phases, each a 2x2 conv run as Winograd F(2x2,2x2) — 36 multiplies per 4x4 output pixels
  * instead of 64 (sivae_conv2d_wino_fwd with upsample) or 144 (direct).  x_half is [B][Ci][H/2][W/2], y is
  * [B][Co][H][W]; same BatchNorm+LeakyReLU prologue and BatchNorm-partials epilogue (stats_partial has
- * sivae_conv2d_wino_up_num_px_tiles(B, H, W) rows).  Forward only (the data gradient keeps the F(2x2,3x3) kernel). */
+ * sivae_conv2d_wino_up_num_px_tiles(B, H, W) rows).  Forward only (the data gradient keeps the F(2x2,3x3) kernel).
+ * Supported maps: H >= 16 even, W >= 32 with W % 4 == 0 (the kernel writes four output pixels per 16-byte store; y must be
+ * 16-byte aligned). */
 size_t sivae_pack_wino_up_weight_bytes(int Co, int Ci);
 int sivae_pack_wino_up_weight(const float* w /*[Co][Ci][3][3]*/, float* up, int Co, int Ci, sivae_stream_t stream);
 int sivae_conv2d_wino_up_supported(int H, int W);

@@ -74,16 +74,24 @@ struct Wino4Args {
 #define W4_PXH 16
 #define W4_PXW 32
 
-__device__ __forceinline__ void buf_store_f32x4(__amdgpu_buffer_rsrc_t r, float4 v, unsigned voff) {
+// cache policy of the output stores (auxiliary bits of the buffer instruction: 2 = nt)
+#ifndef W4_STORE_AUX
+#define W4_STORE_AUX 0
+#endif
+// out-of-range marker of 16-byte stores: beyond every window (Co*H*W*4 < 2^31 is checked at launch), and neither the
+// store's own 16 bytes nor a row offset added on top wraps around 2^32 (a dwordx4 store at 0xFFFFFFFF drops only its first
+// dword: the other three wrap into the window)
+#define W4_OOB16 0x80000000u
+__device__ __forceinline__ void buf_store_f32x4(__amdgpu_buffer_rsrc_t r, float4 v, unsigned voff, unsigned soff = 0u) {
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
   f32x4 f = {v.x, v.y, v.z, v.w};
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f), r, (int)voff, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f), r, (int)voff, (int)soff, W4_STORE_AUX);
 }
 
 #define W4_PRO_MAX 1024  // prologue table entries (segments x padded input channels)
 
-// Timing ablations (compile with -DW4_ABLATE=<bits>; results are WRONG with any bit set — tools/r3_w4_ablate.sh):
-//   1 no halo loads in the K loop, 2 no U refills, 8 no chunk barriers
+// Timing ablations (compile with -DW4_ABLATE=<bits>; results are WRONG with any bit set — tools/w4_timing.py):
+//   1 no halo loads in the K loop, 2 no U refills, 8 no chunk barriers, 16 no output stores
 #ifndef W4_ABLATE
 #define W4_ABLATE 0
 #endif
@@ -104,6 +112,21 @@ __device__ __forceinline__ void buf_store_f32x4(__amdgpu_buffer_rsrc_t r, float4
 // buffer chunk c's transform freed; across work items the chunk numbering simply continues (the first two chunks of the
 // NEXT item are requested / transformed during the last two chunks of the current one).  With the fused BatchNorm +
 // LeakyReLU prologue every thread rewrites the two groups it requested before the barrier publishes them.
+// Phase stamps of the first items of every block (tools/w4_timing.py; a -DW4_TIMING build only)
+#ifdef W4_TIMING
+__device__ long long w4_dbg[256 * 8 * 16];
+#define W4_STAMP(SLOT)                                                                       \
+  if (tid == 0 && it_n < 8) w4_dbg[((int)blockIdx.x * 8 + it_n) * 16 + (SLOT)] = ((SLOT) == 6 || (SLOT) == 7) ? clock64() : wall_clock64();
+extern "C" int sivae_debug_w4_read(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(w4_dbg), sizeof(long long) * 256 * 8 * 16);
+}
+#define W4_STAMPK(CH) \
+  if (tid == 0 && it_n < 8 && (CH) < 16) w4_dbg[((int)blockIdx.x * 8 + it_n) * 16 + 8 + ((CH) >> 1)] = wall_clock64();
+#else
+#define W4_STAMP(SLOT)
+#define W4_STAMPK(CH)
+#endif
+
 template <bool PRO>
 __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
   constexpr int CK = W4_CK, RS = W4_RS, PLANE = W4_PLANE, XBUF = W4_XBUF, VBUF = W4_VBUF;
@@ -419,7 +442,12 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
   W4_DMA1(2, 0, 1)
   unsigned xo_f = xo;  // offsets / segment the halo pieces awaiting their fix-up were requested with
   int pseg_f = pseg;
+#ifdef W4_TIMING
+  int it_n = 0;
+#endif
   for (;;) {
+    W4_STAMP(0)
+    W4_STAMP(6)
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -429,10 +457,17 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
     const int next = item + (int)gridDim.x;
     const bool has_next = next < n_items;
     if (pair05) {
-      for (int ch = 0; ch < nchunks; ch += 2) W4_PAIR(ch, true)
+      for (int ch = 0; ch < nchunks; ch += 2) {
+        W4_PAIR(ch, true)
+        W4_STAMPK(ch)
+      }
     } else {
-      for (int ch = 0; ch < nchunks; ch += 2) W4_PAIR(ch, false)
+      for (int ch = 0; ch < nchunks; ch += 2) {
+        W4_PAIR(ch, false)
+        W4_STAMPK(ch)
+      }
     }
+    W4_STAMP(1)
 
     // ---- output transform.  acc[i][r]: frequency (i, wj), tile = l31, channel = ws*32 + (r&3) + 8*(r>>2) + 4*hh.
     // Round a = output row a of every tile: Z[a][j] = sum_i A^T[a][i] M[i][j] in registers -> ex[j][s][r][lane] (48 KB:
@@ -453,19 +488,33 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
       // pair mode: tile columns 4-7 are image e_b + 1
       const int tx_ = a.two ? (lane_ & 3) : (lane_ & 7);
       const unsigned img_off = a.two ? (unsigned)((lane_ >> 2) & 1) * (unsigned)(a.Co * HW) * 4u : 0u;
+      // row transform Z = A^T M in place (acc[a][r] <- Z[a][wj] of channel slot r): the partial sums m1 +- m2, m3 +- m4
+      // are shared by the four output rows (10 VALU per slot instead of 14)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
+        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+        acc[0][r] = m0 + s12 + s34;
+        acc[1][r] = d12 + 2.f * d34;
+        acc[2][r] = s12 + 4.f * s34;
+        acc[3][r] = d12 + 8.f * d34 + m5;
+      }
+      // byte offset of output row 0 of this lane's tile for each of the wave's (s, r) pairs; the row of round a is added
+      // through the scalar offset of the store (not range-checked: the marker of a padded channel stays out of range)
+      unsigned off0[3];
+#pragma unroll
+      for (int qi = 0; qi < 3; ++qi) {
+        const int q = wave + 12 * qi;
+        const int chn = e_co0 + (q >> 4) * 32 + (q & 3) + 8 * ((q & 15) >> 2) + 4 * hh_;
+        off0[qi] = chn < a.Co ? (unsigned)((chn * H + e_r0 + 4 * ty_) * W + e_c0 + 4 * tx_) * 4u + img_off : W4_OOB16;
+      }
 #pragma unroll
       for (int ar = 0; ar < 4; ++ar) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
-          float z;
-          if (ar == 0) z = m0 + (m1 + m2) + (m3 + m4);
-          else if (ar == 1) z = (m1 - m2) + 2.f * (m3 - m4);
-          else if (ar == 2) z = (m1 + m2) + 4.f * (m3 + m4);
-          else z = (m1 - m2) + 8.f * (m3 - m4) + m5;
-          ex[((wj * 2 + ws) * 16 + r) * 64 + lane_] = z;
-        }
+        for (int r = 0; r < 16; ++r) ex[((wj * 2 + ws) * 16 + r) * 64 + lane_] = acc[ar][r];
         __syncthreads();
+        if (ar == 0) { W4_STAMP(2) }
+        const unsigned row_off = (unsigned)(ar * W) * 4u;
 #pragma unroll
         for (int qi = 0; qi < 3; ++qi) {
           const int q = wave + 12 * qi;
@@ -479,19 +528,19 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
             o.y = (z[1] - z[2]) + 2.f * (z[3] - z[4]);
             o.z = (z[1] + z[2]) + 4.f * (z[3] + z[4]);
             o.w = (z[1] - z[2]) + 8.f * (z[3] - z[4]) + z[5];
-            const int chn = e_co0 + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh_;
-            const unsigned off = chn < a.Co ? (unsigned)((chn * H + e_r0 + 4 * ty_ + ar) * W + e_c0 + 4 * tx_) * 4u + img_off : SIVAE_OOB;
             if (a.accumulate) {
-              const float4 old = buf_load_f32x4(yrsrc, off, 0u);
+              const float4 old = buf_load_f32x4(yrsrc, off0[qi], row_off);
               o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
             }
-            buf_store_f32x4(yrsrc, o, off);
+            if (!((W4_ABLATE & 16) && item >= 0)) buf_store_f32x4(yrsrc, o, off0[qi], row_off);
             ssum[qi] += (o.x + o.y) + (o.z + o.w);
             ssq[qi] += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
           }
         }
         __syncthreads();
+        if (ar == 0) { W4_STAMP(3) }
       }
+      W4_STAMP(4)
       if (a.stats != nullptr) {
 #pragma unroll
         for (int qi = 0; qi < 3; ++qi) {
@@ -509,6 +558,11 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
         }
       }
     }
+    W4_STAMP(5)
+    W4_STAMP(7)
+#ifdef W4_TIMING
+    ++it_n;
+#endif
     if (!has_next) break;
     item = next;
     ua_cur = ua_base;

@@ -57,6 +57,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_kernel(WinoUpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;  // [2][CK][PLANE]
   float4* pro4 = reinterpret_cast<float4*>(smem + 2 * XBUF);
+  float* ex = smem + 2 * XBUF + (PRO ? 4 * a.Ci_pad : 0);  // [4 waves][16 slots][2][64 lanes]: the epilogue's exchange
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -234,33 +235,36 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_kernel(WinoUpArgs a) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) WUP_LOAD_A(kk, kk)
     }
-    // ---- output transform, entirely in this wave's registers: acc[i*3+j][r] -> Y[2][2] of tile l31, channel
-    // e_co0 + (r&3) + 8*(r>>2) + 4*hh; the phase's pixels are (2*(e_r0 + 2*ty + a) + pp, 2*(e_c0 + 2*tx + b) + pq)
+    // ---- output transform in this wave's registers: acc[i*3+j][r] -> Y[2][2] of tile l31, channel
+    // e_co0 + (r&3) + 8*(r>>2) + 4*hh; the phase's pixels are (2*(e_r0 + 2*ty + a) + pp, 2*(e_c0 + 2*tx + b) + pq).
+    // A phase holds every OTHER pixel of its rows: stored from here they would be 4-byte writes at an 8-byte stride —
+    // partial lines that L2 completes by FETCHING them (round 4, FETCH_SIZE: this kernel read ~1.3 bytes of y per byte it
+    // wrote).  So the two column phases of a row phase swap halves through LDS: wave (pp, 0) stores row a = 0 of every
+    // tile, wave (pp, 1) row a = 1, each as ONE 16-byte store of four consecutive pixels per lane and channel slot.
     {
       const __amdgpu_buffer_rsrc_t yrsrc =
           make_rsrc(a.y + (size_t)e_b * a.Co * H * W, (unsigned long long)a.Co * H * W * 4ull);
       const int li = e_r0 + 2 * ty, lj = e_c0 + 2 * tx;  // low-resolution coordinates of the tile
       const bool ok00 = li < Hs && lj < Ws, ok01 = li < Hs && lj + 1 < Ws;
       const bool ok10 = li + 1 < Hs && lj < Ws, ok11 = li + 1 < Hs && lj + 1 < Ws;
-      const unsigned base = (unsigned)((2 * li + pp) * W + 2 * lj + pq) * 4u;
+      float* exw = ex + wave * (16 * 2 * 64) + lane;
+      const float* exr = ex + (wave ^ 1) * (16 * 2 * 64) + lane;
+      float keep[16][2];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int chn = e_co0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
         const float s00 = acc[0][r] + acc[3][r], s01 = acc[1][r] + acc[4][r], s02 = acc[2][r] + acc[5][r];
         const float s10 = acc[3][r] - acc[6][r], s11 = acc[4][r] - acc[7][r], s12 = acc[5][r] - acc[8][r];
         const float y00 = s00 + s01, y01 = s01 - s02, y10 = s10 + s11, y11 = s11 - s12;
-        const bool cok = chn < a.Co;
-        const unsigned cb = base + (unsigned)chn * (unsigned)(H * W) * 4u;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y00), yrsrc,
-                                              (int)((cok && ok00) ? cb : SIVAE_OOB), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y01), yrsrc,
-                                              (int)((cok && ok01) ? cb + 8u : SIVAE_OOB), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y10), yrsrc,
-                                              (int)((cok && ok10) ? cb + (unsigned)(2 * W) * 4u : SIVAE_OOB), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y11), yrsrc,
-                                              (int)((cok && ok11) ? cb + (unsigned)(2 * W) * 4u + 8u : SIVAE_OOB), 0,
-                                              0);
+        if (pq == 0) {  // (wave-uniform)
+          keep[r][0] = y00; keep[r][1] = y01;
+          exw[(r * 2 + 0) * 64] = y10; exw[(r * 2 + 1) * 64] = y11;
+        } else {
+          keep[r][0] = y10; keep[r][1] = y11;
+          exw[(r * 2 + 0) * 64] = y00; exw[(r * 2 + 1) * 64] = y01;
+        }
         if (a.stats != nullptr) {
+          const bool cok = chn < a.Co;
           float s = (ok00 ? y00 : 0.f) + (ok01 ? y01 : 0.f) + (ok10 ? y10 : 0.f) + (ok11 ? y11 : 0.f);
           float q = (ok00 ? y00 * y00 : 0.f) + (ok01 ? y01 * y01 : 0.f) + (ok10 ? y10 * y10 : 0.f) +
                     (ok11 ? y11 * y11 : 0.f);
@@ -271,6 +275,24 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_kernel(WinoUpArgs a) {
             dst[0] = s;
             dst[1] = q;
           }
+        }
+      }
+      // (LDS-only barrier: __syncthreads() would also wait out the next item's operand loads requested above)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // row a = pq of the tile: output row 2*(li + pq) + pp, columns 2*lj .. 2*lj + 3 = (b, q) = (0,0) (0,1) (1,0) (1,1)
+      const bool rok = pq == 0 ? li < Hs : li + 1 < Hs;
+      const unsigned base = (unsigned)((2 * (li + pq) + pp) * W + 2 * lj) * 4u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int chn = e_co0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const float o0 = exr[(r * 2 + 0) * 64], o1 = exr[(r * 2 + 1) * 64];  // the other column phase, b = 0, 1
+        const unsigned cb = base + (unsigned)chn * (unsigned)(H * W) * 4u;
+        const float c0_ = pq == 0 ? keep[r][0] : o0, c1_ = pq == 0 ? o0 : keep[r][0];
+        const float c2_ = pq == 0 ? keep[r][1] : o1, c3_ = pq == 0 ? o1 : keep[r][1];
+        if (rok && lj < Ws && chn < a.Co) {  // (W % 4 == 0: a tile's two low-resolution columns are inside together)
+          typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+          const f32x4 f = {c0_, c1_, c2_, c3_};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f), yrsrc, (int)cb, 0, 0);
         }
       }
     }
@@ -375,7 +397,7 @@ extern "C" int sivae_pack_wino_up_weight(const float* w, float* up, int Co, int 
 // H, W = OUTPUT size.  Low-resolution width >= 16 (tile blocks of 8x16 or 4x32 low-res pixels), even low-res size
 // not required; smaller maps use sivae_conv2d_wino_fwd with its upsample flag.
 extern "C" int sivae_conv2d_wino_up_supported(int H, int W) {
-  return (H >= 16 && W >= 32 && !(H & 1) && !(W & 1)) ? 1 : 0;
+  return (H >= 16 && W >= 32 && !(H & 1) && !(W & 3)) ? 1 : 0;  // (W % 4: 16-byte stores of four output pixels)
 }
 
 static inline bool wup_wide(int W) { return (W >> 1) >= 32; }
@@ -408,7 +430,8 @@ static int wup_launch(WinoUpArgs& a, hipStream_t stream) {
   a.n_co_tiles = cdiv(a.Co, WUP_TCO);
   const long long nblk = (long long)a.B * a.nbh * a.nbw * a.n_co_tiles;
   if (nblk > 0x7fffffffLL) return SIVAE_ERR_RANGE;
-  const size_t lds = (size_t)2 * WUP_CK * PLANE * sizeof(float) + (a.pro_mean ? (size_t)a.Ci_pad * 16 : 0);
+  const size_t lds = (size_t)2 * WUP_CK * PLANE * sizeof(float) + (a.pro_mean ? (size_t)a.Ci_pad * 16 : 0) +
+                     (size_t)4 * 16 * 2 * 64 * sizeof(float);
   auto kern = a.pro_mean ? conv_wino_up_kernel<TTH_L2, TTW_L2, true> : conv_wino_up_kernel<TTH_L2, TTW_L2, false>;
   {
     static size_t lds_hwm[2] = {0, 0};
@@ -432,6 +455,7 @@ extern "C" int sivae_conv2d_wino_up_fwd(const float* x_half, const float* up, fl
   if (pro_mean && !(pro_slope >= 0.f && pro_slope <= 1.f)) return SIVAE_ERR_MODE;
   const long long hw = (long long)H * W;
   if ((long long)Ci * (hw / 4) * 4 >= 0x7fffffffLL || (long long)Co * hw * 4 >= 0x7fffffffLL) return SIVAE_ERR_RANGE;
+  if (((uintptr_t)y & 15u) != 0) return SIVAE_ERR_SHAPE;  // 16-byte row stores
   WinoUpArgs a;
   a.x = x_half;
   a.up = up;
