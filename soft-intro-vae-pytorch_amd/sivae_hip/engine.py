@@ -278,7 +278,10 @@ class SoftIntroEngine:
                 self._zn_src = (z.data_ptr(), z._version, noise.data_ptr(), noise._version)
                 y2 = m.decoder(self._zn, cache=self._cache_pair, nseg=2, seg_rev=True)
             fake = y2[B:]
-            rec = m.decoder(z, cache=SF.cache_segment(self._cache_pair, 0, 2), replay_update=False, check_input=False)
+            view = SF.cache_segment(self._cache_pair, 0, 2)
+            if view is None:
+                raise RuntimeError("sivae_hip: the paired decoder pass did not fill its replay cache")
+            rec = m.decoder(z, cache=view, replay_update=False, check_input=False)
         else:
             fake = m.decoder(noise, cache=self._cache_fake)
             real_mu, real_logvar = m.encode(real)

@@ -312,6 +312,10 @@ class ResBlockFn(torch.autograd.Function):
             ctx.training = st1.training and st2.training
             ctx.save_for_backward(x, a, h, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2, b2)
             return y.view_as(y)
+        if not replay_update:
+            # a `cache_segment` view that cannot be replayed (sub-cache not filled, weights changed since the fill) would be
+            # recomputed HERE with a third running-statistics update the reference never makes — fail instead
+            raise RuntimeError("sivae_hip: replay_update=False needs a filled, current replay cache for this block")
         idt = x
         if w_exp is not None:
             # a 1x1 conv commutes with nearest upsampling pixel for pixel (bit-exactly): with x_up it runs on the

@@ -743,6 +743,13 @@ def bn_stats_from_conv(partials, B, C, HW, running_mean=None, running_var=None, 
     _require(partials, running_mean, running_var, num_batches_tracked)
     mean = torch.empty(nseg * C, dtype=torch.float32, device=partials.device)
     invstd = torch.empty(nseg * C, dtype=torch.float32, device=partials.device)
+    if nseg > 1:
+        # a partial row covers a pixel tile of ONE image, or — image pairs on 16 x 16 maps, several images per tile on the
+        # 8 x 8 / 4 x 4 maps — a whole number of images: it must never straddle two segments (their statistics would mix)
+        rows = partials.shape[0]
+        per_row = B // rows if rows < B else 1
+        if rows % nseg or (rows < B and B % rows) or (rows >= B and rows % B) or (B // nseg) % per_row:
+            raise ValueError("sivae_hip: %d statistics rows of %d images cannot be cut into %d segments" % (rows, B, nseg))
     if nseg > 1 and SYNC_BN is not None:
         raise RuntimeError("sivae_hip: segmented batches and synchronised BatchNorm do not combine")
     if SYNC_BN is None:
