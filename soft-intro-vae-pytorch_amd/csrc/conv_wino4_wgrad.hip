@@ -31,15 +31,16 @@
 //     stage's raw halo in place (zero padding restored through the table select).
 // Two LDS-only barriers per stage.  The three task roles (x, x pair (0,5), dY) and the task-less waves run separate copies
 // of the loop.  The sum over tiles is split across blocks ("slices") of whole stage triples; every slice writes its
-// partial dU, the slices are added in a fixed order (wide split-K reducer from 8 slices up) and a last kernel applies
-// G^T . G (no atomics, run-to-run reproducible).
+// partial — already row-transformed in registers, G^T dU: 18 values per (co, ci) instead of 36 —, the slices are added in a
+// fixed order (wide split-K reducer from 8 slices up) and a last kernel applies the column half . G (no atomics,
+// run-to-run reproducible).
 #include "common.h"
 #include <stdlib.h>
 
 struct Wino4WgArgs {
   const float* x;
   const float* dy;
-  float* ws;  // [n_slices][36][Co_pad][Ci_pad]
+  float* ws;  // [n_slices][3][6][Co_pad][Ci_pad]: row-transformed partials G^T dU
   const float* pro_mean;
   const float* pro_invstd;
   const float* pro_gamma;
@@ -458,61 +459,64 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  // ---- partial dU of this slice: acc[i][r] -> frequency (i, wj), co = co0 + wsb*32 + row(r, hh), ci = ci0 + l31
+  // ---- partial of this slice.  acc[i][r] = dU of frequency (i, wj), co = co0 + wsb*32 + row(r, hh), ci = ci0 + l31: a
+  // wave owns a whole frequency COLUMN, so the row half of G^T dU G — T[a][wj] = sum_i G[i][a] dU[i][wj], 6 -> 3 values —
+  // is done here in registers (linear: it commutes with the sum over slices); the partials and everything the reducers
+  // read are half the size ([n_slices][3][6][Co_pad][Ci_pad]).  The column half runs in wino4_wgrad_reduce_kernel.
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    float* base = a.ws + ((size_t)(slice * 36 + i * 6 + wj) * a.Co_pad + co0 + wsb * 32) * a.Ci_pad + ci0 + l31;
+  for (int r = 0; r < 16; ++r) {
+    const float u0 = acc[0][r], u1 = acc[1][r], u2 = acc[2][r], u3 = acc[3][r], u4 = acc[4][r], u5 = acc[5][r];
+    const float s12 = u1 + u2, d12 = u2 - u1, s34 = u3 + u4, d34 = u3 - u4;
+    acc[0][r] = 0.25f * u0 - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+    acc[1][r] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+    acc[2][r] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + u5;
+  }
+#pragma unroll
+  for (int ar = 0; ar < 3; ++ar) {
+    float* base = a.ws + ((size_t)(slice * 18 + ar * 6 + wj) * a.Co_pad + co0 + wsb * 32) * a.Ci_pad + ci0 + l31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-      base[(size_t)row * a.Ci_pad] = acc[i][r];
+      base[(size_t)row * a.Ci_pad] = acc[ar][r];
     }
   }
 }
 
-// dW[co][ci] = G^T (sum over slices dU[.][.][co][ci]) G.  Block = one co x 64 ci x 4 slice phases.
+// dW[co][ci] = (sum over slices T[.][.][co][ci]) G, T = G^T dU the row-transformed partials [3][6] of the kernel above.
+// Block = one co x 64 ci x 4 slice phases.
 __global__ void __launch_bounds__(256) wino4_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                                  int Co, int Ci, int Co_pad, int Ci_pad, int n_slices) {
-  __shared__ float red[3][36][64];
+  __shared__ float red[3][18][64];
   const int cil = threadIdx.x & 63, ph = threadIdx.x >> 6;
   const int n_cic = (Ci + 63) / 64;
   const int co = blockIdx.x / n_cic, ci = (blockIdx.x % n_cic) * 64 + cil;
-  float u[36];
+  float t[18];
 #pragma unroll
-  for (int f = 0; f < 36; ++f) u[f] = 0.f;
+  for (int f = 0; f < 18; ++f) t[f] = 0.f;
   if (ci < Ci) {
     for (int s = ph; s < n_slices; s += 4) {
-      const float* p = ws + ((size_t)(s * 36) * Co_pad + co) * Ci_pad + ci;
+      const float* p = ws + ((size_t)(s * 18) * Co_pad + co) * Ci_pad + ci;
 #pragma unroll
-      for (int f = 0; f < 36; ++f) u[f] += p[(size_t)f * Co_pad * Ci_pad];
+      for (int f = 0; f < 18; ++f) t[f] += p[(size_t)f * Co_pad * Ci_pad];
     }
   }
   if (ph > 0) {
 #pragma unroll
-    for (int f = 0; f < 36; ++f) red[ph - 1][f][cil] = u[f];
+    for (int f = 0; f < 18; ++f) red[ph - 1][f][cil] = t[f];
   }
   __syncthreads();
   if (ph == 0 && ci < Ci) {
 #pragma unroll
-    for (int f = 0; f < 36; ++f) u[f] = ((u[f] + red[0][f][cil]) + red[1][f][cil]) + red[2][f][cil];
-    // t[r][j] = sum_i G[i][r] u[i][j];  G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]
-    float t[3][6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const float u0 = u[0 * 6 + j], u1 = u[1 * 6 + j], u2 = u[2 * 6 + j], u3 = u[3 * 6 + j], u4 = u[4 * 6 + j],
-                  u5 = u[5 * 6 + j];
-      const float s12 = u1 + u2, d12 = u2 - u1, s34 = u3 + u4, d34 = u3 - u4;
-      t[0][j] = 0.25f * u0 - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
-      t[1][j] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
-      t[2][j] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + u5;
-    }
+    for (int f = 0; f < 18; ++f) t[f] = ((t[f] + red[0][f][cil]) + red[1][f][cil]) + red[2][f][cil];
+    // dW[r][.] = T[r][.] G;  G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]
     float* dst = dw + ((size_t)co * Ci + ci) * 9;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      const float s12 = t[r][1] + t[r][2], d12 = t[r][2] - t[r][1], s34 = t[r][3] + t[r][4], d34 = t[r][3] - t[r][4];
-      dst[r * 3 + 0] = 0.25f * t[r][0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+      const float* tr = t + r * 6;
+      const float s12 = tr[1] + tr[2], d12 = tr[2] - tr[1], s34 = tr[3] + tr[4], d34 = tr[3] - tr[4];
+      dst[r * 3 + 0] = 0.25f * tr[0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
       dst[r * 3 + 1] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
-      dst[r * 3 + 2] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + t[r][5];
+      dst[r * 3 + 2] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + tr[5];
     }
   }
 }
@@ -534,7 +538,7 @@ int wino4_wg_plan(int B, int Ci, int Co, int H, int W, Wino4WgPlan* p) {
   p->nstages = (int)ns;
   const int ntiles = p->n_ci_tiles * p->n_co_tiles;
   // one block per CU is resident (12 waves, ~158 KB LDS): aim at SIVAE_WG4_SLOTS blocks (default: one round of the CUs),
-  // at least 24 stages per slice so that the 288 KB partial-dU write-out of a block stays small next to its MFMA work
+  // at least 24 stages per slice so that the 144 KB partial write-out of a block stays small next to its MFMA work
   static int slots = 0;
   if (slots == 0) {
     const char* e = getenv("SIVAE_WG4_SLOTS");
@@ -569,7 +573,7 @@ extern "C" size_t sivae_conv2d_wino4_wgrad_workspace_bytes(int B, int Ci, int Co
   if (B <= 0 || Ci <= 0 || Co <= 0 || !sivae_conv2d_wino4_wgrad_supported(H, W)) return 0;
   if (wino4_wg_plan(B, Ci, Co, H, W, &p) != SIVAE_OK) return 0;
   // (+ one slice-sized slot: from 8 slices up the slices are summed by the wide split-K reducer first)
-  return (size_t)(p.n_slices + 1) * 36 * p.Co_pad * p.Ci_pad * sizeof(float);
+  return (size_t)(p.n_slices + 1) * 18 * p.Co_pad * p.Ci_pad * sizeof(float);
 }
 
 // dw[Co][Ci][3][3] = weight gradient of y = conv3x3(x', w) given dy, x' = x or (pro_mean != NULL) LeakyReLU(BatchNorm(x))
@@ -590,7 +594,7 @@ extern "C" int sivae_conv2d_wino4_wgrad(const float* x, const float* dy, float* 
   Wino4WgPlan p;
   int rc = wino4_wg_plan(B, Ci, Co, H, W, &p);
   if (rc != SIVAE_OK) return rc;
-  const size_t slice_elems = (size_t)36 * p.Co_pad * p.Ci_pad;
+  const size_t slice_elems = (size_t)18 * p.Co_pad * p.Ci_pad;  // (row-transformed partials: [3][6] per (co, ci))
   const size_t need = (size_t)(p.n_slices + 1) * slice_elems * sizeof(float);
   if (workspace_bytes < need) return SIVAE_ERR_WORKSPACE;
   Wino4WgArgs a;

@@ -179,7 +179,7 @@ def test_round3_entry_points_validate_arguments():
         == [1, 1, 0, 0, 1]
     assert L.sivae_conv2d_wino4_wgrad_pays(128, 128, 128, 128, 128) == 1 and L.sivae_conv2d_wino4_wgrad_pays(1, 64, 64, 16, 16) == 0
     nb = L.sivae_conv2d_wino4_wgrad_workspace_bytes(128, 128, 128, 128, 128)
-    assert nb > 0 and nb % (36 * 128 * 128 * 4) == 0
+    assert nb > 0 and nb % (18 * 128 * 128 * 4) == 0  # (row-transformed partials: 3 x 6 values per (co, ci))
     assert L.sivae_conv2d_wino4_wgrad(one, one, one, null, null, null, null, 0.2, 2, 32, 32, 8, 8, 0, one, 1 << 30, null) == -2
     assert L.sivae_conv2d_wino4_wgrad(one, null, one, null, null, null, null, 0.2, 2, 32, 32, 16, 16, 0, one, 1 << 30, null) == -1
     assert L.sivae_conv2d_wino4_wgrad(one, one, one, null, null, null, null, 0.2, 2, 32, 32, 16, 16, 0, one, 16, null) == -4
