@@ -14,15 +14,15 @@
 // operands are built in registers from raw LDS reads (4 dy values of the wave's parity class, a 3x3 patch of x).
 // Stages of 16 tiles (4 x 16 low-res pixels: an 8 x 32 block of dy, a 6 x 18 halo of x), double-buffered LDS
 // (122 KB, one block per CU), one barrier per stage, next stage's global loads in flight during the MFMA phase.
-// Deterministic split over tiles + fixed-order reduce kernel (which also applies G^T . G and folds the four
-// phase filters back into the 3x3 filter).
+// Deterministic split over tiles; a slice's partial is G^T dU G already (formed in registers: 16 instead of 36 values per
+// (co, ci)); the fixed-order reduce kernel adds the slices and folds the four phase filters back into the 3x3 filter.
 #include "common.h"
 #include <stdlib.h>
 
 struct WinoUpWgArgs {
   const float* x;   // [B][Ci][Hs][Ws]
   const float* dy;  // [B][Co][2Hs][2Ws]
-  float* ws;        // [n_slices][36][Co_pad][Ci_pad]
+  float* ws;        // [n_slices][4 phases][2][2][Co_pad][Ci_pad]: transformed partials G^T dU G
   int B, Ci, Co, Hs, Ws;
   int Ci_pad, Co_pad;
   int nrh, nrw, nstages, sps;
@@ -197,10 +197,22 @@ __global__ void __launch_bounds__(512, 2) wino_up_wgrad_kernel(WinoUpWgArgs a) {
 #undef WUW_KSTEP
 #undef WUW_MMA
 
-  // ---- partial dU of this slice: acc[f][r] -> plane ph*9 + f, co = co0 + row(r, hh), ci = ci0 + cg*32 + l31
+  // ---- partial of this slice.  acc[f][r] = dU of frequency f = i*3 + j of phase ph, co = co0 + row(r, hh), ci = ci0 +
+  // cg*32 + l31: the wave holds all nine frequencies of its phase, so dg = G^T dU G (3x3 -> 2x2, G = [[1,0],[1,1],[0,1]],
+  // all +1: 8 additions) is formed here in registers — linear, so it commutes with the sum over slices — and the partials
+  // and everything the reducer reads shrink from 36 to 16 values per (co, ci): plane ph*4 + a*2 + b.
 #pragma unroll
-  for (int f = 0; f < 9; ++f) {
-    float* base = a.ws + ((size_t)(slice * 36 + ph * 9 + f) * a.Co_pad + co0) * a.Ci_pad + ci0 + cg * 32 + l31;
+  for (int r = 0; r < 16; ++r) {
+    const float t00 = acc[0][r] + acc[3][r], t01 = acc[1][r] + acc[4][r], t02 = acc[2][r] + acc[5][r];
+    const float t10 = acc[3][r] + acc[6][r], t11 = acc[4][r] + acc[7][r], t12 = acc[5][r] + acc[8][r];
+    acc[0][r] = t00 + t01;
+    acc[1][r] = t01 + t02;
+    acc[2][r] = t10 + t11;
+    acc[3][r] = t11 + t12;
+  }
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    float* base = a.ws + ((size_t)(slice * 16 + ph * 4 + f) * a.Co_pad + co0) * a.Ci_pad + ci0 + cg * 32 + l31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -209,33 +221,33 @@ __global__ void __launch_bounds__(512, 2) wino_up_wgrad_kernel(WinoUpWgArgs a) {
   }
 }
 
-// dW[co][ci][3][3] from the slice partials: per phase dg = G^T dU G (G = [[1,0],[1,1],[0,1]]), then
+// dW[co][ci][3][3] from the slice partials dg_pq[a][b] ([n_slices][4 phases][2][2], transformed in the kernel above):
 // dW[r][c] = sum_pq dg_pq[a_p(r)][b_q(c)],  a_0 = (0,1,1), a_1 = (0,0,1).  Block = one co x 64 ci x 4 slice phases.
 __global__ void __launch_bounds__(256) wino_up_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                                    int Co, int Ci, int Co_pad, int Ci_pad,
                                                                    int n_slices) {
-  __shared__ float red[3][36][64];
+  __shared__ float red[3][16][64];
   const int cil = threadIdx.x & 63, sp = threadIdx.x >> 6;
   const int n_cic = (Ci + 63) / 64;
   const int co = blockIdx.x / n_cic, ci = (blockIdx.x % n_cic) * 64 + cil;
-  float u[36];
+  float u[16];
 #pragma unroll
-  for (int f = 0; f < 36; ++f) u[f] = 0.f;
+  for (int f = 0; f < 16; ++f) u[f] = 0.f;
   if (ci < Ci) {
     for (int s = sp; s < n_slices; s += 4) {
-      const float* p = ws + ((size_t)(s * 36) * Co_pad + co) * Ci_pad + ci;
+      const float* p = ws + ((size_t)(s * 16) * Co_pad + co) * Ci_pad + ci;
 #pragma unroll
-      for (int f = 0; f < 36; ++f) u[f] += p[(size_t)f * Co_pad * Ci_pad];
+      for (int f = 0; f < 16; ++f) u[f] += p[(size_t)f * Co_pad * Ci_pad];
     }
   }
   if (sp > 0) {
 #pragma unroll
-    for (int f = 0; f < 36; ++f) red[sp - 1][f][cil] = u[f];
+    for (int f = 0; f < 16; ++f) red[sp - 1][f][cil] = u[f];
   }
   __syncthreads();
   if (sp == 0 && ci < Ci) {
 #pragma unroll
-    for (int f = 0; f < 36; ++f) u[f] = ((u[f] + red[0][f][cil]) + red[1][f][cil]) + red[2][f][cil];
+    for (int f = 0; f < 16; ++f) u[f] = ((u[f] + red[0][f][cil]) + red[1][f][cil]) + red[2][f][cil];
     float dwv[3][3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -245,26 +257,14 @@ __global__ void __launch_bounds__(256) wino_up_wgrad_reduce_kernel(const float* 
     for (int p = 0; p < 2; ++p)
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const float* U = u + (p * 2 + q) * 9;
-        float t[2][3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          t[0][j] = U[0 * 3 + j] + U[1 * 3 + j];
-          t[1][j] = U[1 * 3 + j] + U[2 * 3 + j];
-        }
-        float g[2][2];
-#pragma unroll
-        for (int a_ = 0; a_ < 2; ++a_) {
-          g[a_][0] = t[a_][0] + t[a_][1];
-          g[a_][1] = t[a_][1] + t[a_][2];
-        }
+        const float* g = u + (p * 2 + q) * 4;
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             const int ar = p == 0 ? (r == 0 ? 0 : 1) : (r == 2 ? 1 : 0);
             const int bc = q == 0 ? (c == 0 ? 0 : 1) : (c == 2 ? 1 : 0);
-            dwv[r][c] += g[ar][bc];
+            dwv[r][c] += g[ar * 2 + bc];
           }
       }
     float* dst = dw + ((size_t)co * Ci + ci) * 9;
@@ -308,7 +308,7 @@ extern "C" size_t sivae_conv2d_wino_up_wgrad_workspace_bytes(int B, int Ci, int 
   WuwPlan p;
   if (B <= 0 || Ci <= 0 || Co <= 0 || !sivae_conv2d_wino_up_wgrad_supported(Hs, Ws)) return 0;
   if (wuw_plan(B, Ci, Co, Hs, Ws, &p) != SIVAE_OK) return 0;
-  return (size_t)p.n_slices * 36 * p.Co_pad * p.Ci_pad * sizeof(float);
+  return (size_t)p.n_slices * 16 * p.Co_pad * p.Ci_pad * sizeof(float);
 }
 
 extern "C" int sivae_conv2d_wino_up_wgrad(const float* x_half, const float* dy, float* dw, int B, int Ci, int Co,
@@ -322,7 +322,7 @@ extern "C" int sivae_conv2d_wino_up_wgrad(const float* x_half, const float* dy, 
   WuwPlan p;
   int rc = wuw_plan(B, Ci, Co, Hs, Ws, &p);
   if (rc != SIVAE_OK) return rc;
-  const size_t need = (size_t)p.n_slices * 36 * p.Co_pad * p.Ci_pad * sizeof(float);
+  const size_t need = (size_t)p.n_slices * 16 * p.Co_pad * p.Ci_pad * sizeof(float);
   if (workspace_bytes < need) return SIVAE_ERR_WORKSPACE;
   WinoUpWgArgs a;
   a.x = x_half;
