@@ -58,6 +58,17 @@ def calc_reconstruction_loss(x, recon_x, loss_type="mse", reduction="sum"):
     return SF.ReconFn.apply(x, recon_x, loss_type, "total", 1.0 if reduction == "sum" else 1.0 / (B * D))
 
 
+_HALVES_BY_SLICE = os.environ.get("SIVAE_HALVES_SLICE", "0") == "1"  # (A/B switch of the note in e_step)
+
+
+def _halves(t):
+    """the two passes of a paired batch"""
+    if _HALVES_BY_SLICE:
+        n = t.shape[0] // 2
+        return t[:n], t[n:]
+    return t.chunk(2)
+
+
 def _recon_rows(x, recon_x, loss_type):
     """per-sample reconstruction sums [B] — what the reference builds for the exp-ELBO terms as
     calc_reconstruction_loss(..., reduction='none') followed by `while len(shape) > 1: sum(-1)` (:574-579).  For l1 / bce
@@ -296,8 +307,11 @@ class SoftIntroEngine:
             mu2, logvar2 = m.encoder(x2, nseg=2)
             z2 = reparameterize(mu2, logvar2, self._eps2(eps[1], eps[2], real_mu))
             rr2 = dec2(z2, nseg=2)
-            rec_mu, rec_logvar, fake_mu, fake_logvar = mu2[:B], logvar2[:B], mu2[B:], logvar2[B:]
-            rec_rec, rec_fake = rr2[:B], rr2[B:]
+            # (chunk, not two slices: ONE autograd node per tensor whose backward is a single cat — a slice's backward
+            # allocates a zero tensor of the whole pair, copies its half in and adds the two: ~35 small launches and
+            # 3 GB of traffic per iteration at batch 128)
+            (rec_mu, fake_mu), (rec_logvar, fake_logvar) = _halves(mu2), _halves(logvar2)
+            rec_rec, rec_fake = _halves(rr2)
         else:
             rec_mu, rec_logvar = m.encode(rec.detach())
             z_rec = reparameterize(rec_mu, rec_logvar, eps[1])
@@ -346,7 +360,7 @@ class SoftIntroEngine:
             # replay of the E-step's [rec; fake] pair (same inputs, unchanged decoder), now WITH a graph: one segmented
             # backward instead of two
             y2 = m.decoder(self._zn, cache=self._cache_pair, nseg=2, seg_rev=True)
-            rec, fake = y2[:B], y2[B:]
+            rec, fake = _halves(y2)
         else:
             fake = m.decoder(noise, cache=self._cache_fake)
             rec = m.decoder(z.detach(), cache=self._cache_rec)
@@ -358,8 +372,8 @@ class SoftIntroEngine:
             mu2, logvar2 = m.encoder(y2 if y2 is not None else torch.cat([rec, fake]), nseg=2)
             z2 = reparameterize(mu2, logvar2, self._eps2(eps[0], eps[1], z))
             rr2 = dec2(z2, nseg=2) if self.bootstrap else m.decoder(z2.detach(), nseg=2)
-            rec_mu, rec_logvar, fake_mu, fake_logvar = mu2[:B], logvar2[:B], mu2[B:], logvar2[B:]
-            rec_rec, rec_fake = rr2[:B], rr2[B:]
+            (rec_mu, fake_mu), (rec_logvar, fake_logvar) = _halves(mu2), _halves(logvar2)
+            rec_rec, rec_fake = _halves(rr2)
         else:
             rec_mu, rec_logvar = m.encode(rec)
             z_rec = reparameterize(rec_mu, rec_logvar, eps[0])
