@@ -66,6 +66,13 @@ def test_round1_late_entry_points_validate_arguments():
     assert L.sivae_conv2d_wino_supported(256, 256) == 1 and L.sivae_conv2d_wino_supported(4, 4) == 1
     assert L.sivae_conv2d_wino_supported(7, 7) == 0 and L.sivae_conv2d_wino_supported(28, 28) == 1
     assert L.sivae_conv2d_wino_up_supported(16, 32) == 1 and L.sivae_conv2d_wino_up_supported(8, 8) == 0
+    # (round 4: the forward kernel stores four output pixels per 16-byte store: W % 4 == 0 and a 16-byte aligned output)
+    assert L.sivae_conv2d_wino_up_supported(16, 34) == 0 and L.sivae_conv2d_wino_up_supported(16, 36) == 1
+    assert L.sivae_conv2d_wino_up_fwd(one, one, ctypes.c_void_p(20), null, null, null, null, 0.2, null, 2, 16, 16, 16, 32,
+                                      null) == -2
+    # weight-gradient partials are written transformed: 16 (upsample-phase) / 18 (F(4x4,3x3)) values per (co, ci) and slice
+    nb = L.sivae_conv2d_wino_up_wgrad_workspace_bytes(16, 64, 64, 64, 64)
+    assert nb > 0 and nb % (16 * 64 * 64 * 4) == 0
 
 
 def test_round2_entry_points_validate_arguments():
