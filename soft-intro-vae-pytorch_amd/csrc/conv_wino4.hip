@@ -482,8 +482,10 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
       // The lane index is laundered once per item: otherwise hipcc hoists the lane-dependent LDS / global offsets of this
       // epilogue out of the persistent item loop, spills them, and reloads each one behind an s_waitcnt vmcnt(0) — which
       // also waits for every output store issued so far (stores share vmcnt on gfx9): ~25 K cycles per item.
-      int lane_ = lane;
-      asm volatile("" : "+v"(lane_));
+      // (and it is RECOMPUTED, not copied: `lane` itself is spilled by then, and its reload — `s_waitcnt vmcnt(1)` at the
+      // epilogue's entry, in order behind the next item's halo requests — waited out an HBM latency per item)
+      int lane_;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_));
       const int ty_ = (lane_ >> 3) & 3, hh_ = lane_ >> 5;
       // pair mode: tile columns 4-7 are image e_b + 1
       const int tx_ = a.two ? (lane_ & 3) : (lane_ & 7);
