@@ -518,6 +518,16 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch, args.cpu_iters, args.cpu_threads)
         out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+    if also is not None:
+        # the LAST key of the line (a truncated stdout tail still carries it): the shard-size legs and their ratios
+        out["zz_shard_summary"] = {
+            "headline_img_s": round(out.get("value_untimed", value), 2),
+            "celeb256_bs16_shard_img_s": also["celeb256_fp32_bs16_shard"]["value"],
+            "rate_vs_bs128": also["celeb256_fp32_bs16_shard"]["rate_vs_bs128"],
+            "bootstrap256_bs64_img_s": also["bootstrap256_fp32_bs64"]["value"],
+            "bootstrap256_bs8_shard_img_s": also["bootstrap256_fp32_bs8_shard"]["value"],
+            "rate_vs_bs64": also["bootstrap256_fp32_bs8_shard"]["rate_vs_bs64"],
+            **{k + "_img_s": also[k]["value"] for k in also if k.startswith(("cifar10", "celeb128"))}}
     print(json.dumps(out))
 
 

@@ -538,6 +538,20 @@ int sivae_bn_bwd_seg(const float* dy, const float* y, const unsigned char* mask,
 int sivae_bn_bwd_fused_supported(int B, int C, int H, int W, int seg_images);
 size_t sivae_bn_bwd_fused_workspace_bytes(int B, int C, int H, int W, int seg_images);
 int sivae_bn_bwd_fused_state_uints(void);
+/* Grid-barrier timeout (round 5): a persistent launch whose grid is not fully resident no longer traps — after
+ * SIVAE_BN_FUSED_SPIN_LIMIT polls (default 2^24, tens of seconds) the waiting block sets word
+ * sivae_bn_bwd_fused_poison_word() of `state` and every block leaves the kernel (that launch's outputs are garbage, later
+ * launches on the same state return at once).  The host reads that word where it reads results back anyway, raises, and
+ * zeroes the whole state (sivae_hip.ops.bn_fused_check).  Plans also refuse the persistent form under a CU mask
+ * (HSA_CU_MASK / ROC_GLOBAL_CU_MASK), with SIVAE_BN_FUSED_PERSISTENT=0, or when the runtime reports fewer than two
+ * resident blocks per CU: sivae_bn_bwd_fused_supported() then returns 0 for plane sets that need the barrier and the
+ * callers keep the three-launch form.  sivae_debug_bn_fused_break_next(extra): test hook — the next persistent launch
+ * waits for `extra` arrivals per XCD that never come (exercises the timeout path). */
+int sivae_bn_bwd_fused_poison_word(void);
+int sivae_debug_bn_fused_break_next(int extra);
+/* test support: a kernel that only holds `blocks` x `threads` threads + `lds_bytes` of LDS for `ticks` 100-MHz periods (or
+ * until *stop != 0) — the footprint of a collective on a side stream next to the persistent kernels */
+int sivae_debug_squatter(int blocks, int threads, int lds_bytes, long long ticks, const int* stop, sivae_stream_t stream);
 int sivae_bn_bwd_fused(const float* dy, const float* y, const unsigned char* mask, const float* x, const float* mean,
                        const float* invstd, const float* gamma, const float* beta, int act_mode, float slope, float* dx,
                        float* dz_out, float* dgamma, float* dbeta, int B, int C, int H, int W, int dy_pooled, int dz_sum,

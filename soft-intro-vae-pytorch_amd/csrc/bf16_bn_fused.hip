@@ -38,20 +38,28 @@ struct Bf16BnFusedArgs {
   int l2_qpp, l2_qw;  // log2(quads per plane), log2(quads per row); a quad = 2 x 2 pixels
   int spc, cpg, ngroups, nx, nsub, local;
   int dzmode;  // 0 none, 1 full resolution, 2 2x2 block sums
+  unsigned spin_limit;  // polls of the barrier wait before the launch is abandoned (bn_fused_common.h)
 };
 
-// 16-byte buffer store + a guard.  Measured on gfx950 / ROCm 7.2 (this kernel, memory pipe saturated): when the VALU
-// instructions that follow a buffer_store_dwordx4 rewrite its data registers within a few issue slots, the store can
-// pick up the NEW values in lanes 12-15 of every 16-lane row (the last quad of each row is read last) — the two wait
-// states hipcc inserts for the store-data hazard are not enough under back-pressure.  Symptom here: isolated dwords of dx
-// in every fourth quad of a row wrong, only in blocks that start while the other half-grid streams, and only in some
-// runs.  The guard keeps the scheduler from moving anything across and leaves 16 idle cycles behind the store.
+// 16-byte buffer stores and the lifetime of their data registers.  Measured on gfx950 / ROCm 7.2 (this kernel, memory pipe
+// saturated, round 4): when the VALU instructions that follow a buffer_store_dwordx4 rewrite its data registers within a
+// few issue slots, the store can pick up the NEW values in lanes 12-15 of every 16-lane row (the last quad of each row is
+// read last) — the two wait states hipcc inserts for the store-data hazard are not enough under back-pressure.  Round 4
+// padded every store with idle cycles; since round 5 the data of the stores lives in registers that nothing rewrites
+// before the next group's loads (packed dx replaces the raw x vector it was computed from, packed dz the raw dy vector;
+// B16_KEEP pins them up to the loads that overwrite them — VMEM executes in order — and the kernel's end waits vmcnt(0)):
+// see bn_fused.hip::BF_KEEP.  The one variant without a dead payload register for dz (pooled dy + full-resolution dz)
+// keeps the padded store.
 __device__ __forceinline__ void bf_store_u32x4(__amdgpu_buffer_rsrc_t r, u32x4_t v, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void bf_store_u32x4_padded(__amdgpu_buffer_rsrc_t r, u32x4_t v, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
+#define B16_KEEP(V) asm volatile("" ::"v"((V)[0]), "v"((V)[1]), "v"((V)[2]), "v"((V)[3]));
 
 // ACT: 1 sign from the saved output y, 2 recomputed from xhat * gamma + beta, 3 from the sign bytes
 template <int ACT, bool POOL, int NU>
@@ -67,6 +75,7 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
   unsigned* bar = a.bar + sub * BF_BAR_UINTS;
   const int xcd = bid % a.nx;
   const unsigned bpx = (unsigned)(nb_sub / a.nx);
+  __shared__ int bar_failed;
   unsigned target = 0;
   if (t == 0 && !local) target = bf_load_u32(bar + (9 + xcd) * 32);
   const int W = a.W, HW = a.H * a.W, Cb = a.Cb;
@@ -78,10 +87,17 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
   const unsigned row_b = (unsigned)W * 16u;
   const unsigned long long win = ((unsigned long long)(a.B - 1) * Cb + 1ull) * HW * 16ull;
 
+  u32x4_t dq[NU][POOL ? 1 : 4], xq[NU][4];
+#pragma unroll
+  for (int j = 0; j < NU; ++j)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      xq[j][v] = u32x4_t{0u, 0u, 0u, 0u};
+      if (!POOL || v == 0) dq[j][POOL ? 0 : v] = u32x4_t{0u, 0u, 0u, 0u};
+    }
   for (int grp = sub; grp < (local ? 1 : a.ngroups); grp += a.nsub) {
     const int cb = local ? bid : grp * a.cpg + ci;
     const bool active = local ? true : (ci < a.cpg && cb < Cb);
-    u32x4_t dq[NU][POOL ? 1 : 4], xq[NU][4];
     unsigned sg_bits[NU];  // sign bytes of the quad's 4 vectors (row 0: bytes 0, 1; row 1: bytes 2, 3)
     float mu[8], is[8];
     const unsigned qbase = (unsigned)(slab * (256 * NU) + t);
@@ -111,6 +127,12 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
 #pragma unroll
       for (int j = 0; j < NU; ++j) {
         const unsigned vo = quad_off(qbase + j * 256);
+        // (the previous group's store data stays pinned in these registers up to here)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          B16_KEEP(xq[j][v])
+          if (!POOL || v == 0) B16_KEEP(dq[j][POOL ? 0 : v])
+        }
         xq[j][0] = buf_load_u32x4(rx, vo, 0);
         xq[j][1] = buf_load_u32x4(rx, vo == BF_OOB ? BF_OOB : vo + 16u, 0);
         xq[j][2] = buf_load_u32x4(rx, vo, row_b);
@@ -219,9 +241,10 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
     if (!local) {
       if (t == 0) {
         ++target;
-        bf_grid_barrier(bar, xcd, a.nx, bpx, target);
+        bar_failed = bf_grid_barrier(bar, a.bar + BF_POISON_WORD, xcd, a.nx, bpx, target, a.spin_limit) ? 0 : 1;
       }
       __syncthreads();
+      if (bar_failed) return;  // abandoned launch (poison word set; the host raises)
       if (!active) continue;
       // the channel block's 16 sums over its slabs: thread (value v = t & 15, row r = t >> 4) strides over the slabs,
       // rows folded in order through LDS — the same in every block of the channel block
@@ -293,13 +316,33 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
           xv[e] = gi[e] * (g[e] - c1[e] - xh * c2[e]);
         }
         const unsigned vv = vo + (v & 1) * 16u, so = (v >> 1) ? row_b : 0u;
-        if (a.dzmode == 1) bf_store_u32x4(rdz, pack8(g), vv, so);
-        bf_store_u32x4(rdx, pack8(xv), vv, so);
+        // store data in place of the raw vectors it was computed from (dead from here on)
+        xq[j][v] = pack8(xv);
+        if (a.dzmode == 1) {
+          if (POOL) {
+            bf_store_u32x4_padded(rdz, pack8(g), vv, so);
+          } else {
+            dq[j][v] = pack8(g);
+            bf_store_u32x4(rdz, dq[j][v], vv, so);
+          }
+        }
+        bf_store_u32x4(rdx, xq[j][v], vv, so);
       }
-      if (a.dzmode == 2) bf_store_u32x4(rdz, pack8(zs), half_off(qbase + j * 256), 0);
+      if (a.dzmode == 2) {  // (never with pooled dy: the raw dy vectors are dead here)
+        dq[j][0] = pack8(zs);
+        bf_store_u32x4(rdz, dq[j][0], half_off(qbase + j * 256), 0);
+      }
     }
     __syncthreads();  // (coef / red are reused by the next group)
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < NU; ++j)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      B16_KEEP(xq[j][v])
+      if (!POOL || v == 0) B16_KEEP(dq[j][POOL ? 0 : v])
+    }
 }
 
 struct B16Plan {
@@ -313,6 +356,7 @@ static bool b16_plan(int B, int Cb, int HW, B16Plan* out) {
     *out = B16Plan{NU, 1, 1, Cb, Cb, 1, 1};
     return true;
   }
+  if (!bf_persistent_allowed()) return false;  // (CU mask / switched off: the three-launch form)
   for (int nsub = 2; nsub >= 1; --nsub) {
     const int nb_sub = sivae_num_cus() * (nsub == 2 ? 1 : 2);
     const int NU = 4;
@@ -394,6 +438,7 @@ extern "C" int sivae_bf16_bn_bwd_fused(const void* dy, int dy_pooled, const void
   a.nsub = p.nsub;
   a.local = p.local;
   a.dzmode = !dz ? 0 : (dz_sum ? 2 : 1);
+  a.spin_limit = bf_spin_limit();
   const int act = sign_mask ? 3 : (y ? 1 : 2);
   const dim3 grid((unsigned)(p.local ? Cb : p.nsub * p.nb_sub)), block(256);
 #define B16_LAUNCH(A, P, N) hipLaunchKernelGGL((bf16_bn_bwd_fused_kernel<A, P, N>), grid, block, 0, stream, a)

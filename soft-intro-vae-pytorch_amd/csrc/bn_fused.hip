@@ -47,6 +47,8 @@ struct BnFusedArgs {
   int nsub;    // 2: two independent half-grids walking alternate groups; 1: one grid (plane sets too big for a half)
   int local;   // 1: every (segment, channel) plane set fits ONE block (spc == 1): grid = VC ordinary blocks, no barrier
   int dzmode;  // 0: none, 1: dz at full resolution, 2: 2x2 block sums [.][H/2][W/2]
+  unsigned spin_limit;  // polls of the barrier wait before the launch is abandoned (poison word set)
+  int dbg_extra;        // test hook: arrivals the barrier expects on top of the real ones (never come -> timeout path)
 };
 
 __device__ __forceinline__ void bf_sign_nibble(float4& g, unsigned nib, float slope) {
@@ -69,12 +71,16 @@ __device__ __forceinline__ void bf_store4(__amdgpu_buffer_rsrc_t r, const float4
   f[2] = v.z;
   f[3] = v.w;
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f), r, (int)voff, (int)soff, 0);
-  // (store-data guard: see bf16_bn_fused.hip::bf_store_u32x4 — on gfx950 a 16-byte buffer store whose data registers are
-  // rewritten a few slots later can store the new values in the last quad of each 16-lane row under back-pressure)
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
 }
+// Store-data lifetime (round 5; replaces round 4's `s_nop` pad).  Observed on gfx950 with the memory pipe saturated: a
+// 16-byte buffer store whose data registers were rewritten by VALU instructions a few issue slots later stored the NEW
+// values in the last quad of each 16-lane row.  Instead of padding with idle cycles, the data of every 16-byte store of
+// this kernel lives in registers that NOTHING rewrites before the next group's loads are issued: dx is formed in place
+// in the xhat registers of the payload, dz is stored from the payload itself, and BF_KEEP pins those values (an empty
+// asm that "reads" them) at the point up to which their registers must not be recycled.  The next writers of those
+// registers are VMEM loads, which the memory pipe executes in order behind the stores; the first VALU write follows an
+// s_waitcnt vmcnt that — vmcnt being one in-order counter for loads and stores — covers the stores as well.
+#define BF_KEEP(V) asm volatile("" ::"v"((V).x), "v"((V).y), "v"((V).z), "v"((V).w));
 
 // ACT: 0 none, 1 sign from the saved output y, 2 sign recomputed from x (gamma, beta), 3 sign from the 1-bit mask.
 // POOL: dy is the gradient of AvgPool2d(2)(output) at half resolution (read through the pool's adjoint).
@@ -95,7 +101,8 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
   unsigned* bar = a.bar + sub * BF_BAR_UINTS;
   unsigned* chcnt = a.bar + 2 * BF_BAR_UINTS;
   const int xcd = bid % a.nx;
-  const unsigned bpx = (unsigned)(nb_sub / a.nx);
+  const unsigned bpx = (unsigned)(nb_sub / a.nx + a.dbg_extra);
+  __shared__ int bar_failed;
   unsigned target = 0;
   if (t == 0 && !local) target = bf_load_u32(bar + (9 + xcd) * 32);
   const int C = a.C, W = a.W, HW = a.H * a.W;
@@ -109,11 +116,13 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
   const unsigned long long win = ((unsigned long long)(a.Bs - 1) * C + 1ull) * HW * 4ull;  // bytes of a plane set's window
 
   // (local form: one pass of the loop body, vc = the block index)
+  float4 g0[NQ], g1[NQ], x0[NQ], x1[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) g0[j] = g1[j] = x0[j] = x1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int grp = sub; grp < (local ? 1 : a.ngroups); grp += a.nsub) {
     const int vc = local ? bid : grp * a.cpg + ci;
     const bool active = local ? true : (ci < a.cpg && vc < VC);
     double t1 = 0.0, t2 = 0.0;
-    float4 g0[NQ], g1[NQ], x0[NQ], x1[NQ];
     float m = 0.f, is = 0.f, gs = 0.f;
     int c = 0;
     size_t base = 0;  // element index of the plane (segment's first image, channel c)
@@ -145,6 +154,8 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
 #pragma unroll
       for (int j = 0; j < NQ; ++j) {
         const unsigned vo = quad_off(qbase + j * 256);
+        // (the previous group's store data — dx in x0 / x1, dz in g0 / g1 — stays pinned up to here: see BF_KEEP)
+        BF_KEEP(x0[j]) BF_KEEP(x1[j]) BF_KEEP(g0[j]) BF_KEEP(g1[j])
         x0[j] = buf_load_f32x4(rx, vo, 0);
         x1[j] = buf_load_f32x4(rx, vo, row_b);
         if (POOL) {
@@ -210,9 +221,10 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
       // ---- barrier: every slab of every channel of this group is published
       if (t == 0) {
         ++target;
-        bf_grid_barrier(bar, xcd, a.nx, bpx, target);
+        bar_failed = bf_grid_barrier(bar, a.bar + BF_POISON_WORD, xcd, a.nx, bpx, target, a.spin_limit) ? 0 : 1;
       }
       __syncthreads();
+      if (bar_failed) return;  // abandoned launch (poison word set): no trap, no hang; the host raises
       if (!active) continue;
       // ---- phase 2: coefficients of this channel (fixed order: thread-strided slabs, then the block tree — the same
       // in every block of the channel), then dx straight from the registers
@@ -255,18 +267,18 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
       // (measured on gfx950: a 16-byte buffer store at voffset 0xFFFFFFFF is NOT dropped as a whole — dwords 1..3 wrap
       // into the window and zeros landed inside dz; so the stores of quads past the end are skipped by the exec mask and
       // the out-of-range marker keeps all four dwords of a vector beyond any window)
+      // dx in place of xhat (dead after this): the registers a store reads are not rewritten before the next group
+      x0[j].x = gs * (g0[j].x - c1 - x0[j].x * c2);
+      x0[j].y = gs * (g0[j].y - c1 - x0[j].y * c2);
+      x0[j].z = gs * (g0[j].z - c1 - x0[j].z * c2);
+      x0[j].w = gs * (g0[j].w - c1 - x0[j].w * c2);
+      x1[j].x = gs * (g1[j].x - c1 - x1[j].x * c2);
+      x1[j].y = gs * (g1[j].y - c1 - x1[j].y * c2);
+      x1[j].z = gs * (g1[j].z - c1 - x1[j].z * c2);
+      x1[j].w = gs * (g1[j].w - c1 - x1[j].w * c2);
       if (vo == BF_OOB) continue;
-      float4 d;
-      d.x = gs * (g0[j].x - c1 - x0[j].x * c2);
-      d.y = gs * (g0[j].y - c1 - x0[j].y * c2);
-      d.z = gs * (g0[j].z - c1 - x0[j].z * c2);
-      d.w = gs * (g0[j].w - c1 - x0[j].w * c2);
-      bf_store4(rdx, d, vo, 0);
-      d.x = gs * (g1[j].x - c1 - x1[j].x * c2);
-      d.y = gs * (g1[j].y - c1 - x1[j].y * c2);
-      d.z = gs * (g1[j].z - c1 - x1[j].z * c2);
-      d.w = gs * (g1[j].w - c1 - x1[j].w * c2);
-      bf_store4(rdx, d, vo, row_b);
+      bf_store4(rdx, x0[j], vo, 0);
+      bf_store4(rdx, x1[j], vo, row_b);
       if (a.dzmode == 1) {
         bf_store4(rdz, g0[j], vo, 0);
         bf_store4(rdz, g1[j], vo, row_b);
@@ -278,6 +290,10 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
       }
     }
   }
+  // the last group's stores: their data registers stay untouched until the stores have completed
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) { BF_KEEP(x0[j]) BF_KEEP(x1[j]) BF_KEEP(g0[j]) BF_KEEP(g1[j]) }
 }
 
 struct BfPlan {
@@ -285,6 +301,25 @@ struct BfPlan {
   int spc, cpg, ngroups, nb_sub, nsub;
   int local;  // plane sets of one block each: an ordinary launch of VC blocks
 };
+
+// do two blocks of the heaviest instantiation fit one CU on this device?  (They do by construction —
+// __launch_bounds__(256, 2), a few hundred bytes of LDS —; the query guards against a runtime / driver that disagrees.
+// Without a device — planning queries on a build box — the answer is yes.)
+static bool bf_occupancy_ok() {
+  static int ok = -1;
+  if (ok < 0) {
+    int ndev = 0, n = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+      (void)hipGetLastError();
+      ok = 1;
+    } else {
+      const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bn_bwd_fused_kernel<3, false, 10>, 256, 0);
+      ok = (e != hipSuccess || n >= 2) ? 1 : 0;
+      if (e != hipSuccess) (void)hipGetLastError();
+    }
+  }
+  return ok == 1;
+}
 
 // the NQ (quads per thread) of {10, 8, 4} with the smallest modelled time: groups per (half-)grid x (fixed barrier /
 // latency cost + streaming time of a group).  A channel plane set must fit one group (spc <= blocks of the (half-)grid).
@@ -304,6 +339,9 @@ static bool bf_plan(int Bs, int VC, int HW, int max_nq, BfPlan* out) {
     out->local = 1;
     return true;
   }
+  // the persistent form needs its whole grid (2 blocks per CU) resident: not under a CU mask, not when the runtime says
+  // fewer than two blocks of the heaviest variant fit a CU -> the callers keep the three-launch form
+  if (!bf_persistent_allowed() || !bf_occupancy_ok()) return false;
   // two half-grids (one block per CU each) when a plane set fits a half; otherwise one grid of two blocks per CU
   for (int nsub = 2; nsub >= 1; --nsub) {
     const int nb_sub = sivae_num_cus() * (nsub == 2 ? 1 : 2);
@@ -339,19 +377,34 @@ static bool bf_plan(int Bs, int VC, int HW, int max_nq, BfPlan* out) {
   return false;
 }
 
+static int bf_dbg_break_next = 0;
+
 static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 }  // namespace
 
 // shapes the one-pass backward takes: power-of-two maps from 4x4 up (H even, W % 4 == 0 by construction), per-(segment,
 // channel) plane sets that fit one group of a half-grid, at most 8192 channels
+// (plans with the register budget of the tightest variant — act_mode 1, 8 quads per thread —, so that a shape this
+// query accepts is accepted by every variant of the launch)
 extern "C" int sivae_bn_bwd_fused_supported(int B, int C, int H, int W, int seg_images) {
   if (B <= 0 || C <= 0 || C > BF_CH_COUNTERS || !is_pow2(H) || !is_pow2(W) || H < 2 || W < 4) return 0;
   if (seg_images <= 0 || B % seg_images != 0) return 0;
   if ((long long)B * C * H * W >= 0xffffffffLL) return 0;
   if ((long long)seg_images * C * H * W * 4 >= 0xfffffe00LL) return 0;  // (a plane set's window: 32-bit byte offsets)
   BfPlan p;
-  return bf_plan(seg_images, (B / seg_images) * C, H * W, 10, &p) ? 1 : 0;
+  return bf_plan(seg_images, (B / seg_images) * C, H * W, 8, &p) ? 1 : 0;
+}
+
+// index (in unsigned ints) of the state word a timed-out grid barrier sets: the host checks it where it reads results
+// back anyway (sivae_hip.ops.bn_fused_check) and must zero the whole state before the next launch when it is non-zero
+extern "C" int sivae_bn_bwd_fused_poison_word() { return BF_POISON_WORD; }
+
+// test hook: the next persistent launch of sivae_bn_bwd_fused expects `extra` arrivals per XCD that never come, i.e. it
+// takes the timeout path (poison word set, every block returns) — tests/kernel_checks.py::check_bn_fused_timeout
+extern "C" int sivae_debug_bn_fused_break_next(int extra) {
+  bf_dbg_break_next = extra;
+  return SIVAE_OK;
 }
 
 // partial sums [VC][spc][2] + per-(segment, channel) sums [VC][2], doubles
@@ -431,6 +484,9 @@ extern "C" int sivae_bn_bwd_fused(const float* dy, const float* y, const unsigne
   a.nsub = p.nsub;
   a.local = p.local;
   a.dzmode = !dz_out ? 0 : (dz_sum ? 2 : 1);
+  a.dbg_extra = p.local ? 0 : bf_dbg_break_next;
+  if (!p.local) bf_dbg_break_next = 0;
+  a.spin_limit = a.dbg_extra ? (1u << 14) : bf_spin_limit();  // (the test hook gives up after milliseconds)
   const dim3 grid((unsigned)(p.local ? VC : p.nsub * p.nb_sub)), block(256);
 #define BF_LAUNCH(A, P, Q) hipLaunchKernelGGL((bn_bwd_fused_kernel<A, P, Q>), grid, block, 0, stream, a)
 #define BF_NQ(A, P)                                 \

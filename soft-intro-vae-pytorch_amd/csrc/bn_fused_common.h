@@ -2,6 +2,7 @@
 // the barrier / counter state layout, the fence-free XCD-hierarchical grid barrier, and the group plan.
 #pragma once
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -18,15 +19,27 @@ __device__ __forceinline__ double bf_load_f64(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Word of the state that carries the "grid barrier timed out" flag (its own 128-byte line in the unused tail of the
+// first barrier area).  Non-zero: some launch gave up waiting for a block that never arrived (the grid was not fully
+// resident); every block that sees it leaves the kernel, the results of that launch are garbage and the barrier counters
+// are inconsistent -> the host must zero the whole state before the next launch (sivae_hip.ops.bn_fused_check raises).
+constexpr int BF_POISON_WORD = BF_BAR_UINTS - 32;
+constexpr unsigned BF_SPIN_LIMIT_DEFAULT = 1u << 24;  // polls of ~1 us: tens of seconds, then the launch is abandoned
+
 // grid barrier of one half-grid, called by thread 0 of every block.  `bar`: arrival counters [xcd] at bar + 32*xcd, the
 // top counter at bar + 256, generation flags at bar + 32*(9 + xcd).  Counters are reset by the last arriver (nobody
-// arrives again before the generation flips), the generation only ever advances: the state needs no re-initialisation
-// between launches.
+// arrives again before the generation flips); every generation flag only ever advances BY ONE per barrier and a block
+// compares its own XCD's flag with the value it read at kernel start plus the barriers it has passed — the flags need
+// not agree with each other, so launches that use different numbers of XCD groups (nx) can share the state, and the state
+// needs no re-initialisation between launches.
 // No fences: everything that crosses blocks (the partial sums, the counters, the flags) is written with agent-scope
 // (write-through, `sc1`) stores / atomics and read with agent-scope loads, ordered by explicit vmcnt(0) waits.  A release
 // fence here would write back the whole L2 of the XCD — the dx stores of the previous group, megabytes — once per block
 // and barrier (first form of this kernel: 46 us per group instead of the ~13 us its bytes need).
-__device__ __forceinline__ void bf_grid_barrier(unsigned* bar, int xcd, int nx, unsigned bpx, unsigned target) {
+// Returns false when the wait was abandoned (spin limit reached here or in another block: the poison word is set) — the
+// caller's block must leave the kernel; nothing traps and nothing hangs.
+__device__ __forceinline__ bool bf_grid_barrier(unsigned* bar, unsigned* poison, int xcd, int nx, unsigned bpx,
+                                                unsigned target, unsigned spin_limit) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's partial sums (sc1 stores) have reached memory
   unsigned* cnt = bar + xcd * 32;
   const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -38,15 +51,48 @@ __device__ __forceinline__ void bf_grid_barrier(unsigned* bar, int xcd, int nx, 
     if (o2 == (unsigned)nx - 1u) {
       __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      for (int i = 0; i < nx; ++i) __hip_atomic_store(bar + (9 + i) * 32, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = 0; i < nx; ++i)
+        __hip_atomic_fetch_add(bar + (9 + i) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   const unsigned* gen = bar + (9 + xcd) * 32;
   unsigned spins = 0;
   while (bf_load_u32(gen) != target) {
     __builtin_amdgcn_s_sleep(1);
-    if (++spins > (1u << 27)) __builtin_trap();  // (a block of this grid is not resident: fail loudly instead of hanging)
+    ++spins;
+    if ((spins & 255u) == 0u && bf_load_u32(poison) != 0u) return false;
+    if (spins > spin_limit) {  // a block of this grid is not resident (or never will be): flag it and give up
+      __hip_atomic_store(poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
   }
+  return true;
+}
+
+// may a persistent (grid-barrier) launch assume that all CUs sivae_num_cus() reports are available to it?  Not under a CU
+// mask (HSA_CU_MASK / ROC_GLOBAL_CU_MASK: the device still reports every CU); SIVAE_BN_FUSED_PERSISTENT=0 forces the
+// answer (the callers then keep the three-launch form for plane sets that need the barrier).
+static inline bool bf_persistent_allowed() {
+  static int ok = -1;
+  if (ok < 0) {
+    const char* f = getenv("SIVAE_BN_FUSED_PERSISTENT");
+    const char* m1 = getenv("HSA_CU_MASK");
+    const char* m2 = getenv("ROC_GLOBAL_CU_MASK");
+    if (f && f[0] == '0') ok = 0;
+    else if ((m1 && m1[0]) || (m2 && m2[0])) ok = 0;
+    else ok = 1;
+  }
+  return ok == 1;
+}
+static inline unsigned bf_spin_limit() {
+  static long long lim = -1;
+  if (lim < 0) {
+    const char* e = getenv("SIVAE_BN_FUSED_SPIN_LIMIT");
+    lim = e ? atoll(e) : (long long)BF_SPIN_LIMIT_DEFAULT;
+    if (lim < 16) lim = 16;
+    if (lim > 0x7fffffffLL) lim = 0x7fffffffLL;
+  }
+  return (unsigned)lim;
 }
 
 

@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(Conv1sArgs a) {
     // pixels past the end of the plane are masked through the buffer range (HW % 4 == 0: whole vectors in or out)
     const __amdgpu_buffer_rsrc_t xrs =
         make_rsrc(a.x + (size_t)(live ? b : 0) * Ci * HW, live ? (unsigned long long)Ci * HW * 4ull : 0ull);
-    const unsigned pin = (p0 + 4 * l31 < HW) ? (unsigned)p0 * 4u + xlane : SIVAE_OOB;
+    const unsigned pin = (p0 + 4 * l31 < HW) ? (unsigned)p0 * 4u + xlane : SIVAE_OOB16;  // (16-byte loads)
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(Conv1sArgs a) {
 #define C1S_LOAD(BUF, S0)                                                                          \
   _Pragma("unroll") for (int g = 0; g < C1S_G; ++g) {                                              \
     const int s_ = (S0) + g;                                                                       \
-    BUF[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(s_ < nks ? pin : SIVAE_OOB), (int)((unsigned)s_ * xkstep), 0)); \
+    BUF[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(s_ < nks ? pin : SIVAE_OOB16), (int)((unsigned)s_ * xkstep), 0)); \
   }
 #define C1S_MMA(BUF, S0)                                                                           \
   _Pragma("unroll") for (int g = 0; g < C1S_G; ++g) {                                              \
@@ -105,12 +105,14 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(Conv1sArgs a) {
     const __amdgpu_buffer_rsrc_t yrs =
         make_rsrc(a.y + (size_t)(live ? b : 0) * a.Co * HW, live ? (unsigned long long)a.Co * HW * 4ull : 0ull);
     const unsigned pout = (p0 + 4 * l31 < HW) ? (unsigned)(p0 + 4 * l31) * 4u : SIVAE_OOB;
+    f32x4 v_prev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-        const unsigned off = (co < a.Co && pout != SIVAE_OOB) ? pout + (unsigned)co * (unsigned)HW * 4u : SIVAE_OOB;
+        // (16-byte accesses: SIVAE_OOB16 — at 0xFFFFFFFF the upper three dwords of a store would wrap into the window)
+        const unsigned off = (co < a.Co && pout != SIVAE_OOB) ? pout + (unsigned)co * (unsigned)HW * 4u : SIVAE_OOB16;
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[m][e][r];
@@ -119,7 +121,10 @@ __global__ void __launch_bounds__(256, 2) conv1x1_stream_kernel(Conv1sArgs a) {
           v += __builtin_bit_cast(f32x4, o);
         }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), yrs, (int)off, 0, 0);
+        SIVAE_PIN4(v_prev)  // (store-data lifetime: common.h)
+        v_prev = v;
       }
+    SIVAE_PIN4(v_prev)
   }
 }
 

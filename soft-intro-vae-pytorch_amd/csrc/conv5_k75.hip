@@ -199,18 +199,23 @@ __global__ void __launch_bounds__(256, 2) conv5_k75_kernel(Conv5K75Args a) {
           for (int r = 0; r < 16; ++r)
             tw[((r & 3) + 8 * (r >> 2) + 4 * kk) * K75_TS + l31] = acc[m][t][r] + bias[r];
           const int row = e_r0 + 2 * wave + t;
+          typedef float f32x4p_t __attribute__((ext_vector_type(4)));
+          f32x4p_t fv_prev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int col_l = (lane >> 3) + 8 * i, c4 = (lane & 7) * 4;
             const float4 v = *reinterpret_cast<const float4*>(tw + col_l * K75_TS + c4);
             const int co = m * 32 + col_l;
             const bool ok = co < a.Co && row < H && e_c0 + c4 < W;
-            const unsigned off = ok ? (unsigned)((co * H + row) * W + e_c0 + c4) * 4u : SIVAE_OOB;
+            const unsigned off = ok ? (unsigned)((co * H + row) * W + e_c0 + c4) * 4u : SIVAE_OOB16;  // (16-byte store)
             typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
             typedef float f32x4_t __attribute__((ext_vector_type(4)));
             f32x4_t fv = {v.x, v.y, v.z, v.w};
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, fv), yrs, (int)off, 0, 0);
+            SIVAE_PIN4(fv_prev)  // (store-data lifetime: common.h)
+            fv_prev = fv;
           }
+          SIVAE_PIN4(fv_prev)
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -284,7 +289,7 @@ extern "C" int sivae_conv5_k75_fwd(const float* x, const float* wq, float* y, co
   if (!x || !wq || !y) return SIVAE_ERR_NULL;
   if (B <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
   if (!sivae_conv5_k75_supported(Ci, Co)) return SIVAE_ERR_SHAPE;
-  if ((long long)Co * H * W * 4 >= 0xffffffffLL || (long long)Ci * H * W * 4 >= 0x7fffffffLL) return SIVAE_ERR_RANGE;
+  if ((long long)Co * H * W * 4 >= 0xfffffff0LL || (long long)Ci * H * W * 4 >= 0x7fffffffLL) return SIVAE_ERR_RANGE;
   Conv5K75Args a;
   a.x = x;
   a.wq = wq;

@@ -510,6 +510,13 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
         const int chn = e_co0 + (q >> 4) * 32 + (q & 3) + 8 * ((q & 15) >> 2) + 4 * hh_;
         off0[qi] = chn < a.Co ? (unsigned)((chn * H + e_r0 + 4 * ty_) * W + e_c0 + 4 * tx_) * 4u + img_off : W4_OOB16;
       }
+      // Store-data lifetime (see bn_fused.hip::BF_KEEP): the registers a 16-byte store reads stay pinned until the NEXT
+      // store of the wave has been issued (six LDS reads, their wait and ~20 VALU later; the last one of a round until
+      // the barrier behind it) — nothing recycles them while the store may still be reading its data under
+      // back-pressure.  (Pinning a whole round — 12 registers — spilled 50-80 registers of this 168-register kernel.)
+      float4 held[3];
+      held[0] = held[1] = held[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+#define W4_KEEP(V) asm volatile("" ::"v"((V).x), "v"((V).y), "v"((V).z), "v"((V).w));
 #pragma unroll
       for (int ar = 0; ar < 4; ++ar) {
 #pragma unroll
@@ -534,15 +541,19 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
               const float4 old = buf_load_f32x4(yrsrc, off0[qi], row_off);
               o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
             }
-            if (!((W4_ABLATE & 16) && item >= 0)) buf_store_f32x4(yrsrc, o, off0[qi], row_off);
+            held[qi] = o;
+            if (!((W4_ABLATE & 16) && item >= 0)) buf_store_f32x4(yrsrc, held[qi], off0[qi], row_off);
+            if (qi > 0) W4_KEEP(held[qi - 1])
             ssum[qi] += (o.x + o.y) + (o.z + o.w);
             ssq[qi] += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
           }
         }
         __syncthreads();
+        W4_KEEP(held[1]) W4_KEEP(held[2])
         if (ar == 0) { W4_STAMP(3) }
       }
       W4_STAMP(4)
+#undef W4_KEEP
       if (a.stats != nullptr) {
 #pragma unroll
         for (int qi = 0; qi < 3; ++qi) {
@@ -550,8 +561,8 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
           const float s_ = half_wave_sum_hi(ssum[qi]);
           const float q_ = half_wave_sum_hi(ssq[qi]);
           if (q < 32) {
-            const int chn = e_co0 + (q >> 4) * 32 + (q & 3) + 8 * ((q & 15) >> 2) + 4 * hh;
-            if (l31 == 31 && chn < a.Co) {
+            const int chn = e_co0 + (q >> 4) * 32 + (q & 3) + 8 * ((q & 15) >> 2) + 4 * hh_;
+            if ((lane_ & 31) == 31 && chn < a.Co) {  // (lane_ / hh_: the recomputed lane index — no spill reload here)
               float* dst = a.stats + ((size_t)e_pt * a.Co + chn) * 2;
               dst[0] = s_;
               dst[1] = q_;

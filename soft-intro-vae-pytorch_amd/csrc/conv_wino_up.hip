@@ -288,6 +288,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_kernel(WinoUpArgs a) {
       // row a = pq of the tile: output row 2*(li + pq) + pp, columns 2*lj .. 2*lj + 3 = (b, q) = (0,0) (0,1) (1,0) (1,1)
       const bool rok = pq == 0 ? li < Hs : li + 1 < Hs;
       const unsigned base = (unsigned)((2 * (li + pq) + pp) * W + 2 * lj) * 4u;
+      f32x4 f_prev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int chn = e_co0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -299,8 +300,11 @@ __global__ void __launch_bounds__(256, 2) conv_wino_up_kernel(WinoUpArgs a) {
           typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
           const f32x4 f = {c0_, c1_, c2_, c3_};
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f), yrsrc, (int)cb, 0, 0);
+          SIVAE_PIN4(f_prev)  // (the previous store's data registers stay untouched until this store is issued)
+          f_prev = f;
         }
       }
+      SIVAE_PIN4(f_prev)
     }
     __builtin_amdgcn_s_setprio(0);
     if (!has_next) break;

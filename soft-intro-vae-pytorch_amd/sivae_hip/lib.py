@@ -42,6 +42,7 @@ _CTYPE = {
     "double": ctypes.c_double,
     "size_t": ctypes.c_size_t,
     "unsigned long long": ctypes.c_ulonglong,
+    "long long": ctypes.c_longlong,
     "sivae_stream_t": ctypes.c_void_p,
     "const char*": ctypes.c_char_p,
 }
@@ -97,7 +98,13 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     _protos = parse_header()
     for name, (restype, argtypes) in _protos.items():
-        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn = getattr(lib, name, None)
+        if fn is None:
+            # a declared symbol the .so does not export is an error — except for an OLDER build of the ABI selected with
+            # SIVAE_LIB for an A/B measurement (tools/profile.sh `ab`), which may lack the newest entry points
+            if os.environ.get("SIVAE_LIB") and os.environ.get("SIVAE_LIB_ALLOW_MISSING") == "1":
+                continue
+            raise AttributeError("%s does not export %s (declared in %s)" % (LIB_PATH, name, HEADER_PATH))
         fn.restype = restype
         fn.argtypes = argtypes
     ver = lib.sivae_abi_version()

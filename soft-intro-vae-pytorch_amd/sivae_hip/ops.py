@@ -162,6 +162,25 @@ def bn_fused_state(device):
     return buf
 
 
+def bn_fused_check():
+    """Was a persistent BatchNorm-backward launch abandoned (its grid barrier timed out because the grid was not fully
+    resident — another persistent kernel, a CU mask the runtime does not report)?  Reads one word per barrier state (a
+    device->host copy: call it where results are read back anyway — the training loops do, once per logging interval);
+    if set: zeroes the state (the counters of an abandoned launch are inconsistent) and raises.  The outputs of the
+    abandoned launch and of everything after it are garbage."""
+    if not _bn_states:
+        return
+    w = _lib.load().sivae_bn_bwd_fused_poison_word()
+    bad = [k for k, buf in _bn_states.items() if int(buf[w].item()) != 0]
+    if bad:
+        for k in bad:
+            _bn_states[k].zero_()
+        raise RuntimeError("sivae_hip: a one-pass BatchNorm backward (sivae_bn_bwd_fused) gave up at its grid barrier on "
+                           "device/stream %s: its grid was not fully resident (another persistent kernel or process on "
+                           "the GPU, or a CU mask).  The iteration's gradients are invalid.  Set SIVAE_BN_FUSED=0 (the "
+                           "three-launch form) or SIVAE_BN_FUSED_PERSISTENT=0 for this deployment." % (bad,))
+
+
 def _bn_bwd_fused_ok(x, nseg):
     if not BN_FUSED or SYNC_BN is not None or x.dim() != 4:
         return False
@@ -176,9 +195,17 @@ def _bn_bwd_fused(dy, y, mask, x, mean, invstd, gamma, beta, act_mode, slope, dx
     B, C, H, W = x.shape
     L = _lib.load()
     ws = workspace(L.sivae_bn_bwd_fused_workspace_bytes(B, C, H, W, B // nseg), x.device)
-    _lib.call("sivae_bn_bwd_fused", _p(dy), _p(y), _p(mask), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta),
-              int(act_mode), float(slope), _p(dx), _p(dz), _p(dgamma), _p(dbeta), B, C, H, W, int(bool(dy_pooled)),
-              int(bool(dz_sum)), B // nseg, _p(bn_fused_state(x.device)), _p(ws), ws.numel(), _s(x))
+    try:
+        _lib.call("sivae_bn_bwd_fused", _p(dy), _p(y), _p(mask), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta),
+                  int(act_mode), float(slope), _p(dx), _p(dz), _p(dgamma), _p(dbeta), B, C, H, W, int(bool(dy_pooled)),
+                  int(bool(dz_sum)), B // nseg, _p(bn_fused_state(x.device)), _p(ws), ws.numel(), _s(x))
+    except _lib.SivaeError as e:
+        if e.code != -2:
+            raise
+        # a shape the plan of this variant does not take after all (the query and the launch plan with the same
+        # register budget since round 5, so this is a safety net): the three-launch form takes every shape
+        _bn_bwd_seg(dy, y, mask, x, mean, invstd, gamma, beta, act_mode, slope, dx, dz, dgamma, dbeta, dy_pooled, dz_sum,
+                    nseg)
 
 
 def _out(out, shape, device):

@@ -23,6 +23,7 @@ import torch.nn as nn
 from sivae_hip import data as _data
 from sivae_hip import dp as _dp
 from sivae_hip import engine as _engine
+from sivae_hip import ops as _ops
 from sivae_hip import rng as _rng
 from sivae_hip.engine import calc_kl, calc_reconstruction_loss, reparameterize  # noqa: F401  (reference API)
 from sivae_hip.nn import Decoder, Encoder, ResidualBlock  # noqa: F401
@@ -310,6 +311,7 @@ def _train(dataset, z_dim, lr_e, lr_d, batch_size, num_workers, start_epoch, exi
                 return
             rows = torch.stack(pending).cpu()  # ONE device->host copy for the whole interval
             pending.clear()
+            _ops.bn_fused_check()  # (an abandoned persistent BatchNorm backward raises here instead of trapping the GPU)
             # the abort is COLLECTIVE under DP: every rank drains at the same iterations, the flag is all-reduced, and
             # all ranks raise together (a rank raising alone would leave the others in the next all-reduce)
             if _dp.any_rank(bool(torch.isnan(rows[:, :2]).any()), device if world > 1 else None):

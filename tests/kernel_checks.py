@@ -4,6 +4,7 @@ Each check returns (name, err, tol) where err = max|hip - ref| / (max|ref| + 1e-
 tests/test_kernels_gpu.py (pytest -m gpu) and by `python tests/kernel_checks.py` which prints the
 whole table without stopping at the first failure (one GPU call -> the complete picture).
 """
+import ctypes
 import math
 import sys
 import traceback
@@ -1191,6 +1192,307 @@ def check_bn_bwd_fused():
     return res
 
 
+def _bn_fp64_ref(x, r, gamma, beta, dy, nseg, act, pooled):
+    """torch CPU fp64 reference of BatchNorm2d (training statistics per batch SEGMENT, shared affine) [+ residual]
+    + LeakyReLU(0.2) [+ AvgPool2d(2)] backward (reference ops: train_soft_intro_vae.py:57-63,71-74,90-93)
+    -> dx, dz (gradient of the residual branch, or None), dgamma, dbeta"""
+    xt = x.clone().requires_grad_()
+    gt, bt = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    rt = r.clone().requires_grad_() if act in (1, 3) else None
+    Bs = x.shape[0] // nseg
+    ys = []
+    for g in range(nseg):
+        sl = slice(g * Bs, (g + 1) * Bs)
+        v = F.batch_norm(xt[sl], None, None, gt, bt, True, 0.1, 1e-5)
+        if rt is not None:
+            v = v + rt[sl]
+        if act != 0:
+            v = F.leaky_relu(v, 0.2)
+        ys.append(v)
+    y = torch.cat(ys)
+    if pooled:
+        y = F.avg_pool2d(y, 2)
+    y.backward(dy)
+    return xt.grad, (rt.grad if rt is not None else None), gt.grad, bt.grad
+
+
+def check_bn_bwd_fused_fp64():
+    """the PERSISTENT forms of the one-pass BatchNorm backward (bn_fused.hip) directly against torch CPU fp64 — every
+    sign source, pooled dy, dz at full resolution and as 2x2 block sums — at shapes that force (i) two half-grids walking
+    several groups each, (ii) the one-grid form (a plane set larger than a half-grid holds), (iii) two segments (the
+    last-arriver fold of dgamma / dbeta over segments)."""
+    from sivae_hip import ops
+    res = []
+    L = ops._lib.load()
+    assert ops.BN_FUSED
+    for (B, C, H, W, nseg, what) in [(32, 8, 256, 256, 1, "halfgrids"), (128, 2, 256, 256, 1, "onegrid"),
+                                     (32, 6, 256, 256, 2, "2seg"), (64, 24, 128, 128, 2, "2seg128")]:
+        tag = "_%s(%d,%d,%d,%d,seg%d)" % (what, B, C, H, W, nseg)
+        Bs = B // nseg
+        assert L.sivae_bn_bwd_fused_supported(B, C, H, W, Bs) == 1, tag
+        assert Bs * H * W // 8 > 256 * 10, tag  # (not the barrier-free local form)
+        x = _rand(B, C, H, W, seed=1) * 1.5 + 0.3
+        r = _rand(B, C, H, W, seed=2)
+        gamma, beta = _rand(C, seed=8).abs() + 0.5, _rand(C, seed=9)
+        dy = _rand(B, C, H, W, seed=4)
+        dyh = _rand(B, C, H // 2, W // 2, seed=5)
+        xd, rd, gd, bd, dyd, dyhd = _d(x), _d(r), _d(gamma), _d(beta), _d(dy), _d(dyh)
+        xf = xd.cpu().double()  # (the reference sees the fp32-rounded inputs)
+        rf, gf, bf_, dyf, dyhf = rd.cpu().double(), gd.cpu().double(), bd.cpu().double(), dyd.cpu().double(), dyhd.cpu().double()
+        xs = xf.view(nseg, Bs, C, H * W)
+        mean = _d(xs.mean((1, 3)).reshape(-1))
+        invstd = _d((1.0 / torch.sqrt(xs.var((1, 3), unbiased=False) + 1e-5)).reshape(-1))
+        tol = 2e-5
+        # act 0 (no activation) and act 2 (sign recomputed from x)
+        for act in (0, 2):
+            ref = _bn_fp64_ref(xf, rf, gf, bf_, dyf, nseg, act, False)
+            out = ops.bn_bwd(dyd, None, xd, mean, invstd, gd, 0.2, beta=bd, act_mode=act, nseg=nseg)
+            for n_, i_ in (("dx", 0), ("dgamma", 2), ("dbeta", 3)):
+                res.append(("bn_fused64_act%d_%s%s" % (act, n_, tag), _err(out[i_], ref[i_]), tol))
+        # act 1 (sign from the saved output): dz full, pooled dy, dz block sums
+        y = ops.bn_apply_act(xd, rd, mean, invstd, gd, bd, 0.2, nseg=nseg)
+        ref = _bn_fp64_ref(xf, rf, gf, bf_, dyf, nseg, 1, False)
+        out = ops.bn_bwd(dyd, y, xd, mean, invstd, gd, 0.2, want_dz=True, act_mode=1, nseg=nseg)
+        for n_, i_ in (("dx", 0), ("dz", 1), ("dgamma", 2), ("dbeta", 3)):
+            res.append(("bn_fused64_act1_%s%s" % (n_, tag), _err(out[i_], ref[i_]), tol))
+        out = ops.bn_bwd_dzsum(dyd, y, xd, mean, invstd, gd, 0.2, nseg=nseg)
+        refz = 4.0 * F.avg_pool2d(ref[1], 2)
+        for n_, o_, r_ in (("dx", out[0], ref[0]), ("dzh", out[1], refz), ("dgamma", out[2], ref[2]), ("dbeta", out[3], ref[3])):
+            res.append(("bn_fused64_act1_dzsum_%s%s" % (n_, tag), _err(o_, r_), tol))
+        refp = _bn_fp64_ref(xf, rf, gf, bf_, dyhf, nseg, 1, True)
+        out = ops.bn_bwd(dyhd, y, xd, mean, invstd, gd, 0.2, want_dz=True, act_mode=1, dy_pooled=True, nseg=nseg)
+        for n_, i_ in (("dx", 0), ("dz", 1), ("dgamma", 2), ("dbeta", 3)):
+            res.append(("bn_fused64_act1_pooled_%s%s" % (n_, tag), _err(out[i_], refp[i_]), tol))
+        # act 3 (1-bit sign mask)
+        _, _, mask = ops.bn_apply_act_signmask(xd, rd, mean, invstd, gd, bd, 0.2, nseg=nseg)
+        out = ops.bn_bwd_signmask(dyd, mask, xd, mean, invstd, gd, 0.2, nseg=nseg)
+        for n_, i_ in (("dx", 0), ("dz", 1), ("dgamma", 2), ("dbeta", 3)):
+            res.append(("bn_fused64_mask_%s%s" % (n_, tag), _err(out[i_], ref[i_]), tol))
+        out = ops.bn_bwd_signmask(dyhd, mask, xd, mean, invstd, gd, 0.2, dy_pooled=True, nseg=nseg)
+        for n_, i_ in (("dx", 0), ("dz", 1), ("dgamma", 2), ("dbeta", 3)):
+            res.append(("bn_fused64_mask_pooled_%s%s" % (n_, tag), _err(out[i_], refp[i_]), tol))
+        del x, r, dy, xf, rf, dyf, ref, refp, out, y, mask
+    return res
+
+
+def _side_traffic(stop_after):
+    """a streaming-store / copy load on a second stream (saturates the memory pipe next to the kernel under test);
+    returns (stream, launcher)"""
+    side = torch.cuda.Stream()
+    buf = torch.empty(256 << 20, dtype=torch.float32, device=DEV)  # 1 GiB
+    src = torch.empty(64 << 20, dtype=torch.float32, device=DEV)
+
+    def pump(n):
+        with torch.cuda.stream(side):
+            for i in range(n):
+                buf.fill_(float(i))
+                buf[:src.numel()].copy_(src)
+    return side, pump
+
+
+def check_store_hazard_stress():
+    """Hazard stress (round-4 finding: a 16-byte buffer store picked up rewritten data registers under back-pressure):
+    200 back-to-back calls of the persistent BatchNorm backward at its headline shape 256 x 64 x 256^2 (two segments, sign
+    mask, block-summed dz) with a streaming-store kernel running on a second stream — every result bit-equal to the first,
+    and equal to the three-launch form to rounding; then the same over the 16-byte-store epilogues of conv_wino4
+    (64 -> 64 @ 256^2) and conv_wino_up (64 -> 64 @ 128^2 -> 256^2), 60 calls each."""
+    from sivae_hip import ops
+    res = []
+    side, pump = _side_traffic(0)
+    B, C, H, W, nseg = 256, 64, 256, 256, 2
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(B, C, H, W, device=DEV, generator=g) * 1.5 + 0.3
+    r = torch.randn(B, C, H, W, device=DEV, generator=g)
+    dy = torch.randn(B, C, H, W, device=DEV, generator=g)
+    gamma = torch.rand(C, device=DEV, generator=g) + 0.5
+    beta = torch.randn(C, device=DEV, generator=g)
+    Bs = B // nseg
+    xs = x.view(nseg, Bs, C, H * W)
+    mean = xs.mean((1, 3)).reshape(-1).contiguous()
+    invstd = (1.0 / torch.sqrt(xs.var((1, 3), unbiased=False) + 1e-5)).reshape(-1).contiguous()
+    _, _, mask = ops.bn_apply_act_signmask(x, r, mean, invstd, gamma, beta, 0.2, nseg=nseg)
+    del r
+    first = ops.bn_bwd_signmask(dy, mask, x, mean, invstd, gamma, 0.2, dz_sum=True, nseg=nseg)
+    first = [t.clone() for t in first]
+    torch.cuda.synchronize()
+    nbad = 0
+    for it in range(200):
+        if it % 10 == 0:
+            pump(6)
+        out = ops.bn_bwd_signmask(dy, mask, x, mean, invstd, gamma, 0.2, dz_sum=True, nseg=nseg)
+        nbad += int(not all(torch.equal(a, b) for a, b in zip(out, first)))
+        del out
+    torch.cuda.synchronize()
+    res.append(("hazard_bn_fused_200x_bitwise(256,64,256,256,seg2)", float(nbad), 0.0))
+    ops.BN_FUSED = False
+    try:
+        ref = ops.bn_bwd_signmask(dy, mask, x, mean, invstd, gamma, 0.2, dz_sum=True, nseg=nseg)
+    finally:
+        ops.BN_FUSED = True
+    for n_, i_ in (("dx", 0), ("dzh", 1), ("dgamma", 2), ("dbeta", 3)):
+        res.append(("hazard_bn_fused_vs_3launch_%s" % n_, _err(first[i_], ref[i_]), 3e-6))
+    ops.bn_fused_check()
+    del first, ref, mask, dy, xs
+    # conv_wino4 epilogue
+    w = torch.randn(64, 64, 3, 3, device=DEV, generator=g) / 24.0
+    pw = ops.PackedW(w, 0)
+    y0 = ops.conv2d_fwd(x, pw, 64, 3, want_stats=True)
+    y0 = [t.clone() for t in y0] if isinstance(y0, (tuple, list)) else [y0.clone()]
+    nbad = 0
+    for it in range(60):
+        if it % 10 == 0:
+            pump(6)
+        y1 = ops.conv2d_fwd(x, pw, 64, 3, want_stats=True)
+        y1 = list(y1) if isinstance(y1, (tuple, list)) else [y1]
+        nbad += int(not all(torch.equal(a, b) for a, b in zip(y1, y0) if a is not None))
+        del y1
+    torch.cuda.synchronize()
+    res.append(("hazard_conv_wino4_60x_bitwise(256,64,64,256,256)", float(nbad), 0.0))
+    del y0
+    # conv_wino_up epilogue: conv3x3(upsample2(x_low))
+    xl = x[:, :, :128, :128].contiguous()
+    del x
+    y0 = ops.conv2d_fwd(xl, pw, 64, 3, upsample=True, want_stats=True)
+    y0 = [t.clone() for t in y0] if isinstance(y0, (tuple, list)) else [y0.clone()]
+    nbad = 0
+    for it in range(60):
+        if it % 10 == 0:
+            pump(6)
+        y1 = ops.conv2d_fwd(xl, pw, 64, 3, upsample=True, want_stats=True)
+        y1 = list(y1) if isinstance(y1, (tuple, list)) else [y1]
+        nbad += int(not all(torch.equal(a, b) for a, b in zip(y1, y0) if a is not None))
+        del y1
+    torch.cuda.synchronize()
+    res.append(("hazard_conv_wino_up_60x_bitwise(256,64,64,256,256)", float(nbad), 0.0))
+    return res
+
+
+def check_bn_fused_squatter():
+    """Forward progress and bit-equality of the persistent BatchNorm backward while another kernel HOLDS part of the chip
+    (the footprint of a collective on a side stream: 48 workgroups x 512 threads + 32 KB of LDS each, resident for
+    ~0.4 s): headline shapes 256 x 64 x 256^2 and 256 x 128 x 128^2; then next to a real (world-size-1) `nccl` process
+    group issuing all_reduce(async_op=True) of 110 MB in a loop.  The calls must complete within a bound (no deadlock,
+    no trap, poison word clear) and reproduce the undisturbed bits."""
+    import time
+    from sivae_hip import ops
+    L = ops._lib.load()
+    res = []
+    g = torch.Generator(device=DEV).manual_seed(5)
+    stop = torch.zeros(1, dtype=torch.int32, device=DEV)
+    side = torch.cuda.Stream()
+    for (B, C, H, W, nseg) in [(256, 64, 256, 256, 2), (256, 128, 128, 128, 2)]:
+        tag = "(%d,%d,%d,%d,seg%d)" % (B, C, H, W, nseg)
+        x = torch.randn(B, C, H, W, device=DEV, generator=g) * 1.5 + 0.3
+        dy = torch.randn(B, C, H, W, device=DEV, generator=g)
+        gamma = torch.rand(C, device=DEV, generator=g) + 0.5
+        beta = torch.randn(C, device=DEV, generator=g)
+        Bs = B // nseg
+        xs = x.view(nseg, Bs, C, H * W)
+        mean = xs.mean((1, 3)).reshape(-1).contiguous()
+        invstd = (1.0 / torch.sqrt(xs.var((1, 3), unbiased=False) + 1e-5)).reshape(-1).contiguous()
+        alone = ops.bn_bwd(dy, None, x, mean, invstd, gamma, 0.2, beta=beta, act_mode=2, nseg=nseg)
+        alone = [t.clone() for t in alone if t is not None]
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(5):
+            ops.bn_bwd(dy, None, x, mean, invstd, gamma, 0.2, beta=beta, act_mode=2, nseg=nseg)
+        torch.cuda.synchronize()
+        t_alone = (time.time() - t0) / 5
+        # squatter: 48 x 512 threads x 32 KB for 0.4 s on the side stream, BN calls on the main stream meanwhile
+        stop.zero_()
+        torch.cuda.synchronize()
+        ops._lib.call("sivae_debug_squatter", 48, 512, 32768, 40_000_000, ops._p(stop),
+                      ctypes.c_void_p(side.cuda_stream))
+        t0 = time.time()
+        nbad = 0
+        for _ in range(5):
+            out = ops.bn_bwd(dy, None, x, mean, invstd, gamma, 0.2, beta=beta, act_mode=2, nseg=nseg)
+            out = [t for t in out if t is not None]
+            nbad += int(not all(torch.equal(a, b) for a, b in zip(out, alone)))
+        torch.cuda.current_stream().synchronize()
+        t_sq = (time.time() - t0) / 5
+        stop.fill_(1)  # release the squatter
+        torch.cuda.synchronize()
+        ops.bn_fused_check()
+        res.append(("squatter_bn_fused_bitwise%s" % tag, float(nbad), 0.0))
+        # bound: it may wait for the squatter to leave (0.4 s over 5 calls) but must not hang: < 1 s per call
+        res.append(("squatter_bn_fused_seconds_per_call%s alone=%.4f" % (tag, t_alone), t_sq, 1.0))
+        del x, dy, alone, xs
+    # a real collective on a side stream (world size 1: RCCL still launches its kernel)
+    import os
+    import torch.distributed as dist
+    made = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        made = True
+    try:
+        B, C, H, W, nseg = 256, 64, 256, 256, 2
+        x = torch.randn(B, C, H, W, device=DEV, generator=g) * 1.5 + 0.3
+        dy = torch.randn(B, C, H, W, device=DEV, generator=g)
+        gamma = torch.rand(C, device=DEV, generator=g) + 0.5
+        beta = torch.randn(C, device=DEV, generator=g)
+        xs = x.view(nseg, B // nseg, C, H * W)
+        mean = xs.mean((1, 3)).reshape(-1).contiguous()
+        invstd = (1.0 / torch.sqrt(xs.var((1, 3), unbiased=False) + 1e-5)).reshape(-1).contiguous()
+        alone = [t.clone() for t in ops.bn_bwd(dy, None, x, mean, invstd, gamma, 0.2, beta=beta, act_mode=2, nseg=nseg)
+                 if t is not None]
+        flat = torch.randn(27_500_000, device=DEV, generator=g)  # 110 MB: the encoder's flat gradient
+        torch.cuda.synchronize()
+        t0 = time.time()
+        nbad = 0
+        works = []
+        for it in range(20):
+            with torch.cuda.stream(side):
+                works.append(dist.all_reduce(flat, async_op=True))
+            out = [t for t in ops.bn_bwd(dy, None, x, mean, invstd, gamma, 0.2, beta=beta, act_mode=2, nseg=nseg)
+                   if t is not None]
+            nbad += int(not all(torch.equal(a, b) for a, b in zip(out, alone)))
+        for w_ in works:
+            w_.wait()
+        torch.cuda.synchronize()
+        ops.bn_fused_check()
+        res.append(("nccl_allreduce_bn_fused_bitwise(256,64,256,256,seg2)", float(nbad), 0.0))
+        res.append(("nccl_allreduce_bn_fused_seconds_per_call", (time.time() - t0) / 20, 1.0))
+    finally:
+        if made:
+            dist.destroy_process_group()
+    return res
+
+
+def check_bn_fused_timeout():
+    """the grid barrier's timeout path: a persistent launch that waits for arrivals that never come (test hook) must END
+    — no trap, no hang —, set the poison word (ops.bn_fused_check raises and resets the state), and the next call must
+    work and reproduce the three-launch form."""
+    import os
+    from sivae_hip import ops
+    L = ops._lib.load()
+    res = []
+    B, C, H, W = 32, 8, 256, 256
+    x = _d(_rand(B, C, H, W, seed=1) * 1.5 + 0.3)
+    dy = _d(_rand(B, C, H, W, seed=4))
+    gamma, beta = _d(_rand(C, seed=8).abs() + 0.5), _d(_rand(C, seed=9))
+    mean, invstd = ops.bn_stats(x)
+    good = [t.clone() for t in ops.bn_bwd(dy, None, x, mean, invstd, gamma, 0.2, beta=beta, act_mode=2) if t is not None]
+    torch.cuda.synchronize()
+    ops.bn_fused_check()
+    L.sivae_debug_bn_fused_break_next(1)
+    ops.bn_bwd(dy, None, x, mean, invstd, gamma, 0.2, beta=beta, act_mode=2)  # abandoned after the spin limit
+    torch.cuda.synchronize()  # (returns: the kernel ended by itself)
+    raised = 0.0
+    try:
+        ops.bn_fused_check()
+    except RuntimeError:
+        raised = 1.0
+    res.append(("bn_fused_timeout_raises", 1.0 - raised, 0.0))
+    again = [t for t in ops.bn_bwd(dy, None, x, mean, invstd, gamma, 0.2, beta=beta, act_mode=2) if t is not None]
+    torch.cuda.synchronize()
+    ops.bn_fused_check()
+    res.append(("bn_fused_after_reset_bitwise", float(not all(torch.equal(a, b) for a, b in zip(again, good))), 0.0))
+    return res
+
+
 def all_checks():
     """-> list of (label, thunk) ; every thunk returns a list of (name, err, tol)"""
     checks = []
@@ -1268,6 +1570,10 @@ def all_checks():
     checks.append(("bn_bwd_dzsum", check_bn_bwd_dzsum))
     checks.append(("bn_signmask", check_bn_signmask))
     checks.append(("bn_bwd_fused", check_bn_bwd_fused))
+    checks.append(("bn_bwd_fused_fp64", check_bn_bwd_fused_fp64))
+    checks.append(("store_hazard_stress", check_store_hazard_stress))
+    checks.append(("bn_fused_squatter", check_bn_fused_squatter))
+    checks.append(("bn_fused_timeout", check_bn_fused_timeout))
     checks.append(("output_u8", check_output_u8))
     checks.append(("space_to_depth", check_space_to_depth))
     checks.append(("bn_apply_resup", check_bn_apply_resup))

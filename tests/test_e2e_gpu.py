@@ -361,7 +361,7 @@ def _oracle_vs_hip(cdim, zdim, channels, image_size, B, hp, boot=False, seed=0, 
     opt_e = O.Adam(P, O.trainable_keys(P, "encoder."), lr)
     opt_d = O.Adam(P, O.trainable_keys(P, "decoder."), lr)
     g32_1t = None
-    if referee:
+    if referee is True:  # (referee="fp64": the fp64 run only — a single-threaded fp32 pass of a full-size net takes minutes)
         nthreads = torch.get_num_threads()
         torch.set_num_threads(1)
         P1 = {k: v.clone() for k, v in P.items()}
@@ -379,7 +379,7 @@ def _oracle_vs_hip(cdim, zdim, channels, image_size, B, hp, boot=False, seed=0, 
             problems.append(("E/" + k, err))
     if g64 is not None:
         for k in g64:
-            ref_err = max(_rel(g32[k], g64[k]), _rel(g32_1t[k], g64[k]))
+            ref_err = _rel(g32[k], g64[k]) if g32_1t is None else max(_rel(g32[k], g64[k]), _rel(g32_1t[k], g64[k]))
             hip = grads["E"][k[len("encoder."):]]
             hip_err = _rel(hip, g64[k])
             # (the referee's yardstick is the reference's OWN fp32 error against fp64.  F(4x4,3x3) — the large-map 3x3
@@ -490,6 +490,21 @@ def test_bootstrap256_full_config_vs_oracle():
     vs the live oracle — the full-width counterpart of test_bootstrap_6level_topology_vs_oracle"""
     hp = dict(beta_rec=0.5, beta_kl=1.0, beta_neg=1024.0, gamma_r=1.0)
     assert not _oracle_vs_hip(3, 512, [64, 128, 256, 512, 512, 512], 256, 2, hp, boot=True, seed=5, referee=False)
+
+
+def test_celeb256_exact_net_shard16_vs_oracle():
+    """config 4's PER-GPU dispatch (8 GPUs x 16 images): the exact 256x256 network ([64,128,256,512,512,512], z 512) at
+    B = 16 — split-K F(4x4,3x3) on the deep layers, conv_wino_fwd_splitk_seg, the barrier-free BatchNorm backward — one full
+    iteration vs the CPU oracle, encoder gradients against the fp64 referee"""
+    hp = dict(beta_rec=0.5, beta_kl=1.0, beta_neg=1024.0, gamma_r=1e-8)
+    assert not _oracle_vs_hip(3, 512, [64, 128, 256, 512, 512, 512], 256, 16, hp, seed=12, referee="fp64")
+
+
+def test_bootstrap256_exact_net_shard8_vs_oracle():
+    """config 5's PER-GPU dispatch (8 GPUs x 8 images): the exact bootstrap network at B = 8, one full iteration vs the
+    CPU oracle with the fp64 gradient referee"""
+    hp = dict(beta_rec=0.5, beta_kl=1.0, beta_neg=1024.0, gamma_r=1.0)
+    assert not _oracle_vs_hip(3, 512, [64, 128, 256, 512, 512, 512], 256, 8, hp, boot=True, seed=13, referee="fp64")
 
 
 def test_celeb1024_topology_reduced_width_vs_oracle():

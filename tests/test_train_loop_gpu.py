@@ -75,6 +75,72 @@ def test_bootstrap_entry_point_runs(tmp_path, monkeypatch):
             assert torch.equal(v, sd["target_" + k]), k
 
 
+def test_pretrained_and_start_epoch_through_the_entry_point(tmp_path, monkeypatch):
+    """`pretrained=` + `start_epoch=` (reference train_soft_intro_vae.py:443-444,471): the second call loads the first call's
+    checkpoint (reference format) and runs epochs [start_epoch, num_epochs) only.  With lr 0 nothing but the BatchNorm
+    buffers may move: the weights stay bit-equal to the checkpoint, and the BatchNorm pass counter shows exactly one
+    Soft-Intro epoch on top of the loaded one."""
+    import train_soft_intro_vae as T
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("SIVAE_SYNTHETIC_IMAGES", "32")
+    dev = torch.device("cuda:0")
+    kw = dict(dataset="synthetic-cifar10", z_dim=16, batch_size=16, num_workers=0, beta_kl=1.0, beta_rec=1.0, beta_neg=256,
+              seed=7, test_iter=1000, device=dev)
+    m1 = T.train_soft_intro_vae(num_epochs=1, save_interval=1, **kw)
+    sd1 = {k: v.clone() for k, v in m1.state_dict().items()}
+    ckpts = sorted(c for c in os.listdir(tmp_path / "saves") if c.endswith(".pth"))
+    assert ckpts
+    path = str(tmp_path / "saves" / ckpts[-1])
+    saved = torch.load(path, map_location="cpu")
+    assert set(saved) == {"epoch", "model"}
+    m2 = T.train_soft_intro_vae(num_epochs=2, start_epoch=1, pretrained=path, lr_e=0.0, lr_d=0.0, save_interval=50, **kw)
+    sd2 = m2.state_dict()
+    for k, v in saved["model"].items():
+        if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            continue
+        assert torch.equal(sd2[k].cpu(), v), k  # (started from the checkpoint, lr 0: unchanged)
+    # the constructor's probe pass does not survive load_model (the counter is loaded): checkpoint value + one epoch of
+    # 2 iterations x 5 encoder passes + the deterministic dump at cur_iter 0 (test_iter) + the final dump
+    n0 = int(saved["model"]["encoder.main.1.num_batches_tracked"])
+    assert n0 == int(sd1["encoder.main.1.num_batches_tracked"])
+    assert int(sd2["encoder.main.1.num_batches_tracked"]) == n0 + 2 * 5 + 1 + 1
+    # start_epoch == num_epochs: no epoch runs at all, the loaded model comes back as is
+    m3 = T.train_soft_intro_vae(num_epochs=1, start_epoch=1, pretrained=path, save_interval=50, **kw)
+    for k, v in saved["model"].items():
+        assert torch.equal(m3.state_dict()[k].cpu(), v), k
+
+
+def test_exit_on_negative_diff_through_the_entry_point(tmp_path, monkeypatch):
+    """`exit_on_negative_diff` (reference :652-657): after epoch 50 an epoch whose mean kl_fake - kl_real is below -1
+    aborts with SystemError("Negative KL Difference"); with the flag off the same run completes.  The statistics come from
+    the real engine (one real iteration per epoch on the GPU) with kl_fake shifted down by 5 on the device, so the abort
+    is decided by the loop's own epoch means."""
+    import train_soft_intro_vae as T
+    from sivae_hip import engine as E
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("SIVAE_SYNTHETIC_IMAGES", "8")
+    orig = E.SoftIntroEngine.soft_intro_step
+    i_fake, i_real = E.STAT_NAMES.index("kl_fake"), E.STAT_NAMES.index("kl_real")
+    calls = []
+
+    def shifted(self, real, *a, **k):
+        out = orig(self, real, *a, **k)
+        st = out["stats"].clone()
+        st[i_fake] = st[i_real] - 5.0
+        out["stats"] = st
+        calls.append(1)
+        return out
+    monkeypatch.setattr(E.SoftIntroEngine, "soft_intro_step", shifted)
+    kw = dict(dataset="synthetic-cifar10", z_dim=16, batch_size=8, num_workers=0, beta_kl=1.0, beta_rec=1.0, beta_neg=256,
+              seed=9, test_iter=100000, save_interval=1000, device=torch.device("cuda:0"))
+    with pytest.raises(SystemError, match="Negative KL Difference"):
+        T.train_soft_intro_vae(num_epochs=60, exit_on_negative_diff=True, **kw)
+    assert len(calls) == 52  # epochs 0..51: the check needs epoch > 50 (reference :652)
+    calls.clear()
+    T.train_soft_intro_vae(num_epochs=53, exit_on_negative_diff=False, **kw)
+    assert len(calls) == 53
+
+
 def test_nan_raises_system_error(tmp_path, monkeypatch):
     import train_soft_intro_vae as T
     monkeypatch.chdir(tmp_path)

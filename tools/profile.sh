@@ -70,11 +70,11 @@ PY
       old="$name"
       for rep in 1 2; do
         for which in new old; do
-          if [ $which == old ]; then export SIVAE_LIB="$old"; else unset SIVAE_LIB; fi
+          if [ $which == old ]; then export SIVAE_LIB="$old" SIVAE_LIB_ALLOW_MISSING=1; else unset SIVAE_LIB SIVAE_LIB_ALLOW_MISSING; fi
           timeout 400 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-also $flags 2>/dev/null | tail -1 | \
             python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$which', d['value'], d['ms_per_step'])" | tee -a "$O/ab.txt"
         done
-      done; unset SIVAE_LIB ;;
+      done; unset SIVAE_LIB SIVAE_LIB_ALLOW_MISSING ;;
     *) echo "unknown job $job"; exit 2 ;;
   esac
 done
