@@ -549,9 +549,11 @@ int sivae_bn_bwd_fused_state_uints(void);
  * waits for `extra` arrivals per XCD that never come (exercises the timeout path). */
 int sivae_bn_bwd_fused_poison_word(void);
 int sivae_debug_bn_fused_break_next(int extra);
-/* test support: a kernel that only holds `blocks` x `threads` threads + `lds_bytes` of LDS for `ticks` 100-MHz periods (or
- * until *stop != 0) — the footprint of a collective on a side stream next to the persistent kernels */
-int sivae_debug_squatter(int blocks, int threads, int lds_bytes, long long ticks, const int* stop, sivae_stream_t stream);
+/* test support: a kernel that only holds `blocks` x `threads` threads + `lds_bytes` of LDS (fat != 0: and ~200 VGPRs per
+ * wave, so that no wave of a 256-register kernel fits beside it) for `ticks` 100-MHz periods (or until *stop != 0) — the
+ * footprint of a collective on a side stream next to the persistent kernels */
+int sivae_debug_squatter(int blocks, int threads, int lds_bytes, int fat, long long ticks, const int* stop,
+                         sivae_stream_t stream);
 int sivae_bn_bwd_fused(const float* dy, const float* y, const unsigned char* mask, const float* x, const float* mean,
                        const float* invstd, const float* gamma, const float* beta, int act_mode, float slope, float* dx,
                        float* dz_out, float* dgamma, float* dbeta, int B, int C, int H, int W, int dy_pooled, int dz_sum,

@@ -1398,25 +1398,29 @@ def check_bn_fused_squatter():
             ops.bn_bwd(dy, None, x, mean, invstd, gamma, 0.2, beta=beta, act_mode=2, nseg=nseg)
         torch.cuda.synchronize()
         t_alone = (time.time() - t0) / 5
-        # squatter: 48 x 512 threads x 32 KB for 0.4 s on the side stream, BN calls on the main stream meanwhile
-        stop.zero_()
-        torch.cuda.synchronize()
-        ops._lib.call("sivae_debug_squatter", 48, 512, 32768, 40_000_000, ops._p(stop),
-                      ctypes.c_void_p(side.cuda_stream))
-        t0 = time.time()
-        nbad = 0
-        for _ in range(5):
-            out = ops.bn_bwd(dy, None, x, mean, invstd, gamma, 0.2, beta=beta, act_mode=2, nseg=nseg)
-            out = [t for t in out if t is not None]
-            nbad += int(not all(torch.equal(a, b) for a, b in zip(out, alone)))
-        torch.cuda.current_stream().synchronize()
-        t_sq = (time.time() - t0) / 5
-        stop.fill_(1)  # release the squatter
-        torch.cuda.synchronize()
-        ops.bn_fused_check()
-        res.append(("squatter_bn_fused_bitwise%s" % tag, float(nbad), 0.0))
-        # bound: it may wait for the squatter to leave (0.4 s over 5 calls) but must not hang: < 1 s per call
-        res.append(("squatter_bn_fused_seconds_per_call%s alone=%.4f" % (tag, t_alone), t_sq, 1.0))
+        # squatter: 48 x 512 threads x 32 KB for 0.4 s on the side stream, BN calls on the main stream meanwhile.
+        # thin: the BatchNorm grid still fits beside it (slower); fat (~200 VGPRs per wave): 48 CUs take NO BatchNorm block,
+        # the grid is not fully resident -> the first call waits at its barrier until the squatter leaves
+        for fat in (0, 1):
+            stop.zero_()
+            torch.cuda.synchronize()
+            ops._lib.call("sivae_debug_squatter", 48, 512, 32768, fat, 40_000_000, ops._p(stop),
+                          ctypes.c_void_p(side.cuda_stream))
+            t0 = time.time()
+            nbad = 0
+            for _ in range(5):
+                out = ops.bn_bwd(dy, None, x, mean, invstd, gamma, 0.2, beta=beta, act_mode=2, nseg=nseg)
+                out = [t for t in out if t is not None]
+                nbad += int(not all(torch.equal(a, b) for a, b in zip(out, alone)))
+            torch.cuda.current_stream().synchronize()
+            t_sq = (time.time() - t0) / 5
+            stop.fill_(1)  # release the squatter
+            torch.cuda.synchronize()
+            ops.bn_fused_check()  # (no barrier gave up)
+            kind = "fat" if fat else "thin"
+            res.append(("squatter_%s_bn_fused_bitwise%s" % (kind, tag), float(nbad), 0.0))
+            # bound: it may wait for the squatter to leave (0.4 s over 5 calls) but must not hang: < 1 s per call
+            res.append(("squatter_%s_bn_fused_seconds_per_call%s alone=%.4f" % (kind, tag, t_alone), t_sq, 1.0))
         del x, dy, alone, xs
     # a real collective on a side stream (world size 1: RCCL still launches its kernel)
     import os
@@ -1439,6 +1443,7 @@ def check_bn_fused_squatter():
         alone = [t.clone() for t in ops.bn_bwd(dy, None, x, mean, invstd, gamma, 0.2, beta=beta, act_mode=2, nseg=nseg)
                  if t is not None]
         flat = torch.randn(27_500_000, device=DEV, generator=g)  # 110 MB: the encoder's flat gradient
+        dist.all_reduce(flat)  # (communicator set-up happens in the first collective: not part of the timing)
         torch.cuda.synchronize()
         t0 = time.time()
         nbad = 0
