@@ -51,7 +51,8 @@ int sivae_pack_conv_weight(const float* w /*[Co][Ci][ks][ks]*/, float* wp, int C
  * 5).  A job table lives in device memory and is reused from step to step (the packed buffers do not move):
  *   sivae_pack_job_fill   writes job `index` of a HOST table (sivae_pack_job_bytes() bytes per job) for operand form
  *                         0 direct (ks, mode) / 1 Winograd F(2x2,3x3) (mode) / 2 Winograd F(4x4,3x3) (mode) /
- *                         3 upsample-phase forward / 4 upsample-phase data gradient; dst = the buffer the per-weight
+ *                         3 upsample-phase forward / 4 upsample-phase data gradient / 5 Winograd F(4x4,3x3) pre-split
+ *                         into three bf16 pieces (mode; sivae_pack_wino4_b6_weight); dst = the buffer the per-weight
  *                         sivae_pack_* call of that form writes; returns the job's block count (its blocks are
  *                         [first_block, first_block + count) of the launch) or an error code (< 0)
  *   sivae_pack_batch      the launch: jobs_dev = the uploaded table, block_job_dev[b] = job index of block b (uint16) */
@@ -606,6 +607,26 @@ int sivae_conv2d_wino4_fwd_splitk(const float* x, const float* up, float* y, con
                                   const float* pro_gamma, const float* pro_beta, float pro_slope, float* stats_partial, int B,
                                   int Ci, int Co, int H, int W, int accumulate, int seg_images, void* workspace,
                                   size_t workspace_bytes, sivae_stream_t stream);
+
+/* The same F(4x4,3x3) forward / data gradient with its 36 frequency GEMMs on the BF16 matrix pipe and FP32-EXACT products
+ * (conv_wino4_b6.hip, round 5): every fp32 operand is split into three bf16 pieces by truncation (exact), a product is the
+ * fp32 sum of six of the nine piece products (the dropped terms are <= 2^-24 of it) — the accuracy of v_mfma_f32_32x32x2_f32
+ * (profiles/r4_probe_bf16x6_accuracy.txt), at 1/2.7 of its matrix cycles.  Replaces the same nn.Conv2d(k=3, s=1, p=1)
+ * (soft_intro_vae/train_soft_intro_vae.py:56-61) with the same argument meaning as sivae_conv2d_wino4_fwd_pro /
+ * sivae_conv2d_wino4_fwd_splitk (pro_mean may be NULL; no limit on segments x channels: the prologue parameters are read
+ * through scalar loads); `up` = the pre-split operand of sivae_pack_wino4_b6_weight ([j][Ci_pad/16][Co_pad/32][i][piece]
+ * blocks of 64 lanes x 8 bf16, 1.5x the bytes of the fp32 pack); maps: sivae_conv2d_wino4_supported; the split-K plan
+ * and workspace are those of sivae_conv2d_wino4_splitk / _splitk_workspace_bytes. */
+size_t sivae_pack_wino4_b6_weight_bytes(int Co, int Ci, int mode);
+int sivae_pack_wino4_b6_weight(const float* w, void* up, int Co, int Ci, int mode, sivae_stream_t stream);
+int sivae_conv2d_wino4_b6_fwd(const float* x, const void* up, float* y, const float* pro_mean, const float* pro_invstd,
+                              const float* pro_gamma, const float* pro_beta, float pro_slope, float* stats_partial, int B,
+                              int Ci, int Co, int H, int W, int accumulate, int seg_images, sivae_stream_t stream);
+int sivae_conv2d_wino4_b6_fwd_splitk(const float* x, const void* up, float* y, const float* pro_mean,
+                                     const float* pro_invstd, const float* pro_gamma, const float* pro_beta,
+                                     float pro_slope, float* stats_partial, int B, int Ci, int Co, int H, int W,
+                                     int accumulate, int seg_images, void* workspace, size_t workspace_bytes,
+                                     sivae_stream_t stream);
 
 /* Winograd F(4x4,3x3) weight gradient (conv_wino4_wgrad.hip) — the weight half of aten::convolution_backward of the
  * nn.Conv2d(k=3) layers (soft_intro_vae/train_soft_intro_vae.py:56-61) on maps with H % 4 == 0, W % 16 == 0:

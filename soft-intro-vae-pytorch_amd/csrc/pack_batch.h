@@ -20,7 +20,8 @@ struct SivaePackJob {
 #define SIVAE_PACK_WINO4 2
 #define SIVAE_PACK_WINO_UP 3
 #define SIVAE_PACK_WINO_UP_DGRAD 4
-#define SIVAE_PACK_NTYPES 5
+#define SIVAE_PACK_WINO4_B6 5
+#define SIVAE_PACK_NTYPES 6
 
 static inline unsigned sivae_pack_job_blocks(unsigned long long total) {
   unsigned long long nb = (total + 511) / 512;  // ~2 elements (weight pairs: 9 loads, 16-48 stores each) per thread
@@ -33,10 +34,12 @@ static inline unsigned sivae_pack_job_blocks(unsigned long long total) {
 int sivae_packjob_direct(SivaePackJob* j, int Co, int Ci, int ks, int mode);
 int sivae_packjob_wino(SivaePackJob* j, int Co, int Ci, int mode);
 int sivae_packjob_wino4(SivaePackJob* j, int Co, int Ci, int mode);
+int sivae_packjob_wino4_b6(SivaePackJob* j, int Co, int Ci, int mode);
 int sivae_packjob_wino_up(SivaePackJob* j, int Co, int Ci);
 int sivae_packjob_wino_up_dgrad(SivaePackJob* j, int Co, int Ci);
 void sivae_packbatch_direct(const SivaePackJob* jobs, const unsigned short* block_job, int nblocks, hipStream_t s);
 void sivae_packbatch_wino(const SivaePackJob* jobs, const unsigned short* block_job, int nblocks, hipStream_t s);
 void sivae_packbatch_wino4(const SivaePackJob* jobs, const unsigned short* block_job, int nblocks, hipStream_t s);
+void sivae_packbatch_wino4_b6(const SivaePackJob* jobs, const unsigned short* block_job, int nblocks, hipStream_t s);
 void sivae_packbatch_wino_up(const SivaePackJob* jobs, const unsigned short* block_job, int nblocks, hipStream_t s);
 void sivae_packbatch_wino_up_dgrad(const SivaePackJob* jobs, const unsigned short* block_job, int nblocks, hipStream_t s);

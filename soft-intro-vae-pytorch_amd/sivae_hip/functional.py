@@ -81,7 +81,7 @@ def repack(params, owner):
     if not PACK_BATCH:
         return
     L = ops._lib.load()
-    entries, jobs = [], [[] for _ in range(5)]
+    entries, jobs = [], [[] for _ in range(6)]
     for p in params:
         store = p.__dict__.get("_sivae_pack")
         if not store:
@@ -99,7 +99,7 @@ def repack(params, owner):
                 del store[slot]  # (the small-channel 5x5 packs: rebuilt on demand)
     if not entries:
         return
-    key = tuple((f, obj.w.data_ptr(), buf.data_ptr()) for f in range(5) for obj, buf in jobs[f])
+    key = tuple((f, obj.w.data_ptr(), buf.data_ptr()) for f in range(6) for obj, buf in jobs[f])
     plan = owner.__dict__.get("_sivae_pack_plan")
     if plan is None or plan["key"] != key:
         if torch.cuda.is_current_stream_capturing():
@@ -109,7 +109,7 @@ def repack(params, owner):
         jb = L.sivae_pack_job_bytes()
         dev = entries[0][0].device
         launches = []
-        for f in range(5):
+        for f in range(6):
             if not jobs[f]:
                 continue
             if len(jobs[f]) > 32767:

@@ -264,6 +264,15 @@ WINO_UP = os.environ.get("SIVAE_WINO_UP", "1") != "0"  # phase-decomposed F(2x2,
 # Winograd F(4x4,3x3) for the large-map 3x3 convs without a fused prologue (SIVAE_WINO4=0: F(2x2,3x3) everywhere);
 # SIVAE_WINO4_MAXC: largest channel count it takes (its U slab per 64-channel tile is 2.25x the F(2x2,3x3) one)
 WINO4 = os.environ.get("SIVAE_WINO4", "1") != "0"
+# SIVAE_WINO4_B6: the F(4x4,3x3) forward / data gradient on the bf16 matrix pipe with fp32-exact products (six bf16 MFMAs
+# per fp32 product, conv_wino4_b6.hip) for layers with at least SIVAE_WINO4_B6_MINC input channels; 0: the fp32-MFMA kernel
+WINO4_B6 = os.environ.get("SIVAE_WINO4_B6", "0") != "0"
+WINO4_B6_MINC = int(os.environ.get("SIVAE_WINO4_B6_MINC", "16"))
+WINO4_B6_PRO = os.environ.get("SIVAE_WINO4_B6_PRO", "1") != "0"
+
+
+def wino4_b6_takes(Ci, pro):
+    return WINO4_B6 and Ci >= WINO4_B6_MINC and (pro is None or WINO4_B6_PRO)
 WINO4_MAXC = int(os.environ.get("SIVAE_WINO4_MAXC", "512"))
 # F(4x4,3x3) weight gradient (conv_wino4_wgrad.hip); SIVAE_WINO4_WGRAD=0: the F(2x2,3x3) one everywhere
 WINO4_WGRAD = WINO4 and os.environ.get("SIVAE_WINO4_WGRAD", "1") != "0"
@@ -301,7 +310,8 @@ class PackedW:
         return self._direct
 
     # operand forms sivae_pack_batch rebuilds in place: (form id of include/sivae_hip.h, attribute holding the buffer)
-    _BATCH_FORMS = ((0, "_direct"), (1, "_wino"), (2, "_wino4"), (3, "_wino_up"), (4, "_wino_up_dgrad"))
+    _BATCH_FORMS = ((0, "_direct"), (1, "_wino"), (2, "_wino4"), (3, "_wino_up"), (4, "_wino_up_dgrad"),
+                    (5, "_wino4_b6"))
 
     def batch_forms(self):
         """[(form id, buffer)] of the operand forms built so far that the batched repack can rebuild in place"""
@@ -327,6 +337,17 @@ class PackedW:
             _lib.call("sivae_pack_wino4_weight", _p(w), _p(up), Co, Ci, self.mode, _s(w))
             self._wino4 = up
         return self._wino4
+
+    def wino4_b6(self):
+        """the F(4x4,3x3) filter transform pre-split into three bf16 pieces, MFMA-ready (conv_wino4_b6.hip)"""
+        if getattr(self, "_wino4_b6", None) is None:
+            w = self.w
+            Co, Ci = w.shape[0], w.shape[1]
+            nbytes = _lib.load().sivae_pack_wino4_b6_weight_bytes(Co, Ci, self.mode)
+            up = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+            _lib.call("sivae_pack_wino4_b6_weight", _p(w), _p(up), Co, Ci, self.mode, _s(w))
+            self._wino4_b6 = up
+        return self._wino4_b6
 
     def wino_up_dgrad(self):
         if getattr(self, "_wino_up_dgrad", None) is None:
@@ -498,12 +519,14 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
             pm, pi, pg, pb, slope = pro
             _require(pm, pi, pg, pb)
         t0 = TIMER.begin() if TIMER is not None else None
-        _lib.call("sivae_conv2d_wino4_fwd_splitk", _p(x), _p(wp.wino4()), _p(y), _p(pm), _p(pi), _p(pg), _p(pb),
+        b6 = wino4_b6_takes(Ci, pro)
+        _lib.call("sivae_conv2d_wino4_b6_fwd_splitk" if b6 else "sivae_conv2d_wino4_fwd_splitk", _p(x),
+                  _p(wp.wino4_b6() if b6 else wp.wino4()), _p(y), _p(pm), _p(pi), _p(pg), _p(pb),
                   float(slope), _p(stats), B, Ci, Co, H, W, int(bool(accumulate)), (B // nseg) if nseg > 1 else 0,
                   _p(ws), ws.numel(), _s(x))
         if t0 is not None:
             flops = 2.0 * B * H * W * Co * Ci * 9
-            TIMER.end("conv_wino4_kernel<%s>" % ("true" if pro is not None else "false"), flops, t0,
+            TIMER.end("conv_wino4%s_kernel<%s>" % ("_b6" if b6 else "", "true" if pro is not None else "false"), flops, t0,
                       executed=flops * 36.0 / 144.0)
         return (y, stats) if want_stats else y
     if w4_ok and (L.sivae_conv2d_wino4_pays(B, Ci, Co, H, W) == 1 or WINO4_FORCE):
@@ -514,7 +537,17 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
         stats = (torch.empty((L.sivae_conv2d_wino4_num_px_tiles(B, H, W), Co, 2), dtype=torch.float32, device=x.device)
                  if want_stats else None)
         t0 = TIMER.begin() if TIMER is not None else None
-        if pro is not None:
+        b6 = wino4_b6_takes(Ci, pro)
+        if b6:
+            pm = pi = pg = pb = None
+            slope = 1.0
+            if pro is not None:
+                pm, pi, pg, pb, slope = pro
+                _require(pm, pi, pg, pb)
+            _lib.call("sivae_conv2d_wino4_b6_fwd", _p(x), _p(wp.wino4_b6()), _p(y), _p(pm), _p(pi), _p(pg), _p(pb),
+                      float(slope), _p(stats), B, Ci, Co, H, W, int(bool(accumulate)), (B // nseg) if nseg > 1 else 0,
+                      _s(x))
+        elif pro is not None:
             pm, pi, pg, pb, slope = pro
             _require(pm, pi, pg, pb)
             _lib.call("sivae_conv2d_wino4_fwd_pro", _p(x), _p(wp.wino4()), _p(y), _p(pm), _p(pi), _p(pg), _p(pb),
@@ -525,7 +558,7 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
                       int(bool(accumulate)), _s(x))
         if t0 is not None:
             flops = 2.0 * B * H * W * Co * Ci * 9
-            TIMER.end("conv_wino4_kernel<%s>" % ("true" if pro is not None else "false"), flops, t0,
+            TIMER.end("conv_wino4%s_kernel<%s>" % ("_b6" if b6 else "", "true" if pro is not None else "false"), flops, t0,
                       executed=flops * 36.0 / 144.0)
         return (y, stats) if want_stats else y
     wino = (WINO and ks == 3 and bias is None and isinstance(wp, PackedW)

@@ -631,8 +631,9 @@ def check_conv1x1_stream():
 WINO4_TOL = 4e-5  # F(4x4,3x3) in fp32: transform coefficients up to 8 and 1/24 (measured 0.5-1.5e-5 per layer)
 
 
-def check_wino4(shape, accumulate=False, stats=False, mode=0):
-    """F(4x4,3x3) kernel (conv_wino4.hip) vs the fp64 convolution: forward (mode 0) / data gradient (mode 1)"""
+def check_wino4(shape, accumulate=False, stats=False, mode=0, b6=False):
+    """F(4x4,3x3) kernel (conv_wino4.hip; b6: conv_wino4_b6.hip, six bf16 MFMAs per fp32 product — SAME tolerances) vs the
+    fp64 convolution: forward (mode 0) / data gradient (mode 1)"""
     from sivae_hip import lib, ops
     B, Ci, Co, H, W = shape
     L = lib.load()
@@ -648,18 +649,22 @@ def check_wino4(shape, accumulate=False, stats=False, mode=0):
         _conv_ref(xin, w).backward(x)
         ref = xin.grad
     wp = ops.PackedW(_d(w), mode)
-    up = wp.wino4()
+    up = wp.wino4_b6() if b6 else wp.wino4()
     y0 = _rand(B, Co, H, W, seed=7) if accumulate else None
     y = _d(y0) if accumulate else torch.empty((B, Co, H, W), dtype=torch.float32, device=DEV)
     part = (torch.empty((L.sivae_conv2d_wino4_num_px_tiles(B, H, W), Co, 2), dtype=torch.float32, device=DEV)
             if stats else None)
     xd = _d(x)  # (named: a temporary would be freed — and its block reused — before the launch reads it)
-    lib.call("sivae_conv2d_wino4_fwd", ops._p(xd), ops._p(up), ops._p(y), ops._p(part), B, Ci, Co, H, W,
-             int(accumulate), ops._s())
+    if b6:
+        lib.call("sivae_conv2d_wino4_b6_fwd", ops._p(xd), ops._p(up), ops._p(y), None, None, None, None, 1.0, ops._p(part),
+                 B, Ci, Co, H, W, int(accumulate), 0, ops._s())
+    else:
+        lib.call("sivae_conv2d_wino4_fwd", ops._p(xd), ops._p(up), ops._p(y), ops._p(part), B, Ci, Co, H, W,
+                 int(accumulate), ops._s())
     torch.cuda.synchronize()
     if accumulate:
         ref = ref + y0
-    tag = "wino4_%s%s%s" % ("fwd" if mode == 0 else "dgrad", "_acc" if accumulate else "", shape)
+    tag = "wino4%s_%s%s%s" % ("b6" if b6 else "", "fwd" if mode == 0 else "dgrad", "_acc" if accumulate else "", shape)
     res.append((tag, _err(y, ref), WINO4_TOL))
     if stats:
         s = part.double().sum(0).cpu()
@@ -676,7 +681,7 @@ def check_wino4(shape, accumulate=False, stats=False, mode=0):
     return res
 
 
-def check_wino4_splitk(shape, pro=False, nseg=1, accumulate=False):
+def check_wino4_splitk(shape, pro=False, nseg=1, accumulate=False, b6=False):
     """split-K form of the F(4x4,3x3) kernel (few work items): output, accumulate, per-image statistics, prologue/segments"""
     from sivae_hip import lib, ops
     B, Ci, Co, H, W = shape
@@ -707,13 +712,13 @@ def check_wino4_splitk(shape, pro=False, nseg=1, accumulate=False):
         ref = ref + y0
     part = torch.empty((B, Co, 2), dtype=torch.float32, device=DEV)
     wp = ops.PackedW(_d(w), 0)
-    xd, up = _d(x), wp.wino4()
+    xd, up = _d(x), (wp.wino4_b6() if b6 else wp.wino4())
     ws = ops.workspace(L.sivae_conv2d_wino4_splitk_workspace_bytes(B, Ci, Co, H, W), xd.device)
-    lib.call("sivae_conv2d_wino4_fwd_splitk", ops._p(xd), ops._p(up), ops._p(y), ops._p(pm), ops._p(pi), ops._p(pg),
+    lib.call("sivae_conv2d_wino4_b6_fwd_splitk" if b6 else "sivae_conv2d_wino4_fwd_splitk", ops._p(xd), ops._p(up), ops._p(y), ops._p(pm), ops._p(pi), ops._p(pg),
              ops._p(pb), 0.2, ops._p(part), B, Ci, Co, H, W, int(accumulate), (B // nseg) if nseg > 1 else 0, ops._p(ws),
              ws.numel(), ops._s())
     torch.cuda.synchronize()
-    tag = "wino4_splitk%s%s%s%s" % ("_pro" if pro else "", "_seg%d" % nseg if nseg > 1 else "", "_acc" if accumulate else "",
+    tag = "wino4%s_splitk%s%s%s%s" % ("b6" if b6 else "", "_pro" if pro else "", "_seg%d" % nseg if nseg > 1 else "", "_acc" if accumulate else "",
                                    shape)
     res.append((tag, _err(y, ref), WINO4_TOL))
     res.append((tag + "_stats_rows", _err(part.double().cpu()[..., 0], ref.sum((2, 3))), 4e-5))
@@ -721,7 +726,7 @@ def check_wino4_splitk(shape, pro=False, nseg=1, accumulate=False):
     return res
 
 
-def check_wino4_pro(shape, nseg=1):
+def check_wino4_pro(shape, nseg=1, b6=False):
     """F(4x4,3x3) with the fused BatchNorm + LeakyReLU prologue (and per-segment statistics) vs fp64"""
     from sivae_hip import ops
     B, Ci, Co, H, W = shape
@@ -743,14 +748,35 @@ def check_wino4_pro(shape, nseg=1):
     y = torch.empty((B, Co, H, W), dtype=torch.float32, device=DEV)
     part = torch.empty((L.sivae_conv2d_wino4_num_px_tiles(B, H, W), Co, 2), dtype=torch.float32, device=DEV)
     pm, pi, pg, pb = _d(mean.reshape(-1)), _d(invstd.reshape(-1)), _d(gamma), _d(beta)
-    xd, up = _d(x), wp.wino4()  # (named: a temporary would be freed — and its block reused — before the launch reads it)
+    xd, up = _d(x), (wp.wino4_b6() if b6 else wp.wino4())  # (named: a temporary would be freed before the launch reads it)
     # (straight through the C ABI: ops.conv2d_fwd only picks this kernel from one work item per CU up)
-    lib.call("sivae_conv2d_wino4_fwd_pro", ops._p(xd), ops._p(up), ops._p(y), ops._p(pm), ops._p(pi), ops._p(pg),
+    lib.call("sivae_conv2d_wino4_b6_fwd" if b6 else "sivae_conv2d_wino4_fwd_pro", ops._p(xd), ops._p(up), ops._p(y), ops._p(pm), ops._p(pi), ops._p(pg),
              ops._p(pb), 0.2, ops._p(part), B, Ci, Co, H, W, 0, (B // nseg) if nseg > 1 else 0, ops._s())
     torch.cuda.synchronize()
-    tag = "wino4_pro%s%s" % ("_seg%d" % nseg if nseg > 1 else "", shape)
+    tag = "wino4%s_pro%s%s" % ("b6" if b6 else "", "_seg%d" % nseg if nseg > 1 else "", shape)
     s_ = part.double().sum(0).cpu()
     return [(tag, _err(y, ref), WINO4_TOL), (tag + "_stats_sum", _err(s_[:, 0], ref.sum((0, 2, 3))), 4e-5)]
+
+
+def check_wino4_b6_pack():
+    """the pre-split operand of conv_wino4_b6.hip: the three bf16 pieces of every entry add up to the fp32 U of
+    sivae_pack_wino4_weight EXACTLY (the split is by truncation), in the MFMA-ready block order, both modes, ragged channels"""
+    from sivae_hip import ops
+    res = []
+    for (Co, Ci, mode) in [(64, 64, 0), (72, 100, 0), (40, 130, 1), (128, 32, 1)]:
+        w = _d(_rand(Co, Ci, 3, 3, seed=Co + Ci))
+        wp = ops.PackedW(w, mode)
+        kdim, ndim = (Ci, Co) if mode == 0 else (Co, Ci)
+        kpad, npad = (kdim + 31) // 32 * 32, (ndim + 63) // 64 * 64
+        u32 = wp.wino4().view(6, kpad, npad, 6).cpu()          # [j][k][n][i]
+        raw = wp.wino4_b6().cpu().view(torch.int16)             # bf16 bit patterns
+        blk = raw.view(6, kpad // 16, npad // 32, 6, 3, 64, 8)   # [j][step][sub][i][piece][lane][e]
+        f = (blk.to(torch.int32) << 16).view(torch.float32).double().sum(4)  # pieces added (exactly representable sums)
+        # lane = (n & 31) + 32 kg, k = 16 step + 8 kg + e
+        f = f.view(6, kpad // 16, npad // 32, 6, 2, 32, 8)       # [j][step][sub][i][kg][n31][e]
+        f = f.permute(0, 1, 4, 6, 2, 5, 3).reshape(6, kpad, npad, 6)  # [j][step,kg,e -> k][sub,n31 -> n][i]
+        res.append(("wino4b6_pack_exact(Co%d,Ci%d,mode%d)" % (Co, Ci, mode), float((f - u32.double()).abs().max()), 0.0))
+    return res
 
 
 def check_wino4_wgrad(shape, pro=False, nseg=1):
@@ -1554,6 +1580,24 @@ def all_checks():
                        + check_wino4_splitk(s, pro=True)))
     checks.append(("wino4_splitk_seg", lambda: check_wino4_splitk((4, 256, 64, 32, 32), pro=True, nseg=2)
                    + check_wino4_splitk((8, 512, 64, 16, 16), pro=True, nseg=2)))
+    # the same F(4x4,3x3) checks on the bf16-pipe kernel with fp32-exact products (conv_wino4_b6.hip): tolerances unchanged
+    checks.append(("wino4b6_pack", check_wino4_b6_pack))
+    for s in [(2, 64, 64, 32, 32), (1, 64, 128, 16, 64), (3, 128, 64, 32, 32), (2, 32, 40, 16, 32), (1, 256, 256, 32, 32),
+              (2, 100, 72, 48, 64)]:
+        checks.append(("wino4b6%s" % (s,), lambda s=s: check_wino4(s, stats=True, b6=True)
+                       + check_wino4(s, accumulate=True, b6=True) + check_wino4(s, mode=1, b6=True)))
+    for s in [(2, 64, 64, 32, 32), (4, 128, 64, 16, 32), (2, 100, 72, 48, 64), (2, 512, 64, 16, 32)]:
+        checks.append(("wino4b6_pro%s" % (s,), lambda s=s: check_wino4_pro(s, b6=True) + check_wino4_pro(s, nseg=2, b6=True)))
+    for s in [(2, 64, 64, 16, 16), (6, 40, 72, 16, 16), (4, 512, 128, 16, 16)]:
+        checks.append(("wino4b6_pair%s" % (s,), lambda s=s: check_wino4(s, stats=True, b6=True)
+                       + check_wino4(s, accumulate=True, b6=True) + check_wino4(s, mode=1, b6=True)))
+    for s in [(4, 64, 64, 16, 16), (8, 96, 40, 16, 16)]:
+        checks.append(("wino4b6_pair_pro%s" % (s,), lambda s=s: check_wino4_pro(s, b6=True) + check_wino4_pro(s, nseg=2, b6=True)))
+    for s in [(2, 256, 64, 32, 32), (4, 512, 128, 16, 16), (1, 128, 100, 16, 32)]:
+        checks.append(("wino4b6_splitk%s" % (s,), lambda s=s: check_wino4_splitk(s, b6=True)
+                       + check_wino4_splitk(s, accumulate=True, b6=True) + check_wino4_splitk(s, pro=True, b6=True)))
+    checks.append(("wino4b6_splitk_seg", lambda: check_wino4_splitk((4, 256, 64, 32, 32), pro=True, nseg=2, b6=True)
+                   + check_wino4_splitk((8, 512, 64, 16, 16), pro=True, nseg=2, b6=True)))
     for s in [(2, 64, 64, 32, 32), (1, 32, 64, 16, 16), (4, 128, 64, 16, 32), (3, 100, 72, 48, 64), (2, 96, 160, 8, 48),
               (7, 64, 128, 4, 16)]:
         checks.append(("wino4_wgrad%s" % (s,), lambda s=s: check_wino4_wgrad(s) + check_wino4_wgrad(s, pro=True)))
