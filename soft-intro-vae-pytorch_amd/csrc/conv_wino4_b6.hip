@@ -72,6 +72,27 @@ __device__ __forceinline__ void b6_store_f32x4(__amdgpu_buffer_rsrc_t r, float4 
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f), r, (int)voff, (int)soff, 0);
 }
 
+// Timing ablations (compile with -DB6_ABLATE=<bits>; results are WRONG with any bit set — tools/b6_timing.py):
+//   1 no A-operand loads, 2 no T phase, 4 no halo requests, 8 no MFMAs, 16 no B-operand reads
+#ifndef B6_ABLATE
+#define B6_ABLATE 0
+#endif
+#ifndef B6_PREFETCH
+#define B6_PREFETCH 0
+#endif
+// Phase times (a -DB6_TIMING build only; tools/b6_timing.py): every wave reads the 100 MHz wall clock at the phase
+// boundaries and keeps running totals in scalar registers — no memory traffic inside the loop; wave 0 of a block writes
+// {T phases, M phases, epilogues + item set-up, steps, items} at the end.
+#ifdef B6_TIMING
+__device__ long long b6_dbg[256 * 8];
+extern "C" int sivae_debug_b6_read(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(b6_dbg), sizeof(long long) * 256 * 8);
+}
+#define B6_CLK(V) const long long V = (long long)wall_clock64();
+#else
+#define B6_CLK(V)
+#endif
+
 typedef const float __attribute__((address_space(4))) * b6_cptr;  // constant address space: uniform loads become s_load
 
 template <bool PRO>
@@ -81,6 +102,9 @@ __global__ void __launch_bounds__(B6_NT, 1) conv_wino4_b6_kernel(Wino4B6Args a) 
   __shared__ __attribute__((aligned(16))) float raw0[XBUF];
   __shared__ __attribute__((aligned(16))) float raw1[XBUF];
   __shared__ __attribute__((aligned(16))) unsigned vp[B6_VP];
+  // target of the halo PREFETCH (LDS-direct loads of the step after next whose only purpose is to pull the lines into L2
+  // a whole step early; every wave writes the same 1 KB, nobody reads it)
+  __shared__ __attribute__((aligned(16))) float sink[256];
 #define RAWB(BUF) ((BUF) ? raw1 : raw0)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -120,11 +144,16 @@ __global__ void __launch_bounds__(B6_NT, 1) conv_wino4_b6_kernel(Wino4B6Args a) 
 
   int item = blockIdx.x;
   if (a.xcd_group) item = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+  // Item coordinates (B6_SETUP: the item whose halo the REAL requests fetch, whose U stream the M phase reads and — through
+  // the e_* copies taken at its start — whose outputs the epilogue stores) and the light set the halo PREFETCH needs when
+  // it has reached the next item (B6_SETUP_PF, from the second-last step of an item on: image, K-slice base, lane offset).
   int b, r0, c0, co0, pt;
   int cbase = 0, kslice = 0;
   __amdgpu_buffer_rsrc_t xrsrc;
   unsigned xo, ua_base;
   int pseg = 0;
+  int b_p = 0, cbase_p = 0;
+  unsigned xo_p = SIVAE_OOB;
 #define B6_SETUP(ITEM)                                                   \
   {                                                                      \
     const int co_tile = (ITEM) % a.n_co_tiles;                           \
@@ -147,16 +176,28 @@ __global__ void __launch_bounds__(B6_NT, 1) conv_wino4_b6_kernel(Wino4B6Args a) 
     ua_base = (unsigned)(((wj * nsteps_all + (cbase >> 4)) * n_cosub + (co0 >> 5) + ws)) * (18u * B6_ABLK); \
     if (PRO) pseg = (b / a.pro_seg_images) * a.Ci + cbase;               \
   }
-  // halo of step ST: four 16-byte LDS-direct loads per wave (planes dpl0, dpl0 + 4 of both halves)
-#define B6_DMA(ST)                                                       \
-  _Pragma("unroll") for (int n_ = 0; n_ < 4; ++n_) {                     \
+#define B6_SETUP_PF(ITEM)                                                \
+  {                                                                      \
+    const int iq_ = (ITEM) / a.n_co_tiles;                               \
+    const int ptq_ = iq_ / a.ksl;                                        \
+    cbase_p = (iq_ % a.ksl) * a.sps * 16;                                \
+    const int t2 = ptq_ / a.nbw;                                         \
+    b_p = a.two ? 2 * ptq_ : t2 / a.nbh;                                 \
+    const int r = (t2 % a.nbh) * B6_PXH - 1 + prow, c = (ptq_ % a.nbw) * B6_PXW - 4 + 4 * pk; \
+    xo_p = (pvalid && r >= 0 && r < H && c >= 0 && c < two_w)            \
+               ? (unsigned)((c >> 4) * two_img + r * W + (c & two_mask)) * 4u : SIVAE_OOB; \
+  }
+  // halo of step ST of item set (XR, XO, CB): four 16-byte LDS-direct loads per wave (planes dpl0, dpl0 + 4 of both halves)
+#define B6_DMA_TO(ST, XR, XO, CB, SINK)                                  \
+  if (!((B6_ABLATE & 4) && item >= 0)) _Pragma("unroll") for (int n_ = 0; n_ < 4; ++n_) { \
     const int ck = dpl0 + 4 * (n_ & 1);                                  \
-    const int ci = cbase + (ST)*16 + 8 * (n_ >> 1) + ck;                 \
+    const int ci = (CB) + (ST)*16 + 8 * (n_ >> 1) + ck;                  \
     const int cic = ci < a.Ci ? ci : a.Ci - 1;                           \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(                            \
-        xrsrc, (float __attribute__((address_space(3)))*)(RAWB(n_ >> 1) + ck * PLANE + dsub * 256), 16, xo, \
+        XR, (float __attribute__((address_space(3)))*)((SINK) ? sink : RAWB(n_ >> 1) + ck * PLANE + dsub * 256), 16, XO, \
         (unsigned)cic * (unsigned)HW * 4u, 0, 0);                        \
   }
+#define B6_DMA(ST) B6_DMA_TO(ST, xrsrc, xo, cbase, false)
   // fused BatchNorm + LeakyReLU prologue on the four groups this thread requested (parameters by scalar loads: the
   // channel is wave-uniform); padded channels (ci >= Ci) become 0 like the zero padding
 #define B6_FIXUP(ST, XO, PSEG, CB)                                       \
@@ -187,9 +228,13 @@ __global__ void __launch_bounds__(B6_NT, 1) conv_wino4_b6_kernel(Wino4B6Args a) 
 
   f32x16 acc[6];
   u32x4_t A0[3], A1[3], A2[3];  // the three-slot ring of A pieces (one frequency each)
+#if B6_ABLATE & 1
+#pragma unroll
+  for (int q_ = 0; q_ < 3; ++q_) A0[q_] = A1[q_] = A2[q_] = u32x4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+#endif
   // A pieces of frequency I of the 16-channel step at byte offset SO of this wave's U stream
 #define B6_LOAD_A(SLOT, SO, I)                                           \
-  {                                                                      \
+  if (!(B6_ABLATE & 1)) {                                                \
     SLOT[0] = buf_load_u32x4(ursrc, va0, (SO) + (unsigned)(((I)*3 + 0)) * B6_ABLK); \
     SLOT[1] = buf_load_u32x4(ursrc, va0, (SO) + (unsigned)(((I)*3 + 1)) * B6_ABLK); \
     SLOT[2] = buf_load_u32x4(ursrc, va0, (SO) + (unsigned)(((I)*3 + 2)) * B6_ABLK); \
@@ -198,21 +243,24 @@ __global__ void __launch_bounds__(B6_NT, 1) conv_wino4_b6_kernel(Wino4B6Args a) 
 #define B6_LDS_BARRIER asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   // B pieces of frequency I
 #define B6_READB(I, BV)                                                  \
-  {                                                                      \
+  if (!(B6_ABLATE & 16)) {                                               \
     const unsigned* p_ = vp + (I)*6 * B6_FSTR + vrb_;                    \
     _Pragma("unroll") for (int pc = 0; pc < 3; ++pc)                     \
       _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_) BV[pc][m_] = p_[pc * B6_PSTR + m_ * 32]; \
   }
 #define B6_MF(I, AP, BP)                                                 \
-  acc[I] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, AP), __builtin_bit_cast(bf16x8_t, BP), \
+  if (!(B6_ABLATE & 8)) acc[I] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, AP), __builtin_bit_cast(bf16x8_t, BP), \
                                                    acc[I], 0, 0, 0);
   // the six products of one frequency, smallest terms first
 #define B6_MMA(I, SLOT, BV)                                              \
   B6_MF(I, SLOT[0], BV[2]) B6_MF(I, SLOT[1], BV[1]) B6_MF(I, SLOT[2], BV[0]) \
   B6_MF(I, SLOT[0], BV[1]) B6_MF(I, SLOT[1], BV[0]) B6_MF(I, SLOT[0], BV[0])
 
-  // ---- transform pieces (conv_wino4's arithmetic): rows R0, R0 + 1 of one channel's patch -> column dot products
-  // (two rows at a time: the 18 staging registers of a three-row read were what pushed the T phase over 168 registers)
+  // ---- transform pieces (conv_wino4's arithmetic): rows R0, R0 + 1 of one channel's patch -> column dot products.
+  // Two rows at a time: with 96 accumulator registers live there are ~70 registers for everything else.  (Requesting all
+  // twelve rows of a thread's two channels up front — one exposed LDS latency per phase instead of six: the twelve waves
+  // leave the step's barrier in lock step — needs 16 registers more than there are: hipcc then spills one accumulator
+  // tile around every T phase and the kernel runs at 0.67x; measured, profiles/r5_conv_wino4_b6_experiments.txt.)
 #define B6_TROWS(P, R0, P05)                                             \
   {                                                                      \
     const float* p_ = (P) + (R0)*RS;                                     \
@@ -223,7 +271,7 @@ __global__ void __launch_bounds__(B6_NT, 1) conv_wino4_b6_kernel(Wino4B6Args a) 
       if (P05) {                                                         \
         te0_[r] = p_[r * RS - 1];                                        \
         te5_[r] = p_[r * RS + 4];                                        \
-        if (a.two) {                                                     \
+        if (a.two) { /* the seam between the two images is zero padding for both (tile columns 3 | 4) */ \
           asm volatile("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(te0_[r]) : "s"(seam_m0)); \
           asm volatile("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(te5_[r]) : "s"(seam_m5)); \
         }                                                                \
@@ -261,14 +309,6 @@ __global__ void __launch_bounds__(B6_NT, 1) conv_wino4_b6_kernel(Wino4B6Args a) 
     OUT[4] = fmaf(-2.f, D_, C_);                                         \
     OUT[5] = fmaf(4.f, T[1], fmaf(-5.f, T[3], T[5]));                    \
   }
-  // one channel: six patch rows -> 12 transformed values OUT[0..5] (column jA), OUT[6..11] (column jB)
-#define B6_TCHAN(P, OUT, P05)                                            \
-  {                                                                      \
-    float tA_[6], tB_[6];                                                \
-    B6_TSTAGE1(P, P05)                                                   \
-    B6_TCOL(tA_, (OUT))                                                  \
-    B6_TCOL(tB_, ((OUT) + 6))                                            \
-  }
   // exact three-way split of the pair (X: channel 2 tc, Y: channel 2 tc + 1) of frequency (I, J): three packed dwords
 #define B6_SPLIT_STORE(X, Y, I, J)                                       \
   {                                                                      \
@@ -285,13 +325,17 @@ __global__ void __launch_bounds__(B6_NT, 1) conv_wino4_b6_kernel(Wino4B6Args a) 
   }
   // T phase of one step: raw halves (this wave's: kgT) -> Vp.  Channel a is transformed first (12 values kept), then channel
   // b column by column, each column's six pairs split and stored at once: the live set stays at ~42 registers next to the
-  // 96 accumulators and the 12 registers of the A pieces in flight (the scheduling fences keep hipcc from interleaving
-  // the two channels, which spilled ~100 registers).
+  // 96 accumulators (the scheduling fences keep hipcc from interleaving the two channels, which spilled ~100 registers).
 #define B6_TPHASE(P05)                                                   \
   {                                                                      \
     float va_[12];                                                       \
     const float* pa_ = RAWB(kgT) + trb_;                                 \
-    B6_TCHAN(pa_, va_, P05)                                              \
+    {                                                                    \
+      float tA_[6], tB_[6];                                              \
+      B6_TSTAGE1(pa_, P05)                                               \
+      B6_TCOL(tA_, va_)                                                  \
+      B6_TCOL(tB_, (va_ + 6))                                            \
+    }                                                                    \
     B6_FENCE                                                             \
     {                                                                    \
       float tA_[6], tB_[6];                                              \
@@ -317,22 +361,25 @@ __global__ void __launch_bounds__(B6_NT, 1) conv_wino4_b6_kernel(Wino4B6Args a) 
   // halo (the next item's first step at the end of an item) is requested right after the T phase's barrier.
 #define B6_STEP(ST, P05)                                                 \
   {                                                                      \
-    u32x4_t bv_[3];                                                      \
+    u32x4_t bv_[3], bw_[3];                                              \
+    B6_CLK(c0_)                                                          \
     const unsigned so_ = ua_cur + (unsigned)(ST)*ua_step;                \
     /* laundered once per step: otherwise hipcc hoists the ~110 LDS addresses of a step (base + constant) out of the K \
        loop as loop invariants, spills them, and reloads one from scratch in front of every ds_read / ds_write */ \
     int vrb_ = vrb, tvb_ = tvb, trb_ = trb;                              \
     asm volatile("" : "+v"(vrb_), "+v"(tvb_), "+v"(trb_));               \
-    B6_TPHASE(P05)                                                       \
+    if (!(B6_ABLATE & 2)) B6_TPHASE(P05) else B6_LOAD_A(A0, so_, 0)      \
     B6_FENCE                                                             \
     B6_LOAD_A(A1, so_, 1)                                                \
     B6_LOAD_A(A2, so_, 2)                                                \
     B6_FENCE                                                             \
     B6_LDS_BARRIER /* Vp complete; raw0 / raw1 free */                   \
+    B6_CLK(c1_)                                                          \
     B6_FENCE                                                             \
     B6_READB(0, bv_)                                                     \
     B6_FENCE                                                             \
     const bool last_ = (ST) + 1 == nsteps;                               \
+    if ((ST) + 2 == nsteps && has_next) B6_SETUP_PF(next)                \
     if (last_ && has_next) B6_SETUP(next)                                \
     const int dst_ = last_ ? 0 : (ST) + 1;                               \
     B6_DMA(dst_)                                                         \
@@ -341,34 +388,53 @@ __global__ void __launch_bounds__(B6_NT, 1) conv_wino4_b6_kernel(Wino4B6Args a) 
     cb_f = cbase;                                                        \
     st_f = dst_;                                                         \
     B6_FENCE                                                             \
+    /* the B pieces are double-buffered: frequency i + 1 is read while the MFMAs of frequency i run (the twelve waves \
+       leave the barrier in lock step: with one buffer every wave sat out the LDS latency with an idle matrix pipe) */ \
+    B6_READB(1, bw_)                                                     \
+    B6_FENCE                                                             \
     B6_MMA(0, A0, bv_)                                                   \
     B6_FENCE                                                             \
     B6_LOAD_A(A0, so_, 3)                                                \
-    B6_READB(1, bv_)                                                     \
+    B6_READB(2, bv_)                                                     \
     B6_FENCE                                                             \
-    B6_MMA(1, A1, bv_)                                                   \
+    B6_MMA(1, A1, bw_)                                                   \
     B6_FENCE                                                             \
     B6_LOAD_A(A1, so_, 4)                                                \
-    B6_READB(2, bv_)                                                     \
+    B6_READB(3, bw_)                                                     \
     B6_FENCE                                                             \
     B6_MMA(2, A2, bv_)                                                   \
     B6_FENCE                                                             \
     B6_LOAD_A(A2, so_, 5)                                                \
-    B6_READB(3, bv_)                                                     \
-    B6_FENCE                                                             \
-    B6_MMA(3, A0, bv_)                                                   \
-    B6_FENCE                                                             \
     B6_READB(4, bv_)                                                     \
+    B6_FENCE                                                             \
+    B6_MMA(3, A0, bw_)                                                   \
+    B6_FENCE                                                             \
+    B6_READB(5, bw_)                                                     \
     B6_FENCE                                                             \
     B6_MMA(4, A1, bv_)                                                   \
     B6_FENCE                                                             \
-    B6_READB(5, bv_)                                                     \
+    B6_MMA(5, A2, bw_)                                                   \
     B6_FENCE                                                             \
-    B6_MMA(5, A2, bv_)                                                   \
-    B6_FENCE                                                             \
-    /* this wave's halo requests have landed; every wave is done reading Vp */ \
-    __builtin_amdgcn_s_waitcnt(0x0F70);                                  \
+    /* PREFETCH: the halo of the step after next (the next item's from the second-last step on) is requested into the \
+       sink — the real request a step later finds the lines in L2 instead of paying an HBM latency inside the M phase.  \
+       These four loads stay outstanding across the barrier (vmcnt(4)): the real requests, older, have landed. */ \
+    if (B6_PREFETCH) {                                                   \
+      const bool wrap_ = (ST) + 2 >= nsteps;                             \
+      const int ps_ = wrap_ ? (ST) + 2 - nsteps : (ST) + 2;              \
+      /* (at the last step B6_SETUP has already moved the R set on to the next item: P == R then) */ \
+      const int bq_ = (wrap_ && !last_) ? b_p : b;                       \
+      const __amdgpu_buffer_rsrc_t xr_ =                                 \
+          make_rsrc(a.x + (size_t)bq_ * a.Ci * HW, (unsigned long long)(a.two ? 2 : 1) * a.Ci * HW * 4ull); \
+      const unsigned xq_ = (wrap_ && !last_) ? xo_p : xo;                \
+      const int cq_ = (wrap_ && !last_) ? cbase_p : cbase;               \
+      B6_DMA_TO(ps_, xr_, xq_, cq_, true)                                \
+      __builtin_amdgcn_s_waitcnt(0x0F74);                                \
+    } else {                                                             \
+      __builtin_amdgcn_s_waitcnt(0x0F70);                                \
+    }                                                                    \
     B6_LDS_BARRIER                                                       \
+    B6_CLK(c2_)                                                          \
+    B6_TACC                                                              \
     if (PRO) {                                                           \
       B6_FIXUP(st_f, xo_f, pseg_f, cb_f)                                 \
       B6_LDS_BARRIER                                                     \
@@ -386,6 +452,13 @@ __global__ void __launch_bounds__(B6_NT, 1) conv_wino4_b6_kernel(Wino4B6Args a) 
     B6_FIXUP(0, xo_f, pseg_f, cb_f)
     B6_LDS_BARRIER
   }
+#ifdef B6_TIMING
+  long long t_T = 0, t_M = 0, t_E = 0, n_st = 0, n_it = 0;
+  long long c_last = (long long)wall_clock64();
+#define B6_TACC { t_E += c0_ - c_last; t_T += c1_ - c0_; t_M += c2_ - c1_; c_last = c2_; ++n_st; }
+#else
+#define B6_TACC
+#endif
   for (;;) {
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -483,11 +556,22 @@ __global__ void __launch_bounds__(B6_NT, 1) conv_wino4_b6_kernel(Wino4B6Args a) 
         }
       }
     }
+#ifdef B6_TIMING
+    ++n_it;
+#endif
     if (!has_next) break;
     item = next;
     ua_cur = ua_base;
   }
+#ifdef B6_TIMING
+  if (tid == 0 && blockIdx.x < 256) {
+    long long* d_ = b6_dbg + (int)blockIdx.x * 8;
+    d_[0] = t_T; d_[1] = t_M; d_[2] = t_E + ((long long)wall_clock64() - c_last); d_[3] = n_st; d_[4] = n_it;
+  }
+#endif
 #undef B6_SETUP
+#undef B6_SETUP_PF
+#undef B6_DMA_TO
 #undef B6_DMA
 #undef B6_FIXUP
 #undef B6_LOAD_A
@@ -499,7 +583,6 @@ __global__ void __launch_bounds__(B6_NT, 1) conv_wino4_b6_kernel(Wino4B6Args a) 
 #undef B6_TROWS
 #undef B6_TSTAGE1
 #undef B6_TCOL
-#undef B6_TCHAN
 #undef B6_SPLIT_STORE
 #undef B6_TPHASE
 #undef B6_STEP
@@ -676,7 +759,19 @@ static int wino4_b6_impl(const float* x, const void* up, float* y, const float* 
   a.n_items = (int)nitems;
   const int cus = sivae_num_cus();
   const int grid = nitems < cus ? (int)nitems : cus;
-  a.xcd_group = (sivae_xcd_remap() && a.n_co_tiles > 1 && !(grid & 7)) ? 1 : 0;
+  // Block order.  xcd_group: the co-tile siblings of a pixel tile run on ONE XCD and share the halo in its L2 (conv_wino4's
+  // order); plain order: block b takes item b, i.e. co-tile (b mod n_co_tiles) on XCD (b mod 8) — the blocks of one XCD walk
+  // the SAME co-tile's U slab in step and share it in that L2.  This kernel streams 221 KB of U pieces against 48 KB of halo
+  // per 16 channels and block, so sharing U is what matters once U no longer fits an L2 (SIVAE_B6_XCD_GROUP=0/1 forces it).
+  static int xg = -2;
+  if (xg == -2) {
+    const char* e = getenv("SIVAE_B6_XCD_GROUP");
+    xg = e ? atoi(e) : -1;
+  }
+  const bool u_fits_l2 = 36ull * a.Ci_pad * a.Co_pad * 6ull <= (2ull << 20);
+  (void)u_fits_l2;  // (measured: the plain order loses 4-20 % on the 128 ... 512-channel layers: the halo sharing wins)
+  const bool want_group = xg >= 0 ? xg != 0 : true;
+  a.xcd_group = (sivae_xcd_remap() && want_group && a.n_co_tiles > 1 && !(grid & 7)) ? 1 : 0;
   if (pro_mean)
     hipLaunchKernelGGL(conv_wino4_b6_kernel<true>, dim3((unsigned)grid), dim3(B6_NT), 0, stream, a);
   else
