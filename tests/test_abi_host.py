@@ -375,3 +375,69 @@ def test_lib_call_raises_on_error_codes():
         lib.call("sivae_pack_batch", 7, ctypes.c_void_p(16), ctypes.c_void_p(16), 4, None)
     assert ei.value.code == -6 and "sivae_pack_batch" in str(ei.value) and "SIVAE_ERR_MODE" in str(ei.value)
     assert len(lib.sha256()) == 64 and lib.sha256() == lib.sha256()
+
+
+def test_round5_entry_points_validate_arguments():
+    """round 5: the six-product F(4x4,3x3) kernel's pack / launch entry points, the barrier-timeout word and the test-support
+    kernels — size queries and host-side validation (every call returns before any kernel launch)"""
+    L = lib.load()
+    null = None
+    one = ctypes.c_void_p(16)
+    # pre-split operand: 36 frequencies x padded channels x 3 pieces x 2 bytes = 1.5x the fp32 F(4x4,3x3) pack
+    for (Co, Ci, mode) in ((64, 64, 0), (72, 100, 0), (40, 130, 1), (512, 512, 1)):
+        assert L.sivae_pack_wino4_b6_weight_bytes(Co, Ci, mode) * 2 == L.sivae_pack_wino4_weight_bytes(Co, Ci, mode) * 3
+    assert L.sivae_pack_wino4_b6_weight_bytes(0, 64, 0) == 0 and L.sivae_pack_wino4_b6_weight_bytes(64, 64, 2) == 0
+    assert L.sivae_pack_wino4_b6_weight(null, one, 64, 64, 0, null) == -1
+    assert L.sivae_pack_wino4_b6_weight(one, one, 64, 0, 0, null) == -2
+    assert L.sivae_pack_wino4_b6_weight(one, one, 64, 64, 3, null) == -6
+    assert L.sivae_pack_wino4_b6_weight(one, ctypes.c_void_p(20), 64, 64, 0, null) == -2  # 16-byte aligned operand
+    f = L.sivae_conv2d_wino4_b6_fwd
+    assert f(null, one, one, null, null, null, null, 1.0, null, 2, 64, 64, 32, 32, 0, 0, null) == -1
+    assert f(one, one, one, null, null, null, null, 1.0, null, 2, 64, 64, 30, 32, 0, 0, null) == -2   # map not in 16 x 32 blocks
+    assert f(one, one, one, null, null, null, null, 1.0, null, 3, 64, 64, 16, 16, 0, 0, null) == -2   # 16 x 16 maps: image pairs
+    assert f(one, one, ctypes.c_void_p(20), null, null, null, null, 1.0, null, 2, 64, 64, 32, 32, 0, 0, null) == -2
+    assert f(one, one, one, one, null, null, null, 0.2, null, 2, 64, 64, 32, 32, 0, 0, null) == -1    # prologue: all four arrays
+    assert f(one, one, one, one, one, one, one, 1.5, null, 2, 64, 64, 32, 32, 0, 0, null) == -6       # slope in [0, 1]
+    assert f(one, one, one, null, null, null, null, 1.0, null, 4, 64, 64, 32, 32, 0, 3, null) == -2   # segments divide B
+    g = L.sivae_conv2d_wino4_b6_fwd_splitk
+    assert L.sivae_conv2d_wino4_splitk(2, 256, 64, 32, 32) > 1
+    assert g(one, one, one, null, null, null, null, 1.0, null, 2, 256, 64, 32, 32, 0, 0, null, 0, null) == -1   # no workspace
+    assert g(one, one, one, null, null, null, null, 1.0, null, 2, 256, 64, 32, 32, 0, 0, one, 16, null) == -4   # too small
+    # pack-batch form 5 (the pre-split operand) fills a job like form 2
+    jb = L.sivae_pack_job_bytes()
+    host = ctypes.create_string_buffer(jb)
+    assert L.sivae_pack_job_fill(host, 0, 5, one, one, 64, 64, 3, 0, 0) > 0
+    assert L.sivae_pack_job_fill(host, 0, 5, one, one, 64, 64, 1, 0, 0) == -3   # 3x3 only
+    assert L.sivae_pack_job_fill(host, 0, 6, one, one, 64, 64, 3, 0, 0) == -6   # unknown form
+    # the grid-barrier timeout word lies inside the barrier state, on its own 128-byte line behind the 17 used lines
+    w = L.sivae_bn_bwd_fused_poison_word()
+    assert 17 * 32 <= w < 1024 and w % 32 == 0 and w < L.sivae_bn_bwd_fused_state_uints()
+    assert L.sivae_debug_bn_fused_break_next(0) == 0
+    # a (256, 64, 256, 256) batch of 129..160 images per segment fits the 10-quad plan only: the query now plans with the
+    # tightest variant's budget (8 quads), so the callers fall back instead of hitting SIVAE_ERR_SHAPE in the launch
+    assert L.sivae_bn_bwd_fused_supported(160, 64, 256, 256, 160) == 0
+    assert L.sivae_bn_bwd_fused_supported(128, 64, 256, 256, 128) == 1
+    # test-support kernel: argument validation
+    sq = L.sivae_debug_squatter
+    assert sq(0, 256, 1024, 0, 1000, null, null) == -2 and sq(4, 2048, 1024, 0, 1000, null, null) == -2
+    assert sq(4, 256, 1 << 20, 0, 1000, null, null) == -2 and sq(4, 256, 1024, 0, 0, null, null) == -2
+
+
+def test_bn_fused_persistent_form_is_refused_under_a_cu_mask():
+    """plans of the one-pass BatchNorm backward refuse the grid-barrier form when the process runs under a CU mask (the
+    device still reports every CU: the grid could never become resident) or with SIVAE_BN_FUSED_PERSISTENT=0; the
+    barrier-free form for plane sets of one block stays available"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from sivae_hip import lib; L = lib.load(); "
+            "print(L.sivae_bn_bwd_fused_supported(256, 64, 256, 256, 128), L.sivae_bn_bwd_fused_supported(8, 512, 4, 4, 8), "
+            "L.sivae_bf16_bn_bwd_fused_supported(128, 64, 128, 128), L.sivae_bf16_bn_bwd_fused_supported(8, 512, 4, 4))"
+            % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "soft-intro-vae-pytorch_amd"))
+    for env_add, want in (({}, "1 1 1 1"), ({"HSA_CU_MASK": "0:0-31"}, "0 1 0 1"), ({"SIVAE_BN_FUSED_PERSISTENT": "0"}, "0 1 0 1")):
+        env = dict(os.environ)
+        for k in ("HSA_CU_MASK", "ROC_GLOBAL_CU_MASK", "SIVAE_BN_FUSED_PERSISTENT"):
+            env.pop(k, None)
+        env.update(env_add)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-400:]
+        assert out.stdout.strip().splitlines()[-1] == want, (env_add, out.stdout)
