@@ -88,6 +88,12 @@ def repack(params, owner):
             continue
         for slot, (tag, obj) in list(store.items()):
             if isinstance(obj, ops.PackedW):
+                # a pack captured BEFORE the parameter's storage moved (FlatAdam re-homes p.data into its slab; .to();
+                # a second optimizer on a used model) holds a detached alias of the OLD storage: rebuilding it from there
+                # and re-tagging it valid would freeze the weights of that slot — drop it, it is rebuilt on demand
+                if obj.w.data_ptr() != p.data_ptr() or obj.w.shape != p.shape or tag[2] != p.data_ptr():
+                    del store[slot]
+                    continue
                 forms = obj.batch_forms()
                 if forms:
                     entries.append((p, store, slot, obj))
@@ -130,6 +136,8 @@ def repack(params, owner):
             bj = torch.tensor(block_job, dtype=torch.int16).to(dev)  # (indices < 32768: uint16 and int16 agree)
             launches.append((f, jt, bj, nblocks))
         plan = {"key": key, "launches": launches, "keep": [b for fl in jobs for _, b in fl]}
+        # (job tables of earlier plans stay alive: a HIP graph captured while they were current still launches with them)
+        owner.__dict__.setdefault("_sivae_pack_plan_old", []).append(owner.__dict__.get("_sivae_pack_plan"))
         owner.__dict__["_sivae_pack_plan"] = plan
     for f, jt, bj, nblocks in plan["launches"]:
         ops._lib.call("sivae_pack_batch", f, ops._p(jt), ops._p(bj), nblocks, ops._s(jt))
