@@ -439,6 +439,28 @@ def test_bootstrap_6level_topology_vs_oracle():
     assert not _oracle_vs_hip(3, 64, [8, 16, 32, 64, 64, 64], 256, 2, hp, boot=True, seed=4, referee=False)
 
 
+def test_forced_wino4_b6_kernels_vs_oracle(monkeypatch):
+    """the same two iterations with SIVAE_WINO4_B6 on: every F(4x4,3x3) forward / data gradient (plain, prologue, pairs)
+    runs conv_wino4_b6.hip (fp32 products from six bf16 MFMAs) — the oracle tolerances and the fp64 gradient referee are
+    the ones of the fp32-MFMA kernels"""
+    from sivae_hip import ops
+    monkeypatch.setattr(ops, "WINO4_FORCE", True)
+    monkeypatch.setattr(ops, "WINO4_B6", True)
+    calls = []
+    orig = ops._lib.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+    monkeypatch.setattr(ops._lib, "call", spy)
+    hp = dict(beta_rec=0.5, beta_kl=1.0, beta_neg=256.0, gamma_r=1e-8)
+    assert not _oracle_vs_hip(3, 64, [32, 64, 64, 96], 128, 4, hp, seed=21)
+    hp = dict(beta_rec=0.5, beta_kl=1.0, beta_neg=256.0, gamma_r=1.0)
+    assert not _oracle_vs_hip(3, 48, [32, 48, 64], 64, 4, hp, boot=True, seed=22, referee=False)
+    assert any(c.startswith("sivae_conv2d_wino4_b6_fwd") for c in calls)
+    assert not any(c in ("sivae_conv2d_wino4_fwd", "sivae_conv2d_wino4_fwd_pro") for c in calls)
+
+
 def test_forced_wino4_kernels_vs_oracle(monkeypatch):
     """Both F(4x4,3x3) kernels (forward / data gradient AND the weight gradient) on every layer they support — at the
     oracle comparisons' batch sizes the dispatch would keep most layers on F(2x2,3x3) — one iteration vs the live oracle

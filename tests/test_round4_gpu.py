@@ -233,14 +233,17 @@ def test_celeb256_exact_network_forward_at_batch_128_vs_oracle():
             torch.set_num_threads(nt)
 
 
+@pytest.mark.parametrize("b6", [False, True], ids=["fp32mfma", "b6"])
 @pytest.mark.parametrize("Ci,Co,H", [(256, 256, 64), (512, 512, 32), (512, 512, 16)])
-def test_wino4_layers_at_headline_size_vs_fp64(Ci, Co, H):
+def test_wino4_layers_at_headline_size_vs_fp64(Ci, Co, H, b6, monkeypatch):
     """The 256- / 512-channel F(4x4,3x3) layers of the headline at batch 128 (16x16: the image-pair mode) against torch-CPU
     fp64: forward (plain and with the fused BatchNorm + LeakyReLU prologue) on three images, the data gradient BY VALUE on
     three images (not only through the adjoint identity), the weight gradient over the whole batch for two output
     channels."""
     import torch.nn.functional as F
     from sivae_hip import ops
+    # b6: the same layers with SIVAE_WINO4_B6 on (conv_wino4_b6.hip: fp32 products from six bf16 MFMAs) — the SAME bounds
+    monkeypatch.setattr(ops, "WINO4_B6", bool(b6))
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(1000 + H)
     B = 128
