@@ -352,6 +352,13 @@ int sivae_expelbo_fwd(const float* L, const float* KL, float scale, float beta_r
                       float* e, float* out, sivae_stream_t stream);
 int sivae_expelbo_bwd(const float* gout, const float* e, float scale, float beta_rec, float beta_neg, int B,
                       float* dL, float* dKL, sivae_stream_t stream);
+/* Weighted sum of up to six device scalars in one launch, terms added in index order: out[0] = sum_i w_i * p_i[0], i < n.
+ * Replaces the 0-dim torch arithmetic of lossE / lossD (train_soft_intro_vae.py:583-586, :618-620). */
+int sivae_lincomb(const float* p0, const float* p1, const float* p2, const float* p3, const float* p4, const float* p5,
+                  float w0, float w1, float w2, float w3, float w4, float w5, int n, float* out, sivae_stream_t stream);
+/* its gradient: out[i] = g[0] * w_i, i < n. */
+int sivae_lincomb_bwd(const float* g, float w0, float w1, float w2, float w3, float w4, float w5, int n, float* out,
+                      sivae_stream_t stream);
 /* Philox4x32-10 standard normals (replaces torch.randn / randn_like :264,:547 in fast mode). */
 int sivae_randn(float* out, size_t n, unsigned long long seed, unsigned long long offset, sivae_stream_t stream);
 /* same stream with its position kept in device memory (*offset_dev is read, then advanced by ceil(n/4)): nothing

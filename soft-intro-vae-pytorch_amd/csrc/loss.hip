@@ -407,6 +407,44 @@ extern "C" int sivae_expelbo_bwd(const float* gout, const float* e, float scale,
                      dKL);
   return sivae_launch_status();
 }
+// ---- loss assembly: lossE = scale * (beta_rec * loss_rec + beta_kl * kl_real) + 0.25 * (expelbo_rec + expelbo_fake)
+// (train_soft_intro_vae.py:583-586) and lossD (:618-620) are weighted sums of up to six device scalars.  As torch arithmetic
+// on 0-dim tensors each is 7-9 launches forward and as many backward (25 of an iteration's launches); here one each.
+struct LinCombArgs {
+  const float* p[6];
+  float w[6];
+  int n;
+};
+__global__ void lincomb_kernel(LinCombArgs a, float* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  float s = 0.f;
+  for (int i = 0; i < a.n; ++i) s += a.w[i] * a.p[i][0];
+  out[0] = s;
+}
+__global__ void lincomb_bwd_kernel(const float* __restrict__ g, LinCombArgs a, float* __restrict__ out) {
+  if ((int)threadIdx.x < a.n) out[threadIdx.x] = g[0] * a.w[threadIdx.x];
+}
+// out[0] = sum_i w[i] * p[i][0], i < n <= 6 (terms added in index order); unused pointers may be NULL
+extern "C" int sivae_lincomb(const float* p0, const float* p1, const float* p2, const float* p3, const float* p4,
+                             const float* p5, float w0, float w1, float w2, float w3, float w4, float w5, int n,
+                             float* out, hipStream_t stream) {
+  if (!out) return SIVAE_ERR_NULL;
+  if (n <= 0 || n > 6) return SIVAE_ERR_SHAPE;
+  LinCombArgs a = {{p0, p1, p2, p3, p4, p5}, {w0, w1, w2, w3, w4, w5}, n};
+  for (int i = 0; i < n; ++i)
+    if (!a.p[i]) return SIVAE_ERR_NULL;
+  hipLaunchKernelGGL(lincomb_kernel, dim3(1), dim3(64), 0, stream, a, out);
+  return sivae_launch_status();
+}
+// its gradient: out[i] = g[0] * w[i], i < n
+extern "C" int sivae_lincomb_bwd(const float* g, float w0, float w1, float w2, float w3, float w4, float w5, int n,
+                                 float* out, hipStream_t stream) {
+  if (!g || !out) return SIVAE_ERR_NULL;
+  if (n <= 0 || n > 6) return SIVAE_ERR_SHAPE;
+  LinCombArgs a = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, {w0, w1, w2, w3, w4, w5}, n};
+  hipLaunchKernelGGL(lincomb_bwd_kernel, dim3(1), dim3(64), 0, stream, g, a, out);
+  return sivae_launch_status();
+}
 extern "C" int sivae_randn(float* out, size_t n, unsigned long long seed, unsigned long long offset,
                            hipStream_t stream) {
   if (!out) return SIVAE_ERR_NULL;

@@ -326,7 +326,8 @@ class SoftIntroEngine:
         l_rec_fake = _recon_rows(fake, rec_fake, lt)
         expelbo_rec = SF.expelbo(l_rec_rec, kl_rec, scale, br, bn)
         expelbo_fake = SF.expelbo(l_rec_fake, kl_fake, scale, br, bn)
-        lossE = scale * (br * loss_rec + bk * kl_real) + 0.25 * (expelbo_rec + expelbo_fake)
+        # lossE = scale * (br * loss_rec + bk * kl_real) + 0.25 * (expelbo_rec + expelbo_fake)  (:583-586), one launch
+        lossE = SF.lincomb([loss_rec, kl_real, expelbo_rec, expelbo_fake], [scale * br, scale * bk, 0.25, 0.25])
         self.opt_e.zero_grad()
         self._arm(self.opt_e)
         lossE.backward()
@@ -393,7 +394,9 @@ class SoftIntroEngine:
             l_fr = calc_reconstruction_loss(fake.detach(), rec_fake, lt, "mean")
         kl_rec = calc_kl(rec_logvar, rec_mu, reduce="mean")
         kl_fake = calc_kl(fake_logvar, fake_mu, reduce="mean")
-        lossD = scale * (loss_rec * br + (kl_rec + kl_fake) * 0.5 * bk + gr * 0.5 * br * (l_rr + l_fr))
+        # lossD = scale * (loss_rec * br + (kl_rec + kl_fake) * 0.5 * bk + gr * 0.5 * br * (l_rr + l_fr))  (:618-620)
+        lossD = SF.lincomb([loss_rec, kl_rec, kl_fake, l_rr, l_fr],
+                           [scale * br, scale * 0.5 * bk, scale * 0.5 * bk, scale * gr * 0.5 * br, scale * gr * 0.5 * br])
         self.opt_d.zero_grad()
         self._arm(self.opt_d)
         lossD.backward()

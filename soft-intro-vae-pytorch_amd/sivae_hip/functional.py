@@ -746,6 +746,31 @@ class ExpElboFn(torch.autograd.Function):
         return dL, dKL, None, None, None
 
 
+class LinCombFn(torch.autograd.Function):
+    """sum_i w_i * t_i over device scalars — the assembly of lossE / lossD (train_soft_intro_vae.py:583-586, :618-620)"""
+
+    @staticmethod
+    def forward(ctx, ws, *ts):
+        ctx.ws = ws
+        return ops.lincomb([t.detach().reshape(()).contiguous() for t in ts], ws)
+
+    @staticmethod
+    def backward(ctx, g):
+        gs = ops.lincomb_bwd(g.contiguous(), ctx.ws)
+        return (None,) + tuple(gs[i] if need else None for i, need in enumerate(ctx.needs_input_grad[1:]))
+
+
+def lincomb(ts, ws):
+    """differentiable sum_i ws[i] * ts[i] (python-float weights, 0-dim float32 device tensors), one launch each way"""
+    ts = list(ts)
+    if not 0 < len(ts) <= 6 or len(ts) != len(ws):
+        raise ValueError("sivae_hip.lincomb: 1..6 terms with one weight each")
+    for t in ts:
+        if t.numel() != 1 or t.dtype != torch.float32 or not t.is_cuda:
+            raise ValueError("sivae_hip.lincomb: terms must be float32 device scalars")
+    return LinCombFn.apply(tuple(float(w) for w in ws), *ts)
+
+
 def residual_block(x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post=None, cache=None, x_up=False, nseg=1,
                    seg_rev=False, replay_update=True):
     return _apply(ResBlockFn, x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache, x_up, nseg, seg_rev,

@@ -1233,6 +1233,26 @@ def expelbo_bwd(gout, e, scale, beta_rec, beta_neg):
     return dL, dKL
 
 
+def lincomb(ts, ws):
+    """sum_i ws[i] * ts[i] of up to six device scalars, one launch (lossE / lossD)"""
+    n = len(ts)
+    _require(*ts)
+    out = torch.empty((), dtype=torch.float32, device=ts[0].device)
+    ps = [_p(t) for t in ts] + [None] * (6 - n)
+    w = [float(v) for v in ws] + [0.0] * (6 - n)
+    _lib.call("sivae_lincomb", *ps, *w, n, _p(out), _s())
+    return out
+
+
+def lincomb_bwd(g, ws):
+    n = len(ws)
+    _require(g)
+    out = torch.empty(n, dtype=torch.float32, device=g.device)
+    w = [float(v) for v in ws] + [0.0] * (6 - n)
+    _lib.call("sivae_lincomb_bwd", _p(g), *w, n, _p(out), _s())
+    return out
+
+
 def randn(shape, seed, offset, device):
     out = torch.empty(shape, dtype=torch.float32, device=device)
     _require(out)

@@ -458,6 +458,20 @@ def check_losses():
         res.append(("expelbo_dL(%d)" % B, _err(dL, L.grad), 1e-5))
         res.append(("expelbo_dKL(%d)" % B, _err(dKL, KL.grad), 1e-5))
         res.append(("vec_sum(%d)" % B, _err(ops.vec_sum(_d(L.detach()), 0.5), 0.5 * L.detach().sum()), 1e-6))
+    # the loss assembly (lossE: 4 terms, lossD: 5; reference :583-586, :618-620) through the autograd function: value and
+    # the gradient of every term against torch's own 0-dim arithmetic in fp64
+    from sivae_hip import functional as SF
+    for n in (1, 4, 5, 6):
+        vals = [float(v) for v in (_rand(n, seed=7) * 10)]
+        ws = [1.0 / 196608 * 0.5 * (i + 1) if i % 2 == 0 else 0.25 for i in range(n)]
+        ts = [torch.tensor(v, dtype=torch.float32, device=DEV, requires_grad=(i != 1)) for i, v in enumerate(vals)]
+        out = SF.lincomb(ts, ws)
+        out.backward(torch.tensor(3.0, device=DEV))
+        ref = sum(w * float(torch.tensor(v, dtype=torch.float32)) for w, v in zip(ws, vals))
+        res.append(("lincomb(%d)" % n, _err(out.detach().reshape(1), torch.tensor([ref], dtype=torch.float64)), 1e-6))
+        gerr = max(abs(float(t.grad) - 3.0 * w) / abs(3.0 * w) for i, (t, w) in enumerate(zip(ts, ws)) if i != 1)
+        res.append(("lincomb_grad(%d)" % n, gerr, 1e-6))
+        res.append(("lincomb_no_grad_for_detached(%d)" % n, float(n > 1 and ts[1].grad is not None), 0.0))
     return res
 
 
@@ -570,8 +584,9 @@ def check_wino_splitk():
     from sivae_hip import lib, ops
     L = lib.load()
     res = []
+    # (planes of 16 / 64 / 256 pixels are summed by the vector reducer, the 32 x 32 map by the scalar one)
     for shape in [(16, 512, 512, 4, 4, 3), (16, 512, 512, 8, 8, 3), (8, 256, 384, 4, 4, 3), (3, 200, 72, 8, 8, 3),
-                  (2, 512, 512, 16, 16, 3)]:
+                  (2, 512, 512, 16, 16, 3), (1, 512, 128, 32, 32, 3)]:
         B, Ci, Co, H, W, ks = shape
         S = L.sivae_conv2d_wino_splitk(B, Ci, Co, H, W)
         res.append(("splitk%s slices=%d" % (shape, S), 0.0 if S > 1 else float("inf"), 0.5))
@@ -614,17 +629,22 @@ def check_conv1x1_stream():
     res = [("conv1x1_stream supported", float(L.sivae_conv1x1_stream_supported(2, 64, 128, 1024) != 1
                                               or L.sivae_conv1x1_stream_supported(2, 64, 128, 49) != 0
                                               or L.sivae_conv1x1_stream_supported(2, 63, 128, 64) != 0
-                                              or L.sivae_conv1x1_stream_supported(2, 512, 128, 64) != 0), 0.0)]
+                                              or L.sivae_conv1x1_stream_supported(2, 512, 128, 64) != 1
+                                              or L.sivae_conv1x1_stream_supported(2, 514, 128, 64) != 0), 0.0)]
     for shape in [(2, 64, 128, 32, 32, 1), (5, 128, 64, 16, 16, 1), (3, 100, 200, 6, 10, 1), (1, 256, 72, 20, 36, 1),
-                  (7, 2, 3, 4, 8, 1), (2, 64, 128, 128, 128, 1)]:
+                  (7, 2, 3, 4, 8, 1), (2, 64, 128, 128, 128, 1),
+                  # the three wave tiles: 64 x 128 (>= 512 block items), 32 x 128, 32 x 64 (round 5: the shard-size launches)
+                  (16, 64, 128, 128, 128, 1), (16, 64, 128, 64, 64, 1), (8, 256, 512, 32, 32, 1), (16, 128, 200, 44, 36, 1),
+                  # more than 256 input channels: always the 32-channel tile (Decoder 512 -> 256, the data gradient of 256 -> 512)
+                  (4, 512, 256, 32, 32, 1), (32, 512, 256, 32, 32, 1), (3, 384, 100, 12, 12, 1)]:
         res += check_conv_fwd(shape)
         res += check_conv_dgrad(shape)
-    # accumulate (the expand conv's data gradient is added onto the conv1 branch's)
-    B, Ci, Co, H, W = 3, 128, 64, 12, 20
-    x, w, y0 = _rand(B, Ci, H, W, seed=1), _rand(Co, Ci, 1, 1, seed=2, scale=0.1), _rand(B, Co, H, W, seed=3)
-    y = _d(y0)
-    ops.conv2d_fwd(_d(x), ops.pack_weight(_d(w), 0), Co, 1, out=y, accumulate=True)
-    res.append(("conv1x1_stream accumulate", _err(y, y0 + _conv_ref(x, w)), 1e-5))
+    # accumulate (the expand conv's data gradient is added onto the conv1 branch's), once per wave tile
+    for B, Ci, Co, H, W in [(3, 128, 64, 12, 20), (16, 128, 64, 64, 64), (16, 64, 72, 128, 128)]:
+        x, w, y0 = _rand(B, Ci, H, W, seed=1), _rand(Co, Ci, 1, 1, seed=2, scale=0.1), _rand(B, Co, H, W, seed=3)
+        y = _d(y0)
+        ops.conv2d_fwd(_d(x), ops.pack_weight(_d(w), 0), Co, 1, out=y, accumulate=True)
+        res.append(("conv1x1_stream accumulate %s" % ((B, Ci, Co, H, W),), _err(y, y0 + _conv_ref(x, w)), 1e-5))
     return res
 
 
@@ -1575,7 +1595,7 @@ def all_checks():
                        + check_wino4(s, mode=1)))
     for s in [(4, 64, 64, 16, 16), (8, 96, 40, 16, 16)]:
         checks.append(("wino4_pair_pro%s" % (s,), lambda s=s: check_wino4_pro(s) + check_wino4_pro(s, nseg=2)))
-    for s in [(2, 256, 64, 32, 32), (4, 512, 128, 16, 16), (1, 128, 100, 16, 32)]:
+    for s in [(2, 256, 64, 32, 32), (4, 512, 128, 16, 16), (1, 128, 100, 16, 32), (1, 512, 64, 64, 64)]:
         checks.append(("wino4_splitk%s" % (s,), lambda s=s: check_wino4_splitk(s) + check_wino4_splitk(s, accumulate=True)
                        + check_wino4_splitk(s, pro=True)))
     checks.append(("wino4_splitk_seg", lambda: check_wino4_splitk((4, 256, 64, 32, 32), pro=True, nseg=2)

@@ -417,6 +417,16 @@ def test_round5_entry_points_validate_arguments():
     # tightest variant's budget (8 quads), so the callers fall back instead of hitting SIVAE_ERR_SHAPE in the launch
     assert L.sivae_bn_bwd_fused_supported(160, 64, 256, 256, 160) == 0
     assert L.sivae_bn_bwd_fused_supported(128, 64, 256, 256, 128) == 1
+    # loss assembly: 1..6 terms, every used pointer present
+    lc = L.sivae_lincomb
+    assert lc(one, one, null, null, null, null, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 3, one, null) == -1
+    assert lc(one, one, null, null, null, null, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 2, null, null) == -1
+    assert lc(one, one, one, one, one, one, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 7, one, null) == -2
+    assert lc(one, null, null, null, null, null, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, one, null) == -2
+    assert L.sivae_lincomb_bwd(null, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 2, one, null) == -1
+    assert L.sivae_lincomb_bwd(one, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 9, one, null) == -2
+    # the streaming 1x1 kernel takes up to 512 input channels (32-channel tile above 256)
+    assert L.sivae_conv1x1_stream_supported(2, 512, 256, 1024) == 1 and L.sivae_conv1x1_stream_supported(2, 514, 256, 1024) == 0
     # test-support kernel: argument validation
     sq = L.sivae_debug_squatter
     assert sq(0, 256, 1024, 0, 1000, null, null) == -2 and sq(4, 2048, 1024, 0, 1000, null, null) == -2
