@@ -38,6 +38,7 @@ struct Bf16BnFusedArgs {
   int l2_qpp, l2_qw;  // log2(quads per plane), log2(quads per row); a quad = 2 x 2 pixels
   int spc, cpg, ngroups, nx, nsub, local;
   int dzmode;  // 0 none, 1 full resolution, 2 2x2 block sums
+  int pf;      // 1: the NEXT group's x is requested into LDS between the barrier's arrival and its wait (as bn_fused.hip)
   unsigned spin_limit;  // polls of the barrier wait before the launch is abandoned (bn_fused_common.h)
 };
 
@@ -67,7 +68,13 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
   __shared__ float red[4][16];
   __shared__ double red2[16][16];
   __shared__ float coef[16];  // c1[8] = sg / N, c2[8] = sgx / N of this block's channel block
+  // x of the NEXT group for up to 3 of the 4 units per thread (48 KB per block — the bound of bn_fused.hip's request
+  // buffer, for the same reasons): [unit][vector][256 threads] 16-byte vectors, a wave's 64 lanes 1 KB contiguous
+  extern __shared__ __attribute__((aligned(16))) u32x4_t b16_pfx[];
+  constexpr int PFU = NU < 3 ? NU : 3;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wave64 = __builtin_amdgcn_readfirstlane(t >> 6) * 64;
+  const bool pf = NU == 4 && a.pf != 0;
   const bool local = a.local != 0;
   const int nb_sub = local ? (int)gridDim.x : (int)gridDim.x / a.nsub;
   const int sub = (!local && (int)blockIdx.x >= nb_sub) ? 1 : 0;
@@ -95,20 +102,33 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
       xq[j][v] = u32x4_t{0u, 0u, 0u, 0u};
       if (!POOL || v == 0) dq[j][POOL ? 0 : v] = u32x4_t{0u, 0u, 0u, 0u};
     }
+  const unsigned qbase = (unsigned)(slab * (256 * NU) + t);
+  auto quad_off = [&](unsigned q) -> unsigned {  // byte offset of the quad's first vector (row 0) inside the window
+    const unsigned b = q >> a.l2_qpp, r = q & qpp_m, h2 = r >> a.l2_qw, w2 = r & qw_m;
+    return q < (unsigned)nq ? b * img_pitch + (2u * h2 * (unsigned)W + 2u * w2) * 16u : BF_OOB;
+  };
+  auto half_off = [&](unsigned q) -> unsigned {  // the quad's vector in a half-resolution tensor [.][H/2][W/2][8]
+    const unsigned b = q >> a.l2_qpp, r = q & qpp_m;
+    return q < (unsigned)nq ? b * (img_pitch >> 2) + r * 16u : BF_OOB;
+  };
+  auto request_x = [&](int cbn) {  // x of channel block cbn (this block's slab) -> LDS, 4 * PFU LDS-direct loads
+    const __amdgpu_buffer_rsrc_t rxn = make_rsrc(reinterpret_cast<const char*>(a.x) + (size_t)cbn * HW * 16, win);
+#pragma unroll
+    for (int j = 0; j < PFU; ++j) {
+      const unsigned vo = quad_off(qbase + j * 256);
+      const unsigned vo1 = vo == BF_OOB ? BF_OOB : vo + 16u;
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rxn, (float __attribute__((address_space(3)))*)(b16_pfx + (4 * j + v) * 256 + wave64),
+                                                 16, (int)((v & 1) ? vo1 : vo), (int)((v >> 1) ? row_b : 0u), 0, 0);
+    }
+  };
+  if (pf && !local && ci < a.cpg && sub * a.cpg + ci < Cb && sub < a.ngroups) request_x(sub * a.cpg + ci);
   for (int grp = sub; grp < (local ? 1 : a.ngroups); grp += a.nsub) {
     const int cb = local ? bid : grp * a.cpg + ci;
     const bool active = local ? true : (ci < a.cpg && cb < Cb);
     unsigned sg_bits[NU];  // sign bytes of the quad's 4 vectors (row 0: bytes 0, 1; row 1: bytes 2, 3)
     float mu[8], is[8];
-    const unsigned qbase = (unsigned)(slab * (256 * NU) + t);
-    auto quad_off = [&](unsigned q) -> unsigned {  // byte offset of the quad's first vector (row 0) inside the window
-      const unsigned b = q >> a.l2_qpp, r = q & qpp_m, h2 = r >> a.l2_qw, w2 = r & qw_m;
-      return q < (unsigned)nq ? b * img_pitch + (2u * h2 * (unsigned)W + 2u * w2) * 16u : BF_OOB;
-    };
-    auto half_off = [&](unsigned q) -> unsigned {  // the quad's vector in a half-resolution tensor [.][H/2][W/2][8]
-      const unsigned b = q >> a.l2_qpp, r = q & qpp_m;
-      return q < (unsigned)nq ? b * (img_pitch >> 2) + r * 16u : BF_OOB;
-    };
     double tsum = 0.0;  // (threads t < 256: value t & 15 of the channel block's 16 sums)
     if (active) {
 #pragma unroll
@@ -133,10 +153,12 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
           B16_KEEP(xq[j][v])
           if (!POOL || v == 0) B16_KEEP(dq[j][POOL ? 0 : v])
         }
-        xq[j][0] = buf_load_u32x4(rx, vo, 0);
-        xq[j][1] = buf_load_u32x4(rx, vo == BF_OOB ? BF_OOB : vo + 16u, 0);
-        xq[j][2] = buf_load_u32x4(rx, vo, row_b);
-        xq[j][3] = buf_load_u32x4(rx, vo == BF_OOB ? BF_OOB : vo + 16u, row_b);
+        if (!pf || j >= PFU) {
+          xq[j][0] = buf_load_u32x4(rx, vo, 0);
+          xq[j][1] = buf_load_u32x4(rx, vo == BF_OOB ? BF_OOB : vo + 16u, 0);
+          xq[j][2] = buf_load_u32x4(rx, vo, row_b);
+          xq[j][3] = buf_load_u32x4(rx, vo == BF_OOB ? BF_OOB : vo + 16u, row_b);
+        }
         if (POOL) {
           dq[j][0] = buf_load_u32x4(rdy, half_off(qbase + j * 256), 0);
         } else {
@@ -170,6 +192,13 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
         } else {
           sg_bits[j] = 0;
         }
+      }
+      if (pf) {
+        // (requested a barrier ago: older in the in-order memory pipe than everything issued above)
+#pragma unroll
+        for (int j = 0; j < PFU; ++j)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) xq[j][v] = b16_pfx[(4 * j + v) * 256 + t];
       }
       float gm[8], bt[8];
       if (ACT == 2) {
@@ -241,8 +270,13 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
     if (!local) {
       if (t == 0) {
         ++target;
-        bar_failed = bf_grid_barrier(bar, a.bar + BF_POISON_WORD, xcd, a.nx, bpx, target, a.spin_limit) ? 0 : 1;
+        bf_grid_arrive(bar, xcd, a.nx, bpx);
       }
+      if (pf) {
+        const int cbn = (grp + a.nsub) * a.cpg + ci;
+        if (grp + a.nsub < a.ngroups && ci < a.cpg && cbn < Cb) request_x(cbn);
+      }
+      if (t == 0) bar_failed = bf_grid_wait(bar, a.bar + BF_POISON_WORD, xcd, target, a.spin_limit) ? 0 : 1;
       __syncthreads();
       if (bar_failed) return;  // abandoned launch (poison word set; the host raises)
       if (!active) continue;
@@ -439,9 +473,16 @@ extern "C" int sivae_bf16_bn_bwd_fused(const void* dy, int dy_pooled, const void
   a.local = p.local;
   a.dzmode = !dz ? 0 : (dz_sum ? 2 : 1);
   a.spin_limit = bf_spin_limit();
+  static int pf_on = -1;
+  if (pf_on < 0) {
+    const char* e = getenv("SIVAE_BN_FUSED_PREFETCH");
+    pf_on = (e && e[0] == '0') ? 0 : 1;
+  }
+  a.pf = (pf_on && !p.local && p.nu == 4 && p.ngroups > p.nsub) ? 1 : 0;
+  const size_t lds = a.pf ? (size_t)3 * 4 * 256 * 16 : 0;  // 48 KB
   const int act = sign_mask ? 3 : (y ? 1 : 2);
   const dim3 grid((unsigned)(p.local ? Cb : p.nsub * p.nb_sub)), block(256);
-#define B16_LAUNCH(A, P, N) hipLaunchKernelGGL((bf16_bn_bwd_fused_kernel<A, P, N>), grid, block, 0, stream, a)
+#define B16_LAUNCH(A, P, N) hipLaunchKernelGGL((bf16_bn_bwd_fused_kernel<A, P, N>), grid, block, lds, stream, a)
 #define B16_NU(A, P)                       \
   {                                        \
     if (p.nu == 4) B16_LAUNCH(A, P, 4);    \

@@ -13,6 +13,12 @@
 //             coefficients — deterministic), forms dx from the registers and stores it (+ dz, or its 2x2 block sums).
 // The grid is two independent half-grids (one block per CU each) that walk alternate groups with their own barrier state:
 // while one half waits at its barrier the other half's loads / stores keep the HBM pipe busy.
+// Round 5: between its arrival at a group's barrier and the wait, a block requests its slab of the NEXT group's x into LDS
+// (LDS-direct loads, up to 6 of the 8 quads per thread = 48 KB per block): the memory pipe is otherwise idle from the
+// moment the last block's loads have landed until the partial sums are folded (~1/3 of a group's 30 us on the 256x256
+// layers, whose plane sets fill the whole grid so that the half-grid overlap above does not apply).  -4 % per call on
+// those layers, -8..-11 % on the others, +1.4 % on the headline iteration (SIVAE_BN_FUSED_PREFETCH=0 switches it off).
+// The request buffer is sized by what the chip's co-tenants allow, see PFQ below.
 // dgamma / dbeta sum over the segments of a channel: the last (segment, channel) leader to finish adds the segments'
 // sums in segment order (per-channel arrival counter), so the result does not depend on which one is last.
 //
@@ -47,6 +53,7 @@ struct BnFusedArgs {
   int nsub;    // 2: two independent half-grids walking alternate groups; 1: one grid (plane sets too big for a half)
   int local;   // 1: every (segment, channel) plane set fits ONE block (spc == 1): grid = VC ordinary blocks, no barrier
   int dzmode;  // 0: none, 1: dz at full resolution, 2: 2x2 block sums [.][H/2][W/2]
+  int pf;      // 1: the NEXT group's x is requested into LDS (LDS-direct loads) between the barrier's arrival and its wait
   unsigned spin_limit;  // polls of the barrier wait before the launch is abandoned (poison word set)
   int dbg_extra;        // test hook: arrivals the barrier expects on top of the real ones (never come -> timeout path)
 };
@@ -93,7 +100,17 @@ __device__ __forceinline__ void bf_store4(__amdgpu_buffer_rsrc_t r, const float4
 template <int ACT, bool POOL, int NQ>
 __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
   __shared__ double red[4];
+  // x of the NEXT group, requested while this block waits at the grid barrier (a.pf): [NQ][2 rows][256 threads] float4 —
+  // a wave's 64 lanes are 1 KB contiguous, the layout an LDS-direct load writes (M0 base + lane * 16)
+  extern __shared__ __attribute__((aligned(16))) float4 bf_pfx[];
   const int t = threadIdx.x;
+  const int wave64 = __builtin_amdgcn_readfirstlane(t >> 6) * 64;
+  const bool pf = NQ <= 8 && a.pf != 0;  // (10 quads per thread: no code for the request buffer)
+  // quads per thread that go through the request buffer: at most 6 = 48 KB per block.  Two blocks then fit a CU beside
+  // 64 KB of somebody else's LDS, and no single co-tenant allocation can fragment the CU's 160 KB such that the second
+  // block never fits (that needs a block > 160 / 3 KB): with all 8 quads (64 KB) a 32-KB co-tenant that left did exactly
+  // that — the grid never became resident (tests/kernel_checks.py::check_bn_fused_squatter)
+  constexpr int PFQ = NQ < 6 ? NQ : 6;
   const bool local = a.local != 0;
   const int nb_sub = local ? (int)gridDim.x : (int)gridDim.x / a.nsub;
   const int sub = (!local && (int)blockIdx.x >= nb_sub) ? 1 : 0;
@@ -119,6 +136,35 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
   float4 g0[NQ], g1[NQ], x0[NQ], x1[NQ];
 #pragma unroll
   for (int j = 0; j < NQ; ++j) g0[j] = g1[j] = x0[j] = x1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const unsigned qbase = (unsigned)(slab * (256 * NQ) + t);
+  // byte offset of row 0 of quad q inside the window (or out of range)
+  auto quad_off = [&](unsigned q) -> unsigned {
+    const unsigned b = q >> a.l2_qpp, r = q & qpp_m, h2 = r >> a.l2_qw, w4 = r & qw_m;
+    const unsigned off = b * img_pitch + (2u * h2 * (unsigned)W + 4u * w4) * 4u;
+    return q < (unsigned)nq ? off : BF_OOB;
+  };
+  // the same quad in a half-resolution tensor [.][H/2][W/2] (pooled dy, dz block sums): 2 floats
+  auto half_off = [&](unsigned q) -> unsigned {
+    const unsigned b = q >> a.l2_qpp, r = q & qpp_m, h2 = r >> a.l2_qw, w4 = r & qw_m;
+    const unsigned off = b * (img_pitch >> 2) + (h2 * (unsigned)(W >> 1) + 2u * w4) * 4u;
+    return q < (unsigned)nq ? off : BF_OOB;
+  };
+  // x of plane set `vcn` (this block's slab of it) -> LDS, 2 * NQ LDS-direct loads of 16 bytes per lane.  Issued for group
+  // g + 1 between the arrival at group g's barrier and the wait: the memory pipe, otherwise idle until the last block has
+  // arrived and the partial sums are folded, delivers a third of the next group's bytes meanwhile (round 5).
+  auto request_x = [&](int vcn) {
+    const int segn = vcn / C, cn = vcn - segn * C;
+    const __amdgpu_buffer_rsrc_t rxn = make_rsrc(a.x + ((size_t)segn * a.Bs * C + cn) * (size_t)HW, win);
+#pragma unroll
+    for (int j = 0; j < PFQ; ++j) {
+      const unsigned vo = quad_off(qbase + j * 256);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rxn, (float __attribute__((address_space(3)))*)(bf_pfx + (2 * j) * 256 + wave64),
+                                               16, (int)vo, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rxn, (float __attribute__((address_space(3)))*)(bf_pfx + (2 * j + 1) * 256 + wave64),
+                                               16, (int)vo, (int)row_b, 0, 0);
+    }
+  };
+  if (pf && !local && ci < a.cpg && sub * a.cpg + ci < VC && sub < a.ngroups) request_x(sub * a.cpg + ci);
   for (int grp = sub; grp < (local ? 1 : a.ngroups); grp += a.nsub) {
     const int vc = local ? bid : grp * a.cpg + ci;
     const bool active = local ? true : (ci < a.cpg && vc < VC);
@@ -126,19 +172,6 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
     float m = 0.f, is = 0.f, gs = 0.f;
     int c = 0;
     size_t base = 0;  // element index of the plane (segment's first image, channel c)
-    const unsigned qbase = (unsigned)(slab * (256 * NQ) + t);
-    // byte offset of row 0 of quad q inside the window (or out of range)
-    auto quad_off = [&](unsigned q) -> unsigned {
-      const unsigned b = q >> a.l2_qpp, r = q & qpp_m, h2 = r >> a.l2_qw, w4 = r & qw_m;
-      const unsigned off = b * img_pitch + (2u * h2 * (unsigned)W + 4u * w4) * 4u;
-      return q < (unsigned)nq ? off : BF_OOB;
-    };
-    // the same quad in a half-resolution tensor [.][H/2][W/2] (pooled dy, dz block sums): 2 floats
-    auto half_off = [&](unsigned q) -> unsigned {
-      const unsigned b = q >> a.l2_qpp, r = q & qpp_m, h2 = r >> a.l2_qw, w4 = r & qw_m;
-      const unsigned off = b * (img_pitch >> 2) + (h2 * (unsigned)(W >> 1) + 2u * w4) * 4u;
-      return q < (unsigned)nq ? off : BF_OOB;
-    };
     if (active) {
       const int seg = vc / C;
       c = vc - seg * C;
@@ -156,8 +189,10 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
         const unsigned vo = quad_off(qbase + j * 256);
         // (the previous group's store data — dx in x0 / x1, dz in g0 / g1 — stays pinned up to here: see BF_KEEP)
         BF_KEEP(x0[j]) BF_KEEP(x1[j]) BF_KEEP(g0[j]) BF_KEEP(g1[j])
-        x0[j] = buf_load_f32x4(rx, vo, 0);
-        x1[j] = buf_load_f32x4(rx, vo, row_b);
+        if (!pf || j >= PFQ) {
+          x0[j] = buf_load_f32x4(rx, vo, 0);
+          x1[j] = buf_load_f32x4(rx, vo, row_b);
+        }
         if (POOL) {
           const float2 d = buf_load_f32x2(rdy, half_off(qbase + j * 256), 0);
           g0[j] = make_float4(0.25f * d.x, 0.25f * d.x, 0.25f * d.y, 0.25f * d.y);
@@ -179,6 +214,15 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
           const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + base, win);
           bf_sign_val(g0[j], buf_load_f32x4(ry, vo, 0), slope);
           bf_sign_val(g1[j], buf_load_f32x4(ry, vo, row_b), slope);
+        }
+      }
+      if (pf) {
+        // x was requested a barrier ago (behind it in the in-order memory pipe: the previous group's stores and the loads
+        // above, which are needed now anyway)
+#pragma unroll
+        for (int j = 0; j < PFQ; ++j) {
+          x0[j] = bf_pfx[(2 * j) * 256 + t];
+          x1[j] = bf_pfx[(2 * j + 1) * 256 + t];
         }
       }
       double s1 = 0.0, s2 = 0.0;
@@ -221,8 +265,13 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
       // ---- barrier: every slab of every channel of this group is published
       if (t == 0) {
         ++target;
-        bar_failed = bf_grid_barrier(bar, a.bar + BF_POISON_WORD, xcd, a.nx, bpx, target, a.spin_limit) ? 0 : 1;
+        bf_grid_arrive(bar, xcd, a.nx, bpx);
       }
+      if (pf) {
+        const int vcn = (grp + a.nsub) * a.cpg + ci;
+        if (grp + a.nsub < a.ngroups && ci < a.cpg && vcn < VC) request_x(vcn);
+      }
+      if (t == 0) bar_failed = bf_grid_wait(bar, a.bar + BF_POISON_WORD, xcd, target, a.spin_limit) ? 0 : 1;
       __syncthreads();
       if (bar_failed) return;  // abandoned launch (poison word set): no trap, no hang; the host raises
       if (!active) continue;
@@ -313,7 +362,12 @@ static bool bf_occupancy_ok() {
       (void)hipGetLastError();
       ok = 1;
     } else {
-      const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bn_bwd_fused_kernel<3, false, 10>, 256, 0);
+      // (8 quads per thread with the 48-KB request buffer is the LDS-heaviest launch, 10 quads the register-heaviest)
+      hipError_t e = hipSuccess;
+      int n8 = 0;
+      if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n8, bn_bwd_fused_kernel<3, false, 8>, 256, 48 * 1024);
+      if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bn_bwd_fused_kernel<3, false, 10>, 256, 0);
+      if (e == hipSuccess && n8 < n) n = n8;
       ok = (e != hipSuccess || n >= 2) ? 1 : 0;
       if (e != hipSuccess) (void)hipGetLastError();
     }
@@ -487,13 +541,22 @@ extern "C" int sivae_bn_bwd_fused(const float* dy, const float* y, const unsigne
   a.dbg_extra = p.local ? 0 : bf_dbg_break_next;
   if (!p.local) bf_dbg_break_next = 0;
   a.spin_limit = a.dbg_extra ? (1u << 14) : bf_spin_limit();  // (the test hook gives up after milliseconds)
+  // the next group's x requested into LDS across the barrier (up to 6 quads per thread = 48 KB per block): persistent
+  // forms with up to 8 quads per thread and more than one group per (half-)grid
+  static int pf_on = -1;
+  if (pf_on < 0) {
+    const char* e = getenv("SIVAE_BN_FUSED_PREFETCH");
+    pf_on = (e && e[0] == '0') ? 0 : 1;
+  }
+  a.pf = (pf_on && !p.local && p.nq_per_thread <= 8 && p.ngroups > p.nsub) ? 1 : 0;
+  const size_t lds = a.pf ? (size_t)(p.nq_per_thread < 6 ? p.nq_per_thread : 6) * 2 * 256 * sizeof(float4) : 0;
   const dim3 grid((unsigned)(p.local ? VC : p.nsub * p.nb_sub)), block(256);
-#define BF_LAUNCH(A, P, Q) hipLaunchKernelGGL((bn_bwd_fused_kernel<A, P, Q>), grid, block, 0, stream, a)
+#define BF_LAUNCH(A, P, Q) hipLaunchKernelGGL((bn_bwd_fused_kernel<A, P, Q>), grid, block, lds, stream, a);  // (lds <= 48 KB)
 #define BF_NQ(A, P)                                 \
   {                                                 \
-    if (p.nq_per_thread == 10) BF_LAUNCH(A, P, 10); \
-    else if (p.nq_per_thread == 8) BF_LAUNCH(A, P, 8); \
-    else BF_LAUNCH(A, P, 4);                        \
+    if (p.nq_per_thread == 10) BF_LAUNCH(A, P, 10) \
+    else if (p.nq_per_thread == 8) BF_LAUNCH(A, P, 8) \
+    else BF_LAUNCH(A, P, 4)                         \
   }
 #define BF_ACT(A)              \
   {                            \

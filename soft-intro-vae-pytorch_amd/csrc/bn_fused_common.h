@@ -38,8 +38,9 @@ constexpr unsigned BF_SPIN_LIMIT_DEFAULT = 1u << 24;  // polls of ~1 us: tens of
 // and barrier (first form of this kernel: 46 us per group instead of the ~13 us its bytes need).
 // Returns false when the wait was abandoned (spin limit reached here or in another block: the poison word is set) — the
 // caller's block must leave the kernel; nothing traps and nothing hangs.
-__device__ __forceinline__ bool bf_grid_barrier(unsigned* bar, unsigned* poison, int xcd, int nx, unsigned bpx,
-                                                unsigned target, unsigned spin_limit) {
+// The two halves separately (a caller may issue independent memory traffic between its arrival and its wait — the
+// persistent BatchNorm backward requests the next group's x there, bn_fused.hip):
+__device__ __forceinline__ void bf_grid_arrive(unsigned* bar, int xcd, int nx, unsigned bpx) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's partial sums (sc1 stores) have reached memory
   unsigned* cnt = bar + xcd * 32;
   const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -55,6 +56,9 @@ __device__ __forceinline__ bool bf_grid_barrier(unsigned* bar, unsigned* poison,
         __hip_atomic_fetch_add(bar + (9 + i) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+__device__ __forceinline__ bool bf_grid_wait(const unsigned* bar, unsigned* poison, int xcd, unsigned target,
+                                             unsigned spin_limit) {
   const unsigned* gen = bar + (9 + xcd) * 32;
   unsigned spins = 0;
   while (bf_load_u32(gen) != target) {
@@ -67,6 +71,11 @@ __device__ __forceinline__ bool bf_grid_barrier(unsigned* bar, unsigned* poison,
     }
   }
   return true;
+}
+__device__ __forceinline__ bool bf_grid_barrier(unsigned* bar, unsigned* poison, int xcd, int nx, unsigned bpx,
+                                                unsigned target, unsigned spin_limit) {
+  bf_grid_arrive(bar, xcd, nx, bpx);
+  return bf_grid_wait(bar, poison, xcd, target, spin_limit);
 }
 
 // may a persistent (grid-barrier) launch assume that all CUs sivae_num_cus() reports are available to it?  Not under a CU
