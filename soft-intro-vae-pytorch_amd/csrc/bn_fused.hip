@@ -100,7 +100,7 @@ __device__ __forceinline__ void bf_store4(__amdgpu_buffer_rsrc_t r, const float4
 template <int ACT, bool POOL, int NQ>
 __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
   __shared__ double red[4];
-  // x of the NEXT group, requested while this block waits at the grid barrier (a.pf): [NQ][2 rows][256 threads] float4 —
+  // x of the NEXT group, requested while this block waits at the grid barrier (a.pf): [PFQ][2 rows][256 threads] float4 —
   // a wave's 64 lanes are 1 KB contiguous, the layout an LDS-direct load writes (M0 base + lane * 16)
   extern __shared__ __attribute__((aligned(16))) float4 bf_pfx[];
   const int t = threadIdx.x;
@@ -149,9 +149,9 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
     const unsigned off = b * (img_pitch >> 2) + (h2 * (unsigned)(W >> 1) + 2u * w4) * 4u;
     return q < (unsigned)nq ? off : BF_OOB;
   };
-  // x of plane set `vcn` (this block's slab of it) -> LDS, 2 * NQ LDS-direct loads of 16 bytes per lane.  Issued for group
+  // x of plane set `vcn` (this block's slab of it) -> LDS, 2 * PFQ LDS-direct loads of 16 bytes per lane.  Issued for group
   // g + 1 between the arrival at group g's barrier and the wait: the memory pipe, otherwise idle until the last block has
-  // arrived and the partial sums are folded, delivers a third of the next group's bytes meanwhile (round 5).
+  // arrived and the partial sums are folded, delivers a quarter of the next group's bytes meanwhile (round 5).
   auto request_x = [&](int vcn) {
     const int segn = vcn / C, cn = vcn - segn * C;
     const __amdgpu_buffer_rsrc_t rxn = make_rsrc(a.x + ((size_t)segn * a.Bs * C + cn) * (size_t)HW, win);
