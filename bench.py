@@ -29,8 +29,8 @@ Prints ONE JSON line (rank 0). Besides the contract keys it carries
   also          (N = 1, default invocation) the other BASELINE.json configurations and the per-GPU shards of the
                 data-parallel ones, each measured in this same process: celeb256 at the 16-image shard (config 4 on 8
                 GPUs), soft_intro_vae_bootstrap at batch 64 and at its 8-image shard (config 5), cifar10 batch 256
-                (config 2), celeb128 batch 128 in bf16 mode (config 3, with its HBM fraction).  `value` there is the
-                untimed rate; `mfma_issued_frac` comes from a few instrumented iterations of the same engine.
+                (config 2), celeb128 batch 128 in bf16 mode (config 3, with its HBM fraction), and the bf16 mode at the
+                headline workload (celeb256 batch 128 and its 16-image shard).  `value` there is the untimed rate; `mfma_issued_frac` comes from a few instrumented iterations of the same engine.
 """
 import argparse
 import contextlib
@@ -292,6 +292,11 @@ def measure(args, cfg, gbatch, world, rank, dev, scaling, steps=None, warmup=Non
         dp.barrier()
         torch.cuda.synchronize()
         dt_untimed = time.perf_counter() - t1
+    # a persistent BatchNorm backward that gave up at its grid barrier leaves garbage gradients behind and a FAST iteration:
+    # never report such a run (collective under DP, like the training loop's drain())
+    poisoned = ops.bn_fused_poisoned()
+    if dp.any_rank(poisoned is not None, dev if world > 1 else None):
+        raise SystemExit(poisoned or "another rank's one-pass BatchNorm backward gave up at its grid barrier")
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -315,6 +320,9 @@ def also_legs(args, world, rank, dev):
         ("bootstrap256_fp32_bs8_shard", "celeb256", 8, True, "fp32", 20, 4, 3),
         ("cifar10_fp32_bs256", "cifar10", 256, False, "fp32", 25, 5, 5),
         ("celeb128_bf16_bs128", "celeb128", 128, False, "bf16", 14, 4, 4),
+        # SURVEY 8 gives config 4 as "fp32 parity / bf16 perf": the build-defined bf16 mode at the headline workload
+        ("celeb256_bf16_bs128", "celeb256", 128, False, "bf16", 6, 2, 2),
+        ("celeb256_bf16_bs16_shard", "celeb256", 16, False, "bf16", 12, 3, 3),
     ]
     out = {}
     for name, config, gb, boot, dtype, n_untimed, n_timed, n_warm in legs:
@@ -386,6 +394,20 @@ def main():
                     help="re-execute the two D-step decoder forwards whose inputs and weights are unchanged since the "
                          "E-step (the reference does); default: replay them from the E-step's activations")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N` (the shape of the N = 1 command): become the launcher — one process
+        # per GPU under torch.distributed.run on the loopback address, rank 0 prints the ONE JSON line.  (The reference's own
+        # multi-GPU precedent self-spawns too: style_soft_intro_vae/launcher.py:126-129.)
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.stdout.flush()
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                  "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+                                  "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
 
     from sivae_hip import dp
 
@@ -527,7 +549,7 @@ def main():
             "bootstrap256_bs64_img_s": also["bootstrap256_fp32_bs64"]["value"],
             "bootstrap256_bs8_shard_img_s": also["bootstrap256_fp32_bs8_shard"]["value"],
             "rate_vs_bs64": also["bootstrap256_fp32_bs8_shard"]["rate_vs_bs64"],
-            **{k + "_img_s": also[k]["value"] for k in also if k.startswith(("cifar10", "celeb128"))}}
+            **{k + "_img_s": also[k]["value"] for k in also if k.startswith(("cifar10", "celeb128", "celeb256_bf16"))}}
     print(json.dumps(out))
 
 

@@ -553,15 +553,10 @@ int sivae_bn_bwd_fused_state_uints(void);
  * zeroes the whole state (sivae_hip.ops.bn_fused_check).  Plans also refuse the persistent form under a CU mask
  * (HSA_CU_MASK / ROC_GLOBAL_CU_MASK), with SIVAE_BN_FUSED_PERSISTENT=0, or when the runtime reports fewer than two
  * resident blocks per CU: sivae_bn_bwd_fused_supported() then returns 0 for plane sets that need the barrier and the
- * callers keep the three-launch form.  sivae_debug_bn_fused_break_next(extra): test hook — the next persistent launch
- * waits for `extra` arrivals per XCD that never come (exercises the timeout path). */
+ * callers keep the three-launch form.  (The timeout path is exercised without a hook in this library: the test
+ * corrupts the caller-owned `state` so that the arrivals never add up and shortens the spin limit for that call; the
+ * resource-holding "squatter" kernel of the co-residency tests lives in tests/support/, not here.) */
 int sivae_bn_bwd_fused_poison_word(void);
-int sivae_debug_bn_fused_break_next(int extra);
-/* test support: a kernel that only holds `blocks` x `threads` threads + `lds_bytes` of LDS (fat != 0: and ~200 VGPRs per
- * wave, so that no wave of a 256-register kernel fits beside it) for `ticks` 100-MHz periods (or until *stop != 0) — the
- * footprint of a collective on a side stream next to the persistent kernels */
-int sivae_debug_squatter(int blocks, int threads, int lds_bytes, int fat, long long ticks, const int* stop,
-                         sivae_stream_t stream);
 int sivae_bn_bwd_fused(const float* dy, const float* y, const unsigned char* mask, const float* x, const float* mean,
                        const float* invstd, const float* gamma, const float* beta, int act_mode, float slope, float* dx,
                        float* dz_out, float* dgamma, float* dbeta, int B, int C, int H, int W, int dy_pooled, int dz_sum,

@@ -383,6 +383,31 @@ struct B16Plan {
   int nu, spc, cpg, ngroups, nb_sub, nsub, local;
 };
 
+// how many blocks of the heaviest instantiation (4 units per thread) does the runtime place on one CU, with and without
+// the 48-KB request buffer?  (bn_fused.hip's bf_occupancy_ok for this kernel.  Two by construction —
+// __launch_bounds__(256, 2), 2.4 KB of static LDS + 48 KB —; the query guards against a runtime that disagrees: fewer
+// than two without the buffer -> no persistent form; fewer than two with it -> the buffer is switched off.  Margin next
+// to a co-tenant: two blocks hold 2 x 50.4 KB, i.e. they fit beside up to 59 KB of somebody else's LDS, and no block is
+// larger than 160 / 3 KB, so a co-tenant that leaves cannot fragment the CU against the second block.)
+static int b16_occupancy(bool with_buffer) {
+  static int occ[2] = {-1, -1};
+  int& o = occ[with_buffer ? 1 : 0];
+  if (o < 0) {
+    int ndev = 0, n = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+      (void)hipGetLastError();
+      o = 2;  // (planning queries on a build box)
+    } else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bf16_bn_bwd_fused_kernel<3, false, 4>, 256,
+                                                            with_buffer ? 48 * 1024 : 0) != hipSuccess) {
+      (void)hipGetLastError();
+      o = 2;
+    } else {
+      o = n;
+    }
+  }
+  return o;
+}
+
 static bool b16_plan(int B, int Cb, int HW, B16Plan* out) {
   const long long nq = (long long)B * HW / 4;
   for (int NU : {1, 2, 4}) {
@@ -390,7 +415,7 @@ static bool b16_plan(int B, int Cb, int HW, B16Plan* out) {
     *out = B16Plan{NU, 1, 1, Cb, Cb, 1, 1};
     return true;
   }
-  if (!bf_persistent_allowed()) return false;  // (CU mask / switched off: the three-launch form)
+  if (!bf_persistent_allowed() || b16_occupancy(false) < 2) return false;  // (CU mask / switched off: three launches)
   for (int nsub = 2; nsub >= 1; --nsub) {
     const int nb_sub = sivae_num_cus() * (nsub == 2 ? 1 : 2);
     const int NU = 4;
@@ -478,7 +503,7 @@ extern "C" int sivae_bf16_bn_bwd_fused(const void* dy, int dy_pooled, const void
     const char* e = getenv("SIVAE_BN_FUSED_PREFETCH");
     pf_on = (e && e[0] == '0') ? 0 : 1;
   }
-  a.pf = (pf_on && !p.local && p.nu == 4 && p.ngroups > p.nsub) ? 1 : 0;
+  a.pf = (pf_on && !p.local && p.nu == 4 && p.ngroups > p.nsub && b16_occupancy(true) >= 2) ? 1 : 0;
   const size_t lds = a.pf ? (size_t)3 * 4 * 256 * 16 : 0;  // 48 KB
   const int act = sign_mask ? 3 : (y ? 1 : 2);
   const dim3 grid((unsigned)(p.local ? Cb : p.nsub * p.nb_sub)), block(256);

@@ -55,7 +55,6 @@ struct BnFusedArgs {
   int dzmode;  // 0: none, 1: dz at full resolution, 2: 2x2 block sums [.][H/2][W/2]
   int pf;      // 1: the NEXT group's x is requested into LDS (LDS-direct loads) between the barrier's arrival and its wait
   unsigned spin_limit;  // polls of the barrier wait before the launch is abandoned (poison word set)
-  int dbg_extra;        // test hook: arrivals the barrier expects on top of the real ones (never come -> timeout path)
 };
 
 __device__ __forceinline__ void bf_sign_nibble(float4& g, unsigned nib, float slope) {
@@ -118,7 +117,7 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
   unsigned* bar = a.bar + sub * BF_BAR_UINTS;
   unsigned* chcnt = a.bar + 2 * BF_BAR_UINTS;
   const int xcd = bid % a.nx;
-  const unsigned bpx = (unsigned)(nb_sub / a.nx + a.dbg_extra);
+  const unsigned bpx = (unsigned)(nb_sub / a.nx);
   __shared__ int bar_failed;
   unsigned target = 0;
   if (t == 0 && !local) target = bf_load_u32(bar + (9 + xcd) * 32);
@@ -431,8 +430,6 @@ static bool bf_plan(int Bs, int VC, int HW, int max_nq, BfPlan* out) {
   return false;
 }
 
-static int bf_dbg_break_next = 0;
-
 static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 }  // namespace
@@ -453,13 +450,6 @@ extern "C" int sivae_bn_bwd_fused_supported(int B, int C, int H, int W, int seg_
 // index (in unsigned ints) of the state word a timed-out grid barrier sets: the host checks it where it reads results
 // back anyway (sivae_hip.ops.bn_fused_check) and must zero the whole state before the next launch when it is non-zero
 extern "C" int sivae_bn_bwd_fused_poison_word() { return BF_POISON_WORD; }
-
-// test hook: the next persistent launch of sivae_bn_bwd_fused expects `extra` arrivals per XCD that never come, i.e. it
-// takes the timeout path (poison word set, every block returns) — tests/kernel_checks.py::check_bn_fused_timeout
-extern "C" int sivae_debug_bn_fused_break_next(int extra) {
-  bf_dbg_break_next = extra;
-  return SIVAE_OK;
-}
 
 // partial sums [VC][spc][2] + per-(segment, channel) sums [VC][2], doubles
 extern "C" size_t sivae_bn_bwd_fused_workspace_bytes(int B, int C, int H, int W, int seg_images) {
@@ -538,9 +528,7 @@ extern "C" int sivae_bn_bwd_fused(const float* dy, const float* y, const unsigne
   a.nsub = p.nsub;
   a.local = p.local;
   a.dzmode = !dz_out ? 0 : (dz_sum ? 2 : 1);
-  a.dbg_extra = p.local ? 0 : bf_dbg_break_next;
-  if (!p.local) bf_dbg_break_next = 0;
-  a.spin_limit = a.dbg_extra ? (1u << 14) : bf_spin_limit();  // (the test hook gives up after milliseconds)
+  a.spin_limit = bf_spin_limit();
   // the next group's x requested into LDS across the barrier (up to 6 quads per thread = 48 KB per block): persistent
   // forms with up to 8 quads per thread and more than one group per (half-)grid
   static int pf_on = -1;

@@ -93,14 +93,12 @@ static inline bool bf_persistent_allowed() {
   }
   return ok == 1;
 }
+// (read per launch, not cached: tests/kernel_checks.py::check_bn_fused_timeout shortens it for one call)
 static inline unsigned bf_spin_limit() {
-  static long long lim = -1;
-  if (lim < 0) {
-    const char* e = getenv("SIVAE_BN_FUSED_SPIN_LIMIT");
-    lim = e ? atoll(e) : (long long)BF_SPIN_LIMIT_DEFAULT;
-    if (lim < 16) lim = 16;
-    if (lim > 0x7fffffffLL) lim = 0x7fffffffLL;
-  }
+  const char* e = getenv("SIVAE_BN_FUSED_SPIN_LIMIT");
+  long long lim = e ? atoll(e) : (long long)BF_SPIN_LIMIT_DEFAULT;
+  if (lim < 16) lim = 16;
+  if (lim > 0x7fffffffLL) lim = 0x7fffffffLL;
   return (unsigned)lim;
 }
 

@@ -137,7 +137,12 @@ def repack(params, owner):
             launches.append((f, jt, bj, nblocks))
         plan = {"key": key, "launches": launches, "keep": [b for fl in jobs for _, b in fl]}
         # (job tables of earlier plans stay alive: a HIP graph captured while they were current still launches with them)
-        owner.__dict__.setdefault("_sivae_pack_plan_old", []).append(owner.__dict__.get("_sivae_pack_plan"))
+        # — the last few only: a workload whose set of cached forms oscillates would otherwise accumulate device memory
+        prev = owner.__dict__.get("_sivae_pack_plan")
+        if prev is not None:
+            old = owner.__dict__.setdefault("_sivae_pack_plan_old", [])
+            old.append(prev)
+            del old[:-4]
         owner.__dict__["_sivae_pack_plan"] = plan
     for f, jt, bj, nblocks in plan["launches"]:
         ops._lib.call("sivae_pack_batch", f, ops._p(jt), ops._p(bj), nblocks, ops._s(jt))
@@ -766,8 +771,8 @@ def lincomb(ts, ws):
     if not 0 < len(ts) <= 6 or len(ts) != len(ws):
         raise ValueError("sivae_hip.lincomb: 1..6 terms with one weight each")
     for t in ts:
-        if t.numel() != 1 or t.dtype != torch.float32 or not t.is_cuda:
-            raise ValueError("sivae_hip.lincomb: terms must be float32 device scalars")
+        if t.dim() != 0 or t.dtype != torch.float32 or not t.is_cuda:
+            raise ValueError("sivae_hip.lincomb: terms must be 0-dim float32 device scalars")
     return LinCombFn.apply(tuple(float(w) for w in ws), *ts)
 
 

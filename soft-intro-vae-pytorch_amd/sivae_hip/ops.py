@@ -162,23 +162,36 @@ def bn_fused_state(device):
     return buf
 
 
+BN_FUSED_POISON_MSG = ("sivae_hip: a one-pass BatchNorm backward (sivae_bn_bwd_fused) gave up at its grid barrier on "
+                       "device/stream %s: its grid was not fully resident (another persistent kernel or process on "
+                       "the GPU, or a CU mask).  The iteration's gradients are invalid.  Set SIVAE_BN_FUSED=0 (the "
+                       "three-launch form) or SIVAE_BN_FUSED_PERSISTENT=0 for this deployment.")
+
+
+def bn_fused_poisoned():
+    """The non-raising form of `bn_fused_check`: None, or the message to raise with.  Data-parallel callers fold the
+    answer into a collective flag first (sivae_hip.dp.any_rank) so that every rank raises together — a rank raising alone
+    leaves the others waiting in the next all-reduce."""
+    if not _bn_states:
+        return None
+    w = _lib.load().sivae_bn_bwd_fused_poison_word()
+    bad = [k for k, buf in _bn_states.items() if int(buf[w].item()) != 0]
+    if not bad:
+        return None
+    for k in bad:
+        _bn_states[k].zero_()
+    return BN_FUSED_POISON_MSG % (bad,)
+
+
 def bn_fused_check():
     """Was a persistent BatchNorm-backward launch abandoned (its grid barrier timed out because the grid was not fully
     resident — another persistent kernel, a CU mask the runtime does not report)?  Reads one word per barrier state (a
     device->host copy: call it where results are read back anyway — the training loops do, once per logging interval);
     if set: zeroes the state (the counters of an abandoned launch are inconsistent) and raises.  The outputs of the
     abandoned launch and of everything after it are garbage."""
-    if not _bn_states:
-        return
-    w = _lib.load().sivae_bn_bwd_fused_poison_word()
-    bad = [k for k, buf in _bn_states.items() if int(buf[w].item()) != 0]
-    if bad:
-        for k in bad:
-            _bn_states[k].zero_()
-        raise RuntimeError("sivae_hip: a one-pass BatchNorm backward (sivae_bn_bwd_fused) gave up at its grid barrier on "
-                           "device/stream %s: its grid was not fully resident (another persistent kernel or process on "
-                           "the GPU, or a CU mask).  The iteration's gradients are invalid.  Set SIVAE_BN_FUSED=0 (the "
-                           "three-launch form) or SIVAE_BN_FUSED_PERSISTENT=0 for this deployment." % (bad,))
+    msg = bn_fused_poisoned()
+    if msg is not None:
+        raise RuntimeError(msg)
 
 
 def _bn_bwd_fused_ok(x, nseg):

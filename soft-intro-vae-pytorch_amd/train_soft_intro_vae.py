@@ -307,13 +307,18 @@ def _train(dataset, z_dim, lr_e, lr_d, batch_size, num_workers, start_epoch, exi
         pending = []  # stats vectors still on the device; read back in one go per logging interval
 
         def drain():
+            # an abandoned persistent BatchNorm backward is reported here instead of trapping the GPU.  The check runs
+            # whether or not statistics are pending (the VAE warm-up epochs queue none) and, like the NaN abort, it is
+            # COLLECTIVE under DP: every rank drains at the same iterations, the flags are all-reduced and all ranks raise
+            # together (a rank raising alone would leave the others in the next all-reduce)
+            poisoned = _ops.bn_fused_poisoned()
+            if _dp.any_rank(poisoned is not None, device if world > 1 else None):
+                raise RuntimeError(poisoned or "sivae_hip: another rank's one-pass BatchNorm backward gave up at its grid "
+                                               "barrier (see that rank's message); this iteration's gradients are invalid")
             if not pending:
                 return
             rows = torch.stack(pending).cpu()  # ONE device->host copy for the whole interval
             pending.clear()
-            _ops.bn_fused_check()  # (an abandoned persistent BatchNorm backward raises here instead of trapping the GPU)
-            # the abort is COLLECTIVE under DP: every rank drains at the same iterations, the flag is all-reduced, and
-            # all ranks raise together (a rank raising alone would leave the others in the next all-reduce)
             if _dp.any_rank(bool(torch.isnan(rows[:, :2]).any()), device if world > 1 else None):
                 raise SystemError
             for r in rows.tolist():

@@ -12,6 +12,8 @@ import traceback
 import torch
 import torch.nn.functional as F
 
+import support as _support  # tests/support: kernels that must not live in the product library
+
 DEV = "cuda"
 
 
@@ -1417,7 +1419,7 @@ def check_bn_fused_squatter():
     """Forward progress and bit-equality of the persistent BatchNorm backward while another kernel HOLDS part of the chip
     (the footprint of a collective on a side stream: 48 workgroups x 512 threads + 32 KB of LDS each, resident for
     ~0.4 s): headline shapes 256 x 64 x 256^2 and 256 x 128 x 128^2; then next to a real (world-size-1) `nccl` process
-    group issuing all_reduce(async_op=True) of 110 MB in a loop.  The calls must complete within a bound (no deadlock,
+    group issuing all_reduce(op=AVG, async_op=True) of 110 MB in a loop (AVG: the one-rank path then runs a kernel).  The calls must complete within a bound (no deadlock,
     no trap, poison word clear) and reproduce the undisturbed bits."""
     import time
     from sivae_hip import ops
@@ -1450,8 +1452,9 @@ def check_bn_fused_squatter():
         for fat in (0, 1):
             stop.zero_()
             torch.cuda.synchronize()
-            ops._lib.call("sivae_debug_squatter", 48, 512, 32768, fat, 40_000_000, ops._p(stop),
-                          ctypes.c_void_p(side.cuda_stream))
+            rc = _support.load().testsupport_squatter(48, 512, 32768, fat, 40_000_000, ops._p(stop),
+                                                      ctypes.c_void_p(side.cuda_stream))
+            assert rc == 0, rc
             t0 = time.time()
             nbad = 0
             for _ in range(5):
@@ -1468,7 +1471,11 @@ def check_bn_fused_squatter():
             # bound: it may wait for the squatter to leave (0.4 s over 5 calls) but must not hang: < 1 s per call
             res.append(("squatter_%s_bn_fused_seconds_per_call%s alone=%.4f" % (kind, tag, t_alone), t_sq, 1.0))
         del x, dy, alone, xs
-    # a real collective on a side stream (world size 1: RCCL still launches its kernel)
+    # a real collective KERNEL on a side stream.  World size 1 (the box has one GPU): a plain in-place SUM is short-circuited
+    # by RCCL (ncclLaunchOneRank: no kernel at all), so the loop uses ReduceOp.AVG — a PreMulSum reduction, for which the
+    # one-rank path launches RCCL's reduce kernel over the whole 110-MB buffer.  tools/rccl_overlap.sh traces this check
+    # with rocprofv3 and tools/rccl_overlap.py lists the RCCL kernel rows that overlap bn_bwd_fused_kernel in time
+    # (profiles/r6_rccl_overlap_bn_fused.txt).
     import os
     import torch.distributed as dist
     made = False
@@ -1489,14 +1496,14 @@ def check_bn_fused_squatter():
         alone = [t.clone() for t in ops.bn_bwd(dy, None, x, mean, invstd, gamma, 0.2, beta=beta, act_mode=2, nseg=nseg)
                  if t is not None]
         flat = torch.randn(27_500_000, device=DEV, generator=g)  # 110 MB: the encoder's flat gradient
-        dist.all_reduce(flat)  # (communicator set-up happens in the first collective: not part of the timing)
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG)  # (communicator set-up happens in the first collective: not timed)
         torch.cuda.synchronize()
         t0 = time.time()
         nbad = 0
         works = []
         for it in range(20):
             with torch.cuda.stream(side):
-                works.append(dist.all_reduce(flat, async_op=True))
+                works.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True))
             out = [t for t in ops.bn_bwd(dy, None, x, mean, invstd, gamma, 0.2, beta=beta, act_mode=2, nseg=nseg)
                    if t is not None]
             nbad += int(not all(torch.equal(a, b) for a, b in zip(out, alone)))
@@ -1513,9 +1520,11 @@ def check_bn_fused_squatter():
 
 
 def check_bn_fused_timeout():
-    """the grid barrier's timeout path: a persistent launch that waits for arrivals that never come (test hook) must END
-    — no trap, no hang —, set the poison word (ops.bn_fused_check raises and resets the state), and the next call must
-    work and reproduce the three-launch form."""
+    """the grid barrier's timeout path, without a hook in the product library: the barrier state is CALLER-owned, so the
+    test corrupts it (every arrival counter of both half-grid areas starts far from zero: the arrivals of the launch never
+    add up to a full XCD group, no generation flag ever advances) and shortens the spin limit for that call
+    (SIVAE_BN_FUSED_SPIN_LIMIT is read per launch).  The launch must END — no trap, no hang —, set the poison word
+    (ops.bn_fused_check raises and zeroes the state), and the next call must work and reproduce the result bit for bit."""
     import os
     from sivae_hip import ops
     L = ops._lib.load()
@@ -1528,9 +1537,23 @@ def check_bn_fused_timeout():
     good = [t.clone() for t in ops.bn_bwd(dy, None, x, mean, invstd, gamma, 0.2, beta=beta, act_mode=2) if t is not None]
     torch.cuda.synchronize()
     ops.bn_fused_check()
-    L.sivae_debug_bn_fused_break_next(1)
-    ops.bn_bwd(dy, None, x, mean, invstd, gamma, 0.2, beta=beta, act_mode=2)  # abandoned after the spin limit
-    torch.cuda.synchronize()  # (returns: the kernel ended by itself)
+    assert ops._bn_states, "the one-pass BatchNorm backward did not run (no barrier state was created)"
+    area = 1024  # uints per half-grid barrier area (bn_fused_common.h: BF_BAR_UINTS), arrival counter of XCD i at 32 i
+    assert L.sivae_bn_bwd_fused_poison_word() == area - 32
+    for buf in ops._bn_states.values():
+        for half in range(2):
+            for xcd in range(8):
+                buf[half * area + 32 * xcd] = 0x40000000
+    old = os.environ.get("SIVAE_BN_FUSED_SPIN_LIMIT")
+    os.environ["SIVAE_BN_FUSED_SPIN_LIMIT"] = str(1 << 14)  # (gives up after milliseconds instead of tens of seconds)
+    try:
+        ops.bn_bwd(dy, None, x, mean, invstd, gamma, 0.2, beta=beta, act_mode=2)  # abandoned after the spin limit
+        torch.cuda.synchronize()  # (returns: the kernel ended by itself)
+    finally:
+        if old is None:
+            os.environ.pop("SIVAE_BN_FUSED_SPIN_LIMIT", None)
+        else:
+            os.environ["SIVAE_BN_FUSED_SPIN_LIMIT"] = old
     raised = 0.0
     try:
         ops.bn_fused_check()

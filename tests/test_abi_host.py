@@ -412,7 +412,6 @@ def test_round5_entry_points_validate_arguments():
     # the grid-barrier timeout word lies inside the barrier state, on its own 128-byte line behind the 17 used lines
     w = L.sivae_bn_bwd_fused_poison_word()
     assert 17 * 32 <= w < 1024 and w % 32 == 0 and w < L.sivae_bn_bwd_fused_state_uints()
-    assert L.sivae_debug_bn_fused_break_next(0) == 0
     # a (256, 64, 256, 256) batch of 129..160 images per segment fits the 10-quad plan only: the query now plans with the
     # tightest variant's budget (8 quads), so the callers fall back instead of hitting SIVAE_ERR_SHAPE in the launch
     assert L.sivae_bn_bwd_fused_supported(160, 64, 256, 256, 160) == 0
@@ -427,8 +426,12 @@ def test_round5_entry_points_validate_arguments():
     assert L.sivae_lincomb_bwd(one, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 9, one, null) == -2
     # the streaming 1x1 kernel takes up to 512 input channels (32-channel tile above 256)
     assert L.sivae_conv1x1_stream_supported(2, 512, 256, 1024) == 1 and L.sivae_conv1x1_stream_supported(2, 514, 256, 1024) == 0
-    # test-support kernel: argument validation
-    sq = L.sivae_debug_squatter
+    # test hooks are not part of the product ABI (the squatter kernel lives in tests/support/, the barrier-timeout test
+    # corrupts the caller-owned state instead of calling a hook)
+    assert not [n for n in lib.prototypes() if "debug" in n]
+    assert not hasattr(L, "sivae_debug_squatter") and not hasattr(L, "sivae_debug_bn_fused_break_next")
+    import support
+    sq = support.load().testsupport_squatter
     assert sq(0, 256, 1024, 0, 1000, null, null) == -2 and sq(4, 2048, 1024, 0, 1000, null, null) == -2
     assert sq(4, 256, 1 << 20, 0, 1000, null, null) == -2 and sq(4, 256, 1024, 0, 0, null, null) == -2
 

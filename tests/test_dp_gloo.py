@@ -162,3 +162,19 @@ def test_gradsync_early_bucket_is_the_early_final_half():
     enc = Opt([10, 20, 30, 40, 50, 800, 900, 1000])  # encoder-like: big tensors last
     split, tail = sync._plan(enc)
     assert split == 10 + 20 + 30 + 40 and sum(p.numel() for p in tail) == 2750
+
+
+def test_bench_without_world_size_becomes_its_own_launcher(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE set must start one process per rank itself (torch.distributed.run on
+    127.0.0.1) instead of refusing: without a GPU each rank then stops at the device check — the message that proves the
+    ranks were started (the old behaviour was a 'launch with torch.distributed.run' exit in the parent)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PYTHONDONTWRITEBYTECODE="1")
+    if torch.cuda.is_available():
+        pytest.skip("the GPU twin of this test is tests/test_dp_gpu.py::test_bench_plain_python_start_spawns_its_own_ranks")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert out.returncode != 0
+    assert "needs a ROCm device" in out.stderr, out.stderr[-1500:]
+    assert "launch with torch.distributed.run" not in out.stderr

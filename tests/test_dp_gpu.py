@@ -182,3 +182,21 @@ def test_bench_two_rank_launch_reports_strong_and_weak_lines(tmp_path):
     import math
     assert all(math.isfinite(v) for v in d["config"]["final_stats"].values())
     assert "cpu_baseline" not in d  # (rank 0 of a multi-GPU launch does not time the CPU loop)
+
+
+def test_bench_plain_python_start_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2 ...` with no WORLD_SIZE in the environment (the shape of the driver's N = 1 command)
+    re-executes itself under torch.distributed.run, one process per rank, and still prints ONE JSON line from rank 0."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device",
+           "--scaling", "strong", "--steps", "1", "--warmup", "1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["per_gpu_batch"] == 64 and d["value"] > 0

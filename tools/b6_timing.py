@@ -1,5 +1,5 @@
-"""Phase timing of conv_wino4_b6 (a -DB6_TIMING build: SIVAE_LIB=tools/ab/b6_timing.so python tools/b6_timing.py) and the
-launch time of ablated builds (SIVAE_LIB=tools/ab/b6_ablN.so python tools/b6_timing.py plain)."""
+"""Phase timing of conv_wino4_b6 (a -DB6_TIMING build: SIVAE_LIB=tools/abx/b6_timing.so python tools/b6_timing.py) and the
+launch time of ablated builds (SIVAE_LIB=tools/abx/b6_ablN.so python tools/b6_timing.py plain)."""
 import ctypes, os, sys
 import numpy as np
 import torch

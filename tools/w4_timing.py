@@ -1,5 +1,5 @@
 """Phase timing of conv_wino4_kernel items (GPU box; needs the -DW4_TIMING build of conv_wino4.hip that
-tools/build_w4_timing.sh [ablate-bits ...] makes: tools/ab/w4_timing_<bits>.so, selected by W4_VARIANT=<bits>).
+tools/build_w4_timing.sh [ablate-bits ...] makes: tools/abx/w4_timing_<bits>.so, selected by W4_VARIANT=<bits>).
 usage: python tools/w4_timing.py [B]     prints per layer the mean microseconds of: K loop | epilogue round 0 write+barrier |
 round 0 read/store | rounds 1-3 | statistics tail, and the shader clock seen by clock64."""
 import ctypes, os, sys
