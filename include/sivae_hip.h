@@ -586,8 +586,16 @@ int sivae_conv2d_wino_wgrad_seg(const float* x, const float* dy, float* dw, cons
  * stats_partial: [sivae_conv2d_wino4_num_px_tiles][Co][2] rows in image order (sivae_bn_stats_from_conv[_seg]). */
 size_t sivae_pack_wino4_weight_bytes(int Co, int Ci, int mode);
 int sivae_pack_wino4_weight(const float* w, float* up, int Co, int Ci, int mode, sivae_stream_t stream);
-int sivae_conv2d_wino4_supported(int H, int W); /* 1: H % 16 == 0, W % 32 == 0; 2: 16 x 16 maps, run as image pairs (B even,
-                                                     seg_images even; stats rows per pair); 0 otherwise */
+int sivae_conv2d_wino4_supported(int H, int W); /* 1: H % 16 == 0, W % 32 == 0; 2 / 3 / 4: 16 x 16 / 8 x 8 / 4 x 4 maps — a
+                                                     work item (32 x 16 pixels) is a grid of 2 x 1 / 4 x 2 / 8 x 4 whole
+                                                     images (round 6: the 8 x 8 and 4 x 4 maps of the deep 512-channel
+                                                     blocks, res_in_8 / res_in_4 of train_soft_intro_vae.py:100-103,
+                                                     153-158), every seam zero padding: B and seg_images must be multiples
+                                                     of sivae_conv2d_wino4_images_per_item; stats rows per item; 0 otherwise */
+int sivae_conv2d_wino4_images_per_item(int H, int W); /* 1, 2, 8, 32 for modes 1..4; 0: unsupported map */
+/* modes 3 / 4 only: 1 when the image-grid launch (with its split-K plan) is expected to beat F(2x2,3x3) — enough
+ * (slices x items) for every CU and a long enough K slice (measured: profiles/r6_wino4_small_maps_vs_f23.txt) */
+int sivae_conv2d_wino4_small_pays(int B, int Ci, int Co, int H, int W);
 int sivae_conv2d_wino4_pays(int B, int Ci, int Co, int H, int W); /* supported AND >= one work item per CU */
 int sivae_conv2d_wino4_num_px_tiles(int B, int H, int W);
 int sivae_conv2d_wino4_fwd(const float* x, const float* up, float* y, float* stats_partial, int B, int Ci, int Co, int H,
@@ -617,7 +625,7 @@ int sivae_conv2d_wino4_fwd_splitk(const float* x, const float* up, float* y, con
  * (soft_intro_vae/train_soft_intro_vae.py:56-61) with the same argument meaning as sivae_conv2d_wino4_fwd_pro /
  * sivae_conv2d_wino4_fwd_splitk (pro_mean may be NULL; no limit on segments x channels: the prologue parameters are read
  * through scalar loads); `up` = the pre-split operand of sivae_pack_wino4_b6_weight ([j][Ci_pad/16][Co_pad/32][i][piece]
- * blocks of 64 lanes x 8 bf16, 1.5x the bytes of the fp32 pack); maps: sivae_conv2d_wino4_supported; the split-K plan
+ * blocks of 64 lanes x 8 bf16, 1.5x the bytes of the fp32 pack); maps: modes 1 and 2 of sivae_conv2d_wino4_supported; the split-K plan
  * and workspace are those of sivae_conv2d_wino4_splitk / _splitk_workspace_bytes. */
 size_t sivae_pack_wino4_b6_weight_bytes(int Co, int Ci, int mode);
 int sivae_pack_wino4_b6_weight(const float* w, void* up, int Co, int Ci, int mode, sivae_stream_t stream);

@@ -55,7 +55,14 @@ struct Wino4Args {
   int accumulate;
   int n_items;
   int xcd_group;
-  int two;  // 16 x 16 maps: a work item is a PAIR of images side by side (32 x 16 pixels)
+  // Maps smaller than a work item's 32 x 16 pixels: the item is a GRID of whole images — 16 x 16: 2 x 1 images, 8 x 8:
+  // 4 x 2, 4 x 4: 8 x 4 (two = 1; iw_l2 / ih_l2 = log2 of the image width / height, 0 otherwise).  Every seam between two
+  // images is zero padding for both: the halo rows 0 / 17 and groups 0 / 9 are out of range for the loader, and the
+  // transform role zeroes patch column 0 / 5 and patch row 0 / 5 of the tiles that touch a seam through the four 64-bit
+  // lane masks below (lane -> tile = lane & 31, tile column = tile & 7, tile row = tile >> 3; computed by the launch).
+  int two;
+  int iw_l2, ih_l2;
+  unsigned long long seam_c0, seam_c5, seam_r0, seam_r5;
   // split-K (launches with fewer work items than CUs): an item = (pixel tile, K slice, co tile); slice ks walks the cps
   // chunks from ks * cps on and writes its partial outputs to y + ks * slice_stride (summed by wino4_splitk_reduce_kernel)
   int ksl, cps;
@@ -127,7 +134,9 @@ extern "C" int sivae_debug_w4_read(long long* out) {
 #define W4_STAMPK(CH)
 #endif
 
-template <bool PRO>
+// GRID: the image-grid mode (maps up to 16 x 16) as its own instantiation — the large-map kernels carry neither its seam
+// masks (eight scalar registers) nor its selects
+template <bool PRO, bool GRID = false>
 __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
   constexpr int CK = W4_CK, RS = W4_RS, PLANE = W4_PLANE, XBUF = W4_XBUF, VBUF = W4_VBUF;
   // the two raw-halo buffers are SEPARATE static arrays: the compiler orders a ds_read behind every in-flight LDS-direct
@@ -158,8 +167,11 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
   const bool pair05 = tp == 2;
   // pair mode: lanes whose tile column is 4 (patch column 0 = the other image's last column) / 3 (patch column 5 = the
   // other image's first column) — as 64-bit lane masks for v_cndmask (tile = lane & 31, column = tile & 7)
-  const unsigned long long seam_m0 = 0x1010101010101010ull, seam_m5 = 0x0808080808080808ull;
-  const int two_w = a.two ? 32 : a.W, two_mask = a.two ? 15 : -1, two_img = a.two ? a.Ci * a.H * a.W : 0;
+  const unsigned long long seam_m0 = a.seam_c0, seam_m5 = a.seam_c5, seam_mr0 = a.seam_r0, seam_mr5 = a.seam_r5;
+  // image grid of an item (branch-free: one image -> bounds H x W, masks ~0, image stride 0)
+  const int two_w = GRID ? W4_PXW : a.W, two_h = GRID ? W4_PXH : a.H;
+  const int two_mask = GRID ? a.W - 1 : -1, two_hmask = GRID ? a.H - 1 : -1;
+  const int two_img = GRID ? a.Ci * a.H * a.W : 0, two_nx = W4_PXW >> a.iw_l2, two_ipi = GRID ? two_nx * (W4_PXH >> a.ih_l2) : 1;
   // ---- MFMA role: B operand V[(i*6 + wj)][2*kk + hh][l31]
   const int vrb = (wj * CK + hh) * 32 + l31;
 
@@ -201,13 +213,15 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
     r0 = tby * W4_PXH;                                                   \
     c0 = tbx * W4_PXW;                                                   \
     co0 = co_tile * W4_TCO;                                              \
-    /* pair mode (16 x 16 maps): images 2 pt, 2 pt + 1 side by side — halo groups 1-4 of a row = image 0, 5-8 = image 1, */ \
-    /* 0 and 9 = zero padding (branch-free: two_w = 32, two_mask = 15, two_img = Ci*HW; otherwise W, ~0, 0) */ \
-    b = a.two ? 2 * pt : b;                                              \
-    xrsrc = make_rsrc(a.x + (size_t)b * a.Ci * HW, (unsigned long long)(a.two ? 2 : 1) * a.Ci * HW * 4ull); \
+    /* image-grid mode (maps up to 16 x 16): images ipi * pt ... in row-major order of the grid — halo row r / group  */ \
+    /* column c belong to image (r >> ih_l2) * nx + (c >> iw_l2) at (r & (H-1), c & (W-1)); rows -1 / 16 and groups   */ \
+    /* -4 / 32 are zero padding (branch-free: bounds 16 x 32, masks H-1 / W-1, stride Ci*HW; otherwise H x W, ~0, 0)   */ \
+    b = GRID ? two_ipi * pt : b;                                        \
+    xrsrc = make_rsrc(a.x + (size_t)b * a.Ci * HW, (unsigned long long)two_ipi * a.Ci * HW * 4ull); \
     const int r = r0 - 1 + prow, c = c0 - 4 + 4 * pk;                    \
-    xo = (pvalid && r >= 0 && r < H && c >= 0 && c < two_w)              \
-             ? (unsigned)((c >> 4) * two_img + r * W + (c & two_mask)) * 4u : SIVAE_OOB; \
+    xo = (pvalid && r >= 0 && r < two_h && c >= 0 && c < two_w)          \
+             ? (unsigned)(((r >> a.ih_l2) * two_nx + (c >> a.iw_l2)) * two_img + (r & two_hmask) * W + (c & two_mask)) * 4u \
+             : SIVAE_OOB;                                                \
     ua_base = (unsigned)((wj * a.Ci_pad + cbase) * a.Co_pad + co0) * 24u; \
     if (PRO) pseg = (b / a.pro_seg_images) * a.Ci_pad + cbase;           \
   }
@@ -290,7 +304,7 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
       if (P05) {                                                         \
         te0_[r] = p_[r * RS - 1];                                        \
         te5_[r] = p_[r * RS + 4];                                        \
-        if (a.two) { /* the seam between the two images is zero padding for both (tile columns 3 | 4) */ \
+        if (GRID) { /* a seam between two images is zero padding for both (16 x 16 maps: tile columns 3 | 4) */   \
           asm volatile("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(te0_[r]) : "s"(seam_m0));                \
           asm volatile("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(te5_[r]) : "s"(seam_m5));                \
         }                                                                \
@@ -309,6 +323,12 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
         tA_[(R0) + r] = a_ + b_;                                         \
         tB_[(R0) + r] = a_ - b_;                                         \
       }                                                                  \
+    }                                                                    \
+    if (GRID) { /* patch row 0 / 5 of a tile at the top / bottom edge of its image is zero padding */ \
+      constexpr int re_ = (R0) == 0 ? 0 : 5;                             \
+      const unsigned long long rm_ = (R0) == 0 ? seam_mr0 : seam_mr5;    \
+      asm volatile("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(tA_[re_]) : "s"(rm_)); \
+      asm volatile("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(tB_[re_]) : "s"(rm_)); \
     }                                                                    \
   }
   // V[.][J] = B^T t (the row direction) for one column of the pair -> V buffer VN
@@ -477,7 +497,7 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
       float* ex = vx + VBUF;
       const __amdgpu_buffer_rsrc_t yrsrc =
           make_rsrc(a.y + (size_t)e_ks * a.slice_stride + (size_t)e_b * a.Co * HW,
-                    (unsigned long long)(a.two ? 2 : 1) * a.Co * HW * 4ull);
+                    (unsigned long long)two_ipi * a.Co * HW * 4ull);
       float ssum[3] = {0.f, 0.f, 0.f}, ssq[3] = {0.f, 0.f, 0.f};
       // The lane index is laundered once per item: otherwise hipcc hoists the lane-dependent LDS / global offsets of this
       // epilogue out of the persistent item loop, spills them, and reloads each one behind an s_waitcnt vmcnt(0) — which
@@ -486,10 +506,12 @@ __global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
       // epilogue's entry, in order behind the next item's halo requests — waited out an HBM latency per item)
       int lane_;
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_));
-      const int ty_ = (lane_ >> 3) & 3, hh_ = lane_ >> 5;
-      // pair mode: tile columns 4-7 are image e_b + 1
-      const int tx_ = a.two ? (lane_ & 3) : (lane_ & 7);
-      const unsigned img_off = a.two ? (unsigned)((lane_ >> 2) & 1) * (unsigned)(a.Co * HW) * 4u : 0u;
+      const int hh_ = lane_ >> 5;
+      // image-grid mode: the tile at (row 4 ty, column 4 tx) of the item lies in image e_b + (4 ty >> ih_l2) * nx + (4 tx >> iw_l2)
+      const int ty4 = ((lane_ >> 3) & 3) * 4, tx4 = (lane_ & 7) * 4;
+      const int ty_ = (ty4 & two_hmask) >> 2, tx_ = (tx4 & two_mask) >> 2;
+      const unsigned img_off =
+          GRID ? (unsigned)((ty4 >> a.ih_l2) * two_nx + (tx4 >> a.iw_l2)) * (unsigned)(a.Co * HW) * 4u : 0u;
       // row transform Z = A^T M in place (acc[a][r] <- Z[a][wj] of channel slot r): the partial sums m1 +- m2, m3 +- m4
       // are shared by the four output rows (10 VALU per slot instead of 14)
 #pragma unroll
@@ -669,15 +691,24 @@ extern "C" int sivae_pack_wino4_weight(const float* w, float* up, int Co, int Ci
   return sivae_launch_status();
 }
 
-// maps the F(4x4,3x3) kernel takes: whole 32 x 16 pixel tile blocks
-// 1: whole 32 x 16 pixel tile blocks; 2: 16 x 16 maps — a work item is a pair of images (B and, with segments, the images
-// per segment must be even)
+// maps the F(4x4,3x3) kernel takes.  1: whole 32 x 16 pixel tile blocks (H % 16 == 0, W % 32 == 0); otherwise a work item
+// is a grid of whole images and the batch (with segments: the images per segment) must be a multiple of
+// sivae_conv2d_wino4_images_per_item — 2: 16 x 16 maps (2 images side by side), 3: 8 x 8 maps (4 x 2 images),
+// 4: 4 x 4 maps (8 x 4 images).  0: not supported.
 extern "C" int sivae_conv2d_wino4_supported(int H, int W) {
   if (H == 16 && W == 16) return 2;
+  if (H == 8 && W == 8) return 3;
+  if (H == 4 && W == 4) return 4;
   return (H >= 16 && W >= 32 && (H % W4_PXH) == 0 && (W % W4_PXW) == 0) ? 1 : 0;
 }
+// images per work item: 1 (mode 1), 2 / 8 / 32 (modes 2 / 3 / 4), 0 (unsupported map)
+extern "C" int sivae_conv2d_wino4_images_per_item(int H, int W) {
+  const int sup = sivae_conv2d_wino4_supported(H, W);
+  return sup == 0 ? 0 : (sup == 1 ? 1 : (W4_PXW / W) * (W4_PXH / H));
+}
 static inline long long w4_px_tiles(int B, int H, int W) {
-  return (H == 16 && W == 16) ? B / 2 : (long long)B * (H / W4_PXH) * (W / W4_PXW);
+  const int ipi = sivae_conv2d_wino4_images_per_item(H, W);
+  return ipi > 1 ? B / ipi : (long long)B * (H / W4_PXH) * (W / W4_PXW);
 }
 
 // does the F(4x4,3x3) kernel beat F(2x2,3x3) for this launch?  Its work item is 64 channels x 512 pixels and a CU holds
@@ -686,14 +717,14 @@ static inline long long w4_px_tiles(int B, int H, int W) {
 // 1.27-1.57x (256x256 shard sizes 8 / 16 / 32 / 128 images).
 extern "C" int sivae_conv2d_wino4_pays(int B, int Ci, int Co, int H, int W) {
   const int sup = sivae_conv2d_wino4_supported(H, W);
-  if (B <= 0 || Ci < 16 || Co <= 0 || !sup || (sup == 2 && (B & 1))) return 0;
+  if (B <= 0 || Ci < 16 || Co <= 0 || !sup || B % sivae_conv2d_wino4_images_per_item(H, W)) return 0;
   const long long items = w4_px_tiles(B, H, W) * ((Co + W4_TCO - 1) / W4_TCO);
   return items >= sivae_num_cus() ? 1 : 0;
 }
 
 extern "C" int sivae_conv2d_wino4_num_px_tiles(int B, int H, int W) {
   const int sup = sivae_conv2d_wino4_supported(H, W);
-  if (B <= 0 || !sup || (sup == 2 && (B & 1))) return SIVAE_ERR_SHAPE;
+  if (B <= 0 || !sup || B % sivae_conv2d_wino4_images_per_item(H, W)) return SIVAE_ERR_SHAPE;
   return (int)w4_px_tiles(B, H, W);
 }
 
@@ -709,7 +740,8 @@ static int wino4_impl(const float* x, const float* up, float* y, const float* pr
   if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
   const int sup = sivae_conv2d_wino4_supported(H, W);
   if (!sup) return SIVAE_ERR_SHAPE;
-  if (sup == 2 && ((B & 1) || (seg_images & 1))) return SIVAE_ERR_SHAPE;  // image pairs inside one segment
+  const int ipi = sivae_conv2d_wino4_images_per_item(H, W);
+  if ((B % ipi) || (seg_images % ipi)) return SIVAE_ERR_SHAPE;  // whole image grids, each inside one segment
   if (((uintptr_t)y & 15u) != 0) return SIVAE_ERR_SHAPE;  // 16-byte stores
   const long long hw = (long long)H * W;
   if ((long long)Ci * hw * 4 >= 0x7fffffffLL || (long long)Co * hw * 4 >= 0x7fffffffLL) return SIVAE_ERR_RANGE;
@@ -734,7 +766,18 @@ static int wino4_impl(const float* x, const float* up, float* y, const float* pr
   a.Co_pad = w4_npad(Co);
   if (pro_mean && a.pro_nseg * a.Ci_pad > W4_PRO_MAX) return SIVAE_ERR_SHAPE;
   if (36ull * a.Ci_pad * a.Co_pad * 4ull >= 0xffffffffull) return SIVAE_ERR_RANGE;
-  a.two = sup == 2 ? 1 : 0;
+  a.two = sup >= 2 ? 1 : 0;
+  a.iw_l2 = a.two ? ilog2_exact(W) : 0;
+  a.ih_l2 = a.two ? ilog2_exact(H) : 0;
+  a.seam_c0 = a.seam_c5 = a.seam_r0 = a.seam_r5 = 0ull;
+  if (a.two)
+    for (int l = 0; l < 64; ++l) {  // lane -> tile = lane & 31 at pixel (4 * (tile >> 3), 4 * (tile & 7)) of the item
+      const int px = 4 * (l & 7), py = 4 * ((l >> 3) & 3);
+      if ((px & (W - 1)) == 0) a.seam_c0 |= 1ull << l;        // patch column 0 lies left of the tile's image
+      if (((px + 4) & (W - 1)) == 0) a.seam_c5 |= 1ull << l;  // patch column 5 lies right of it
+      if ((py & (H - 1)) == 0) a.seam_r0 |= 1ull << l;        // patch row 0 lies above it
+      if (((py + 4) & (H - 1)) == 0) a.seam_r5 |= 1ull << l;  // patch row 5 lies below it
+    }
   a.nbh = a.two ? 1 : H / W4_PXH;
   a.nbw = a.two ? 1 : W / W4_PXW;
   a.n_co_tiles = a.Co_pad / W4_TCO;
@@ -752,10 +795,16 @@ static int wino4_impl(const float* x, const float* up, float* y, const float* pr
   const int cus = sivae_num_cus();
   const int grid = nitems < cus ? (int)nitems : cus;
   a.xcd_group = (sivae_xcd_remap() && a.n_co_tiles > 1 && !(grid & 7)) ? 1 : 0;
-  if (pro_mean)
-    hipLaunchKernelGGL(conv_wino4_kernel<true>, dim3((unsigned)grid), dim3(W4_NT), 0, stream, a);
-  else
-    hipLaunchKernelGGL(conv_wino4_kernel<false>, dim3((unsigned)grid), dim3(W4_NT), 0, stream, a);
+  if (a.two) {
+    if (pro_mean)
+      hipLaunchKernelGGL((conv_wino4_kernel<true, true>), dim3((unsigned)grid), dim3(W4_NT), 0, stream, a);
+    else
+      hipLaunchKernelGGL((conv_wino4_kernel<false, true>), dim3((unsigned)grid), dim3(W4_NT), 0, stream, a);
+  } else if (pro_mean) {
+    hipLaunchKernelGGL((conv_wino4_kernel<true, false>), dim3((unsigned)grid), dim3(W4_NT), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL((conv_wino4_kernel<false, false>), dim3((unsigned)grid), dim3(W4_NT), 0, stream, a);
+  }
   return sivae_launch_status();
 }
 
@@ -868,7 +917,7 @@ __global__ void __launch_bounds__(256) wino4_splitk_reduce_vec_kernel(const floa
 // tile — sivae_conv2d_wino4_num_px_tiles —, otherwise per image: B rows)
 extern "C" int sivae_conv2d_wino4_splitk(int B, int Ci, int Co, int H, int W) {
   const int sup = sivae_conv2d_wino4_supported(H, W);
-  if (B <= 0 || Ci <= 0 || Co <= 0 || !sup || (sup == 2 && (B & 1))) return SIVAE_ERR_SHAPE;
+  if (B <= 0 || Ci <= 0 || Co <= 0 || !sup || B % sivae_conv2d_wino4_images_per_item(H, W)) return SIVAE_ERR_SHAPE;
   static int enabled = -1;
   if (enabled < 0) {
     const char* e = getenv("SIVAE_WINO4_SPLITK");
@@ -887,6 +936,24 @@ extern "C" int sivae_conv2d_wino4_splitk(int B, int Ci, int Co, int H, int W) {
          ((nchunks / (2 * S)) & 1) == 0)
     S *= 2;
   return S;
+}
+
+// Does the image-grid form of the 8 x 8 / 4 x 4 maps (modes 3, 4) beat F(2x2,3x3) for this launch?  Measured per (batch,
+// channels) against conv_wino.hip's kernel (tools/bench_wino4_small.py, profiles/r6_wino4_small_maps_vs_f23.txt): its work
+// item is 64 output channels x 32 tiles with ~25 us of fixed cost around 2.6 us per 8-channel chunk, so it wins — 1.1-1.75x
+// — where (slices x items) fill the chip AND a K slice is long enough; below that F(2x2,3x3) with its 4x smaller items is
+// up to 2x faster.  8 x 8: >= 256 channels per slice, or an unsplit launch with >= 128; 4 x 4 (where F(2x2,3x3) wastes
+// half of every tile column it transforms): >= 64 channels per slice.
+extern "C" int sivae_conv2d_wino4_small_pays(int B, int Ci, int Co, int H, int W) {
+  const int sup = sivae_conv2d_wino4_supported(H, W);
+  if (sup < 3 || B <= 0 || Ci < 16 || Co <= 0 || B % sivae_conv2d_wino4_images_per_item(H, W)) return 0;
+  const int S = sivae_conv2d_wino4_splitk(B, Ci, Co, H, W);
+  if (S < 1) return 0;
+  const long long items = w4_px_tiles(B, H, W) * ((Co + W4_TCO - 1) / W4_TCO);
+  if (items * S < sivae_num_cus()) return 0;
+  const int per_slice = w4_kpad(Ci) / S;
+  if (sup == 3) return (per_slice >= 256 || (S == 1 && per_slice >= 128)) ? 1 : 0;
+  return per_slice >= 64 ? 1 : 0;
 }
 
 extern "C" size_t sivae_conv2d_wino4_splitk_workspace_bytes(int B, int Ci, int Co, int H, int W) {

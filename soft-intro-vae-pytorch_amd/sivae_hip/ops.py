@@ -284,6 +284,12 @@ WINO4_B6_MINC = int(os.environ.get("SIVAE_WINO4_B6_MINC", "16"))
 WINO4_B6_PRO = os.environ.get("SIVAE_WINO4_B6_PRO", "1") != "0"
 
 
+def _w4_key(b6, pro, sup):
+    """KernelTimer key = the kernel instantiation rocprofv3 names: conv_wino4_kernel<PRO, GRID> (GRID: maps up to 16x16)"""
+    p = "true" if pro is not None else "false"
+    return "conv_wino4_b6_kernel<%s>" % p if b6 else "conv_wino4_kernel<%s,%s>" % (p, "true" if sup >= 2 else "false")
+
+
 def wino4_b6_takes(Ci, pro):
     return WINO4_B6 and Ci >= WINO4_B6_MINC and (pro is None or WINO4_B6_PRO)
 WINO4_MAXC = int(os.environ.get("SIVAE_WINO4_MAXC", "512"))
@@ -294,6 +300,9 @@ WINO4_WGRAD = WINO4 and os.environ.get("SIVAE_WINO4_WGRAD", "1") != "0"
 WINO4_FORCE = os.environ.get("SIVAE_WINO4_FORCE", "0") == "1"
 # SIVAE_WINO4_SPLITK=0: no split-K form of the F(4x4,3x3) kernel (launches below one work item per CU stay on F(2x2,3x3))
 WINO4_SPLITK = os.environ.get("SIVAE_WINO4_SPLITK", "1") != "0"
+# SIVAE_WINO4_SMALL=0: 8x8 / 4x4 maps stay on F(2x2,3x3) (the F(4x4,3x3) kernel runs them as grids of 8 / 32 images per item)
+WINO4_SMALL = os.environ.get("SIVAE_WINO4_SMALL", "1") != "0"
+WINO4_SMALL_FORCE = os.environ.get("SIVAE_WINO4_SMALL_FORCE", "0") == "1"  # (tests / tools: wherever it is supported)
 WINO4_PRO = os.environ.get("SIVAE_WINO4_PRO", "1") != "0"  # ... also with a fused BatchNorm prologue (conv2 forward)
 # SIVAE_FUSE_BN_BWD=1: reduce BatchNorm-1's backward sums in the epilogue of conv2's data gradient.  Measured a LOSS at
 # 256x256 bs128 (593 vs 585 ms per iteration: the extra tensor read sits on the kernel's critical path and disables its
@@ -513,9 +522,12 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
             TIMER.end("conv1x1_stream_kernel", 2.0 * B * H * W * Co * Ci, t0)
         return y
     w4_sup = L.sivae_conv2d_wino4_supported(H, W) if (WINO and WINO4) else 0
+    if w4_sup > 2 and not (WINO4_SMALL and (WINO4_SMALL_FORCE or L.sivae_conv2d_wino4_small_pays(B, Ci, Co, H, W) == 1)):
+        w4_sup = 0  # (8x8 / 4x4 maps: only where the image-grid launch beats F(2x2,3x3) — few items or short K slices do not)
+    w4_ipi = L.sivae_conv2d_wino4_images_per_item(H, W) if w4_sup else 1
     w4_ok = (w4_sup and ks == 3 and bias is None and not upsample and isinstance(wp, PackedW)
-             and 16 <= Ci and max(Ci, Co) <= WINO4_MAXC and (w4_sup == 1 or B % 2 == 0)
-             and (nseg == 1 or w4_sup == 1 or (B // nseg) % 2 == 0)  # (16x16 maps: image pairs inside one segment)
+             and 16 <= Ci and max(Ci, Co) <= WINO4_MAXC
+             and (B // nseg) % w4_ipi == 0  # (maps up to 16x16: whole image grids per work item, inside one segment)
              and (pro is None or (WINO4_PRO and nseg * ((Ci + 31) // 32) * 32 <= 1024)))
     # fewer work items than CUs (the deep layers of a per-GPU shard): split over K when that fills the chip
     w4_S = (L.sivae_conv2d_wino4_splitk(B, Ci, Co, H, W) if (w4_ok and WINO4_SPLITK
@@ -532,15 +544,14 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
             pm, pi, pg, pb, slope = pro
             _require(pm, pi, pg, pb)
         t0 = TIMER.begin() if TIMER is not None else None
-        b6 = wino4_b6_takes(Ci, pro)
+        b6 = wino4_b6_takes(Ci, pro) and w4_sup <= 2
         _lib.call("sivae_conv2d_wino4_b6_fwd_splitk" if b6 else "sivae_conv2d_wino4_fwd_splitk", _p(x),
                   _p(wp.wino4_b6() if b6 else wp.wino4()), _p(y), _p(pm), _p(pi), _p(pg), _p(pb),
                   float(slope), _p(stats), B, Ci, Co, H, W, int(bool(accumulate)), (B // nseg) if nseg > 1 else 0,
                   _p(ws), ws.numel(), _s(x))
         if t0 is not None:
             flops = 2.0 * B * H * W * Co * Ci * 9
-            TIMER.end("conv_wino4%s_kernel<%s>" % ("_b6" if b6 else "", "true" if pro is not None else "false"), flops, t0,
-                      executed=flops * 36.0 / 144.0)
+            TIMER.end(_w4_key(b6, pro, w4_sup), flops, t0, executed=flops * 36.0 / 144.0)
         return (y, stats) if want_stats else y
     if w4_ok and (L.sivae_conv2d_wino4_pays(B, Ci, Co, H, W) == 1 or WINO4_FORCE):
         # large maps: F(4x4,3x3) — 2.25 multiplies per output pixel instead of 4
@@ -550,7 +561,7 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
         stats = (torch.empty((L.sivae_conv2d_wino4_num_px_tiles(B, H, W), Co, 2), dtype=torch.float32, device=x.device)
                  if want_stats else None)
         t0 = TIMER.begin() if TIMER is not None else None
-        b6 = wino4_b6_takes(Ci, pro)
+        b6 = wino4_b6_takes(Ci, pro) and w4_sup <= 2
         if b6:
             pm = pi = pg = pb = None
             slope = 1.0
@@ -571,8 +582,7 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
                       int(bool(accumulate)), _s(x))
         if t0 is not None:
             flops = 2.0 * B * H * W * Co * Ci * 9
-            TIMER.end("conv_wino4%s_kernel<%s>" % ("_b6" if b6 else "", "true" if pro is not None else "false"), flops, t0,
-                      executed=flops * 36.0 / 144.0)
+            TIMER.end(_w4_key(b6, pro, w4_sup), flops, t0, executed=flops * 36.0 / 144.0)
         return (y, stats) if want_stats else y
     wino = (WINO and ks == 3 and bias is None and isinstance(wp, PackedW)
             and L.sivae_conv2d_wino_supported(H, W) == 1)

@@ -659,7 +659,9 @@ def check_wino4(shape, accumulate=False, stats=False, mode=0, b6=False):
     from sivae_hip import lib, ops
     B, Ci, Co, H, W = shape
     L = lib.load()
-    assert L.sivae_conv2d_wino4_supported(H, W) in (1, 2)  # (2: 16 x 16 maps, a work item is a pair of images)
+    # (2 / 3 / 4: 16 x 16 / 8 x 8 / 4 x 4 maps, a work item is a grid of 2 / 8 / 32 whole images)
+    assert L.sivae_conv2d_wino4_supported(H, W) in ((1, 2) if b6 else (1, 2, 3, 4))
+    assert B % L.sivae_conv2d_wino4_images_per_item(H, W) == 0
     x = _rand(B, Ci, H, W, seed=1)
     res = []
     if mode == 0:
@@ -1618,6 +1620,18 @@ def all_checks():
                        + check_wino4(s, mode=1)))
     for s in [(4, 64, 64, 16, 16), (8, 96, 40, 16, 16)]:
         checks.append(("wino4_pair_pro%s" % (s,), lambda s=s: check_wino4_pro(s) + check_wino4_pro(s, nseg=2)))
+    # 8 x 8 and 4 x 4 maps (round 6): a work item is a grid of 4 x 2 / 8 x 4 whole images, every seam zero padding
+    for s in [(8, 64, 64, 8, 8), (16, 40, 72, 8, 8), (24, 512, 128, 8, 8), (32, 64, 64, 4, 4), (64, 48, 100, 4, 4),
+              (32, 512, 64, 4, 4)]:
+        checks.append(("wino4_grid%s" % (s,), lambda s=s: check_wino4(s, stats=True) + check_wino4(s, accumulate=True)
+                       + check_wino4(s, mode=1)))
+    for s in [(16, 64, 64, 8, 8), (32, 96, 40, 8, 8), (64, 64, 64, 4, 4), (128, 96, 40, 4, 4)]:
+        checks.append(("wino4_grid_pro%s" % (s,), lambda s=s: check_wino4_pro(s) + check_wino4_pro(s, nseg=2)))
+    for s in [(16, 512, 128, 8, 8), (64, 512, 128, 4, 4), (256, 512, 512, 4, 4)]:
+        checks.append(("wino4_grid_splitk%s" % (s,), lambda s=s: check_wino4_splitk(s) + check_wino4_splitk(s, accumulate=True)
+                       + check_wino4_splitk(s, pro=True)))
+    checks.append(("wino4_grid_splitk_seg", lambda: check_wino4_splitk((32, 512, 64, 8, 8), pro=True, nseg=2)
+                   + check_wino4_splitk((64, 256, 64, 4, 4), pro=True, nseg=2)))
     for s in [(2, 256, 64, 32, 32), (4, 512, 128, 16, 16), (1, 128, 100, 16, 32), (1, 512, 64, 64, 64)]:
         checks.append(("wino4_splitk%s" % (s,), lambda s=s: check_wino4_splitk(s) + check_wino4_splitk(s, accumulate=True)
                        + check_wino4_splitk(s, pro=True)))

@@ -141,9 +141,14 @@ def test_round3_entry_points_validate_arguments():
     L = lib.load()
     null = None
     one = ctypes.c_void_p(16)
-    # domains: 1 = whole 32 x 16 pixel blocks, 2 = 16 x 16 maps as image pairs, 0 = unsupported
-    assert [L.sivae_conv2d_wino4_supported(h, w) for h, w in ((256, 256), (32, 32), (16, 32), (16, 16), (8, 8), (24, 32))] \
-        == [1, 1, 1, 2, 0, 0]
+    # domains: 1 = whole 32 x 16 pixel blocks, 2 / 3 / 4 = 16 x 16 / 8 x 8 / 4 x 4 maps as grids of whole images per work
+    # item (2 / 8 / 32 of them), 0 = unsupported
+    maps = ((256, 256), (32, 32), (16, 32), (16, 16), (8, 8), (4, 4), (24, 32), (8, 16), (2, 2))
+    assert [L.sivae_conv2d_wino4_supported(h, w) for h, w in maps] == [1, 1, 1, 2, 3, 4, 0, 0, 0]
+    assert [L.sivae_conv2d_wino4_images_per_item(h, w) for h, w in maps] == [1, 1, 1, 2, 8, 32, 0, 0, 0]
+    assert L.sivae_conv2d_wino4_num_px_tiles(16, 8, 8) == 2 and L.sivae_conv2d_wino4_num_px_tiles(64, 4, 4) == 2
+    assert L.sivae_conv2d_wino4_num_px_tiles(12, 8, 8) == -2 and L.sivae_conv2d_wino4_num_px_tiles(48, 4, 4) == -2
+    assert L.sivae_conv2d_wino4_pays(12, 64, 64, 8, 8) == 0 and L.sivae_conv2d_wino4_pays(256, 512, 512, 8, 8) == 1
     assert L.sivae_conv2d_wino4_num_px_tiles(4, 32, 64) == 4 * 2 * 2 and L.sivae_conv2d_wino4_num_px_tiles(6, 16, 16) == 3
     assert L.sivae_conv2d_wino4_num_px_tiles(5, 16, 16) == -2  # (an odd batch has no image pairs)
     assert L.sivae_conv2d_wino4_pays(5, 64, 64, 16, 16) == 0 and L.sivae_conv2d_wino4_pays(2, 8, 64, 256, 256) == 0
