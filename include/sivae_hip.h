@@ -642,8 +642,11 @@ int sivae_conv2d_wino4_b6_fwd_splitk(const float* x, const void* up, float* y, c
  * nn.Conv2d(k=3) layers (soft_intro_vae/train_soft_intro_vae.py:56-61) on maps with H % 4 == 0, W % 16 == 0:
  * dw[Co][Ci][3][3] from x [B][Ci][H][W] (or, pro_mean != NULL, LeakyReLU(BatchNorm(x)) recomputed on load; per-segment
  * statistics [nseg][Ci] when seg_images > 0, nseg = B / seg_images <= 2) and dy [B][Co][H][W]; x / dy 16-byte aligned.
- * `pays`: supported AND enough stages for one block per CU. */
+ * `pays`: supported AND enough stages for one block per CU.  Round 6: also the 8 x 8 and 4 x 4 maps (the deep 512-channel
+ * blocks): a stage's 4 x 16 pixel strip is then 2 / 4 whole images side by side (every seam zero padding) and B and
+ * seg_images must be multiples of sivae_conv2d_wino4_wgrad_images_per_stage (1 for W >= 16). */
 int sivae_conv2d_wino4_wgrad_supported(int H, int W);
+int sivae_conv2d_wino4_wgrad_images_per_stage(int H, int W);
 int sivae_conv2d_wino4_wgrad_pays(int B, int Ci, int Co, int H, int W);
 size_t sivae_conv2d_wino4_wgrad_workspace_bytes(int B, int Ci, int Co, int H, int W);
 int sivae_conv2d_wino4_wgrad(const float* x, const float* dy, float* dw, const float* pro_mean, const float* pro_invstd,

@@ -52,6 +52,12 @@ struct Wino4WgArgs {
   int nrh, nrw, nstages, sps;
   int n_co_tiles, n_ci_tiles;
   int nblk, xcd_remap;
+  // Maps narrower than a stage's 16 columns (8 x 8, 4 x 4: round 6): the 4 x 16 strip is `ips` = 16 / W whole images side by
+  // side (nrw = 1, so both column-border flags are set and halo groups 0 / 5 read as zeros); the row halo stays inside
+  // one image (a strip is 4 rows of it).  Patch column 0 / 5 of a tile at the left / right edge of its image is zero padding:
+  // 64-bit lane masks for the (0,5) transform role — lane -> tile = (lane >> 5) [+ 2 in k-step A], per k-step.
+  int ips, iw_l2;
+  unsigned long long seam_e0B, seam_e5B, seam_e0A, seam_e5A;
 };
 
 #define G4_NT 768
@@ -65,7 +71,8 @@ struct Wino4WgArgs {
 #define G4_ABLATE 0
 #endif
 
-template <bool PRO>
+// GRID: the image-strip mode of the 8 x 8 / 4 x 4 maps (its own instantiations: the large-map kernels carry none of it)
+template <bool PRO, bool GRID = false>
 __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
   // every ring slot is its own static array: the compiler orders an LDS access behind each in-flight LDS-direct load
   // it cannot prove disjoint (conv_wino4.hip)
@@ -117,13 +124,18 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
     if (d < 18) {
       const int pos = d * 64 + lane, row = pos / 192, rem = pos - row * 192, ci = rem / 6;
       const int p = (rem - ci * 6 + 6 - ((ci >> 3) & 1)) % 6;  // (the slot holds group p rotated by r(ci), below)
-      rq_off[i] = (ci0 + ci < a.Ci) ? (unsigned)((ci0 + ci) * HW + row * W + 4 * p) * 4u : SIVAE_OOB;
+      // (GRID: group p = 1..4 is column 4 (p - 1) of the strip -> image (4 (p - 1)) >> iw_l2 of the strip at its own column;
+      // the stage base points 4 columns left of the strip, hence the + 4; groups 0 / 5 are always masked: nrw = 1)
+      const int gq = (p >= 1 && p <= 4) ? 4 * (p - 1) : 0;
+      const int gcol = GRID ? (gq >> a.iw_l2) * a.Ci * HW + 4 + (gq & (W - 1)) : 4 * p;
+      rq_off[i] = (ci0 + ci < a.Ci) ? (unsigned)((ci0 + ci) * HW + row * W + gcol) * 4u : SIVAE_OOB;
       rq_lbits |= ((p == 0 ? 4u : 0u) | (p == 5 ? 8u : 0u)) << (8 * i);
       rq_lds[i] = d * 256;
     } else {
       const int dd = d - 18 < 15 ? d - 18 : 15;
       const int pos = dd * 64 + lane, row = pos >> 8, co = (pos & 255) >> 2, p = (pos & 3) ^ ((co >> 2) & 3);
-      rq_off[i] = (co0 + co < a.Co) ? (unsigned)((co0 + co) * HW + row * W + 4 * p) * 4u : SIVAE_OOB;
+      const int gcol = GRID ? ((4 * p) >> a.iw_l2) * a.Co * HW + ((4 * p) & (W - 1)) : 4 * p;
+      rq_off[i] = (co0 + co < a.Co) ? (unsigned)((co0 + co) * HW + row * W + gcol) * 4u : SIVAE_OOB;
       rq_lds[i] = dd * 256;
     }
   }
@@ -173,16 +185,18 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
 
   // ---- stage to request next (scalar): image db, strip row dry, strip column drx
   int sd = s_begin;
-  int db = sd / (a.nrh * a.nrw);
+  const int ips = GRID ? a.ips : 1;  // images per strip
+  int db = sd / (a.nrh * a.nrw);     // strip set -> (below) its first image
   int dry, drx;
   {
     const int rem = sd - db * (a.nrh * a.nrw);
     dry = rem / a.nrw;
     drx = rem - dry * a.nrw;
   }
+  db *= ips;
   // this wave's operand (x for the first six waves, dY for the others) at image db
-  const long long rq_img_step = (long long)(req_x ? a.Ci : a.Co) * HW;
-  const float* rq_img = (req_x ? a.x : a.dy) + (long long)db * rq_img_step;
+  const long long rq_img_step = (long long)(req_x ? a.Ci : a.Co) * HW * ips;
+  const float* rq_img = (req_x ? a.x : a.dy) + (long long)db * ((long long)(req_x ? a.Ci : a.Co) * HW);
   unsigned inf0 = 0, inf1 = 0, inf2 = 0;  // per ring slot: border / tail bits and the segment's table offset << 8
 #define G4_INF(K) ((K) == 0 ? inf0 : ((K) == 1 ? inf1 : inf2))
 #define G4_SETINF(K, V) { if ((K) == 0) inf0 = (V); else if ((K) == 1) inf1 = (V); else inf2 = (V); }
@@ -217,7 +231,7 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
       drx = 0;                                                                                      \
       if (++dry == a.nrh) {                                                                         \
         dry = 0;                                                                                    \
-        ++db;                                                                                       \
+        db += ips;                                                                                  \
         rq_img += rq_img_step;                                                                      \
       }                                                                                             \
     }                                                                                               \
@@ -287,6 +301,10 @@ __global__ void __launch_bounds__(G4_NT, 1) wino4_wgrad_kernel(Wino4WgArgs a) {
         _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                             \
           EX[r] = e0_[r * 192].w;                                                                   \
           EX[3 + r] = e5_[r * 192].x;                                                               \
+          if (GRID) { /* the neighbour column belongs to the next image of the strip: zero padding */ \
+            asm volatile("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(EX[r]) : "s"((XOFF) ? a.seam_e0A : a.seam_e0B));     \
+            asm volatile("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(EX[3 + r]) : "s"((XOFF) ? a.seam_e5A : a.seam_e5B)); \
+          }                                                                                         \
         }                                                                                           \
       }                                                                                             \
     } else if ((ROLE) == 2 && (HALF) == 0) {                                                        \
@@ -522,6 +540,7 @@ __global__ void __launch_bounds__(256) wino4_wgrad_reduce_kernel(const float* __
 }
 
 namespace {
+inline int wino4_wg_ips(int W) { return W >= 16 ? 1 : 16 / W; }  // images per 16-column strip
 struct Wino4WgPlan {
   int Ci_pad, Co_pad, n_ci_tiles, n_co_tiles, nrh, nrw, nstages, sps, n_slices;
 };
@@ -532,8 +551,8 @@ int wino4_wg_plan(int B, int Ci, int Co, int H, int W, Wino4WgPlan* p) {
   p->Ci_pad = p->n_ci_tiles * 32;
   p->Co_pad = p->n_co_tiles * 64;
   p->nrh = H / 4;
-  p->nrw = W / 16;
-  const long long ns = (long long)B * p->nrh * p->nrw;
+  p->nrw = W >= 16 ? W / 16 : 1;
+  const long long ns = (long long)(B / wino4_wg_ips(W)) * p->nrh * p->nrw;
   if (ns > 0x3fffffffLL) return SIVAE_ERR_RANGE;
   p->nstages = (int)ns;
   const int ntiles = p->n_ci_tiles * p->n_co_tiles;
@@ -555,22 +574,40 @@ int wino4_wg_plan(int B, int Ci, int Co, int H, int W, Wino4WgPlan* p) {
 }  // namespace
 
 // maps the F(4x4,3x3) weight gradient takes (its stage is a 4 x 16 pixel strip of whole tiles)
+// (round 6: also the 8 x 8 and 4 x 4 maps, whose strip is 2 / 4 whole images side by side — the batch and the images per
+// segment must then be multiples of sivae_conv2d_wino4_wgrad_images_per_stage)
 extern "C" int sivae_conv2d_wino4_wgrad_supported(int H, int W) {
+  if ((H == 8 && W == 8) || (H == 4 && W == 4)) return 1;
   return (H >= 4 && W >= 16 && (H % 4) == 0 && (W % 16) == 0) ? 1 : 0;
+}
+extern "C" int sivae_conv2d_wino4_wgrad_images_per_stage(int H, int W) {
+  return sivae_conv2d_wino4_wgrad_supported(H, W) ? wino4_wg_ips(W) : 0;
 }
 
 // does it beat the F(2x2,3x3) weight gradient for this launch?  One block per CU is resident: it needs (co, ci) tiles x
 // slices of >= 24 stages for every CU
 extern "C" int sivae_conv2d_wino4_wgrad_pays(int B, int Ci, int Co, int H, int W) {
-  if (B <= 0 || Ci < 16 || Co < 16 || !sivae_conv2d_wino4_wgrad_supported(H, W)) return 0;
-  const long long stages = (long long)B * (H / 4) * (W / 16);
+  if (B <= 0 || Ci < 16 || Co < 16 || !sivae_conv2d_wino4_wgrad_supported(H, W) || B % wino4_wg_ips(W)) return 0;
+  const long long stages = (long long)(B / wino4_wg_ips(W)) * (H / 4) * (W >= 16 ? W / 16 : 1);
   const long long tiles = (long long)cdiv(Ci, 32) * cdiv(Co, 64);
-  return tiles * (stages / 24) >= sivae_num_cus() ? 1 : 0;
+  if (tiles * (stages / 24) >= sivae_num_cus()) return 1;
+  if (wino4_wg_ips(W) > 1) {
+    // 8 x 8 / 4 x 4 maps: the alternative is the direct weight gradient (conv_wgrad.hip), which has a ~60 us floor and
+    // 1.63e-7 us per (image x pixel x co x ci) above it; this kernel costs ~15 us + 2.3 us per stage of a slice
+    // (measured: profiles/r6_wino4_small_maps_vs_f23.txt — 1.3-2.1x at the small batches of a per-GPU shard too)
+    Wino4WgPlan p;
+    if (wino4_wg_plan(B, Ci, Co, H, W, &p) != SIVAE_OK) return 0;
+    const double t4 = 15.0 + 2.3 * p.sps;
+    double td = 1.63e-7 * (double)B * H * W * (double)Ci * Co;
+    if (td < 60.0) td = 60.0;
+    return 1.15 * t4 < td ? 1 : 0;
+  }
+  return 0;
 }
 
 extern "C" size_t sivae_conv2d_wino4_wgrad_workspace_bytes(int B, int Ci, int Co, int H, int W) {
   Wino4WgPlan p;
-  if (B <= 0 || Ci <= 0 || Co <= 0 || !sivae_conv2d_wino4_wgrad_supported(H, W)) return 0;
+  if (B <= 0 || Ci <= 0 || Co <= 0 || !sivae_conv2d_wino4_wgrad_supported(H, W) || B % wino4_wg_ips(W)) return 0;
   if (wino4_wg_plan(B, Ci, Co, H, W, &p) != SIVAE_OK) return 0;
   // (+ one slice-sized slot: from 8 slices up the slices are summed by the wide split-K reducer first)
   return (size_t)(p.n_slices + 1) * 18 * p.Co_pad * p.Ci_pad * sizeof(float);
@@ -586,6 +623,8 @@ extern "C" int sivae_conv2d_wino4_wgrad(const float* x, const float* dy, float* 
   if (seg_images < 0 || (seg_images > 0 && B % seg_images != 0)) return SIVAE_ERR_SHAPE;
   if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
   if (!sivae_conv2d_wino4_wgrad_supported(H, W)) return SIVAE_ERR_SHAPE;
+  const int ips = wino4_wg_ips(W);
+  if ((B % ips) || (seg_images % ips)) return SIVAE_ERR_SHAPE;  // whole image strips, each inside one segment
   if (pro_mean && (!pro_invstd || !pro_gamma || !pro_beta)) return SIVAE_ERR_NULL;
   if (pro_mean && !(pro_slope >= 0.f && pro_slope <= 1.f)) return SIVAE_ERR_MODE;  // prologue uses max(v, v*slope)
   if ((((uintptr_t)x) & 15u) != 0 || (((uintptr_t)dy) & 15u) != 0) return SIVAE_ERR_SHAPE;  // 16-byte LDS-direct loads
@@ -626,7 +665,18 @@ extern "C" int sivae_conv2d_wino4_wgrad(const float* x, const float* dy, float* 
   if (nblk > 0x7fffffffLL) return SIVAE_ERR_RANGE;
   a.nblk = (int)nblk;
   a.xcd_remap = sivae_xcd_remap();
-  auto kern = pro_mean ? wino4_wgrad_kernel<true> : wino4_wgrad_kernel<false>;
+  a.ips = ips;
+  a.iw_l2 = ips > 1 ? ilog2_exact(W) : 0;
+  a.seam_e0B = a.seam_e5B = a.seam_e0A = a.seam_e5A = 0ull;
+  if (ips > 1)
+    for (int l = 0; l < 64; ++l)
+      for (int ka = 0; ka < 2; ++ka) {  // k-step B transforms tiles 0, 1 (tile = lane >> 5), k-step A tiles 2, 3
+        const int px = 4 * ((l >> 5) + 2 * ka);
+        if ((px & (W - 1)) == 0) (ka ? a.seam_e0A : a.seam_e0B) |= 1ull << l;
+        if (((px + 4) & (W - 1)) == 0) (ka ? a.seam_e5A : a.seam_e5B) |= 1ull << l;
+      }
+  auto kern = ips > 1 ? (pro_mean ? wino4_wgrad_kernel<true, true> : wino4_wgrad_kernel<false, true>)
+                      : (pro_mean ? wino4_wgrad_kernel<true, false> : wino4_wgrad_kernel<false, false>);
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.xcd_remap ? (nblk + 7) / 8 * 8 : nblk)), dim3(G4_NT), 0, stream, a);
   rc = sivae_launch_status();
   if (rc != SIVAE_OK) return rc;

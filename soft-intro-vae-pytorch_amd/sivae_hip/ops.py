@@ -665,10 +665,12 @@ def conv2d_wgrad(x, dy, ks, pro=None, upsample=False, out=None, nseg=1):
             flops = 2.0 * B * H * W * Co * Ci * 9
             TIMER.end("wino_up_wgrad_kernel", flops, t0, executed=flops * 9.0 / 36.0)
         return dw
+    w4g_ips = L.sivae_conv2d_wino4_wgrad_images_per_stage(H, W) if ks == 3 else 0  # (8x8 / 4x4 maps: 2 / 4 images per strip)
     if (WINO4_WGRAD and WINO_WGRAD and ks == 3 and not upsample and (pro is None or nseg <= 2)
-            and max(Ci, Co) <= WINO4_MAXC
+            and max(Ci, Co) <= WINO4_MAXC and w4g_ips > 0 and (B // nseg) % w4g_ips == 0
+            and (w4g_ips == 1 or WINO4_SMALL)
             and (L.sivae_conv2d_wino4_wgrad_pays(B, Ci, Co, H, W) == 1
-                 or (WINO4_FORCE and min(Ci, Co) >= 16 and L.sivae_conv2d_wino4_wgrad_supported(H, W) == 1))):
+                 or (WINO4_FORCE and min(Ci, Co) >= 16))):
         # Winograd F(4x4,3x3) weight gradient (conv_wino4_wgrad.hip): 36 instead of 64 multiplies per tile, co, ci
         ws = workspace(L.sivae_conv2d_wino4_wgrad_workspace_bytes(B, Ci, Co, H, W), x.device)
         dw = _out(out, (Co, Ci, 3, 3), x.device)
@@ -682,7 +684,8 @@ def conv2d_wgrad(x, dy, ks, pro=None, upsample=False, out=None, nseg=1):
                   Co, H, W, (B // nseg) if (nseg > 1 and pro is not None) else 0, _p(ws), ws.numel(), _s())
         if t0 is not None:
             flops = 2.0 * B * H * W * Co * Ci * 9
-            TIMER.end("wino4_wgrad_kernel<%s>" % ("true" if pro is not None else "false"), flops, t0,
+            TIMER.end("wino4_wgrad_kernel<%s,%s>" % ("true" if pro is not None else "false",
+                                                     "true" if w4g_ips > 1 else "false"), flops, t0,
                       executed=flops * 36.0 / 144.0)
         return dw
     wino = WINO_WGRAD and ks == 3 and L.sivae_conv2d_wino_wgrad_supported(H, W) == 1

@@ -1660,6 +1660,12 @@ def all_checks():
         checks.append(("wino4_wgrad%s" % (s,), lambda s=s: check_wino4_wgrad(s) + check_wino4_wgrad(s, pro=True)))
     checks.append(("wino4_wgrad_seg", lambda: check_wino4_wgrad((4, 64, 64, 32, 32), pro=True, nseg=2)
                    + check_wino4_wgrad((6, 40, 72, 16, 48), pro=True, nseg=2)))
+    # 8 x 8 and 4 x 4 maps (round 6): a stage's strip is 2 / 4 whole images side by side
+    for s in [(2, 64, 64, 8, 8), (6, 40, 72, 8, 8), (16, 128, 64, 8, 8), (4, 64, 64, 4, 4), (12, 100, 72, 4, 4),
+              (64, 64, 128, 4, 4)]:
+        checks.append(("wino4_wgrad_grid%s" % (s,), lambda s=s: check_wino4_wgrad(s) + check_wino4_wgrad(s, pro=True)))
+    checks.append(("wino4_wgrad_grid_seg", lambda: check_wino4_wgrad((8, 64, 64, 8, 8), pro=True, nseg=2)
+                   + check_wino4_wgrad((24, 40, 72, 4, 4), pro=True, nseg=2)))
     checks.append(("conv1x1_stream", check_conv1x1_stream))
     checks.append(("conv5_edge", check_conv5_edge))
     checks.append(("linear", check_linear))

@@ -187,12 +187,16 @@ def test_round3_entry_points_validate_arguments():
         assert L.sivae_conv2d_wino4_fwd_splitk(one, one, one, null, null, null, null, 1.0, null, 16, 512, 512, 16, 16, 0,
                                                0, one, 64, null) == -4
     # weight gradient: strips of 4 x 16 pixels; at most two segments; 16-byte aligned operands
-    assert [L.sivae_conv2d_wino4_wgrad_supported(h, w) for h, w in ((16, 16), (4, 16), (8, 8), (6, 16), (256, 256))] \
-        == [1, 1, 0, 0, 1]
+    # (round 6: the 8 x 8 / 4 x 4 maps run as strips of 2 / 4 whole images)
+    assert [L.sivae_conv2d_wino4_wgrad_supported(h, w) for h, w in ((16, 16), (4, 16), (8, 8), (4, 4), (6, 16), (256, 256), (8, 4))] \
+        == [1, 1, 1, 1, 0, 1, 0]
+    assert [L.sivae_conv2d_wino4_wgrad_images_per_stage(h, w) for h, w in ((16, 16), (8, 8), (4, 4), (6, 16))] == [1, 2, 4, 0]
+    assert L.sivae_conv2d_wino4_wgrad_pays(256, 512, 512, 8, 8) == 1 and L.sivae_conv2d_wino4_wgrad_pays(255, 512, 512, 8, 8) == 0
     assert L.sivae_conv2d_wino4_wgrad_pays(128, 128, 128, 128, 128) == 1 and L.sivae_conv2d_wino4_wgrad_pays(1, 64, 64, 16, 16) == 0
     nb = L.sivae_conv2d_wino4_wgrad_workspace_bytes(128, 128, 128, 128, 128)
     assert nb > 0 and nb % (18 * 128 * 128 * 4) == 0  # (row-transformed partials: 3 x 6 values per (co, ci))
-    assert L.sivae_conv2d_wino4_wgrad(one, one, one, null, null, null, null, 0.2, 2, 32, 32, 8, 8, 0, one, 1 << 30, null) == -2
+    assert L.sivae_conv2d_wino4_wgrad(one, one, one, null, null, null, null, 0.2, 3, 32, 32, 8, 8, 0, one, 1 << 30, null) == -2
+    assert L.sivae_conv2d_wino4_wgrad(one, one, one, null, null, null, null, 0.2, 2, 32, 32, 8, 4, 0, one, 1 << 30, null) == -2
     assert L.sivae_conv2d_wino4_wgrad(one, null, one, null, null, null, null, 0.2, 2, 32, 32, 16, 16, 0, one, 1 << 30, null) == -1
     assert L.sivae_conv2d_wino4_wgrad(one, one, one, null, null, null, null, 0.2, 2, 32, 32, 16, 16, 0, one, 16, null) == -4
     assert L.sivae_conv2d_wino4_wgrad(one, one, one, one, one, one, one, 0.2, 6, 32, 32, 16, 16, 2, one, 1 << 30, null) == -2

@@ -49,3 +49,27 @@ for H in (8, 4):
                 S = L.sivae_conv2d_wino4_splitk(B, Ci, Co, H, H)
                 print("%-28s %6d %3d %9.1f %9.1f %6.2f" % ("%d %d %d %dx%d %s" % (B, Ci, Co, H, H, "pro" if pro else "-"),
                                                           items, S, t4, t2, t2 / t4))
+
+# ---- weight gradient: the image-strip mode of conv_wino4_wgrad.hip vs the kernels these maps used before
+print()
+print("%-28s %9s %9s %6s   (weight gradient; 'pays' = the library's own policy)" % ("B Ci Co HxW pro", "F(4,3) us", "before us", "ratio"))
+for H in (8, 4):
+    for (Ci, Co) in ((512, 512), (256, 256), (128, 256), (128, 128)):
+        for B in (32, 64, 128, 256, 512):
+            x = torch.randn(B, Ci, H, H, device="cuda")
+            dy = torch.randn(B, Co, H, H, device="cuda")
+            for pro in (None, 1):
+                p = None
+                if pro:
+                    p = (torch.zeros(Ci, device="cuda"), torch.ones(Ci, device="cuda"), torch.ones(Ci, device="cuda"),
+                         torch.zeros(Ci, device="cuda"), 0.2)
+                ops.WINO4_SMALL = True
+                f0 = ops.WINO4_FORCE
+                ops.WINO4_FORCE = True
+                t4 = timeit(lambda: ops.conv2d_wgrad(x, dy, 3, pro=p))
+                ops.WINO4_FORCE = f0
+                ops.WINO4_SMALL = False
+                t2 = timeit(lambda: ops.conv2d_wgrad(x, dy, 3, pro=p))
+                ops.WINO4_SMALL = True
+                print("%-28s %9.1f %9.1f %6.2f  pays=%d" % ("%d %d %d %dx%d %s" % (B, Ci, Co, H, H, "pro" if pro else "-"), t4, t2,
+                                                          t2 / t4, L.sivae_conv2d_wino4_wgrad_pays(B, Ci, Co, H, H)))
