@@ -592,15 +592,15 @@ extern "C" int sivae_conv2d_wino4_wgrad_pays(int B, int Ci, int Co, int H, int W
   const long long tiles = (long long)cdiv(Ci, 32) * cdiv(Co, 64);
   if (tiles * (stages / 24) >= sivae_num_cus()) return 1;
   if (wino4_wg_ips(W) > 1) {
-    // 8 x 8 / 4 x 4 maps: the alternative is the direct weight gradient (conv_wgrad.hip), which has a ~60 us floor and
-    // 1.63e-7 us per (image x pixel x co x ci) above it; this kernel costs ~15 us + 2.3 us per stage of a slice
-    // (measured: profiles/r6_wino4_small_maps_vs_f23.txt — 1.3-2.1x at the small batches of a per-GPU shard too)
+    // 8 x 8 / 4 x 4 maps: the alternative is the direct weight gradient (conv_wgrad.hip): ~45 us + 1.5e-7 us per (image x
+    // pixel x co x ci), never under ~60 us; this kernel costs ~15 us + 2.3 us per stage of a slice (fitted to
+    // profiles/r6_wino4_small_maps_vs_f23.txt: 1.3-2.1x at the small batches of a per-GPU shard too).  Taken with a 10 % margin.
     Wino4WgPlan p;
     if (wino4_wg_plan(B, Ci, Co, H, W, &p) != SIVAE_OK) return 0;
     const double t4 = 15.0 + 2.3 * p.sps;
-    double td = 1.63e-7 * (double)B * H * W * (double)Ci * Co;
+    double td = 45.0 + 1.5e-7 * (double)B * H * W * (double)Ci * Co;
     if (td < 60.0) td = 60.0;
-    return 1.15 * t4 < td ? 1 : 0;
+    return 1.10 * t4 < td ? 1 : 0;
   }
   return 0;
 }

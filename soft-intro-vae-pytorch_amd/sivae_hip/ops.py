@@ -303,6 +303,8 @@ WINO4_SPLITK = os.environ.get("SIVAE_WINO4_SPLITK", "1") != "0"
 # SIVAE_WINO4_SMALL=0: 8x8 / 4x4 maps stay on F(2x2,3x3) (the F(4x4,3x3) kernel runs them as grids of 8 / 32 images per item)
 WINO4_SMALL = os.environ.get("SIVAE_WINO4_SMALL", "1") != "0"
 WINO4_SMALL_FORCE = os.environ.get("SIVAE_WINO4_SMALL_FORCE", "0") == "1"  # (tests / tools: wherever it is supported)
+# SIVAE_WINO4_UP_SMALL=0: convs of an upsampled input on 16x16 / 8x8 output maps stay on F(2x2,3x3) with upsample addressing
+WINO4_UP_SMALL = os.environ.get("SIVAE_WINO4_UP_SMALL", "1") != "0"
 WINO4_PRO = os.environ.get("SIVAE_WINO4_PRO", "1") != "0"  # ... also with a fused BatchNorm prologue (conv2 forward)
 # SIVAE_FUSE_BN_BWD=1: reduce BatchNorm-1's backward sums in the epilogue of conv2's data gradient.  Measured a LOSS at
 # 256x256 bs128 (593 vs 585 ms per iteration: the extra tensor read sits on the kernel's critical path and disables its
@@ -525,13 +527,22 @@ def conv2d_fwd(x, wp, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
     if w4_sup > 2 and not (WINO4_SMALL and (WINO4_SMALL_FORCE or L.sivae_conv2d_wino4_small_pays(B, Ci, Co, H, W) == 1)):
         w4_sup = 0  # (8x8 / 4x4 maps: only where the image-grid launch beats F(2x2,3x3) — few items or short K slices do not)
     w4_ipi = L.sivae_conv2d_wino4_images_per_item(H, W) if w4_sup else 1
-    w4_ok = (w4_sup and ks == 3 and bias is None and not upsample and isinstance(wp, PackedW)
+    # an upsampled input: the phase-form kernels (conv_wino_up.hip) cover the maps from 32x32 up; on the 16x16 / 8x8 outputs of
+    # the deep decoder blocks (Decoder res_in_16 / res_in_8, train_soft_intro_vae.py:153-158) the upsampled tensor is a
+    # few MB — materialise it (one small launch) and take the F(4x4,3x3) image-grid kernel instead of F(2x2,3x3)
+    w4_up = bool(upsample) and w4_sup >= 2 and WINO4_UP_SMALL and pro is None
+    w4_ok = (w4_sup and ks == 3 and bias is None and (not upsample or w4_up) and isinstance(wp, PackedW)
              and 16 <= Ci and max(Ci, Co) <= WINO4_MAXC
              and (B // nseg) % w4_ipi == 0  # (maps up to 16x16: whole image grids per work item, inside one segment)
              and (pro is None or (WINO4_PRO and nseg * ((Ci + 31) // 32) * 32 <= 1024)))
     # fewer work items than CUs (the deep layers of a per-GPU shard): split over K when that fills the chip
     w4_S = (L.sivae_conv2d_wino4_splitk(B, Ci, Co, H, W) if (w4_ok and WINO4_SPLITK
                                                               and L.sivae_conv2d_wino4_pays(B, Ci, Co, H, W) != 1) else 1)
+    if w4_ok and upsample:
+        if w4_S > 1 or L.sivae_conv2d_wino4_pays(B, Ci, Co, H, W) == 1 or WINO4_FORCE:
+            x, upsample = upsample2_fwd(x), False
+        else:
+            w4_ok = False
     if w4_ok and w4_S > 1:
         _require(x, out)
         y = out if out is not None else torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
@@ -666,11 +677,16 @@ def conv2d_wgrad(x, dy, ks, pro=None, upsample=False, out=None, nseg=1):
             TIMER.end("wino_up_wgrad_kernel", flops, t0, executed=flops * 9.0 / 36.0)
         return dw
     w4g_ips = L.sivae_conv2d_wino4_wgrad_images_per_stage(H, W) if ks == 3 else 0  # (8x8 / 4x4 maps: 2 / 4 images per strip)
-    if (WINO4_WGRAD and WINO_WGRAD and ks == 3 and not upsample and (pro is None or nseg <= 2)
+    # (an upsampled x on the 16x16 / 8x8 maps, which the phase-form weight gradient above does not take: materialised, as
+    # in conv2d_fwd)
+    w4g_up = bool(upsample) and WINO4_UP_SMALL and pro is None and H <= 16 and W <= 16
+    if (WINO4_WGRAD and WINO_WGRAD and ks == 3 and (not upsample or w4g_up) and (pro is None or nseg <= 2)
             and max(Ci, Co) <= WINO4_MAXC and w4g_ips > 0 and (B // nseg) % w4g_ips == 0
             and (w4g_ips == 1 or WINO4_SMALL)
             and (L.sivae_conv2d_wino4_wgrad_pays(B, Ci, Co, H, W) == 1
                  or (WINO4_FORCE and min(Ci, Co) >= 16))):
+        if upsample:
+            x = upsample2_fwd(x)
         # Winograd F(4x4,3x3) weight gradient (conv_wino4_wgrad.hip): 36 instead of 64 multiplies per tile, co, ci
         ws = workspace(L.sivae_conv2d_wino4_wgrad_workspace_bytes(B, Ci, Co, H, W), x.device)
         dw = _out(out, (Co, Ci, 3, 3), x.device)
