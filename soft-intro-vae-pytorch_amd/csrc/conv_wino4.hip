@@ -61,12 +61,13 @@ struct Wino4Args {
   // transform role zeroes patch column 0 / 5 and patch row 0 / 5 of the tiles that touch a seam through the four 64-bit
   // lane masks below (lane -> tile = lane & 31, tile column = tile & 7, tile row = tile >> 3; computed by the launch).
   int two;
-  int iw_l2, ih_l2;
-  unsigned long long seam_c0, seam_c5, seam_r0, seam_r5;
   // split-K (launches with fewer work items than CUs): an item = (pixel tile, K slice, co tile); slice ks walks the cps
   // chunks from ks * cps on and writes its partial outputs to y + ks * slice_stride (summed by wino4_splitk_reduce_kernel)
   int ksl, cps;
   long long slice_stride;
+  // image-grid form (conv_wino4_grid_kernel; behind the round-5 fields so that their offsets stay what they were)
+  int iw_l2, ih_l2;
+  unsigned long long seam_c0, seam_c5, seam_r0, seam_r5;
 };
 
 #define W4_CK 8
@@ -134,491 +135,24 @@ extern "C" int sivae_debug_w4_read(long long* out) {
 #define W4_STAMPK(CH)
 #endif
 
-// GRID: the image-grid mode (maps up to 16 x 16) as its own instantiation — the large-map kernels carry neither its seam
-// masks (eight scalar registers) nor its selects
-template <bool PRO, bool GRID = false>
-__global__ void __launch_bounds__(W4_NT, 1) conv_wino4_kernel(Wino4Args a) {
-  constexpr int CK = W4_CK, RS = W4_RS, PLANE = W4_PLANE, XBUF = W4_XBUF, VBUF = W4_VBUF;
-  // the two raw-halo buffers are SEPARATE static arrays: the compiler orders a ds_read behind every in-flight LDS-direct
-  // load it cannot prove disjoint (vmcnt(0) before the read); the transform reads one buffer while the loads fill the other
-  __shared__ __attribute__((aligned(16))) float raw0[XBUF];
-  __shared__ __attribute__((aligned(16))) float raw1[XBUF];
-  __shared__ __attribute__((aligned(16))) float vx[VBUF + W4_EXF];  // V0 | V1 + spare (= the epilogue's exchange area)
-#define RAWB(BUF) ((BUF) ? raw1 : raw0)
-  // {mean, invstd*gamma, beta, -} per (segment, input channel); padded channels carry zeros (-> x' = 0)
-  __shared__ float4 pro4[PRO ? W4_PRO_MAX : 1];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, hh = lane >> 5;
-  const int wj = wave % 6, ws = wave / 6;
-  const int H = a.H, W = a.W, HW = H * W;
-  const int tx = l31 & 7, ty = l31 >> 3;
-
-  // ---- transform role: column pair tp, item (tile tt, channel tc) of the chunk
-  const int tp = wave >> 2;                       // 0: columns (1,2)   1: columns (3,4)   2: columns (0,5)
-  const int ti = (wave & 3) * 64 + lane, tt = ti & 31, tc = ti >> 5;
-  const int trb = tc * PLANE + 4 * (tt >> 3) * RS + 4 * (tt & 7) + 4;  // patch column 1 at LDS column 4*tx + 4
-  const int jA = tp == 0 ? 1 : (tp == 1 ? 3 : 0), jB = tp == 0 ? 2 : (tp == 1 ? 4 : 5);
-  const int tvb = tc * 32 + tt;
-  const float t_al = tp == 0 ? -4.f : -1.f;  // a = d4 + al*d2
-  const float t_be = tp == 0 ? 1.f : 2.f;    // b = be*d3 + ga*d1
-  const float t_ga = tp == 0 ? -4.f : -2.f;
-  const bool pair05 = tp == 2;
-  // pair mode: lanes whose tile column is 4 (patch column 0 = the other image's last column) / 3 (patch column 5 = the
-  // other image's first column) — as 64-bit lane masks for v_cndmask (tile = lane & 31, column = tile & 7)
-  const unsigned long long seam_m0 = a.seam_c0, seam_m5 = a.seam_c5, seam_mr0 = a.seam_r0, seam_mr5 = a.seam_r5;
-  // image grid of an item (branch-free: one image -> bounds H x W, masks ~0, image stride 0)
-  const int two_w = GRID ? W4_PXW : a.W, two_h = GRID ? W4_PXH : a.H;
-  const int two_mask = GRID ? a.W - 1 : -1, two_hmask = GRID ? a.H - 1 : -1;
-  const int two_img = GRID ? a.Ci * a.H * a.W : 0, two_nx = W4_PXW >> a.iw_l2, two_ipi = GRID ? two_nx * (W4_PXH >> a.ih_l2) : 1;
-  // ---- MFMA role: B operand V[(i*6 + wj)][2*kk + hh][l31]
-  const int vrb = (wj * CK + hh) * 32 + l31;
-
-  // ---- halo role: a channel plane is 192 groups of four floats (18 rows x 10 groups + padding), three wave-instructions;
-  // wave w fills third w % 3 of the planes w / 3 + 4n (n = 0, 1).  Group k of a row = image columns c0 - 4 + 4k .. + 3:
-  // entirely inside or entirely outside the image (W % 32 == 0).
-  const int dsub = wave % 3, dpl0 = wave / 3;
-  const int pg = dsub * 64 + lane, prow = pg / 10, pk = pg - prow * 10;
-  const bool pvalid = pg < 180;
-
-  const int n_items = a.n_items;
-  const int nchunks = a.cps;  // chunks per work item: Ci_pad / CK (a multiple of 4), or an even share >= 4 of it per K slice
-  const int ksteps = nchunks * (CK / 2);
-  const __amdgpu_buffer_rsrc_t ursrc = make_rsrc(a.up, 36ull * a.Ci_pad * a.Co_pad * 4ull);
-  const unsigned va0 = (unsigned)(hh * a.Co_pad + ws * 32 + l31) * 24u;
-  const unsigned ua_step = (unsigned)a.Co_pad * 24u;  // bytes per input channel
-
-  // Consecutive blockIdx go round-robin to the 8 XCDs.  With xcd_group the block on XCD x, slot j starts at item
-  // x * (grid / 8) + j: the co-tiles of one pixel tile (consecutive items) run on ONE XCD at the same time and share the
-  // halo in its L2 (the halo stream is 2.4 KB per input channel and item: 2.6 TB/s at full matrix rate with one reader)
-  int item = blockIdx.x;
-  if (a.xcd_group) item = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
-  int b, r0, c0, co0, pt;
-  int cbase = 0, kslice = 0;  // first input channel / index of the item's K slice (split-K)
-  __amdgpu_buffer_rsrc_t xrsrc;
-  unsigned xo, ua_base;
-  int pseg = 0;  // table offset of the segment of the item whose halo is being requested
-#define W4_SETUP(ITEM)                                                   \
-  {                                                                      \
-    const int co_tile = (ITEM) % a.n_co_tiles;                           \
-    const int iq_ = (ITEM) / a.n_co_tiles;                               \
-    kslice = iq_ % a.ksl;                                                \
-    pt = iq_ / a.ksl;                                                    \
-    cbase = kslice * a.cps * CK;                                         \
-    const int tbx = pt % a.nbw;                                          \
-    const int t2 = pt / a.nbw;                                           \
-    const int tby = t2 % a.nbh;                                          \
-    b = t2 / a.nbh;                                                      \
-    r0 = tby * W4_PXH;                                                   \
-    c0 = tbx * W4_PXW;                                                   \
-    co0 = co_tile * W4_TCO;                                              \
-    /* image-grid mode (maps up to 16 x 16): images ipi * pt ... in row-major order of the grid — halo row r / group  */ \
-    /* column c belong to image (r >> ih_l2) * nx + (c >> iw_l2) at (r & (H-1), c & (W-1)); rows -1 / 16 and groups   */ \
-    /* -4 / 32 are zero padding (branch-free: bounds 16 x 32, masks H-1 / W-1, stride Ci*HW; otherwise H x W, ~0, 0)   */ \
-    b = GRID ? two_ipi * pt : b;                                        \
-    xrsrc = make_rsrc(a.x + (size_t)b * a.Ci * HW, (unsigned long long)two_ipi * a.Ci * HW * 4ull); \
-    const int r = r0 - 1 + prow, c = c0 - 4 + 4 * pk;                    \
-    xo = (pvalid && r >= 0 && r < two_h && c >= 0 && c < two_w)          \
-             ? (unsigned)(((r >> a.ih_l2) * two_nx + (c >> a.iw_l2)) * two_img + (r & two_hmask) * W + (c & two_mask)) * 4u \
-             : SIVAE_OOB;                                                \
-    ua_base = (unsigned)((wj * a.Ci_pad + cbase) * a.Co_pad + co0) * 24u; \
-    if (PRO) pseg = (b / a.pro_seg_images) * a.Ci_pad + cbase;           \
-  }
-  // piece N (0, 1) of halo chunk CH -> raw buffer BUF (out-of-image / padding groups receive 0; channels beyond Ci
-  // re-read the last one: their U is zero)
-#define W4_DMA1(CH, BUF, N)                                              \
-  if (!((W4_ABLATE & 1) && item >= 0)) {                                 \
-    const int ck = dpl0 + 4 * (N);                                       \
-    const int ci = cbase + (CH)*CK + ck;                                 \
-    const int cic = ci < a.Ci ? ci : a.Ci - 1;                           \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(                            \
-        xrsrc, (float __attribute__((address_space(3)))*)(RAWB(BUF) + ck * PLANE + dsub * 256), 16, xo, \
-        (unsigned)cic * (unsigned)HW * 4u, 0, 0);                        \
-  }
-  // The fused BatchNorm + LeakyReLU prologue: the halo arrives RAW in LDS (LDS-direct loads bypass the registers), so
-  // every thread rewrites the two 16-byte groups IT requested (no other thread touches them before the chunk's barrier):
-  // x' = max(v, slope * v) * inside-the-image, v = (x - mean) * scale + beta.
-#define W4_FIXUP(CH, BUF, XO, PSEG)                                      \
-  {                                                                      \
-    const float msk_ = (XO) != SIVAE_OOB ? 1.f : 0.f;                    \
-    _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_) {                   \
-      const int ck = dpl0 + 4 * n_;                                      \
-      float4* q_ = reinterpret_cast<float4*>(RAWB(BUF) + ck * PLANE + dsub * 256 + lane * 4); \
-      const float4 p_ = pro4[(PSEG) + (CH)*CK + ck];                     \
-      float4 v_ = *q_;                                                   \
-      v_.x = fmaf(v_.x - p_.x, p_.y, p_.z);                              \
-      v_.y = fmaf(v_.y - p_.x, p_.y, p_.z);                              \
-      v_.z = fmaf(v_.z - p_.x, p_.y, p_.z);                              \
-      v_.w = fmaf(v_.w - p_.x, p_.y, p_.z);                              \
-      v_.x = fmaxf(v_.x, v_.x * a.pro_slope) * msk_;                     \
-      v_.y = fmaxf(v_.y, v_.y * a.pro_slope) * msk_;                     \
-      v_.z = fmaxf(v_.z, v_.z * a.pro_slope) * msk_;                     \
-      v_.w = fmaxf(v_.w, v_.w * a.pro_slope) * msk_;                     \
-      *q_ = v_;                                                          \
-    }                                                                    \
-  }
-
-  f32x16 acc[6];
-  float4 U4[2];
-  float2 U2[2];
-#if W4_ABLATE & 2
-  U4[0] = U4[1] = make_float4(1.f, 0.5f, 0.25f, 2.f);
-  U2[0] = U2[1] = make_float2(1.f, 0.5f);
-#endif
-  // (the U refill is UNCONDITIONAL with a selected base / clamped index: a load inside an `if` makes hipcc assume no
-  // younger load is outstanding at the join and turns every later wait into vmcnt(0))
-#define W4_LOAD_A(UBASE, KS_ABS, SLOT)                                   \
-  if (!(W4_ABLATE & 2)) {                                                \
-    const unsigned so = (UBASE) + (unsigned)(2 * (KS_ABS)) * ua_step;    \
-    U4[SLOT] = buf_load_f32x4(ursrc, va0, so);                           \
-    U2[SLOT] = buf_load_f32x2(ursrc, va0 + 16u, so);                     \
-  }
-#define W4_REFILL(CH, KK)                                                \
-  {                                                                      \
-    const int ks2 = (CH) * (CK / 2) + (KK) + 2;                          \
-    const bool in_item = ks2 < ksteps;                                   \
-    const unsigned ub_ = (in_item || !has_next) ? ua_cur : ua_base;      \
-    const int kq_ = in_item ? ks2 : (has_next ? ks2 - ksteps : ksteps - 1); \
-    W4_LOAD_A(ub_, kq_, (KK)&1)                                          \
-  }
-#define W4_FENCE __builtin_amdgcn_sched_barrier(0);
-  // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a full fence: with LDS-direct loads in flight
-  // (they write LDS, so the compiler counts them) it emits s_waitcnt vmcnt(0) in front of the barrier — i.e. every chunk
-  // would wait out the HBM latency of the halo pieces requested a moment earlier.  Those loads are ordered by hand (their
-  // consumer sits two chunks later, behind U-operand waits that complete after them), so the barriers inside the K loop
-  // wait for this wave's LDS reads / writes only.
-#define W4_LDS_BARRIER asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  // B operands of k-step KK of the transformed chunk in V buffer VB
-#define W4_READB(VB, KK, BV)                                             \
-  {                                                                      \
-    const float* p_ = vx + (VB)*VBUF + 2 * (KK)*32 + vrb;                \
-    _Pragma("unroll") for (int i = 0; i < 6; ++i) BV[i] = p_[i * 6 * CK * 32]; \
-  }
-  // ---- transform slices.  Rows R0..R0+2 of this thread's patch -> the pair's column dot products tA[r], tB[r]
-#define W4_TREAD(RB, R0, P05)                                               \
-  {                                                                      \
-    const float* p_ = RAWB(RB) + trb + (R0)*RS;                          \
-    _Pragma("unroll") for (int r = 0; r < 3; ++r) {                      \
-      td_[r] = *reinterpret_cast<const float4*>(p_ + r * RS);            \
-      if (P05) {                                                         \
-        te0_[r] = p_[r * RS - 1];                                        \
-        te5_[r] = p_[r * RS + 4];                                        \
-        if (GRID) { /* a seam between two images is zero padding for both (16 x 16 maps: tile columns 3 | 4) */   \
-          asm volatile("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(te0_[r]) : "s"(seam_m0));                \
-          asm volatile("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(te5_[r]) : "s"(seam_m5));                \
-        }                                                                \
-      }                                                                  \
-    }                                                                    \
-  }
-#define W4_TDOT(R0, P05)                                                    \
-  {                                                                      \
-    _Pragma("unroll") for (int r = 0; r < 3; ++r) {                      \
-      if (P05) {                                                         \
-        tA_[(R0) + r] = fmaf(4.f, te0_[r], fmaf(-5.f, td_[r].y, td_[r].w)); \
-        tB_[(R0) + r] = fmaf(4.f, td_[r].x, fmaf(-5.f, td_[r].z, te5_[r])); \
-      } else {                                                           \
-        const float a_ = fmaf(t_al, td_[r].y, td_[r].w);                 \
-        const float b_ = fmaf(t_ga, td_[r].x, t_be * td_[r].z);          \
-        tA_[(R0) + r] = a_ + b_;                                         \
-        tB_[(R0) + r] = a_ - b_;                                         \
-      }                                                                  \
-    }                                                                    \
-    if (GRID) { /* patch row 0 / 5 of a tile at the top / bottom edge of its image is zero padding */ \
-      constexpr int re_ = (R0) == 0 ? 0 : 5;                             \
-      const unsigned long long rm_ = (R0) == 0 ? seam_mr0 : seam_mr5;    \
-      asm volatile("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(tA_[re_]) : "s"(rm_)); \
-      asm volatile("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(tB_[re_]) : "s"(rm_)); \
-    }                                                                    \
-  }
-  // V[.][J] = B^T t (the row direction) for one column of the pair -> V buffer VN
-#define W4_TCOL(VN, T, J)                                                \
-  {                                                                      \
-    const float A_ = fmaf(-4.f, T[2], T[4]), B_ = fmaf(-4.f, T[1], T[3]); \
-    const float C_ = T[4] - T[2], D_ = T[3] - T[1];                      \
-    float* q_ = vx + (VN)*VBUF + (J)*CK * 32 + tvb;                      \
-    q_[0 * 6 * CK * 32] = fmaf(4.f, T[0], fmaf(-5.f, T[2], T[4]));       \
-    q_[1 * 6 * CK * 32] = A_ + B_;                                       \
-    q_[2 * 6 * CK * 32] = A_ - B_;                                       \
-    q_[3 * 6 * CK * 32] = fmaf(2.f, D_, C_);                             \
-    q_[4 * 6 * CK * 32] = fmaf(-2.f, D_, C_);                            \
-    q_[5 * 6 * CK * 32] = fmaf(4.f, T[1], fmaf(-5.f, T[3], T[5]));       \
-  }
-#define W4_MF(I, UV, BV) acc[I] = __builtin_amdgcn_mfma_f32_32x32x2f32(UV, BV[I], acc[I], 0, 0, 0);
-  // One chunk c: four k-steps of six MFMAs on V buffer VB; between them the transform of raw buffer VB^1 (chunk c+1)
-  // into V buffer VB^1 — all six patch rows are requested in k-step 0, then a MID barrier: raw buffer VB^1 is free from
-  // there on and receives the halo of chunk c+3 (DCH; both pieces in k-step 3, behind that k-step's U refill: loads
-  // complete in order) — a lead of five k-steps before chunk c+2's transform needs it, against HBM latency under load (the
-  // first form requested chunk c+2 here: three k-steps, and the 128x128 / 256x256 layers, whose inputs stream from HBM,
-  // paid ~25 % more per k-step than the 32x32 ones).  With the prologue the pieces of chunk c+2 (FCH, raw buffer VB,
-  // requested during chunk c-1 with the offsets / segment XOF / PSF of that time) are fixed up in k-step 2.
-#define W4_CHUNK(CH, VB, DCH, FCH, P05)                                  \
-  {                                                                      \
-    float4 td_[3];                                                       \
-    float te0_[3], te5_[3], tA_[6], tB_[6];                              \
-    float b0_[6], b1_[6];                                                \
-    W4_READB(VB, 0, b0_)                                                 \
-    W4_TREAD((VB) ^ 1, 0, P05)                                           \
-    W4_FENCE                                                             \
-    /* k-step 0 */                                                       \
-    W4_READB(VB, 1, b1_)                                                 \
-    W4_MF(0, U4[0].x, b0_) W4_MF(1, U4[0].y, b0_) W4_FENCE               \
-    W4_TDOT(0, P05)                                                      \
-    W4_FENCE                                                             \
-    W4_MF(2, U4[0].z, b0_) W4_MF(3, U4[0].w, b0_) W4_FENCE               \
-    W4_TREAD((VB) ^ 1, 3, P05)                                           \
-    W4_FENCE                                                             \
-    W4_MF(4, U2[0].x, b0_) W4_MF(5, U2[0].y, b0_) W4_FENCE               \
-    W4_REFILL(CH, 0)                                                     \
-    W4_FENCE                                                             \
-    /* every wave has read its rows of raw buffer VB^1 (the reads have returned: lgkmcnt(0)) */ \
-    if (!(W4_ABLATE & 8)) W4_LDS_BARRIER                                 \
-    W4_FENCE                                                             \
-    /* k-step 1 */                                                       \
-    W4_READB(VB, 2, b0_)                                                 \
-    W4_MF(0, U4[1].x, b1_) W4_MF(1, U4[1].y, b1_) W4_FENCE               \
-    W4_TDOT(3, P05)                                                      \
-    W4_FENCE                                                             \
-    W4_MF(2, U4[1].z, b1_) W4_MF(3, U4[1].w, b1_) W4_MF(4, U2[1].x, b1_) W4_MF(5, U2[1].y, b1_) W4_FENCE \
-    W4_REFILL(CH, 1)                                                     \
-    W4_FENCE                                                             \
-    /* k-step 2 */                                                       \
-    W4_READB(VB, 3, b1_)                                                 \
-    W4_MF(0, U4[0].x, b0_) W4_MF(1, U4[0].y, b0_) W4_MF(2, U4[0].z, b0_) W4_FENCE \
-    W4_TCOL((VB) ^ 1, tA_, jA)                                           \
-    W4_FENCE                                                             \
-    W4_MF(3, U4[0].w, b0_) W4_MF(4, U2[0].x, b0_) W4_MF(5, U2[0].y, b0_) W4_FENCE \
-    if (PRO) {                                                           \
-      W4_FIXUP(FCH, VB, xo_f, pseg_f)                                    \
-      W4_FENCE                                                           \
-    }                                                                    \
-    W4_REFILL(CH, 2)                                                     \
-    W4_FENCE                                                             \
-    /* k-step 3 */                                                       \
-    W4_MF(0, U4[1].x, b1_) W4_MF(1, U4[1].y, b1_) W4_MF(2, U4[1].z, b1_) W4_FENCE \
-    W4_TCOL((VB) ^ 1, tB_, jB)                                           \
-    W4_FENCE                                                             \
-    W4_MF(3, U4[1].w, b1_) W4_MF(4, U2[1].x, b1_) W4_MF(5, U2[1].y, b1_) W4_FENCE \
-    W4_REFILL(CH, 3)                                                     \
-    W4_DMA1(DCH, (VB) ^ 1, 0)                                            \
-    W4_DMA1(DCH, (VB) ^ 1, 1)                                            \
-    xo_f = xo;                                                           \
-    pseg_f = pseg;                                                       \
-    W4_FENCE                                                             \
-    /* (the halo requested during the PREVIOUS chunk has landed: the U operands of this k-step, younger, were waited for) */ \
-    if (!(W4_ABLATE & 8)) W4_LDS_BARRIER                                 \
-  }
-  // the whole transform of raw buffer RB into V buffer VN in one go (the very first chunk of a block)
-#define W4_TRANSFORM_ALL(RB, VN, P05)                                    \
-  {                                                                      \
-    float4 td_[3];                                                       \
-    float te0_[3], te5_[3], tA_[6], tB_[6];                              \
-    W4_TREAD(RB, 0, P05)                                                 \
-    W4_TDOT(0, P05)                                                      \
-    W4_TREAD(RB, 3, P05)                                                 \
-    W4_TDOT(3, P05)                                                      \
-    W4_TCOL(VN, tA_, jA)                                                 \
-    W4_TCOL(VN, tB_, jB)                                                 \
-  }
-  // two chunks (V buffers 0 then 1).  Chunk c requests the halo of chunk c+3 and fixes up / will transform chunk c+2:
-  // from the item's third-last chunk on these belong to the NEXT item's chunks 0, 1, 2 (the chunk numbering simply runs
-  // on; the last item of a block re-requests its own: unconditional loads)
-#define W4_PAIR(CH, P05)                                                 \
-  {                                                                      \
-    const int d0_ = (CH) + 3 < nchunks ? (CH) + 3 : (CH) + 3 - nchunks;  \
-    const int f0_ = (CH) + 2 < nchunks ? (CH) + 2 : (CH) + 2 - nchunks;  \
-    W4_CHUNK(CH, 0, d0_, f0_, P05)                                       \
-    if ((CH) + 4 == nchunks && has_next) W4_SETUP(next)                  \
-    const int d1_ = (CH) + 4 < nchunks ? (CH) + 4 : (CH) + 4 - nchunks;  \
-    const int f1_ = (CH) + 3 < nchunks ? (CH) + 3 : (CH) + 3 - nchunks;  \
-    W4_CHUNK((CH) + 1, 1, d1_, f1_, P05)                                 \
-  }
-
-  if (PRO) {
-    for (int idx = tid; idx < a.pro_nseg * a.Ci_pad; idx += W4_NT) {
-      const int c = idx % a.Ci_pad, so = (idx / a.Ci_pad) * a.Ci;  // (segment g's statistics start at g * Ci)
-      pro4[idx] = c < a.Ci ? make_float4(a.pro_mean[so + c], a.pro_invstd[so + c] * a.pro_gamma[c], a.pro_beta[c], 0.f)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
-  }
-  W4_SETUP(item)
-  W4_DMA1(0, 0, 0)
-  W4_DMA1(0, 0, 1)
-  W4_DMA1(1, 1, 0)
-  W4_DMA1(1, 1, 1)
-  unsigned ua_cur = ua_base;
-  W4_LOAD_A(ua_cur, 0, 0)
-  W4_LOAD_A(ua_cur, 1, 1)
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  if (PRO) {
-    W4_FIXUP(0, 0, xo, pseg)
-    W4_FIXUP(1, 1, xo, pseg)
-  }
-  __syncthreads();
-  if (pair05) W4_TRANSFORM_ALL(0, 0, true) else W4_TRANSFORM_ALL(0, 0, false)
-  __syncthreads();
-  W4_DMA1(2, 0, 0)  // chunk 2 into the raw buffer the first transform freed
-  W4_DMA1(2, 0, 1)
-  unsigned xo_f = xo;  // offsets / segment the halo pieces awaiting their fix-up were requested with
-  int pseg_f = pseg;
-#ifdef W4_TIMING
-  int it_n = 0;
-#endif
-  for (;;) {
-    W4_STAMP(0)
-    W4_STAMP(6)
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    // coordinates of the item being accumulated (W4_SETUP overwrites b, r0, ... for the next one in the last pair)
-    const int e_pt = pt, e_b = b, e_r0 = r0, e_c0 = c0, e_co0 = co0, e_ks = kslice;
-    const int next = item + (int)gridDim.x;
-    const bool has_next = next < n_items;
-    if (pair05) {
-      for (int ch = 0; ch < nchunks; ch += 2) {
-        W4_PAIR(ch, true)
-        W4_STAMPK(ch)
-      }
-    } else {
-      for (int ch = 0; ch < nchunks; ch += 2) {
-        W4_PAIR(ch, false)
-        W4_STAMPK(ch)
-      }
-    }
-    W4_STAMP(1)
-
-    // ---- output transform.  acc[i][r]: frequency (i, wj), tile = l31, channel = ws*32 + (r&3) + 8*(r>>2) + 4*hh.
-    // Round a = output row a of every tile: Z[a][j] = sum_i A^T[a][i] M[i][j] in registers -> ex[j][s][r][lane] (48 KB:
-    // the V buffer the item finished on + the spare behind it; V buffer 0 already holds the next item's first chunk);
-    // then pair q = (s, r) of this wave: Y[a][0..3] = Z[a][.] A, one 16-byte store.
-    {
-      float* ex = vx + VBUF;
-      const __amdgpu_buffer_rsrc_t yrsrc =
-          make_rsrc(a.y + (size_t)e_ks * a.slice_stride + (size_t)e_b * a.Co * HW,
-                    (unsigned long long)two_ipi * a.Co * HW * 4ull);
-      float ssum[3] = {0.f, 0.f, 0.f}, ssq[3] = {0.f, 0.f, 0.f};
-      // The lane index is laundered once per item: otherwise hipcc hoists the lane-dependent LDS / global offsets of this
-      // epilogue out of the persistent item loop, spills them, and reloads each one behind an s_waitcnt vmcnt(0) — which
-      // also waits for every output store issued so far (stores share vmcnt on gfx9): ~25 K cycles per item.
-      // (and it is RECOMPUTED, not copied: `lane` itself is spilled by then, and its reload — `s_waitcnt vmcnt(1)` at the
-      // epilogue's entry, in order behind the next item's halo requests — waited out an HBM latency per item)
-      int lane_;
-      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_));
-      const int hh_ = lane_ >> 5;
-      // image-grid mode: the tile at (row 4 ty, column 4 tx) of the item lies in image e_b + (4 ty >> ih_l2) * nx + (4 tx >> iw_l2)
-      const int ty4 = ((lane_ >> 3) & 3) * 4, tx4 = (lane_ & 7) * 4;
-      const int ty_ = (ty4 & two_hmask) >> 2, tx_ = (tx4 & two_mask) >> 2;
-      const unsigned img_off =
-          GRID ? (unsigned)((ty4 >> a.ih_l2) * two_nx + (tx4 >> a.iw_l2)) * (unsigned)(a.Co * HW) * 4u : 0u;
-      // row transform Z = A^T M in place (acc[a][r] <- Z[a][wj] of channel slot r): the partial sums m1 +- m2, m3 +- m4
-      // are shared by the four output rows (10 VALU per slot instead of 14)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
-        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-        acc[0][r] = m0 + s12 + s34;
-        acc[1][r] = d12 + 2.f * d34;
-        acc[2][r] = s12 + 4.f * s34;
-        acc[3][r] = d12 + 8.f * d34 + m5;
-      }
-      // byte offset of output row 0 of this lane's tile for each of the wave's (s, r) pairs; the row of round a is added
-      // through the scalar offset of the store (not range-checked: the marker of a padded channel stays out of range)
-      unsigned off0[3];
-#pragma unroll
-      for (int qi = 0; qi < 3; ++qi) {
-        const int q = wave + 12 * qi;
-        const int chn = e_co0 + (q >> 4) * 32 + (q & 3) + 8 * ((q & 15) >> 2) + 4 * hh_;
-        off0[qi] = chn < a.Co ? (unsigned)((chn * H + e_r0 + 4 * ty_) * W + e_c0 + 4 * tx_) * 4u + img_off : W4_OOB16;
-      }
-      // Store-data lifetime (see bn_fused.hip::BF_KEEP): the registers a 16-byte store reads stay pinned until the NEXT
-      // store of the wave has been issued (six LDS reads, their wait and ~20 VALU later; the last one of a round until
-      // the barrier behind it) — nothing recycles them while the store may still be reading its data under
-      // back-pressure.  (Pinning a whole round — 12 registers — spilled 50-80 registers of this 168-register kernel.)
-      float4 held[3];
-      held[0] = held[1] = held[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-#define W4_KEEP(V) asm volatile("" ::"v"((V).x), "v"((V).y), "v"((V).z), "v"((V).w));
-#pragma unroll
-      for (int ar = 0; ar < 4; ++ar) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ex[((wj * 2 + ws) * 16 + r) * 64 + lane_] = acc[ar][r];
-        __syncthreads();
-        if (ar == 0) { W4_STAMP(2) }
-        const unsigned row_off = (unsigned)(ar * W) * 4u;
-#pragma unroll
-        for (int qi = 0; qi < 3; ++qi) {
-          const int q = wave + 12 * qi;
-          if (q < 32) {
-            const int s = q >> 4, r = q & 15;
-            float z[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) z[j] = ex[((j * 2 + s) * 16 + r) * 64 + lane_];
-            float4 o;
-            o.x = z[0] + (z[1] + z[2]) + (z[3] + z[4]);
-            o.y = (z[1] - z[2]) + 2.f * (z[3] - z[4]);
-            o.z = (z[1] + z[2]) + 4.f * (z[3] + z[4]);
-            o.w = (z[1] - z[2]) + 8.f * (z[3] - z[4]) + z[5];
-            if (a.accumulate) {
-              const float4 old = buf_load_f32x4(yrsrc, off0[qi], row_off);
-              o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
-            }
-            held[qi] = o;
-            if (!((W4_ABLATE & 16) && item >= 0)) buf_store_f32x4(yrsrc, held[qi], off0[qi], row_off);
-            if (qi > 0) W4_KEEP(held[qi - 1])
-            ssum[qi] += (o.x + o.y) + (o.z + o.w);
-            ssq[qi] += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
-          }
-        }
-        __syncthreads();
-        W4_KEEP(held[1]) W4_KEEP(held[2])
-        if (ar == 0) { W4_STAMP(3) }
-      }
-      W4_STAMP(4)
-#undef W4_KEEP
-      if (a.stats != nullptr) {
-#pragma unroll
-        for (int qi = 0; qi < 3; ++qi) {
-          const int q = wave + 12 * qi;
-          const float s_ = half_wave_sum_hi(ssum[qi]);
-          const float q_ = half_wave_sum_hi(ssq[qi]);
-          if (q < 32) {
-            const int chn = e_co0 + (q >> 4) * 32 + (q & 3) + 8 * ((q & 15) >> 2) + 4 * hh_;
-            if ((lane_ & 31) == 31 && chn < a.Co) {  // (lane_ / hh_: the recomputed lane index — no spill reload here)
-              float* dst = a.stats + ((size_t)e_pt * a.Co + chn) * 2;
-              dst[0] = s_;
-              dst[1] = q_;
-            }
-          }
-        }
-      }
-    }
-    W4_STAMP(5)
-    W4_STAMP(7)
-#ifdef W4_TIMING
-    ++it_n;
-#endif
-    if (!has_next) break;
-    item = next;
-    ua_cur = ua_base;
-  }
-#undef W4_SETUP
-#undef W4_FIXUP
-#undef W4_DMA1
-#undef W4_LOAD_A
-#undef W4_REFILL
-#undef W4_READB
-#undef W4_TREAD
-#undef W4_TDOT
-#undef W4_TCOL
-#undef W4_MF
-#undef W4_FENCE
-#undef W4_LDS_BARRIER
-#undef W4_CHUNK
-#undef W4_TRANSFORM_ALL
-#undef W4_PAIR
-#undef RAWB
-}
+#define W4_GRID 0
+#define W4_KERNEL_NAME conv_wino4_kernel
+#define W4_TWO a.two
+#define W4_IPI (a.two ? 2 : 1)
+#include "conv_wino4_kernel.inc"
+#undef W4_GRID
+#undef W4_KERNEL_NAME
+#undef W4_TWO
+#undef W4_IPI
+#define W4_GRID 1
+#define W4_KERNEL_NAME conv_wino4_grid_kernel
+#define W4_TWO true
+#define W4_IPI two_ipi
+#include "conv_wino4_kernel.inc"
+#undef W4_GRID
+#undef W4_KERNEL_NAME
+#undef W4_TWO
+#undef W4_IPI
 
 // ---- weight transform U = G g G^T (6x6), packed [j][ci_pad][co_pad][i]; padding entries are zero
 //   mode 0 (forward): g = w[n][k]            (n = output channel, k = input channel)
@@ -795,15 +329,15 @@ static int wino4_impl(const float* x, const float* up, float* y, const float* pr
   const int cus = sivae_num_cus();
   const int grid = nitems < cus ? (int)nitems : cus;
   a.xcd_group = (sivae_xcd_remap() && a.n_co_tiles > 1 && !(grid & 7)) ? 1 : 0;
-  if (a.two) {
+  if (sup >= 3) {  // (the 16 x 16 pairs, mode 2, stay on the round-5 kernel: a.two)
     if (pro_mean)
-      hipLaunchKernelGGL((conv_wino4_kernel<true, true>), dim3((unsigned)grid), dim3(W4_NT), 0, stream, a);
+      hipLaunchKernelGGL(conv_wino4_grid_kernel<true>, dim3((unsigned)grid), dim3(W4_NT), 0, stream, a);
     else
-      hipLaunchKernelGGL((conv_wino4_kernel<false, true>), dim3((unsigned)grid), dim3(W4_NT), 0, stream, a);
+      hipLaunchKernelGGL(conv_wino4_grid_kernel<false>, dim3((unsigned)grid), dim3(W4_NT), 0, stream, a);
   } else if (pro_mean) {
-    hipLaunchKernelGGL((conv_wino4_kernel<true, false>), dim3((unsigned)grid), dim3(W4_NT), 0, stream, a);
+    hipLaunchKernelGGL(conv_wino4_kernel<true>, dim3((unsigned)grid), dim3(W4_NT), 0, stream, a);
   } else {
-    hipLaunchKernelGGL((conv_wino4_kernel<false, false>), dim3((unsigned)grid), dim3(W4_NT), 0, stream, a);
+    hipLaunchKernelGGL(conv_wino4_kernel<false>, dim3((unsigned)grid), dim3(W4_NT), 0, stream, a);
   }
   return sivae_launch_status();
 }

@@ -123,7 +123,7 @@ _sha = None
 
 
 def sha256():
-    """sha256 over the kernel SOURCES the library is built from (csrc/*.hip, *.h, build.sh, in name order) — what a PMC
+    """sha256 over the kernel SOURCES the library is built from (csrc/*.hip, *.h, *.inc, build.sh, in name order) — what a PMC
     summary is stamped with (tools/profile.sh -> tools/pmc_*.py --lib-sha) and what bench.py compares against, so that
     counter figures taken with other kernels are marked stale.  (The sources, not the .so: a rebuild of the same sources
     on another machine need not be byte-identical.)"""
@@ -133,7 +133,7 @@ def sha256():
         h = hashlib.sha256()
         src = os.path.dirname(BUILD_SCRIPT)
         for name in sorted(os.listdir(src)):
-            if name.endswith((".hip", ".h", ".sh")):
+            if name.endswith((".hip", ".h", ".inc", ".sh")):
                 h.update(name.encode())
                 with open(os.path.join(src, name), "rb") as f:
                     h.update(f.read())

@@ -285,9 +285,9 @@ WINO4_B6_PRO = os.environ.get("SIVAE_WINO4_B6_PRO", "1") != "0"
 
 
 def _w4_key(b6, pro, sup):
-    """KernelTimer key = the kernel instantiation rocprofv3 names: conv_wino4_kernel<PRO, GRID> (GRID: maps up to 16x16)"""
+    """KernelTimer key = the kernel rocprofv3 names: conv_wino4_kernel<PRO>, or conv_wino4_grid_kernel<PRO> on 8x8 / 4x4 maps"""
     p = "true" if pro is not None else "false"
-    return "conv_wino4_b6_kernel<%s>" % p if b6 else "conv_wino4_kernel<%s,%s>" % (p, "true" if sup >= 2 else "false")
+    return ("conv_wino4_b6_kernel<%s>" if b6 else ("conv_wino4_grid_kernel<%s>" if sup >= 3 else "conv_wino4_kernel<%s>")) % p
 
 
 def wino4_b6_takes(Ci, pro):
