@@ -79,15 +79,23 @@ struct Conv5FwdArgs {
   int nrow4;   // row groups of 4
 };
 
-template <int NWT>
+// VEC (round 6; W % 4 == 0 and a 16-byte aligned x): the input tile is staged in 16-byte groups — the LDS column origin is
+// c0 - 4 instead of c0 - 2, so that every group is aligned in memory and lies entirely inside or outside the image;
+// 8 channels x 8 rows x 4 ntile groups = 256 ntile groups per chunk = ntile dwordx4 loads and ntile ds_write_b128 per thread
+// instead of 40 dword loads / stores (the MFMA operand reads shift by two columns).
+// EXACT (round 6): a.ntile == NWT at compile time.  With a run-time tile count every MFMA of the K loop and every staging
+// load / store sat behind its own scalar branch (227 branches in the loop; an s_waitcnt vmcnt(0) in front of every LDS
+// store) — the common widths (ntile = 3: 32 columns, 5: 64, 9: 128 and more) get branch-free instantiations.
+template <int NWT, bool VEC, bool EXACT>
 __global__ void __launch_bounds__(256, 2) conv5_smallco_fwd_kernel(Conv5FwdArgs a) {
+  const int ntile = EXACT ? NWT : a.ntile;
   constexpr int CK = 8, ROWS = 8, NT = 256;
-  constexpr int MAXPOS = (ROWS * 16 * NWT + NT - 1) / NT;
+  constexpr int MAXPOS = VEC ? 1 : (ROWS * 16 * NWT + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, g = lane >> 4;
-  const int LWX = 16 * a.ntile;       // odd multiple of 16 -> the two 16-lane groups of a half-wave hit disjoint banks
+  const int LWX = 16 * ntile;       // odd multiple of 16 -> the two 16-lane groups of a half-wave hit disjoint banks
   const int XPL = ROWS * LWX + 16;    // channel plane stride, == 16 (mod 32)
   float* ws = smem;                   // [CK*5][16]
   float* xs = smem + CK * 5 * 16;     // [CK][XPL]
@@ -106,30 +114,50 @@ __global__ void __launch_bounds__(256, 2) conv5_smallco_fwd_kernel(Conv5FwdArgs 
   const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.x + (size_t)b * a.Ci * HW, (unsigned long long)a.Ci * HW * 4ull);
   const int plane = ROWS * LWX;
   unsigned xo[MAXPOS];
+  // VEC: group p of this thread = (channel gck, row, 16-byte group of the row); byte offset inside the image (+ the channel
+  // part) or OOB, and its LDS float index
+  unsigned gvo[VEC ? NWT : 1];
+  int glds[VEC ? NWT : 1], gck[VEC ? NWT : 1];
+  if (VEC) {
+    const int gpr = 4 * ntile, gpc = ROWS * gpr;  // groups per row / per channel plane
 #pragma unroll
-  for (int p = 0; p < MAXPOS; ++p) {
-    const int pos = tid + p * NT;
-    unsigned off = SIVAE_OOB;
-    if (pos < plane) {
-      const int rr = pos / LWX, q = pos - rr * LWX;
-      const int r = r0 + rr - 2, c = c0 + q - 2;
-      if (r >= 0 && r < H && c >= 0 && c < W) off = (unsigned)(r * W + c) * 4u;
+    for (int p = 0; p < NWT; ++p) {
+      const int gi = tid + p * NT;
+      const int ck = gi / gpc, rem = gi - ck * gpc;
+      const int rr = rem / gpr, q = rem - rr * gpr;
+      const int r = r0 + rr - 2, c = c0 - 4 + 4 * q;
+      const bool ok = p < ntile && r >= 0 && r < H && c >= 0 && c < W;  // (W % 4 == 0: a group never straddles the edge)
+      gvo[p] = ok ? (unsigned)(ck * HW + r * W + c) * 4u : SIVAE_OOB16;
+      glds[p] = ck * XPL + rr * LWX + 4 * q;
+      gck[p] = ck;
     }
-    xo[p] = off;
+  } else {
+#pragma unroll
+    for (int p = 0; p < MAXPOS; ++p) {
+      const int pos = tid + p * NT;
+      unsigned off = SIVAE_OOB;
+      if (pos < plane) {
+        const int rr = pos / LWX, q = pos - rr * LWX;
+        const int r = r0 + rr - 2, c = c0 + q - 2;
+        if (r >= 0 && r < H && c >= 0 && c < W) off = (unsigned)(r * W + c) * 4u;
+      }
+      xo[p] = off;
+    }
   }
-  // per-lane K offsets: k = 4s + g -> (ci_local, kh)
+  // per-lane K offsets: k = 4s + g -> (ci_local, kh)   (VEC: the LDS columns start at c0 - 4, two further left)
   int koff[10];
 #pragma unroll
   for (int s = 0; s < 10; ++s) {
     const int k = 4 * s + g;
     const int cl = k / 5, kh = k - cl * 5;
-    koff[s] = cl * XPL + (wave + kh) * LWX + li;
+    koff[s] = cl * XPL + (wave + kh) * LWX + li + (VEC ? 2 : 0);
   }
   f32x4 acc[NWT];
 #pragma unroll
   for (int t = 0; t < NWT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float xr[MAXPOS][CK];
+  float xr[MAXPOS][VEC ? 1 : CK];
+  float4 xg[VEC ? NWT : 1];
   float wr[3];  // CK*5*16 = 640 floats / 256 threads
   const int nchunks = (a.Ci + CK - 1) / CK;
 
@@ -139,11 +167,18 @@ __global__ void __launch_bounds__(256, 2) conv5_smallco_fwd_kernel(Conv5FwdArgs 
       const int e = tid + q * NT;                                                                     \
       wr[q] = e < CK * 5 * 16 ? a.wq[(size_t)(CH) * (CK * 5 * 16) + e] : 0.f;                         \
     }                                                                                                 \
-    _Pragma("unroll") for (int ck = 0; ck < CK; ++ck) {                                               \
-      const int ci = (CH) * CK + ck;                                                                  \
-      const int cic = ci < a.Ci ? ci : a.Ci - 1;                                                      \
-      _Pragma("unroll") for (int p = 0; p < MAXPOS; ++p)                                              \
-        xr[p][ck] = buf_load_f32(xrs, xo[p], (unsigned)cic * (unsigned)HW * 4u);                      \
+    if (VEC) {                                                                                        \
+      _Pragma("unroll") for (int p = 0; p < NWT; ++p)                                                 \
+        if (p < ntile) /* (channels beyond Ci read as zeros: out-of-range offset) */                      \
+          xg[p] = buf_load_f32x4(xrs, (CH) * CK + gck[p] < a.Ci ? gvo[p] : SIVAE_OOB16,               \
+                                 (unsigned)((CH) * CK) * (unsigned)HW * 4u);                          \
+    } else {                                                                                          \
+      _Pragma("unroll") for (int ck = 0; ck < CK; ++ck) {                                             \
+        const int ci = (CH) * CK + ck;                                                                \
+        const int cic = ci < a.Ci ? ci : a.Ci - 1;                                                    \
+        _Pragma("unroll") for (int p = 0; p < MAXPOS; ++p)                                            \
+          xr[p][ck] = buf_load_f32(xrs, xo[p], (unsigned)cic * (unsigned)HW * 4u);                    \
+      }                                                                                               \
     }                                                                                                 \
   }
 
@@ -154,13 +189,19 @@ __global__ void __launch_bounds__(256, 2) conv5_smallco_fwd_kernel(Conv5FwdArgs 
       const int e = tid + q * NT;
       if (e < CK * 5 * 16) ws[e] = wr[q];
     }
+    if (VEC) {
 #pragma unroll
-    for (int ck = 0; ck < CK; ++ck) {
-      const bool ok = ch * CK + ck < a.Ci;
+      for (int p = 0; p < NWT; ++p)
+        if (p < ntile) *reinterpret_cast<float4*>(xs + glds[p]) = xg[p];
+    } else {
 #pragma unroll
-      for (int p = 0; p < MAXPOS; ++p) {
-        const int pos = tid + p * NT;
-        if (pos < plane) xs[ck * XPL + pos] = ok ? xr[p][ck] : 0.f;
+      for (int ck = 0; ck < CK; ++ck) {
+        const bool ok = ch * CK + ck < a.Ci;
+#pragma unroll
+        for (int p = 0; p < MAXPOS; ++p) {
+          const int pos = tid + p * NT;
+          if (pos < plane) xs[ck * XPL + pos] = ok ? xr[p][ck] : 0.f;
+        }
       }
     }
     __syncthreads();
@@ -170,7 +211,7 @@ __global__ void __launch_bounds__(256, 2) conv5_smallco_fwd_kernel(Conv5FwdArgs 
       const float aw = ws[(4 * s + g) * 16 + li];
 #pragma unroll
       for (int t = 0; t < NWT; ++t) {
-        if (t < a.ntile) acc[t] = mfma16(aw, xs[koff[s] + 16 * t], acc[t]);
+        if (t < ntile) acc[t] = mfma16(aw, xs[koff[s] + 16 * t], acc[t]);
       }
     }
     __syncthreads();
@@ -181,7 +222,7 @@ __global__ void __launch_bounds__(256, 2) conv5_smallco_fwd_kernel(Conv5FwdArgs 
   float* ds = xs + wave * 16 * LWX;  // [16][LWX] per wave (fits: 4*16*LWX <= CK*XPL)
 #pragma unroll
   for (int t = 0; t < NWT; ++t) {
-    if (t < a.ntile) {
+    if (t < ntile) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) ds[(4 * g + r) * LWX + 16 * t + li] = acc[t][r];
     }
@@ -222,7 +263,21 @@ extern "C" int sivae_conv5_smallco_fwd(const float* x, const float* wq, float* y
   const long long nblk = (long long)B * a.nrow4 * a.nseg;
   if (nblk > 0x7fffffffLL) return SIVAE_ERR_RANGE;
   a.xcd_remap = (sivae_xcd_remap() && (nblk & 7) == 0) ? 1 : 0;
-  hipLaunchKernelGGL((conv5_smallco_fwd_kernel<9>), dim3((unsigned)nblk), dim3(256), lds, stream, a);
+  // 16-byte staging where every group is aligned and never straddles the image edge (SIVAE_CONV5_VEC=0: the dword form)
+  static int vec_on = -1;
+  if (vec_on < 0) {
+    const char* e = getenv("SIVAE_CONV5_VEC");
+    vec_on = (e && e[0] == '0') ? 0 : 1;
+  }
+  const bool vec = vec_on && (W & 3) == 0 && (((uintptr_t)x) & 15u) == 0 && a.sw + 6 <= 16 * nt;  // (columns c0 - 4 .. c0 + sw + 1)
+#define C5_GO(N, V, E) hipLaunchKernelGGL((conv5_smallco_fwd_kernel<N, V, E>), dim3((unsigned)nblk), dim3(256), lds, stream, a)
+  if (vec && nt == 9) C5_GO(9, true, true);
+  else if (vec && nt == 5) C5_GO(5, true, true);
+  else if (vec && nt == 3) C5_GO(3, true, true);
+  else if (vec) C5_GO(9, true, false);
+  else if (nt == 9) C5_GO(9, false, true);
+  else C5_GO(9, false, false);
+#undef C5_GO
   return sivae_launch_status();
 }
 
