@@ -328,71 +328,113 @@ __global__ void __launch_bounds__(256, 2) conv5_edge_wgrad_kernel(Conv5WgradArgs
   const int sc = li / 5, skw = li - sc * 5;  // li == 15 -> channel 3 = the all-zero plane
   const int big_row = (wave * 16 + li) * BLD;
 
-  for (int tile = tile_begin; tile < tile_end; ++tile) {
+  // ---- per-tile staging, split into "request into registers" and "write to LDS" so that the NEXT tile's global loads are
+  // in flight during the current tile's MFMAs (round 6: the loop used to stage and compute strictly in turn, and two blocks
+  // per CU — 66 KB of LDS each, no room for a third — covered only half of the load latency: 0.44-0.48 matrix-pipe busy).
+  // A tile that continues the row ring (SMALL_CO, the row group below the previous one) brings 4 new rows = 32 floats per
+  // thread for the large side and <= 3 for the small one; a tile that restarts the ring (first of a slice / of an image
+  // column) needs 64 and is staged unpipelined as before.
+  constexpr int PF = 32;  // large-side floats per thread of a pipelined tile
+  constexpr int SML_PT = (4 * SPL + 255) / 256;
+  float pv[PF], psv[SML_PT];
+  auto tile_coords = [&](int tile, int& b, int& rg, int& r0, int& c0) {
     // row group fastest: consecutive tiles of a block are vertically adjacent, so the 4 halo rows of the large-side
-    // slab that they share (SMALL_CO: 8 staged rows per 4 output rows) were fetched a moment ago and hit in cache
+    // slab that they share (SMALL_CO: 8 staged rows per 4 output rows) stay in the LDS row ring
     int t = tile;
-    const int rg = t % a.nrow4; t /= a.nrow4;
+    rg = t % a.nrow4; t /= a.nrow4;
     const int cseg = t % a.ncol32;
-    const int b = t / a.ncol32;
-    const int r0 = rg * 4, c0 = cseg * 32;
-    const __amdgpu_buffer_rsrc_t brs = make_rsrc(pbig + (size_t)b * Cbig * HW, (unsigned long long)Cbig * HW * 4ull);
+    b = t / a.ncol32;
+    r0 = rg * 4;
+    c0 = cseg * 32;
+  };
+  // small-side tile [4][SROWS][40]: cols c0-2 .. c0+37 (only 36 used), channel >= Csml -> 0
+  auto load_sml = [&](int b, int r0, int c0) {
     const __amdgpu_buffer_rsrc_t srs = make_rsrc(psml + (size_t)b * Csml * HW, (unsigned long long)Csml * HW * 4ull);
-    // ---- large-side slab: positions = ROWS_BIG*32 (256 or 128); SMALL_CO: x rows r0-2.., else dy rows r0..
-    if (SMALL_CO) {
-      // The 8 staged x rows of a tile (r0 - 2 .. r0 + 5) live in a ROW RING (image row R at slot (R + 2) & 7): the next
-      // tile of the block is the row group below, whose first four rows are this tile's last four — they stay where they
-      // are and only the four new rows are fetched (round 4: the slab was re-staged whole, i.e. x was read twice:
-      // 8.8 GB per launch against 4.4 of tensors, and the kernel is bound by these dword loads: 0.40 matrix-pipe busy).
-      const bool cont = tile > tile_begin && rg != 0;  // (previous tile of this block = the row group above: rg is fastest)
-      const int rr0 = cont ? 4 : 0, npos = cont ? 128 : 256, cpt = cont ? 32 : 64;
-      const int pos = tid % npos, cgrp = tid / npos;
-      const int rr = rr0 + (pos >> 5), cc = pos & 31;
-      const int r = r0 - 2 + rr, c = c0 + cc;
-      const int slot = (r0 + rr) & 7;
-      const unsigned off = (r >= 0 && r < H && c < W) ? (unsigned)(r * W + c) * 4u : SIVAE_OOB;
-      for (int q0 = 0; q0 < cpt; q0 += 16) {
-        float v[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          int ch = cb0 + cgrp * cpt + q0 + q;
-          ch = ch < Cbig ? ch : Cbig - 1;
-          v[q] = buf_load_f32(brs, off, (unsigned)ch * (unsigned)HW * 4u);
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) big[(cgrp * cpt + q0 + q) * BLD + slot * 32 + cc] = v[q];
-      }
-    } else {
-      constexpr int NPOSB = ROWS_BIG * 32;
-      const int pos = tid % NPOSB, cgrp = tid / NPOSB;       // cgrp in [0, 256/NPOSB)
-      constexpr int CPT = 64 / (256 / NPOSB);                // channels per thread: 64 or 32
-      const int rr = pos >> 5, cc = pos & 31;
-      const int r = r0 + rr, c = c0 + cc;
-      const unsigned off = (r >= 0 && r < H && c < W) ? (unsigned)(r * W + c) * 4u : SIVAE_OOB;
-#pragma unroll
-      for (int q0 = 0; q0 < CPT; q0 += 16) {
-        float v[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          int ch = cb0 + cgrp * CPT + q0 + q;
-          ch = ch < Cbig ? ch : Cbig - 1;
-          v[q] = buf_load_f32(brs, off, (unsigned)ch * (unsigned)HW * 4u);
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) big[(cgrp * CPT + q0 + q) * BLD + pos] = v[q];
-      }
-    }
-    // ---- small-side tile [4][SROWS][40]: cols c0-2 .. c0+37 (only 36 used), channel >= Csml -> 0
-    for (int e = tid; e < 4 * SPL; e += 256) {
+    for (int q = 0; q < SML_PT; ++q) {
+      const int e = tid + q * 256;
       const int ch = e / SPL, rem = e - ch * SPL;
       const int rr = rem / SLD, cc = rem - rr * SLD;
       const int r = r0 + rr - (SMALL_CO ? 0 : 2), c = c0 + cc - 2;
-      float v = 0.f;
-      if (ch < Csml && r >= 0 && r < H && c >= 0 && c < W)
-        v = buf_load_f32(srs, (unsigned)(r * W + c) * 4u, (unsigned)ch * (unsigned)HW * 4u);
-      sml[e] = v;
+      const bool ok = e < 4 * SPL && ch < Csml && r >= 0 && r < H && c >= 0 && c < W;
+      psv[q] = buf_load_f32(srs, ok ? (unsigned)(r * W + c) * 4u : SIVAE_OOB, (unsigned)(ch < Csml ? ch : 0) * (unsigned)HW * 4u);
     }
-    __syncthreads();
+  };
+  auto store_sml = [&]() {
+#pragma unroll
+    for (int q = 0; q < SML_PT; ++q) {
+      const int e = tid + q * 256;
+      if (e < 4 * SPL) sml[e] = psv[q];
+    }
+  };
+  // large side of a PIPELINED tile: SMALL_CO — the 4 new ring rows (r0 + 2 .. r0 + 5) x 32 columns x 64 channels, 128
+  // positions x 2 channel groups of 32; else — the 4 dY rows, the same shape
+  auto load_big_pf = [&](int b, int r0, int c0) {
+    const __amdgpu_buffer_rsrc_t brs = make_rsrc(pbig + (size_t)b * Cbig * HW, (unsigned long long)Cbig * HW * 4ull);
+    const int pos = tid & 127, cgrp = tid >> 7;
+    const int rr = (SMALL_CO ? 4 : 0) + (pos >> 5), cc = pos & 31;
+    const int r = r0 + rr - (SMALL_CO ? 2 : 0), c = c0 + cc;
+    const unsigned off = (r >= 0 && r < H && c < W) ? (unsigned)(r * W + c) * 4u : SIVAE_OOB;
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      int ch = cb0 + cgrp * PF + q;
+      ch = ch < Cbig ? ch : Cbig - 1;
+      pv[q] = buf_load_f32(brs, off, (unsigned)ch * (unsigned)HW * 4u);
+    }
+  };
+  auto store_big_pf = [&](int r0) {
+    const int pos = tid & 127, cgrp = tid >> 7;
+    const int rr = (SMALL_CO ? 4 : 0) + (pos >> 5), cc = pos & 31;
+    const int slot = SMALL_CO ? ((r0 + rr) & 7) : rr;
+#pragma unroll
+    for (int q = 0; q < PF; ++q) big[(cgrp * PF + q) * BLD + slot * 32 + cc] = pv[q];
+  };
+  // large side of a tile that RESTARTS the ring (SMALL_CO only): all 8 rows, staged in place
+  auto stage_big_full = [&](int b, int r0, int c0) {
+    const __amdgpu_buffer_rsrc_t brs = make_rsrc(pbig + (size_t)b * Cbig * HW, (unsigned long long)Cbig * HW * 4ull);
+    const int rr = tid >> 5, cc = tid & 31;
+    const int r = r0 - 2 + rr, c = c0 + cc;
+    const int slot = (r0 + rr) & 7;
+    const unsigned off = (r >= 0 && r < H && c < W) ? (unsigned)(r * W + c) * 4u : SIVAE_OOB;
+    for (int q0 = 0; q0 < 64; q0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        int ch = cb0 + q0 + q;
+        ch = ch < Cbig ? ch : Cbig - 1;
+        v[q] = buf_load_f32(brs, off, (unsigned)ch * (unsigned)HW * 4u);
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) big[(q0 + q) * BLD + slot * 32 + cc] = v[q];
+    }
+  };
+  // does `tile` continue the ring of the tile before it (same block, the row group below)?
+  auto continues = [&](int tile) { return !SMALL_CO || (tile > tile_begin && tile % a.nrow4 != 0); };
+
+  if (tile_begin < tile_end) {  // first tile of the slice: staged in place
+    int b, rg, r0, c0;
+    tile_coords(tile_begin, b, rg, r0, c0);
+    if (SMALL_CO) {
+      stage_big_full(b, r0, c0);
+    } else {
+      load_big_pf(b, r0, c0);
+      store_big_pf(r0);
+    }
+    load_sml(b, r0, c0);
+    store_sml();
+  }
+  __syncthreads();
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    int b, rg, r0, c0;
+    tile_coords(tile, b, rg, r0, c0);
+    const bool has_next = tile + 1 < tile_end;
+    const bool pipe = has_next && continues(tile + 1);
+    int nb = b, nrg = rg, nr0 = r0, nc0 = c0;
+    if (has_next) tile_coords(tile + 1, nb, nrg, nr0, nc0);
+    if (pipe) {  // the next tile's operands: requested now, consumed behind the MFMAs
+      load_big_pf(nb, nr0, nc0);
+      load_sml(nb, nr0, nc0);
+    }
 #pragma unroll 1
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -411,7 +453,18 @@ __global__ void __launch_bounds__(256, 2) conv5_edge_wgrad_kernel(Conv5WgradArgs
         }
       }
     }
-    __syncthreads();
+    __syncthreads();  // every wave is done with this tile's LDS operands
+    if (has_next) {
+      if (pipe) {
+        store_big_pf(nr0);
+        store_sml();
+      } else {  // ring restart (SMALL_CO): stage the next tile in place
+        stage_big_full(nb, nr0, nc0);
+        load_sml(nb, nr0, nc0);
+        store_sml();
+      }
+      __syncthreads();
+    }
   }
   // ---- partial store: D_kh rows = 4g + reg, cols = li
   float* outp = a.part + (size_t)slice * a.Co * a.Ci * 25;
