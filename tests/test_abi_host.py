@@ -149,6 +149,13 @@ def test_round3_entry_points_validate_arguments():
     assert L.sivae_conv2d_wino4_num_px_tiles(16, 8, 8) == 2 and L.sivae_conv2d_wino4_num_px_tiles(64, 4, 4) == 2
     assert L.sivae_conv2d_wino4_num_px_tiles(12, 8, 8) == -2 and L.sivae_conv2d_wino4_num_px_tiles(48, 4, 4) == -2
     assert L.sivae_conv2d_wino4_pays(12, 64, 64, 8, 8) == 0 and L.sivae_conv2d_wino4_pays(256, 512, 512, 8, 8) == 1
+    # the launch-level policy of the image-grid form against F(2x2,3x3), pinned to the measured table
+    # (profiles/r6_wino4_small_maps_vs_f23.txt: wins need (slices x items) for every CU AND a long K slice)
+    fwd = {(256, 512, 512, 8, 8): 1, (128, 512, 512, 8, 8): 1, (64, 512, 512, 8, 8): 0, (32, 512, 512, 8, 8): 0,
+           (512, 256, 256, 8, 8): 1, (256, 256, 256, 8, 8): 0, (256, 128, 256, 8, 8): 0, (512, 128, 256, 8, 8): 1,
+           (128, 512, 512, 4, 4): 1, (64, 512, 512, 4, 4): 0, (256, 512, 512, 4, 4): 1, (256, 256, 256, 4, 4): 0,
+           (256, 512, 512, 16, 16): 0, (256, 512, 512, 32, 32): 0}  # (modes 1 / 2 are not this query's business)
+    assert {k: L.sivae_conv2d_wino4_small_pays(*k) for k in fwd} == fwd
     assert L.sivae_conv2d_wino4_num_px_tiles(4, 32, 64) == 4 * 2 * 2 and L.sivae_conv2d_wino4_num_px_tiles(6, 16, 16) == 3
     assert L.sivae_conv2d_wino4_num_px_tiles(5, 16, 16) == -2  # (an odd batch has no image pairs)
     assert L.sivae_conv2d_wino4_pays(5, 64, 64, 16, 16) == 0 and L.sivae_conv2d_wino4_pays(2, 8, 64, 256, 256) == 0
@@ -192,6 +199,11 @@ def test_round3_entry_points_validate_arguments():
         == [1, 1, 1, 1, 0, 1, 0]
     assert [L.sivae_conv2d_wino4_wgrad_images_per_stage(h, w) for h, w in ((16, 16), (8, 8), (4, 4), (6, 16))] == [1, 2, 4, 0]
     assert L.sivae_conv2d_wino4_wgrad_pays(256, 512, 512, 8, 8) == 1 and L.sivae_conv2d_wino4_wgrad_pays(255, 512, 512, 8, 8) == 0
+    # small maps below "a block of 24 stages per CU": the cost model against the direct kernel (same measured table)
+    wg = {(32, 512, 512, 8, 8): 1, (128, 256, 256, 8, 8): 1, (64, 256, 256, 8, 8): 0, (256, 128, 256, 8, 8): 1,
+          (64, 128, 128, 8, 8): 0, (32, 512, 512, 4, 4): 1, (32, 256, 256, 4, 4): 1, (256, 256, 256, 4, 4): 0,
+          (256, 128, 128, 4, 4): 0}
+    assert {k: L.sivae_conv2d_wino4_wgrad_pays(*k) for k in wg} == wg
     assert L.sivae_conv2d_wino4_wgrad_pays(128, 128, 128, 128, 128) == 1 and L.sivae_conv2d_wino4_wgrad_pays(1, 64, 64, 16, 16) == 0
     nb = L.sivae_conv2d_wino4_wgrad_workspace_bytes(128, 128, 128, 128, 128)
     assert nb > 0 and nb % (18 * 128 * 128 * 4) == 0  # (row-transformed partials: 3 x 6 values per (co, ci))
