@@ -447,6 +447,45 @@ __global__ void __launch_bounds__(256) wino4_splitk_reduce_vec_kernel(const floa
   }
 }
 
+// The same for the 8 x 8 / 4 x 4 maps of the image-grid form (round 6): a plane is only LPP = 16 / 4 vectors, so a wave of the
+// kernel above would run with 16 / 4 active lanes (21 launches of 25 us per cifar10 iteration).  Here consecutive threads
+// take consecutive vectors — 64 / LPP planes per wave — and the per-plane {sum, sumsq} are folded inside aligned groups of
+// LPP lanes.
+template <int LPP>
+__global__ void __launch_bounds__(256) wino4_splitk_reduce_small_kernel(const float4* __restrict__ part, float4* __restrict__ y,
+                                                                        float* __restrict__ stats, int S, size_t slice_stride4,
+                                                                        int accumulate, int n_planes) {
+  const size_t gt = (size_t)blockIdx.x * 256 + threadIdx.x;  // vector index = plane * LPP + vector of the plane
+  if (gt >= (size_t)n_planes * LPP) return;                   // (whole LPP-groups leave together: LPP divides 256)
+  float4 t[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (k < S) t[k] = part[(size_t)k * slice_stride4 + gt];
+  float4 v = accumulate ? y[gt] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (k < S) {
+      v.x += t[k].x;
+      v.y += t[k].y;
+      v.z += t[k].z;
+      v.w += t[k].w;
+    }
+  y[gt] = v;
+  if (stats != nullptr) {
+    float s = (v.x + v.y) + (v.z + v.w);
+    float q = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+    for (int m = 1; m < LPP; m <<= 1) {
+      s += __shfl_xor(s, m);
+      q += __shfl_xor(q, m);
+    }
+    if ((gt & (LPP - 1)) == 0) {
+      stats[(gt / LPP) * 2 + 0] = s;
+      stats[(gt / LPP) * 2 + 1] = q;
+    }
+  }
+}
+
 // number of K slices sivae_conv2d_wino4_fwd_splitk will use (1: the plain kernel; its statistics rows are then per pixel
 // tile — sivae_conv2d_wino4_num_px_tiles —, otherwise per image: B rows)
 extern "C" int sivae_conv2d_wino4_splitk(int B, int Ci, int Co, int H, int W) {
@@ -520,7 +559,15 @@ extern "C" int sivae_conv2d_wino4_fwd_splitk(const float* x, const float* up, fl
   if ((HW & 3) == 0 && ((uintptr_t)y & 15u) == 0 && S <= 8) {
     const float4* p4 = reinterpret_cast<const float4*>(part);
     float4* y4 = reinterpret_cast<float4*>(y);
-    if (HW <= 256)
+    if (HW == 16 || HW == 64) {
+      const size_t nvec = (size_t)B * Co * (HW / 4);
+      if (HW == 16)
+        hipLaunchKernelGGL(wino4_splitk_reduce_small_kernel<4>, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, stream, p4, y4,
+                           stats_partial, S, slice / 4, accumulate, B * Co);
+      else
+        hipLaunchKernelGGL(wino4_splitk_reduce_small_kernel<16>, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, stream, p4, y4,
+                           stats_partial, S, slice / 4, accumulate, B * Co);
+    } else if (HW <= 256)
       hipLaunchKernelGGL(wino4_splitk_reduce_vec_kernel<64>, dim3((unsigned)((B * Co + 3) / 4)), dim3(256), 0, stream, p4, y4,
                          stats_partial, S, HW / 4, slice / 4, accumulate, B * Co);
     else
