@@ -165,15 +165,24 @@ __global__ void __launch_bounds__(64) linear_wgrad_kernel(LinArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
   const unsigned drow = (unsigned)a.N * 4u, xrow = (unsigned)a.K * 4u;
-  for (int b = 0; b < a.B; b += 2) {
-    // rows b + h; an odd batch's last pair reads one row past the tensor -> out-of-range offset -> 0
-    const bool ok = b + h < a.B;
-    const float dv = buf_load_f32(dr, ok ? d_o : SIVAE_OOB, (unsigned)b * drow);
+  // UB row pairs per step: all their loads are issued before the first MFMA (round 6: one pair per step made every step
+  // wait out a memory round trip — 117 us for the 512-row batches of config 2, where the launch is one wave per CU);
+  // the order of the sum over b is unchanged
+  constexpr int UB = 8;
+  for (int b = 0; b < a.B; b += 2 * UB) {
+    float dv[UB], xv[UB][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const float xv = buf_load_f32(xr, ok ? xo[t] : SIVAE_OOB, (unsigned)b * xrow);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv, xv, acc[t], 0, 0, 0);
+    for (int u = 0; u < UB; ++u) {
+      // rows b + 2u + h; rows past the batch read through an out-of-range offset -> 0
+      const bool ok = b + 2 * u + h < a.B;
+      dv[u] = buf_load_f32(dr, ok ? d_o : SIVAE_OOB, (unsigned)(b + 2 * u) * drow);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) xv[u][t] = buf_load_f32(xr, ok ? xo[t] : SIVAE_OOB, (unsigned)(b + 2 * u) * xrow);
     }
+#pragma unroll
+    for (int u = 0; u < UB; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[u], xv[u][t], acc[t], 0, 0, 0);
   }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
