@@ -50,31 +50,37 @@ __global__ void __launch_bounds__(64) linear_fwd_kernel(LinArgs a) {
   for (int r = 0; r < RB; ++r)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
-  for (int k = k_begin; k < k_end; k += 16) {
-    // two 8-wide k groups per iteration (the second masked off past the slice end)
-    // (K % 4 == 0, so a lane's 4-wide vector is entirely inside or entirely past the slice end)
-    const unsigned so0 = (unsigned)k * 4u;
-    const bool v0 = k + 4 * h < k_end, v1 = k + 8 + 4 * h < k_end;
-    const float4 w0 = buf_load_f32x4(wr, v0 ? wo : SIVAE_OOB, so0);
-    const float4 w1 = buf_load_f32x4(wr, v1 ? wo : SIVAE_OOB, so0 + 32u);
-    float4 x0[RB], x1[RB];
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      x0[r] = buf_load_f32x4(xr, v0 ? xo[r] : SIVAE_OOB, so0);
-      x1[r] = buf_load_f32x4(xr, v1 ? xo[r] : SIVAE_OOB, so0 + 32u);
-    }
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[r].x, w0.x, acc[r], 0, 0, 0);
-      acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[r].y, w0.y, acc[r], 0, 0, 0);
-      acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[r].z, w0.z, acc[r], 0, 0, 0);
-      acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[r].w, w0.w, acc[r], 0, 0, 0);
-      acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[r].x, w1.x, acc[r], 0, 0, 0);
-      acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[r].y, w1.y, acc[r], 0, 0, 0);
-      acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[r].z, w1.z, acc[r], 0, 0, 0);
-      acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[r].w, w1.w, acc[r], 0, 0, 0);
-    }
+  // two 8-wide k groups per step, software-pipelined (round 6): group 1 of step k is requested before the MFMAs of group 0,
+  // group 0 of step k + 16 before the MFMAs of group 1 — a launch is about one wave per SIMD, so nothing else covered the
+  // memory round trip of a step.  Same registers, same order of the sum over k.
+  // (K % 4 == 0, so a lane's 4-wide vector is entirely inside or entirely past the slice end)
+  float4 w0, w1, x0[RB], x1[RB];
+#define LIN_LOAD(KK, W, X)                                                     \
+  {                                                                            \
+    const bool v_ = (KK) + 4 * h < k_end;                                      \
+    W = buf_load_f32x4(wr, v_ ? wo : SIVAE_OOB, (unsigned)(KK) * 4u);          \
+    _Pragma("unroll") for (int r = 0; r < RB; ++r) X[r] = buf_load_f32x4(xr, v_ ? xo[r] : SIVAE_OOB, (unsigned)(KK) * 4u); \
   }
+#define LIN_MMA(W, X)                                                          \
+  _Pragma("unroll") for (int r = 0; r < RB; ++r) {                             \
+    acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(X[r].x, W.x, acc[r], 0, 0, 0); \
+    acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(X[r].y, W.y, acc[r], 0, 0, 0); \
+    acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(X[r].z, W.z, acc[r], 0, 0, 0); \
+    acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(X[r].w, W.w, acc[r], 0, 0, 0); \
+  }
+  LIN_LOAD(k_begin, w0, x0)
+  for (int k = k_begin; k < k_end; k += 16) {
+    LIN_LOAD(k + 8, w1, x1)
+    __builtin_amdgcn_sched_barrier(0);
+    LIN_MMA(w0, x0)
+    __builtin_amdgcn_sched_barrier(0);
+    LIN_LOAD(k + 16, w0, x0)  // (past the slice end: out-of-range offsets, zeros, never used)
+    __builtin_amdgcn_sched_barrier(0);
+    LIN_MMA(w1, x1)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef LIN_LOAD
+#undef LIN_MMA
   // accumulator e of a lane: row (e&3) + 8*(e>>2) + 4*h (batch row within the tile), column i (= n0 + i)
   const int n = n0 + i;
   if (n >= a.N) return;
@@ -115,26 +121,38 @@ __global__ void __launch_bounds__(64) linear_dgrad_kernel(LinArgs a) {
   for (int r = 0; r < RB; ++r)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
-  for (int n = n_begin; n < n_end; n += 8) {
-    const unsigned so = (unsigned)n * 4u;
-    const bool vn = n + 4 * h < n_end;  // (N % 4 == 0: the lane's four n values are all inside or all past the end)
-    float4 d[RB];
-#pragma unroll
-    for (int r = 0; r < RB; ++r) d[r] = buf_load_f32x4(dr, vn ? d_o[r] : SIVAE_OOB, so);
-    const unsigned wso = (unsigned)n * wrow;
-    const unsigned wov = vn ? wo : SIVAE_OOB;
-    const float w0 = buf_load_f32(wr, wov, wso);
-    const float w1 = buf_load_f32(wr, wov, wso + wrow);
-    const float w2 = buf_load_f32(wr, wov, wso + 2u * wrow);
-    const float w3 = buf_load_f32(wr, wov, wso + 3u * wrow);
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[r].x, w0, acc[r], 0, 0, 0);
-      acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[r].y, w1, acc[r], 0, 0, 0);
-      acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[r].z, w2, acc[r], 0, 0, 0);
-      acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[r].w, w3, acc[r], 0, 0, 0);
-    }
+  // software-pipelined like the forward: the next 8-wide n group is requested before the MFMAs of the current one
+  // (N % 4 == 0: the lane's four n values are all inside or all past the end)
+  float4 dA[RB], dB[RB];
+  float wA[4], wB[4];
+#define LIN_LOAD(NN, D, W)                                                     \
+  {                                                                            \
+    const bool vn_ = (NN) + 4 * h < n_end;                                     \
+    _Pragma("unroll") for (int r = 0; r < RB; ++r) D[r] = buf_load_f32x4(dr, vn_ ? d_o[r] : SIVAE_OOB, (unsigned)(NN) * 4u); \
+    const unsigned wso_ = (unsigned)(NN) * wrow;                               \
+    const unsigned wov_ = vn_ ? wo : SIVAE_OOB;                                \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) W[q] = buf_load_f32(wr, wov_, wso_ + (unsigned)q * wrow); \
   }
+#define LIN_MMA(D, W)                                                          \
+  _Pragma("unroll") for (int r = 0; r < RB; ++r) {                             \
+    acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(D[r].x, W[0], acc[r], 0, 0, 0); \
+    acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(D[r].y, W[1], acc[r], 0, 0, 0); \
+    acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(D[r].z, W[2], acc[r], 0, 0, 0); \
+    acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(D[r].w, W[3], acc[r], 0, 0, 0); \
+  }
+  LIN_LOAD(n_begin, dA, wA)
+  for (int n = n_begin; n < n_end; n += 16) {
+    LIN_LOAD(n + 8, dB, wB)
+    __builtin_amdgcn_sched_barrier(0);
+    LIN_MMA(dA, wA)
+    __builtin_amdgcn_sched_barrier(0);
+    LIN_LOAD(n + 16, dA, wA)
+    __builtin_amdgcn_sched_barrier(0);
+    LIN_MMA(dB, wB)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef LIN_LOAD
+#undef LIN_MMA
   const int k = k0 + i;
   if (k >= a.K) return;
   float* dst = a.out + (size_t)s * a.B * a.K;
