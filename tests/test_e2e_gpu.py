@@ -606,6 +606,75 @@ def test_dominant_kernels_at_headline_shapes_and_batch_128():
         del x, xd, y
 
 
+def test_small_map_kernels_at_headline_shapes_through_the_dispatch():
+    """Round 6: the deep 512-channel blocks on 8x8 / 4x4 maps at the headline's own batch (128 images per pass, 256 as a
+    pass pair) must (a) be ROUTED to the F(4x4,3x3) image-grid kernels by ops.conv2d_fwd / conv2d_wgrad (checked through
+    the kernel timer's keys) and (b) agree with torch-CPU fp64: forward (plain, fused prologue over two segments, an
+    upsampled input), the data gradient through the adjoint identity over the whole batch, the weight gradient for a
+    subset of output channels."""
+    import torch.nn.functional as F
+    from sivae_hip import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(23)
+    C = 512
+    try:
+        for (B, H) in [(256, 8), (128, 8), (256, 4), (128, 4)]:
+            ops.TIMER = ops.KernelTimer()
+            x = torch.randn(B, C, H, H, generator=g)
+            w = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
+            xd, wd = x.to(dev), w.to(dev)
+            wp = ops.PackedW(wd, 0)
+            # plain forward + statistics
+            y, part = ops.conv2d_fwd(xd, wp, C, 3, want_stats=True)
+            ref = F.conv2d(x[:3].double(), w.double(), padding=1)
+            assert _rel(y[:3], ref) <= 4e-5, (B, H, _rel(y[:3], ref))
+            rows = part.double().sum(0).cpu()  # (one row per work item of 8 / 32 images, or per image behind split-K)
+            assert _rel(rows[:, 0], y.double().sum((0, 2, 3)).cpu()) <= 1e-5
+            assert _rel(rows[:, 1], (y.double() ** 2).sum((0, 2, 3)).cpu()) <= 1e-5
+            # fused BatchNorm + LeakyReLU prologue with per-segment statistics (the pass pair of a step)
+            nseg = 2
+            mean, invstd = 0.2 * torch.randn(nseg, C, generator=g), torch.rand(nseg, C, generator=g) + 0.5
+            gamma, beta = torch.rand(C, generator=g) + 0.5, 0.1 * torch.randn(C, generator=g)
+            prm = (mean.reshape(-1).to(dev), invstd.reshape(-1).to(dev), gamma.to(dev), beta.to(dev), 0.2)
+            yp, _ = ops.conv2d_fwd(xd, wp, C, 3, pro=prm, want_stats=True, nseg=nseg)
+            for b in (1, B - 2):
+                sgm = b // (B // nseg)
+                v = (x[b:b + 1].double() - mean[sgm].double().view(1, -1, 1, 1)) \
+                    * (invstd[sgm] * gamma).double().view(1, -1, 1, 1) + beta.double().view(1, -1, 1, 1)
+                refp = F.conv2d(torch.where(v > 0, v, 0.2 * v), w.double(), padding=1)
+                assert _rel(yp[b:b + 1], refp) <= 4e-5, (B, H, b, _rel(yp[b:b + 1], refp))
+            # data gradient: adjoint identity over the whole batch
+            dy = torch.randn(B, C, H, H, generator=g).to(dev)
+            dx = ops.conv2d_fwd(dy, ops.PackedW(wd, 1), C, 3)
+            lhs, rhs = float((y.double() * dy.double()).sum()), float((xd.double() * dx.double()).sum())
+            assert abs(lhs - rhs) <= 2e-6 * float(y.double().norm() * dy.double().norm()), (B, H, lhs, rhs)
+            # weight gradient, refereed for two output channels
+            dw = ops.conv2d_wgrad(xd, dy, 3)
+            sub = [5, C - 3]
+            wr = w[sub].double().requires_grad_()
+            F.conv2d(x.double(), wr, padding=1).backward(dy[:, sub].double().cpu())
+            assert _rel(dw[sub], wr.grad) <= 4e-5, (B, H, _rel(dw[sub], wr.grad))
+            # a conv of the nearest-upsampled map (decoder conv1 of the next block): forward and weight gradient
+            yu = ops.conv2d_fwd(xd, wp, C, 3, upsample=True)
+            xu = F.interpolate(x[:2].double(), scale_factor=2, mode="nearest")
+            assert _rel(yu[:2], F.conv2d(xu, w.double(), padding=1)) <= 4e-5
+            dyu = torch.randn(B, C, 2 * H, 2 * H, generator=g).to(dev)
+            dwu = ops.conv2d_wgrad(xd, dyu, 3, upsample=True)
+            wr = w[sub].double().requires_grad_()
+            F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), wr, padding=1).backward(dyu[:, sub].double().cpu())
+            assert _rel(dwu[sub], wr.grad) <= 4e-5, (B, H, _rel(dwu[sub], wr.grad))
+            torch.cuda.synchronize()
+            keys = set(ops.TIMER.summary())
+            # the launches above ran on the image-grid kernels (8x8 / 4x4) or, for the upsampled outputs, on the pair /
+            # grid form of the next size — never on F(2x2,3x3) or the direct weight gradient
+            assert "conv_wino4_grid_kernel<false>" in keys and "conv_wino4_grid_kernel<true>" in keys, keys
+            assert "wino4_wgrad_kernel<false,true>" in keys, keys
+            assert not [k for k in keys if k.startswith(("conv_wino_kernel", "conv_wgrad_kernel", "wino_wgrad_kernel"))], keys
+            del x, xd, y, yp, dy, dx, dw, yu, dyu, dwu
+    finally:
+        ops.TIMER = None
+
+
 def test_size_independent_properties_at_full_batch_shapes():
     """Properties that need no oracle, at the headline layer shapes: dgrad is the adjoint of fwd
     (<conv(x), y> == <x, conv^T(y)>), <wgrad(x, y), w> equals the same inner product, and the fused
