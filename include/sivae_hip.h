@@ -593,6 +593,13 @@ int sivae_conv2d_wino4_supported(int H, int W); /* 1: H % 16 == 0, W % 32 == 0; 
                                                      153-158), every seam zero padding: B and seg_images must be multiples
                                                      of sivae_conv2d_wino4_images_per_item; stats rows per item; 0 otherwise */
 int sivae_conv2d_wino4_images_per_item(int H, int W); /* 1, 2, 8, 32 for modes 1..4; 0: unsupported map */
+/* Round 6: the data gradient of conv3x3(Upsample2(x)) with respect to the low-resolution x (conv1 behind nn.Upsample,
+ * train_soft_intro_vae.py:155,56) in one F(4x4,3x3) pass: dx[B][N][H/2][W/2] (+)= the 2x2 block sums of conv3x3^T(dy[B][C][H][W]),
+ * the block sum folded into the output transform.  up: sivae_pack_wino4_weight(w[C][N][3][3], mode 1).  H % 16 == 0, W % 32 == 0.
+ * `_pays`: N <= 64 and a work item for every CU (there the phase-folded sivae_conv2d_wino_up_dgrad splits K over wave pairs). */
+int sivae_conv2d_wino4_dgrad_pool_pays(int B, int C, int N, int H, int W);
+int sivae_conv2d_wino4_dgrad_pool(const float* dy, const float* up, float* dx, int B, int C, int N, int H, int W,
+                                  int accumulate, sivae_stream_t stream);
 /* modes 3 / 4 only: 1 when the image-grid launch (with its split-K plan) is expected to beat F(2x2,3x3) — enough
  * (slices x items) for every CU and a long enough K slice (measured: profiles/r6_wino4_small_maps_vs_f23.txt) */
 int sivae_conv2d_wino4_small_pays(int B, int Ci, int Co, int H, int W);

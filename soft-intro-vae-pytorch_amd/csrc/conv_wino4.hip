@@ -135,6 +135,7 @@ extern "C" int sivae_debug_w4_read(long long* out) {
 #define W4_STAMPK(CH)
 #endif
 
+#define W4_POOL 0
 #define W4_GRID 0
 #define W4_KERNEL_NAME conv_wino4_kernel
 #define W4_TWO a.two
@@ -153,6 +154,18 @@ extern "C" int sivae_debug_w4_read(long long* out) {
 #undef W4_KERNEL_NAME
 #undef W4_TWO
 #undef W4_IPI
+#undef W4_POOL
+#define W4_POOL 1
+#define W4_GRID 0
+#define W4_KERNEL_NAME conv_wino4_pool_kernel
+#define W4_TWO false
+#define W4_IPI 1
+#include "conv_wino4_kernel.inc"
+#undef W4_GRID
+#undef W4_KERNEL_NAME
+#undef W4_TWO
+#undef W4_IPI
+#undef W4_POOL
 
 // ---- weight transform U = G g G^T (6x6), packed [j][ci_pad][co_pad][i]; padding entries are zero
 //   mode 0 (forward): g = w[n][k]            (n = output channel, k = input channel)
@@ -266,7 +279,8 @@ extern "C" int sivae_conv2d_wino4_num_px_tiles(int B, int H, int W) {
 // of y in image order (sivae_bn_stats_from_conv / _seg).  The data gradient is this function on dy with the mode-1 pack.
 static int wino4_impl(const float* x, const float* up, float* y, const float* pro_mean, const float* pro_invstd,
                       const float* pro_gamma, const float* pro_beta, float pro_slope, float* stats_partial, int B, int Ci,
-                      int Co, int H, int W, int accumulate, int seg_images, hipStream_t stream, int ksl = 1) {
+                      int Co, int H, int W, int accumulate, int seg_images, hipStream_t stream, int ksl = 1,
+                      bool pool = false) {
   if (!x || !up || !y) return SIVAE_ERR_NULL;
   if (pro_mean && (!pro_invstd || !pro_gamma || !pro_beta)) return SIVAE_ERR_NULL;
   if (pro_mean && !(pro_slope >= 0.f && pro_slope <= 1.f)) return SIVAE_ERR_MODE;  // prologue uses max(v, v*slope)
@@ -276,7 +290,7 @@ static int wino4_impl(const float* x, const float* up, float* y, const float* pr
   if (!sup) return SIVAE_ERR_SHAPE;
   const int ipi = sivae_conv2d_wino4_images_per_item(H, W);
   if ((B % ipi) || (seg_images % ipi)) return SIVAE_ERR_SHAPE;  // whole image grids, each inside one segment
-  if (((uintptr_t)y & 15u) != 0) return SIVAE_ERR_SHAPE;  // 16-byte stores
+  if (!pool && ((uintptr_t)y & 15u) != 0) return SIVAE_ERR_SHAPE;  // 16-byte stores
   const long long hw = (long long)H * W;
   if ((long long)Ci * hw * 4 >= 0x7fffffffLL || (long long)Co * hw * 4 >= 0x7fffffffLL) return SIVAE_ERR_RANGE;
   Wino4Args a;
@@ -329,7 +343,9 @@ static int wino4_impl(const float* x, const float* up, float* y, const float* pr
   const int cus = sivae_num_cus();
   const int grid = nitems < cus ? (int)nitems : cus;
   a.xcd_group = (sivae_xcd_remap() && a.n_co_tiles > 1 && !(grid & 7)) ? 1 : 0;
-  if (sup >= 3) {  // (the 16 x 16 pairs, mode 2, stay on the round-5 kernel: a.two)
+  if (pool) {  // (whole-tile maps only, no prologue / statistics / split-K: checked by the caller)
+    hipLaunchKernelGGL(conv_wino4_pool_kernel<false>, dim3((unsigned)grid), dim3(W4_NT), 0, stream, a);
+  } else if (sup >= 3) {  // (the 16 x 16 pairs, mode 2, stay on the round-5 kernel: a.two)
     if (pro_mean)
       hipLaunchKernelGGL(conv_wino4_grid_kernel<true>, dim3((unsigned)grid), dim3(W4_NT), 0, stream, a);
     else
@@ -356,6 +372,26 @@ extern "C" int sivae_conv2d_wino4_fwd_pro(const float* x, const float* up, float
                                           int accumulate, int seg_images, hipStream_t stream) {
   return wino4_impl(x, up, y, pro_mean, pro_invstd, pro_gamma, pro_beta, pro_slope, stats_partial, B, Ci, Co, H, W,
                     accumulate, seg_images, stream);
+}
+
+// ---- data gradient of conv3x3(Upsample2(x)) with respect to the LOW-resolution x (round 6; conv1 behind nn.Upsample,
+// train_soft_intro_vae.py:155,56): dx[B][N][H/2][W/2] (+)= blocksum2x2( conv3x3^T(dy[B][C][H][W]) ) in one F(4x4,3x3) pass with
+// the block sum folded into the output transform (conv_wino4_pool_kernel).  `up`: sivae_pack_wino4_weight(w, mode 1) of the
+// conv's weight w[C][N][3][3].  Maps: H % 16 == 0, W % 32 == 0 (mode 1 of sivae_conv2d_wino4_supported).
+// `_pays`: the launches where it beats the phase-folded F(2x2,2x2) kernel (conv_wino_up_dgrad.hip) — that kernel needs 128
+// output channels per block and splits K over wave pairs below (N <= 64: 0.47 matrix-pipe busy against this kernel's 0.6),
+// so: N <= 64 and at least one work item per CU.
+extern "C" int sivae_conv2d_wino4_dgrad_pool_pays(int B, int C, int N, int H, int W) {
+  if (B <= 0 || C < 16 || N <= 0 || N > 64 || sivae_conv2d_wino4_supported(H, W) != 1) return 0;
+  return w4_px_tiles(B, H, W) * ((N + W4_TCO - 1) / W4_TCO) >= sivae_num_cus() ? 1 : 0;
+}
+extern "C" int sivae_conv2d_wino4_dgrad_pool(const float* dy, const float* up, float* dx, int B, int C, int N, int H,
+                                             int W, int accumulate, hipStream_t stream) {
+  if (!dy || !up || !dx) return SIVAE_ERR_NULL;
+  if (sivae_conv2d_wino4_supported(H, W) != 1) return SIVAE_ERR_SHAPE;
+  if (((uintptr_t)dx & 7u) != 0) return SIVAE_ERR_SHAPE;  // 8-byte stores
+  return wino4_impl(dy, up, dx, nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, B, C, N, H, W, accumulate, 0, stream, 1,
+                    true);
 }
 
 // ---- split-K form for launches that would leave most of the chip idle (the 16-image shard of config 4 runs the

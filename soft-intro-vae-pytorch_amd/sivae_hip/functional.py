@@ -467,13 +467,13 @@ class ResBlockFn(torch.autograd.Function):
                 dwe = ops.conv2d_wgrad(x, dzh, 1, out=_dst(w_exp, k_we))
             if need_x:
                 if up_dg:
-                    dx = ops.conv2d_up_dgrad(da, packed(w1, 0), x.shape[1])
+                    dx = ops.conv2d_up_dgrad(da, packed(w1, 0), x.shape[1], wp1=packed(w1, 1))
                 else:
                     dx = ops.upsample2_bwd(ops.conv2d_fwd(da, packed(w1, 1), x.shape[1], 3))
                 ops.conv2d_fwd(dzh, packed(w_exp, 1), x.shape[1], 1, out=dx, accumulate=True)
         elif up_dg and need_x:
             dx = dzh if dzh is not None else ops.upsample2_bwd(dz)  # identity branch, already at low resolution
-            ops.conv2d_up_dgrad(da, packed(w1, 0), x.shape[1], out=dx, accumulate=True)
+            ops.conv2d_up_dgrad(da, packed(w1, 0), x.shape[1], out=dx, accumulate=True, wp1=packed(w1, 1))
         elif x_up and dzh is not None and dz is None:
             # identity skip behind an Upsample on a map the phase kernel does not take: reduce conv1's full-resolution
             # data gradient, then add the (already reduced) skip gradient

@@ -305,6 +305,8 @@ WINO4_SMALL = os.environ.get("SIVAE_WINO4_SMALL", "1") != "0"
 WINO4_SMALL_FORCE = os.environ.get("SIVAE_WINO4_SMALL_FORCE", "0") == "1"  # (tests / tools: wherever it is supported)
 # SIVAE_WINO4_UP_SMALL=0: convs of an upsampled input on 16x16 / 8x8 output maps stay on F(2x2,3x3) with upsample addressing
 WINO4_UP_SMALL = os.environ.get("SIVAE_WINO4_UP_SMALL", "1") != "0"
+# SIVAE_WINO4_DGRAD_POOL=0: the data gradient of an upsample-conv with <= 64 input channels stays on conv_wino_up_dgrad.hip
+WINO4_DGRAD_POOL = os.environ.get("SIVAE_WINO4_DGRAD_POOL", "1") != "0"
 WINO4_PRO = os.environ.get("SIVAE_WINO4_PRO", "1") != "0"  # ... also with a fused BatchNorm prologue (conv2 forward)
 # SIVAE_FUSE_BN_BWD=1: reduce BatchNorm-1's backward sums in the epilogue of conv2's data gradient.  Measured a LOSS at
 # 256x256 bs128 (593 vs 585 ms per iteration: the extra tensor read sits on the kernel's critical path and disables its
@@ -457,9 +459,10 @@ def conv2d_up_dgrad_supported(Hs, Ws):
     return WINO_UP and _lib.load().sivae_conv2d_wino_up_dgrad_supported(Hs, Ws) == 1
 
 
-def conv2d_up_dgrad(dy, wp, N, out=None, accumulate=False):
+def conv2d_up_dgrad(dy, wp, N, out=None, accumulate=False, wp1=None):
     """gradient of conv3x3(Upsample2(x)) with respect to the LOW-resolution x: dy [B, C, 2Hs, 2Ws] -> [B, N, Hs, Ws]
-    (wp: PackedW of the conv's weight [C, N, 3, 3], mode 0)."""
+    (wp: PackedW of the conv's weight [C, N, 3, 3], mode 0; wp1: the mode-1 PackedW of the same weight — with it the
+    launches with N <= 64 take the F(4x4,3x3) kernel with the 2x2 block sum folded into its output transform)."""
     _require(dy, out)
     B, C, H, W = dy.shape
     Hs, Ws = H // 2, W // 2
@@ -467,6 +470,15 @@ def conv2d_up_dgrad(dy, wp, N, out=None, accumulate=False):
     assert dx.shape == (B, N, Hs, Ws)
     t0 = TIMER.begin() if TIMER is not None else None
     L = _lib.load()
+    if (WINO4_DGRAD_POOL and WINO4 and wp1 is not None and max(C, N) <= WINO4_MAXC
+            and L.sivae_conv2d_wino4_dgrad_pool_pays(B, C, N, H, W) == 1):
+        assert dx.is_contiguous()
+        _lib.call("sivae_conv2d_wino4_dgrad_pool", _p(dy), _p(wp1.wino4()), _p(dx), B, C, N, H, W, int(bool(accumulate)),
+                  _s(dy))
+        if t0 is not None:
+            flops = 2.0 * B * H * W * C * N * 9
+            TIMER.end("conv_wino4_pool_kernel<false>", flops, t0, executed=flops * 36.0 / 144.0)
+        return dx
     if L.sivae_conv2d_wino_up_dgrad_splitk(B, C, N, Hs, Ws) > 1:  # small shards: split the 4C input planes
         ws = workspace(L.sivae_conv2d_wino_up_dgrad_splitk_workspace_bytes(B, C, N, Hs, Ws), dy.device)
         _lib.call("sivae_conv2d_wino_up_dgrad_splitk_run", _p(dy), _p(wp.wino_up_dgrad()), _p(dx), B, C, N, Hs, Ws,

@@ -947,6 +947,27 @@ def check_conv_up_dgrad(shape, accumulate=False):
     return [("wino_up_dgrad%s%s" % ("_acc" if accumulate else "", shape), _err(dx, ref), WINO_TOL)]
 
 
+def check_wino4_dgrad_pool(shape, accumulate=False):
+    """the same data gradient in one F(4x4,3x3) pass with the 2x2 block sum folded into the output transform
+    (sivae_conv2d_wino4_dgrad_pool, straight through the C ABI) vs fp64"""
+    from sivae_hip import lib, ops
+    B, N, C, H, W = shape  # x: [B, N, H/2, W/2] -> conv N -> C at H x W; dy: [B, C, H, W]
+    xs = _rand(B, N, H // 2, W // 2, seed=5).requires_grad_()
+    w = _rand(C, N, 3, 3, seed=2, scale=1.0 / math.sqrt(N * 9))
+    dy = _rand(B, C, H, W, seed=4)
+    _conv_ref(F.interpolate(xs, scale_factor=2, mode="nearest"), w).backward(dy)
+    ref = xs.grad
+    base = _rand(B, N, H // 2, W // 2, seed=12)
+    dx = _d(base).clone() if accumulate else torch.empty((B, N, H // 2, W // 2), dtype=torch.float32, device=DEV)
+    wp1 = ops.PackedW(_d(w), 1)
+    dyd, up = _d(dy), wp1.wino4()
+    lib.call("sivae_conv2d_wino4_dgrad_pool", ops._p(dyd), ops._p(up), ops._p(dx), B, C, N, H, W, int(accumulate), ops._s())
+    torch.cuda.synchronize()
+    if accumulate:
+        ref = ref + base
+    return [("wino4_dgrad_pool%s%s" % ("_acc" if accumulate else "", shape), _err(dx, ref), WINO4_TOL)]
+
+
 def check_space_to_depth():
     from sivae_hip import ops
     x = _rand(3, 5, 12, 20, seed=1)
@@ -1607,6 +1628,8 @@ def all_checks():
         checks.append(("dgrad_bnbwd%s" % (s,), lambda s=s: check_dgrad_bnbwd(s)))
     checks.append(("wino_up_stats", lambda: check_conv_up((3, 32, 72, 32, 64, 3), stats=True)
                    + check_conv_up((2, 20, 33, 16, 32, 3), pro=True, stats=True)))
+    for s in [(2, 64, 64, 32, 32), (1, 64, 64, 16, 64), (3, 40, 72, 48, 64), (2, 64, 128, 32, 32), (1, 24, 200, 16, 32)]:
+        checks.append(("wino4_dgrad_pool%s" % (s,), lambda s=s: check_wino4_dgrad_pool(s) + check_wino4_dgrad_pool(s, True)))
     checks.append(("up_dgrad_splitk", check_up_dgrad_splitk))
     checks.append(("conv5_k75", check_conv5_k75))
     for s in [(2, 64, 64, 32, 32), (1, 64, 128, 16, 64), (3, 128, 64, 32, 32), (2, 32, 40, 16, 32), (1, 256, 256, 32, 32),

@@ -149,6 +149,13 @@ def test_round3_entry_points_validate_arguments():
     assert L.sivae_conv2d_wino4_num_px_tiles(16, 8, 8) == 2 and L.sivae_conv2d_wino4_num_px_tiles(64, 4, 4) == 2
     assert L.sivae_conv2d_wino4_num_px_tiles(12, 8, 8) == -2 and L.sivae_conv2d_wino4_num_px_tiles(48, 4, 4) == -2
     assert L.sivae_conv2d_wino4_pays(12, 64, 64, 8, 8) == 0 and L.sivae_conv2d_wino4_pays(256, 512, 512, 8, 8) == 1
+    # the pooled data gradient of an upsample-conv: whole-tile maps, <= 64 input channels, an item for every CU
+    pp = L.sivae_conv2d_wino4_dgrad_pool_pays
+    assert pp(256, 64, 64, 256, 256) == 1 and pp(128, 64, 64, 256, 256) == 1 and pp(256, 64, 128, 256, 256) == 0
+    assert pp(256, 64, 64, 16, 16) == 0 and pp(1, 64, 64, 32, 32) == 0
+    assert L.sivae_conv2d_wino4_dgrad_pool(one, one, one, 2, 64, 64, 16, 16, 0, null) == -2  # (16 x 16: not a whole-tile map)
+    assert L.sivae_conv2d_wino4_dgrad_pool(one, one, ctypes.c_void_p(20), 2, 64, 64, 32, 32, 0, null) == -2  # (8-byte stores)
+    assert L.sivae_conv2d_wino4_dgrad_pool(null, one, one, 2, 64, 64, 32, 32, 0, null) == -1
     # the launch-level policy of the image-grid form against F(2x2,3x3), pinned to the measured table
     # (profiles/r6_wino4_small_maps_vs_f23.txt: wins need (slices x items) for every CU AND a long K slice)
     fwd = {(256, 512, 512, 8, 8): 1, (128, 512, 512, 8, 8): 1, (64, 512, 512, 8, 8): 0, (32, 512, 512, 8, 8): 0,
