@@ -342,7 +342,16 @@ static int wino4_impl(const float* x, const float* up, float* y, const float* pr
   // (96 KB of static LDS: one block per CU)
   const int cus = sivae_num_cus();
   const int grid = nitems < cus ? (int)nitems : cus;
-  a.xcd_group = (sivae_xcd_remap() && a.n_co_tiles > 1 && !(grid & 7)) ? 1 : 0;
+  // One co tile (Co <= 64) too: a halo row of an item is 160 bytes from 16 bytes in front of a 128-byte line, i.e. THREE
+  // lines of the L2 — with consecutive items (horizontal neighbours) round-robin over the XCDs every L2 fetches all three
+  // (3 x 18/16 = 3.4 reads per input byte: the 64-channel 256 x 256 layers moved 4.7 TB/s through the fabric); grouped, the 32
+  // blocks of an XCD hold a 64-row band of one image at the same time and the edge lines are fetched once.
+  // (SIVAE_W4_XCD_SINGLE=0: the round-5 order, A/B switch)
+  static const int single_ok = [] {
+    const char* e = getenv("SIVAE_W4_XCD_SINGLE");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  a.xcd_group = (sivae_xcd_remap() && (a.n_co_tiles > 1 || single_ok) && !(grid & 7)) ? 1 : 0;
   if (pool) {  // (whole-tile maps only, no prologue / statistics / split-K: checked by the caller)
     hipLaunchKernelGGL(conv_wino4_pool_kernel<false>, dim3((unsigned)grid), dim3(W4_NT), 0, stream, a);
   } else if (sup >= 3) {  // (the 16 x 16 pairs, mode 2, stay on the round-5 kernel: a.two)
