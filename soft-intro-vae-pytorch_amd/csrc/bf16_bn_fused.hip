@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
   const int xcd = bid % a.nx;
   const unsigned bpx = (unsigned)(nb_sub / a.nx);
   __shared__ int bar_failed;
-  unsigned target = 0;
+  unsigned target = 0, nbar = 0;  // (thread 0) generation to wait for; barriers of this launch passed so far
   if (t == 0 && !local) target = bf_load_u32(bar + (9 + xcd) * 32);
   const int W = a.W, HW = a.H * a.W, Cb = a.Cb;
   const int nq = a.B << a.l2_qpp;
@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
     if (!local) {
       if (t == 0) {
         ++target;
-        bf_grid_arrive(bar, xcd, a.nx, bpx);
+        bf_grid_arrive(bar, xcd, a.nx, bpx, nbar++);
       }
       if (pf) {
         const int cbn = (grp + a.nsub) * a.cpg + ci;
@@ -369,6 +369,8 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
     }
     __syncthreads();  // (coef / red are reused by the next group)
   }
+  // the arrival counters of this half-grid back to zero (bn_fused_common.h: they run on through a launch's barriers)
+  if (t == 0 && bid == 0 && nbar != 0u) bf_grid_reset(bar, a.nx);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int j = 0; j < NU; ++j)

@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
   const int xcd = bid % a.nx;
   const unsigned bpx = (unsigned)(nb_sub / a.nx);
   __shared__ int bar_failed;
-  unsigned target = 0;
+  unsigned target = 0, nbar = 0;  // (thread 0) generation to wait for; barriers of this launch passed so far
   if (t == 0 && !local) target = bf_load_u32(bar + (9 + xcd) * 32);
   const int C = a.C, W = a.W, HW = a.H * a.W;
   const int VC = a.nseg * C;
@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
       // ---- barrier: every slab of every channel of this group is published
       if (t == 0) {
         ++target;
-        bf_grid_arrive(bar, xcd, a.nx, bpx);
+        bf_grid_arrive(bar, xcd, a.nx, bpx, nbar++);
       }
       if (pf) {
         const int vcn = (grp + a.nsub) * a.cpg + ci;
@@ -338,6 +338,8 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
       }
     }
   }
+  // the arrival counters of this half-grid back to zero (bn_fused_common.h: they run on through a launch's barriers)
+  if (t == 0 && bid == 0 && nbar != 0u) bf_grid_reset(bar, a.nx);
   // the last group's stores: their data registers stay untouched until the stores have completed
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll

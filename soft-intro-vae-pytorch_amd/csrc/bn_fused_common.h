@@ -27,11 +27,15 @@ constexpr int BF_POISON_WORD = BF_BAR_UINTS - 32;
 constexpr unsigned BF_SPIN_LIMIT_DEFAULT = 1u << 24;  // polls of ~1 us: tens of seconds, then the launch is abandoned
 
 // grid barrier of one half-grid, called by thread 0 of every block.  `bar`: arrival counters [xcd] at bar + 32*xcd, the
-// top counter at bar + 256, generation flags at bar + 32*(9 + xcd).  Counters are reset by the last arriver (nobody
-// arrives again before the generation flips); every generation flag only ever advances BY ONE per barrier and a block
-// compares its own XCD's flag with the value it read at kernel start plus the barriers it has passed — the flags need
-// not agree with each other, so launches that use different numbers of XCD groups (nx) can share the state, and the state
-// needs no re-initialisation between launches.
+// top counter at bar + 256, generation flags at bar + 32*(9 + xcd).  Every generation flag only ever advances BY ONE per
+// barrier and a block compares its own XCD's flag with the value it read at kernel start plus the barriers it has passed —
+// the flags need not agree with each other, so launches that use different numbers of XCD groups (nx) can share the state,
+// and the flags need no re-initialisation between launches.
+// The arrival counters are zero at the start of a launch and run ON through its barriers (round 6): the last arriver of
+// barrier n (0-based, the same n in every block of the half-grid) is the one that finds (n + 1) * bpx - 1 — no reset store
+// and no wait for it between the two levels (the round-5 form reset both counters inside every barrier: two more memory
+// round trips of ~1.5 us on the critical path of each group).  bf_grid_reset puts them back to zero once, behind the
+// launch's last barrier; a launch abandoned by the spin limit leaves them inconsistent, as before (the host zeroes the state).
 // No fences: everything that crosses blocks (the partial sums, the counters, the flags) is written with agent-scope
 // (write-through, `sc1`) stores / atomics and read with agent-scope loads, ordered by explicit vmcnt(0) waits.  A release
 // fence here would write back the whole L2 of the XCD — the dx stores of the previous group, megabytes — once per block
@@ -40,22 +44,24 @@ constexpr unsigned BF_SPIN_LIMIT_DEFAULT = 1u << 24;  // polls of ~1 us: tens of
 // caller's block must leave the kernel; nothing traps and nothing hangs.
 // The two halves separately (a caller may issue independent memory traffic between its arrival and its wait — the
 // persistent BatchNorm backward requests the next group's x there, bn_fused.hip):
-__device__ __forceinline__ void bf_grid_arrive(unsigned* bar, int xcd, int nx, unsigned bpx) {
+__device__ __forceinline__ void bf_grid_arrive(unsigned* bar, int xcd, int nx, unsigned bpx, unsigned n) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's partial sums (sc1 stores) have reached memory
   unsigned* cnt = bar + xcd * 32;
   const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (old == bpx - 1u) {
-    __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (old == (n + 1u) * bpx - 1u) {
     unsigned* top = bar + 8 * 32;
     const unsigned o2 = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (o2 == (unsigned)nx - 1u) {
-      __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (o2 == (n + 1u) * (unsigned)nx - 1u) {
       for (int i = 0; i < nx; ++i)
         __hip_atomic_fetch_add(bar + (9 + i) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+// Behind the LAST barrier of a launch (every block of the half-grid has arrived at it: nobody touches the counters again),
+// by one thread of the half-grid: the counters go back to zero for the next launch (ordered by the kernel boundary).
+__device__ __forceinline__ void bf_grid_reset(unsigned* bar, int nx) {
+  for (int i = 0; i < nx; ++i) __hip_atomic_store(bar + i * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(bar + 8 * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ bool bf_grid_wait(const unsigned* bar, unsigned* poison, int xcd, unsigned target,
                                              unsigned spin_limit) {
@@ -73,8 +79,8 @@ __device__ __forceinline__ bool bf_grid_wait(const unsigned* bar, unsigned* pois
   return true;
 }
 __device__ __forceinline__ bool bf_grid_barrier(unsigned* bar, unsigned* poison, int xcd, int nx, unsigned bpx,
-                                                unsigned target, unsigned spin_limit) {
-  bf_grid_arrive(bar, xcd, nx, bpx);
+                                                unsigned target, unsigned spin_limit, unsigned n) {
+  bf_grid_arrive(bar, xcd, nx, bpx, n);
   return bf_grid_wait(bar, poison, xcd, target, spin_limit);
 }
 
