@@ -617,6 +617,126 @@ __global__ void __launch_bounds__(64) bf16_splitk_reduce_kernel(const float* __r
   }
 }
 
+// The same for planes of 16 / 64 / 256 pixels (the 4x4 ... 16x16 maps the split-K form exists for): a thread owns FOUR
+// consecutive pixels of one (image, 8-channel block) — 16-byte loads of the partials, a 64-byte run of the blocked output —
+// and the 4 / 16 / 64 lanes of a plane fold their statistics with DPP butterflies (the scalar form above walks a plane with
+// one wave, 16 of 64 lanes active on a 4x4 map, behind 8 x S dependent dword loads: 19 us per call whatever the size).
+// Same summation order over the slices as the scalar form; the statistics add the pixels in another order.
+template <int LPP>  // lanes per plane = HW / 4
+__global__ void __launch_bounds__(256) bf16_splitk_reduce_vec_kernel(const float* __restrict__ part, void* __restrict__ y,
+                                                                     float* __restrict__ stats, int S, int Co, int Cob,
+                                                                     int nplanes, size_t slice_stride, int accumulate) {
+  constexpr int HW = LPP * 4;
+  const int gid = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  const int plane = gid / LPP, q4 = gid - plane * LPP;  // plane = b * Cob + cb
+  const bool live = plane < nplanes;
+  const int b = live ? plane / Cob : 0, cb = live ? plane - b * Cob : 0;
+  float f[8][4];
+  u32x4_t* yv = reinterpret_cast<u32x4_t*>(y) + (size_t)plane * HW + 4 * q4;
+  if (live && accumulate) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float t8[8];
+      unpack8(yv[i], t8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e][i] = t8[e];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f[e][i] = 0.f;
+  }
+  float s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = cb * 8 + e;
+    if (live && c < Co) {
+      const float4* src = reinterpret_cast<const float4*>(part + ((size_t)b * Co + c) * HW) + q4;
+      for (int k = 0; k < S; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (size_t)k * slice_stride);
+        f[e][0] += v.x;
+        f[e][1] += v.y;
+        f[e][2] += v.z;
+        f[e][3] += v.w;
+      }
+    } else {
+      f[e][0] = f[e][1] = f[e][2] = f[e][3] = 0.f;
+    }
+  }
+  float r[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float t8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t8[e] = f[e][i];
+    const u32x4_t o = pack8(t8);
+    if (live) yv[i] = o;
+    unpack8(o, r[i]);
+  }
+  if (stats == nullptr) return;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    s[e] = (r[0][e] + r[1][e]) + (r[2][e] + r[3][e]);
+    q[e] = (r[0][e] * r[0][e] + r[1][e] * r[1][e]) + (r[2][e] * r[2][e] + r[3][e] * r[3][e]);
+  }
+  // (every lane of the block is active here: the butterflies below read their neighbours' registers)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (LPP == 64) {
+      s[e] = wave_sum(s[e]);
+      q[e] = wave_sum(q[e]);
+    } else {
+      s[e] += dpp_mov_f32<0xB1, 0xf>(s[e]);  // quad_perm [1,0,3,2]
+      q[e] += dpp_mov_f32<0xB1, 0xf>(q[e]);
+      s[e] += dpp_mov_f32<0x4E, 0xf>(s[e]);  // quad_perm [2,3,0,1]: every lane of a quad holds the quad's sum
+      q[e] += dpp_mov_f32<0x4E, 0xf>(q[e]);
+      if (LPP == 16) {
+        s[e] += dpp_mov_f32<0x141, 0xf>(s[e]);  // row_half_mirror: ... of its half row
+        q[e] += dpp_mov_f32<0x141, 0xf>(q[e]);
+        s[e] += dpp_mov_f32<0x140, 0xf>(s[e]);  // row_mirror: ... of its 16-lane row
+        q[e] += dpp_mov_f32<0x140, 0xf>(q[e]);
+      }
+    }
+  }
+  if (live && q4 == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = cb * 8 + e;
+      if (c < Co) {
+        stats[((size_t)b * Co + c) * 2 + 0] = s[e];
+        stats[((size_t)b * Co + c) * 2 + 1] = q[e];
+      }
+    }
+  }
+}
+
+static void launch_splitk_reduce(const float* part, void* y, float* stats, int S, int B, int Co, int Cob, int HW,
+                                 size_t slice_stride, int accumulate, hipStream_t stream) {
+  static const int vec_ok = [] {  // SIVAE_BF16_SPLITK_REDUCE_VEC=0: the scalar reducer everywhere (A/B switch)
+    const char* e = getenv("SIVAE_BF16_SPLITK_REDUCE_VEC");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  const int nplanes = B * Cob;
+  const bool aligned = (slice_stride % 4) == 0 && ((uintptr_t)part & 15u) == 0;
+  if (vec_ok && aligned && (HW == 16 || HW == 64 || HW == 256)) {
+    const long long nthreads = (long long)nplanes * (HW / 4);
+    const unsigned nb = (unsigned)((nthreads + 255) / 256);
+    if (HW == 16)
+      hipLaunchKernelGGL(bf16_splitk_reduce_vec_kernel<4>, dim3(nb), dim3(256), 0, stream, part, y, stats, S, Co, Cob, nplanes,
+                         slice_stride, accumulate);
+    else if (HW == 64)
+      hipLaunchKernelGGL(bf16_splitk_reduce_vec_kernel<16>, dim3(nb), dim3(256), 0, stream, part, y, stats, S, Co, Cob, nplanes,
+                         slice_stride, accumulate);
+    else
+      hipLaunchKernelGGL(bf16_splitk_reduce_vec_kernel<64>, dim3(nb), dim3(256), 0, stream, part, y, stats, S, Co, Cob, nplanes,
+                         slice_stride, accumulate);
+    return;
+  }
+  hipLaunchKernelGGL(bf16_splitk_reduce_kernel, dim3((unsigned)nplanes), dim3(64), 0, stream, part, y, stats, S, Co, Cob, HW,
+                     slice_stride, accumulate);
+}
+
 // number of K slices sivae_bf16_conv2d_fwd_splitk uses (1: it is the plain kernel)
 extern "C" int sivae_bf16_conv2d_splitk(int B, int Ci, int Co, int H, int W, int ks) {
   if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
@@ -691,8 +811,7 @@ extern "C" int sivae_bf16_conv2d_fwd_splitk(const void* x, const void* wp, void*
   const int rc = pro_mean ? launch_by_co<3, 1, 5, true, true>(a, c.TCO, stream)
                           : launch_by_co<3, 1, 5, false, true>(a, c.TCO, stream);
   if (rc != SIVAE_OK) return rc;
-  hipLaunchKernelGGL(bf16_splitk_reduce_kernel, dim3((unsigned)(B * a.Cob)), dim3(64), 0, stream,
-                     reinterpret_cast<const float*>(workspace), y, stats_partial, cdiv(nchunks, a.chunks_per_split), Co,
-                     a.Cob, H * W, (size_t)a.split_stride, accumulate);
+  launch_splitk_reduce(reinterpret_cast<const float*>(workspace), y, stats_partial, cdiv(nchunks, a.chunks_per_split), B, Co,
+                       a.Cob, H * W, (size_t)a.split_stride, accumulate, stream);
   return sivae_launch_status();
 }
