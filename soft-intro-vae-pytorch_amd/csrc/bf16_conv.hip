@@ -20,6 +20,7 @@
 // the consumer BatchNorm, fp32 NCHW output (OUTF32: Decoder.predict feeds the fp32 loss kernels).
 #include "bf16_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 struct Bf16ConvArgs {
   const void* x;   // bf16 blocked [B][Cib][Hs][Ws][8]
@@ -43,6 +44,10 @@ struct Bf16ConvArgs {
   // epilogue) to y + s*split_stride floats; bf16_splitk_reduce_kernel sums the slices
   int nblk_base, chunks_per_split;
   long long split_stride;
+  // fastdiv magics (common.h) of the halo tile's plane / row length / row count: the staging map of a thread is five
+  // (vector -> channel block, image, row, column) decompositions — as run-time integer divisions they were 400 of the
+  // kernel's 820 set-up instructions (set by launch_cfg)
+  unsigned magic_plane, magic_lw, magic_lh;
 };
 
 // KS x KW taps (KW = KS except for the kw-packed 5x1 form of the RGB-side layers, ks code 51)
@@ -115,12 +120,12 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
     unsigned off = SIVAE_OOB;
     int cbl = 0;
     if (v < nvec) {
-      cbl = v / plane;
+      cbl = (int)fastdiv((unsigned)v, a.magic_plane);
       const int pos = v - cbl * plane;
-      const int cc = pos % LW;
-      const int t = pos / LW;
-      const int rr = t % LH;
-      const int tb = t / LH;
+      const int t = (int)fastdiv((unsigned)pos, a.magic_lw);
+      const int cc = pos - t * LW;
+      const int tb = (int)fastdiv((unsigned)t, a.magic_lh);
+      const int rr = t - tb * LH;
       const int r = r0 + rr - P, c = c0 + cc - PW;
       if (tb < nb_here && r >= 0 && r < H && c >= 0 && c < W) {
         const int rs = a.upsample ? (r >> 1) : r, cs = a.upsample ? (c >> 1) : c;
@@ -266,59 +271,93 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
 
   const __amdgpu_buffer_rsrc_t yrsrc = make_rsrc(reinterpret_cast<unsigned char*>(a.y) + (size_t)b0 * a.Cob * HW * 16,
                                                  (unsigned long long)nb_here * a.Cob * HW * 16ull);
+  // The run-time switches of the epilogue are block-uniform: one copy of the loop per (accumulate, statistics, whole tile)
+  // combination instead of 149 branches inside it.  Statistics: the lane's {sum, sumsq} of all its WM * 16 channel slots stay
+  // in registers (slot k = (m * 4 + g) * 4 + e) and ONE transposing reduction over the 32 pixel lanes (common.h) leaves
+  // lane k with the totals of slot k — 2 * (WM * 32 - WM) adds instead of WM * 32 five-step butterflies (the round-2 form:
+  // 640 of the epilogue's 1 740 vector instructions).
+  const bool full_tile = nb_here == TB && r0 + TH <= H && c0 + TW <= W;
+  auto epilogue = [&](auto ACC_, auto STATS_, auto FULL_) {
+    constexpr bool ACC = decltype(ACC_)::value, STATS = decltype(STATS_)::value, FULL = decltype(FULL_)::value;
+    float sq[WM * 32];  // [0, WM*16): sums, [WM*16, WM*32): sums of squares (dead code without statistics)
+    if constexpr (STATS) {
 #pragma unroll
-  for (int m = 0; m < WM; ++m) {
+      for (int k = 0; k < WM * 32; ++k) sq[k] = 0.f;
+    }
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int col0 = (wvm * WM + m) * 32 + 8 * g + 4 * hh;  // first of this lane's 4 channels, within the tile
-      const int cb = (co0 >> 3) + (wvm * WM + m) * 4 + g;
-      const bool cb_ok = cb < a.Cob;
-      float bias[4];
+    for (int m = 0; m < WM; ++m) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        bias[e] = (a.bias != nullptr && co0 + col0 + e < a.Co) ? a.bias[co0 + col0 + e] : 0.f;
-      float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-      const unsigned cboff = (unsigned)cb * (unsigned)HW * 16u;
+      for (int g = 0; g < 4; ++g) {
+        const int col0 = (wvm * WM + m) * 32 + 8 * g + 4 * hh;  // first of this lane's 4 channels, within the tile
+        const int cb = (co0 >> 3) + (wvm * WM + m) * 4 + g;
+        const bool cb_ok = cb < a.Cob;
+        float bias[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias != nullptr) {
 #pragma unroll
-      for (int n = 0; n < WN; ++n) {
-        const unsigned off = (cb_ok && px_ok[n]) ? y_off[n] + cboff : SIVAE_OOB;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[m][n][4 * g + e] + bias[e];
-        if (a.accumulate) {
-          const u32x2_t old = __builtin_amdgcn_raw_buffer_load_b64(yrsrc, (int)off, 0, 0);
-          v[0] += bf16_lo(old[0]);
-          v[1] += bf16_hi(old[0]);
-          v[2] += bf16_lo(old[1]);
-          v[3] += bf16_hi(old[1]);
+          for (int e = 0; e < 4; ++e) bias[e] = (co0 + col0 + e < a.Co) ? a.bias[co0 + col0 + e] : 0.f;
         }
-        u32x2_t o;
-        o[0] = pack_bf16(v[0], v[1]);
-        o[1] = pack_bf16(v[2], v[3]);
-        __builtin_amdgcn_raw_buffer_store_b64(o, yrsrc, (int)off, 0, 0);
-        if (want_stats) {
-          const float w0 = bf16_lo(o[0]), w1 = bf16_hi(o[0]), w2 = bf16_lo(o[1]), w3 = bf16_hi(o[1]);
-          const float okf = px_ok[n] ? 1.f : 0.f;
-          s[0] += okf * w0;
-          s[1] += okf * w1;
-          s[2] += okf * w2;
-          s[3] += okf * w3;
-          q[0] += okf * w0 * w0;
-          q[1] += okf * w1 * w1;
-          q[2] += okf * w2 * w2;
-          q[3] += okf * w3 * w3;
-        }
-      }
-      if (want_stats) {
+        const unsigned cboff = (unsigned)cb * (unsigned)HW * 16u;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float ss = half_wave_sum_hi(s[e]);
-          const float qq = half_wave_sum_hi(q[e]);
-          if (l31 == 31) {
-            red[(wvn * TCO + col0 + e) * 2 + 0] = ss;
-            red[(wvn * TCO + col0 + e) * 2 + 1] = qq;
+        for (int n = 0; n < WN; ++n) {
+          const unsigned off = (cb_ok && (FULL || px_ok[n])) ? y_off[n] + cboff : SIVAE_OOB;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[m][n][4 * g + e] + bias[e];
+          if constexpr (ACC) {
+            const u32x2_t old = __builtin_amdgcn_raw_buffer_load_b64(yrsrc, (int)off, 0, 0);
+            v[0] += bf16_lo(old[0]);
+            v[1] += bf16_hi(old[0]);
+            v[2] += bf16_lo(old[1]);
+            v[3] += bf16_hi(old[1]);
+          }
+          u32x2_t o;
+          o[0] = pack_bf16(v[0], v[1]);
+          o[1] = pack_bf16(v[2], v[3]);
+          __builtin_amdgcn_raw_buffer_store_b64(o, yrsrc, (int)off, 0, 0);
+          if constexpr (STATS) {
+            float w[4] = {bf16_lo(o[0]), bf16_hi(o[0]), bf16_lo(o[1]), bf16_hi(o[1])};
+            if constexpr (!FULL) {
+              const float okf = px_ok[n] ? 1.f : 0.f;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) w[e] *= okf;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              sq[(m * 4 + g) * 4 + e] += w[e];
+              sq[WM * 16 + (m * 4 + g) * 4 + e] = fmaf(w[e], w[e], sq[WM * 16 + (m * 4 + g) * 4 + e]);
+            }
           }
         }
+      }
+    }
+    if constexpr (STATS) {
+      lanes32_transpose_sum<WM * 32>(sq, lane);
+      // WM == 2: lane k holds {sum, sumsq} of slot k in sq[0], sq[1];  WM == 1: lanes 0-15 the sum of slot k, lanes 16-31 the
+      // sum of squares of slot k - 16, in sq[0]
+      const int k = WM == 2 ? l31 : (l31 & 15);
+      const int col = (wvm * WM + (k >> 4)) * 32 + 8 * ((k >> 2) & 3) + 4 * hh + (k & 3);
+      if (WM == 2) {
+        red[(wvn * TCO + col) * 2 + 0] = sq[0];
+        red[(wvn * TCO + col) * 2 + 1] = sq[WM == 2 ? 1 : 0];
+      } else {
+        red[(wvn * TCO + col) * 2 + (l31 >> 4)] = sq[0];
+      }
+    }
+  };
+  {
+    using T = std::true_type;
+    using F = std::false_type;
+    if (a.accumulate) {
+      if (want_stats) {
+        if (full_tile) epilogue(T{}, T{}, T{}); else epilogue(T{}, T{}, F{});
+      } else {
+        if (full_tile) epilogue(T{}, F{}, T{}); else epilogue(T{}, F{}, F{});
+      }
+    } else {
+      if (want_stats) {
+        if (full_tile) epilogue(F{}, T{}, T{}); else epilogue(F{}, T{}, F{});
+      } else {
+        if (full_tile) epilogue(F{}, F{}, T{}); else epilogue(F{}, F{}, F{});
       }
     }
   }
@@ -417,6 +456,10 @@ int launch_cfg(Bf16ConvArgs& a, hipStream_t stream) {
   a.nchunks = a.Cib / (2 * CKS);
   const int plane = (1 << g.tb_log2) * ((1 << g.th_log2) + 2 * P) * ((1 << g.tw_log2) + 2 * PW);
   if (2 * CKS * plane > MAXV * NT) return SIVAE_ERR_SHAPE;
+  if (plane >= 1024) return SIVAE_ERR_SHAPE;  // (fastdiv: divisors < 2^10, dividends < 2^22 — MAXV * NT <= 2048 vectors)
+  a.magic_plane = make_magic((unsigned)plane);
+  a.magic_lw = make_magic((unsigned)((1 << g.tw_log2) + 2 * PW));
+  a.magic_lh = make_magic((unsigned)((1 << g.th_log2) + 2 * P));
   size_t lds = (size_t)(NW + 2 * CKS * plane) * 16 + (PRO ? (size_t)a.Cib * 64 : 0);
   const size_t red = (size_t)WVN * TCO * 2 * sizeof(float);
   if (lds < red) lds = red;

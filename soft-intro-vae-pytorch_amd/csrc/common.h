@@ -115,6 +115,41 @@ __device__ __forceinline__ float half_wave_sum_hi(float v) {
   return v;
 }
 
+// Transposing sum of N (a multiple of 32) per-lane values over the 32 lanes that share (lane >> 5): on return v[i], i < N / 32,
+// is the total over those lanes of the caller's v[i * 32 + (lane & 31)] — N - N / 32 adds per lane instead of the 5 N of N
+// separate butterflies.  Step k pairs lane l with l ^ (1 << k): the lane whose bit k is clear keeps the even value of
+// every pair and sends the odd one (quad permutes for bits 0 / 1, ds_swizzle for bit 2 and 4, row_ror:8 for bit 3).
+// Must be called with the whole wave active.
+template <int N>
+__device__ __forceinline__ void lanes32_transpose_sum(float (&v)[N], int lane) {
+  static_assert(N % 32 == 0, "lanes32_transpose_sum: N must be a multiple of 32");
+#define SIVAE_T32_STEP(CNT, BIT, RECV)                                       \
+  {                                                                          \
+    const bool sel_ = (lane >> (BIT)) & 1;                                   \
+    _Pragma("unroll") for (int i = 0; i < (CNT) / 2; ++i) {                  \
+      const float keep_ = sel_ ? v[2 * i + 1] : v[2 * i];                    \
+      const float send_ = sel_ ? v[2 * i] : v[2 * i + 1];                    \
+      v[i] = keep_ + RECV(send_);                                            \
+    }                                                                        \
+  }
+#define SIVAE_T32_Q1(X) dpp_mov_f32<0xB1, 0xf>(X)
+#define SIVAE_T32_Q2(X) dpp_mov_f32<0x4E, 0xf>(X)
+#define SIVAE_T32_X4(X) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, X), 0x101f))
+#define SIVAE_T32_R8(X) dpp_mov_f32<0x128, 0xf>(X)
+#define SIVAE_T32_X16(X) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, X), 0x401f))
+  SIVAE_T32_STEP(N, 0, SIVAE_T32_Q1)
+  SIVAE_T32_STEP(N / 2, 1, SIVAE_T32_Q2)
+  SIVAE_T32_STEP(N / 4, 2, SIVAE_T32_X4)
+  SIVAE_T32_STEP(N / 8, 3, SIVAE_T32_R8)
+  SIVAE_T32_STEP(N / 16, 4, SIVAE_T32_X16)
+#undef SIVAE_T32_STEP
+#undef SIVAE_T32_Q1
+#undef SIVAE_T32_Q2
+#undef SIVAE_T32_X4
+#undef SIVAE_T32_R8
+#undef SIVAE_T32_X16
+}
+
 // Block-wide sum of doubles for blocks of NT threads (NT multiple of 64, <= 1024).
 // `red` must hold NT/64 doubles of LDS. Result valid in every thread.
 template <int NT>
