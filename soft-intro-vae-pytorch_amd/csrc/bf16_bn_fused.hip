@@ -249,12 +249,25 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
         if (ACT == 2) sg_bits[j] = bits;  // (phase 2 reads the bits whatever their source)
       }
       // block fold of the 16 sums: wave butterflies, then the four waves through LDS
+      if constexpr (ACT == 2 && NU == 4) {
+        // (this instantiation has no register to spare: its 32 per-channel scalars already spill into VGPR lanes, and the
+        // selects of the transposing form pushed 180 payload registers into scratch)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float s1 = wave_sum(sg[e]), s2 = wave_sum(sgx[e]);
-        if (lane == 0) {
-          red[wave][e] = s1;
-          red[wave][8 + e] = s2;
+        for (int e = 0; e < 8; ++e) {
+          const float s1 = wave_sum(sg[e]), s2 = wave_sum(sgx[e]);
+          if (lane == 0) {
+            red[wave][e] = s1;
+            red[wave][8 + e] = s2;
+          }
+        }
+      } else {
+        // two transposing reductions of 8 values (common.h): lane l ends with the wave's total of value l & 7 — 20 VALU
+        // + 6 cross-lane operations instead of 96 ds_bpermute butterflies on the path to the grid barrier
+        wave_transpose_sum8(sg, lane);
+        wave_transpose_sum8(sgx, lane);
+        if (lane < 8) {
+          red[wave][lane] = sg[0];
+          red[wave][8 + lane] = sgx[0];
         }
       }
       __syncthreads();

@@ -150,6 +150,34 @@ __device__ __forceinline__ void lanes32_transpose_sum(float (&v)[N], int lane) {
 #undef SIVAE_T32_X16
 }
 
+// 8 per-lane values summed over the whole wave: on return v[0] of lane l is the total of the caller's v[l & 7] (the same
+// transposing steps over lane bits 0-2, then the eight 8-lane groups are added): 7 select-adds + 3 adds instead of 8 six-step
+// ds_bpermute butterflies.  Must be called with the whole wave active.
+__device__ __forceinline__ void wave_transpose_sum8(float (&v)[8], int lane) {
+#define SIVAE_T8_STEP(CNT, BIT, RECV)                                        \
+  {                                                                          \
+    const bool sel_ = (lane >> (BIT)) & 1;                                   \
+    _Pragma("unroll") for (int i = 0; i < (CNT) / 2; ++i) {                  \
+      const float keep_ = sel_ ? v[2 * i + 1] : v[2 * i];                    \
+      const float send_ = sel_ ? v[2 * i] : v[2 * i + 1];                    \
+      v[i] = keep_ + RECV(send_);                                            \
+    }                                                                        \
+  }
+#define SIVAE_T8_Q1(X) dpp_mov_f32<0xB1, 0xf>(X)
+#define SIVAE_T8_Q2(X) dpp_mov_f32<0x4E, 0xf>(X)
+#define SIVAE_T8_X4(X) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, X), 0x101f))
+  SIVAE_T8_STEP(8, 0, SIVAE_T8_Q1)
+  SIVAE_T8_STEP(4, 1, SIVAE_T8_Q2)
+  SIVAE_T8_STEP(2, 2, SIVAE_T8_X4)
+  v[0] += dpp_mov_f32<0x128, 0xf>(v[0]);                                                                   // lane ^ 8 (row_ror:8)
+  v[0] += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v[0]), 0x401f));  // lane ^ 16
+  v[0] += __shfl_xor(v[0], 32, 64);
+#undef SIVAE_T8_STEP
+#undef SIVAE_T8_Q1
+#undef SIVAE_T8_Q2
+#undef SIVAE_T8_X4
+}
+
 // Block-wide sum of doubles for blocks of NT threads (NT multiple of 64, <= 1024).
 // `red` must hold NT/64 doubles of LDS. Result valid in every thread.
 template <int NT>
