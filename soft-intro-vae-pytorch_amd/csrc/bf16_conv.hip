@@ -237,7 +237,9 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
     const int tb = m_pix >> (a.tw_log2 + a.th_log2);
     const int r = r0 + rr, c = c0 + cc;
     px_ok[n] = (tb < nb_here && r < H && c < W) ? 1 : 0;
-    if (OUTF32)
+    if (OUTF32 && KS == 3)  // split-K partials: fp32 in the blocked layout, [b][Cob][H][W][8] floats
+      y_off[n] = px_ok[n] ? (unsigned)((tb * a.Cob * H + r) * W + c) * 32u + (unsigned)hh * 16u : SIVAE_OOB16;  // (16-byte stores)
+    else if (OUTF32)
       y_off[n] = px_ok[n] ? (unsigned)((tb * a.Co * H + r) * W + c) * 4u : SIVAE_OOB;
     else
       y_off[n] = px_ok[n] ? (unsigned)((tb * a.Cob * H + r) * W + c) * 16u + (unsigned)hh * 8u : SIVAE_OOB;
@@ -245,7 +247,29 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
   float* red = reinterpret_cast<float*>(smem_raw);  // [WVN][TCO][2]
   const bool want_stats = a.stats != nullptr;
 
-  if (OUTF32) {
+  if constexpr (OUTF32 && KS == 3) {
+    // Split-K partials (the only use of the 3x3 fp32-output instantiations): the accumulator's own grouping — four
+    // consecutive channels of a pixel per lane and register group — is one 16-byte store into the fp32 twin of the blocked
+    // layout, part[slice][b][Cob][H][W][8] (the NCHW form was 64 range-checked dword stores per lane: 508 vector + 108 branch
+    // instructions behind a K loop of 144 MFMAs).  Padded channels have zero weights: they store zeros, nothing to check.
+    const __amdgpu_buffer_rsrc_t prsrc =
+        make_rsrc(reinterpret_cast<float*>(a.y) + (size_t)slice * a.split_stride + (size_t)b0 * a.Cob * 8 * HW,
+                  (unsigned long long)nb_here * a.Cob * HW * 32ull);
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cb = (co0 >> 3) + (wvm * WM + m) * 4 + g;  // (block-uniform)
+        const unsigned cboff = (unsigned)cb * (unsigned)HW * 32u;
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+          const f32x4 fv = {acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, fv), prsrc, (int)(cb < a.Cob ? y_off[n] : SIVAE_OOB16), (int)cboff, 0);
+        }
+      }
+    }
+    return;
+  } else if constexpr (OUTF32) {
     const __amdgpu_buffer_rsrc_t yrsrc =
         make_rsrc(reinterpret_cast<float*>(a.y) + (size_t)slice * a.split_stride + (size_t)b0 * a.Co * HW,
                   (unsigned long long)nb_here * a.Co * HW * 4ull);
@@ -612,184 +636,89 @@ extern "C" int sivae_bf16_conv2d_fwd(const void* x, const void* wp, void* y, con
 }
 
 // ---- split-K form (3x3, small grids) ------------------------------------------------------------------------------
-// y[b][cb][p][8] = bf16( sum_s part[s][b][c][p] (+ y_old) );  stats[b][c] = {sum, sumsq} of the rounded values
-__global__ void __launch_bounds__(64) bf16_splitk_reduce_kernel(const float* __restrict__ part, void* __restrict__ y,
-                                                                float* __restrict__ stats, int S, int Co, int Cob,
-                                                                int HW, size_t slice_stride, int accumulate) {
-  const int b = blockIdx.x / Cob, cb = blockIdx.x % Cob;
-  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  u32x4_t* yv = reinterpret_cast<u32x4_t*>(y) + ((size_t)b * Cob + cb) * HW;
-  for (int p = threadIdx.x; p < HW; p += 64) {
+// y[b][cb][p][8] = bf16( sum_s part[s][b][cb][p][8] (+ y_old) );  stats[b][c] = {sum, sumsq} of the rounded values.
+// The partials are fp32 in the blocked layout (the conv's 16-byte stores): a thread owns ONE pixel of an (image, channel
+// block) plane — two 16-byte loads per slice, independent across the slices —, sums the slices in order, rounds, and the
+// plane's lanes fold the 16 statistics with a transposing reduction (common.h).
+// ROWS: planes of 16 pixels (4 x 4 maps), one per 16-lane row of a wave.  Otherwise a wave walks one plane, 64 pixels a turn.
+template <bool ROWS>
+__global__ void __launch_bounds__(256) bf16_splitk_reduce_kernel(const float* __restrict__ part, void* __restrict__ y,
+                                                                 float* __restrict__ stats, int S, int Co, int Cob, int HW,
+                                                                 int nplanes, size_t slice_stride, int accumulate) {
+  const int lane = (int)threadIdx.x & 63;
+  const int wave_g = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+  const int plane = ROWS ? wave_g * 4 + (lane >> 4) : wave_g;  // plane = b * Cob + cb
+  const bool live = plane < nplanes;
+  const int b = live ? plane / Cob : 0, cb = live ? plane - b * Cob : 0;
+  float sq[16];  // [0, 8): sums, [8, 16): sums of squares of this lane's pixels
+#pragma unroll
+  for (int k = 0; k < 16; ++k) sq[k] = 0.f;
+  const float4* pp = reinterpret_cast<const float4*>(part) + (size_t)plane * HW * 2;
+  u32x4_t* yv = reinterpret_cast<u32x4_t*>(y) + (size_t)plane * HW;
+  for (int p = ROWS ? (lane & 15) : lane; p < HW; p += 64) {  // (ROWS: HW == 16, one turn)
     float f[8];
-    if (accumulate) {
+    if (live && accumulate) {
       unpack8(yv[p], f);
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = 0.f;
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = cb * 8 + e;
-      if (c < Co) {
-        const float* src = part + ((size_t)b * Co + c) * HW + p;
-        for (int k = 0; k < S; ++k) f[e] += src[(size_t)k * slice_stride];
-      } else {
-        f[e] = 0.f;
+    if (live) {
+#pragma unroll 4
+      for (int k = 0; k < S; ++k) {
+        const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(pp + 2 * p) + (size_t)k * slice_stride);
+        const float4 lo = q[0], hi = q[1];
+        f[0] += lo.x; f[1] += lo.y; f[2] += lo.z; f[3] += lo.w;
+        f[4] += hi.x; f[5] += hi.y; f[6] += hi.z; f[7] += hi.w;
       }
-    }
-    const u32x4_t o = pack8(f);
-    yv[p] = o;
-    float r[8];
-    unpack8(o, r);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      s[e] += r[e];
-      q[e] += r[e] * r[e];
-    }
-  }
-  if (stats != nullptr) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float ss = wave_sum(s[e]), qq = wave_sum(q[e]);
-      const int c = cb * 8 + e;
-      if (threadIdx.x == 0 && c < Co) {
-        stats[((size_t)b * Co + c) * 2 + 0] = ss;
-        stats[((size_t)b * Co + c) * 2 + 1] = qq;
-      }
-    }
-  }
-}
-
-// The same for planes of 16 / 64 / 256 pixels (the 4x4 ... 16x16 maps the split-K form exists for): a thread owns FOUR
-// consecutive pixels of one (image, 8-channel block) — 16-byte loads of the partials, a 64-byte run of the blocked output —
-// and the 4 / 16 / 64 lanes of a plane fold their statistics with DPP butterflies (the scalar form above walks a plane with
-// one wave, 16 of 64 lanes active on a 4x4 map, behind 8 x S dependent dword loads: 19 us per call whatever the size).
-// Same summation order over the slices as the scalar form; the statistics add the pixels in another order.
-template <int LPP>  // lanes per plane = HW / 4
-__global__ void __launch_bounds__(256) bf16_splitk_reduce_vec_kernel(const float* __restrict__ part, void* __restrict__ y,
-                                                                     float* __restrict__ stats, int S, int Co, int Cob,
-                                                                     int nplanes, size_t slice_stride, int accumulate) {
-  constexpr int HW = LPP * 4;
-  const int gid = (int)blockIdx.x * 256 + (int)threadIdx.x;
-  const int plane = gid / LPP, q4 = gid - plane * LPP;  // plane = b * Cob + cb
-  const bool live = plane < nplanes;
-  const int b = live ? plane / Cob : 0, cb = live ? plane - b * Cob : 0;
-  float f[8][4];
-  u32x4_t* yv = reinterpret_cast<u32x4_t*>(y) + (size_t)plane * HW + 4 * q4;
-  if (live && accumulate) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float t8[8];
-      unpack8(yv[i], t8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f[e][i] = t8[e];
-    }
-  } else {
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) f[e][i] = 0.f;
-  }
-  float s[8], q[8];
-  // slices outermost: the eight channels' loads of a slice are independent (eight 16-byte loads in flight per thread; with
-  // the channels outermost a thread waited out S memory round trips per channel: 17 us per call on the 4x4 maps)
-  const float4* src[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int c = cb * 8 + e;
-    const bool ok = live && c < Co;
-    src[e] = reinterpret_cast<const float4*>(part + ((size_t)b * Co + (ok ? c : 0)) * HW) + q4;
-    if (!ok) f[e][0] = f[e][1] = f[e][2] = f[e][3] = 0.f;
-  }
-  if (live) {
-#pragma unroll 2
-    for (int k = 0; k < S; ++k) {
-      float4 v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e)
-        v[e] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src[e]) + (size_t)k * slice_stride);
+        if (cb * 8 + e >= Co) f[e] = 0.f;
+      const u32x4_t o = pack8(f);
+      yv[p] = o;
+      float r[8];
+      unpack8(o, r);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        if (cb * 8 + e < Co) {
-          f[e][0] += v[e].x;
-          f[e][1] += v[e].y;
-          f[e][2] += v[e].z;
-          f[e][3] += v[e].w;
-        }
+        sq[e] += r[e];
+        sq[8 + e] = fmaf(r[e], r[e], sq[8 + e]);
       }
     }
-  }
-  float r[4][8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float t8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) t8[e] = f[e][i];
-    const u32x4_t o = pack8(t8);
-    if (live) yv[i] = o;
-    unpack8(o, r[i]);
   }
   if (stats == nullptr) return;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    s[e] = (r[0][e] + r[1][e]) + (r[2][e] + r[3][e]);
-    q[e] = (r[0][e] * r[0][e] + r[1][e] * r[1][e]) + (r[2][e] * r[2][e] + r[3][e] * r[3][e]);
-  }
-  // (every lane of the block is active here: the butterflies below read their neighbours' registers)
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    if (LPP == 64) {
-      s[e] = wave_sum(s[e]);
-      q[e] = wave_sum(q[e]);
-    } else {
-      s[e] += dpp_mov_f32<0xB1, 0xf>(s[e]);  // quad_perm [1,0,3,2]
-      q[e] += dpp_mov_f32<0xB1, 0xf>(q[e]);
-      s[e] += dpp_mov_f32<0x4E, 0xf>(s[e]);  // quad_perm [2,3,0,1]: every lane of a quad holds the quad's sum
-      q[e] += dpp_mov_f32<0x4E, 0xf>(q[e]);
-      if (LPP == 16) {
-        s[e] += dpp_mov_f32<0x141, 0xf>(s[e]);  // row_half_mirror: ... of its half row
-        q[e] += dpp_mov_f32<0x141, 0xf>(q[e]);
-        s[e] += dpp_mov_f32<0x140, 0xf>(s[e]);  // row_mirror: ... of its 16-lane row
-        q[e] += dpp_mov_f32<0x140, 0xf>(q[e]);
-      }
-    }
-  }
-  if (live && q4 == 0) {
+  // (every lane of the wave is here: the reductions read their neighbours' registers)
+  int k;
+  float tot;
+  if (ROWS) {
+    row16_transpose_sum16(sq, lane);  // lane l: the row's total of value l & 15
+    k = lane & 15;
+    tot = sq[0];
+  } else {
+    float s8[8], q8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int c = cb * 8 + e;
-      if (c < Co) {
-        stats[((size_t)b * Co + c) * 2 + 0] = s[e];
-        stats[((size_t)b * Co + c) * 2 + 1] = q[e];
-      }
+      s8[e] = sq[e];
+      q8[e] = sq[8 + e];
     }
+    wave_transpose_sum8(s8, lane);  // lane l: the wave's total of value l & 7
+    wave_transpose_sum8(q8, lane);
+    k = lane & 15;
+    tot = (lane & 8) ? q8[0] : s8[0];
+    if (lane >= 16) return;
   }
+  const int c = cb * 8 + (k & 7);
+  if (live && c < Co) stats[((size_t)b * Co + c) * 2 + (k >> 3)] = tot;
 }
 
 static void launch_splitk_reduce(const float* part, void* y, float* stats, int S, int B, int Co, int Cob, int HW,
                                  size_t slice_stride, int accumulate, hipStream_t stream) {
-  static const int vec_ok = [] {  // SIVAE_BF16_SPLITK_REDUCE_VEC=0: the scalar reducer everywhere (A/B switch)
-    const char* e = getenv("SIVAE_BF16_SPLITK_REDUCE_VEC");
-    return (e && e[0] == '0') ? 0 : 1;
-  }();
   const int nplanes = B * Cob;
-  const bool aligned = (slice_stride % 4) == 0 && ((uintptr_t)part & 15u) == 0;
-  if (vec_ok && aligned && (HW == 16 || HW == 64 || HW == 256)) {
-    const long long nthreads = (long long)nplanes * (HW / 4);
-    const unsigned nb = (unsigned)((nthreads + 255) / 256);
-    if (HW == 16)
-      hipLaunchKernelGGL(bf16_splitk_reduce_vec_kernel<4>, dim3(nb), dim3(256), 0, stream, part, y, stats, S, Co, Cob, nplanes,
-                         slice_stride, accumulate);
-    else if (HW == 64)
-      hipLaunchKernelGGL(bf16_splitk_reduce_vec_kernel<16>, dim3(nb), dim3(256), 0, stream, part, y, stats, S, Co, Cob, nplanes,
-                         slice_stride, accumulate);
-    else
-      hipLaunchKernelGGL(bf16_splitk_reduce_vec_kernel<64>, dim3(nb), dim3(256), 0, stream, part, y, stats, S, Co, Cob, nplanes,
-                         slice_stride, accumulate);
-    return;
-  }
-  hipLaunchKernelGGL(bf16_splitk_reduce_kernel, dim3((unsigned)nplanes), dim3(64), 0, stream, part, y, stats, S, Co, Cob, HW,
-                     slice_stride, accumulate);
+  if (HW == 16)
+    hipLaunchKernelGGL(bf16_splitk_reduce_kernel<true>, dim3((unsigned)((nplanes + 15) / 16)), dim3(256), 0, stream, part, y,
+                       stats, S, Co, Cob, HW, nplanes, slice_stride, accumulate);
+  else
+    hipLaunchKernelGGL(bf16_splitk_reduce_kernel<false>, dim3((unsigned)((nplanes + 3) / 4)), dim3(256), 0, stream, part, y,
+                       stats, S, Co, Cob, HW, nplanes, slice_stride, accumulate);
 }
 
 // number of K slices sivae_bf16_conv2d_fwd_splitk uses (1: it is the plain kernel)
@@ -816,7 +745,7 @@ extern "C" int sivae_bf16_conv2d_splitk(int B, int Ci, int Co, int H, int W, int
 
 extern "C" size_t sivae_bf16_conv2d_splitk_workspace_bytes(int B, int Ci, int Co, int H, int W, int ks) {
   const int S = sivae_bf16_conv2d_splitk(B, Ci, Co, H, W, ks);
-  return S <= 1 ? 0 : (size_t)S * B * Co * H * W * sizeof(float);
+  return S <= 1 ? 0 : (size_t)S * B * bf16_cblocks(Co) * 8 * H * W * sizeof(float);  // (fp32, blocked: padded channels)
 }
 
 extern "C" int sivae_bf16_conv2d_splitk_stats_rows(int B, int Ci, int Co, int H, int W, int ks) {
@@ -861,7 +790,7 @@ extern "C" int sivae_bf16_conv2d_fwd_splitk(const void* x, const void* wp, void*
   a.upsample = upsample;
   const int nchunks = a.Cib / 2;
   a.chunks_per_split = cdiv(nchunks, S);
-  a.split_stride = (long long)B * Co * H * W;
+  a.split_stride = (long long)B * a.Cob * 8 * H * W;
   const Bf16Cfg c = bf16_cfg(3, Co, Ci);
   const int rc = pro_mean ? launch_by_co<3, 1, 5, true, true>(a, c.TCO, stream)
                           : launch_by_co<3, 1, 5, false, true>(a, c.TCO, stream);

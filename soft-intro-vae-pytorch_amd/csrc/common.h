@@ -178,6 +178,33 @@ __device__ __forceinline__ void wave_transpose_sum8(float (&v)[8], int lane) {
 #undef SIVAE_T8_X4
 }
 
+// 16 per-lane values summed over each 16-lane ROW of the wave: on return v[0] of lane l is the total, over the row of l, of
+// the caller's v[l & 15] (the transposing steps over lane bits 0-3).  Must be called with the whole wave active.
+__device__ __forceinline__ void row16_transpose_sum16(float (&v)[16], int lane) {
+#define SIVAE_R16_STEP(CNT, BIT, RECV)                                       \
+  {                                                                          \
+    const bool sel_ = (lane >> (BIT)) & 1;                                   \
+    _Pragma("unroll") for (int i = 0; i < (CNT) / 2; ++i) {                  \
+      const float keep_ = sel_ ? v[2 * i + 1] : v[2 * i];                    \
+      const float send_ = sel_ ? v[2 * i] : v[2 * i + 1];                    \
+      v[i] = keep_ + RECV(send_);                                            \
+    }                                                                        \
+  }
+#define SIVAE_R16_Q1(X) dpp_mov_f32<0xB1, 0xf>(X)
+#define SIVAE_R16_Q2(X) dpp_mov_f32<0x4E, 0xf>(X)
+#define SIVAE_R16_X4(X) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, X), 0x101f))
+#define SIVAE_R16_R8(X) dpp_mov_f32<0x128, 0xf>(X)
+  SIVAE_R16_STEP(16, 0, SIVAE_R16_Q1)
+  SIVAE_R16_STEP(8, 1, SIVAE_R16_Q2)
+  SIVAE_R16_STEP(4, 2, SIVAE_R16_X4)
+  SIVAE_R16_STEP(2, 3, SIVAE_R16_R8)
+#undef SIVAE_R16_STEP
+#undef SIVAE_R16_Q1
+#undef SIVAE_R16_Q2
+#undef SIVAE_R16_X4
+#undef SIVAE_R16_R8
+}
+
 // Block-wide sum of doubles for blocks of NT threads (NT multiple of 64, <= 1024).
 // `red` must hold NT/64 doubles of LDS. Result valid in every thread.
 template <int NT>
