@@ -490,6 +490,23 @@ int sivae_bf16_bn_bwd_fused(const void* dy, int dy_pooled, const void* y, const 
                             const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
                             void* dx, void* dz, int dz_sum, float* dgamma, float* dbeta, int B, int C, int H, int W,
                             unsigned int* state, void* workspace, size_t workspace_bytes, sivae_stream_t stream);
+/* SEGMENTED batches of the bf16 mode (see "segmented batches" below: B = nseg * seg_images images laid end to end, mean /
+ * invstd [nseg][C], gamma / beta [C], dgamma / dbeta summed over the passes in pass order).  The bf16 convolutions have
+ * no BatchNorm prologue in the default configuration (functional16.MATERIALIZE_H), their statistics rows are in image
+ * order, and the weight gradients sum over the whole batch — so the two BatchNorm kernels are all that needs a _seg form
+ * for the pass pairs of train_soft_intro_vae.py:567-568, :601-608 to run as one launch per layer.  seg_images == B is the
+ * plain form (the entry points above forward to these). */
+int sivae_bf16_bn_apply_act_seg(const void* x, const void* res, int res_up, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, float slope, void* y, void* y_pool,
+                                unsigned char* sign_mask, int B, int C, int H, int W, int seg_images,
+                                sivae_stream_t stream);
+int sivae_bf16_bn_bwd_fused_seg_supported(int B, int C, int H, int W, int seg_images);
+size_t sivae_bf16_bn_bwd_fused_seg_workspace_bytes(int B, int C, int H, int W, int seg_images);
+int sivae_bf16_bn_bwd_fused_seg(const void* dy, int dy_pooled, const void* y, const unsigned char* sign_mask,
+                                const void* x, const float* mean, const float* invstd, const float* gamma,
+                                const float* beta, float slope, void* dx, void* dz, int dz_sum, float* dgamma,
+                                float* dbeta, int B, int C, int H, int W, int seg_images, unsigned int* state,
+                                void* workspace, size_t workspace_bytes, sivae_stream_t stream);
 int sivae_bf16_upsample2_fwd(const void* x, void* y, int B, int C, int Hs, int Ws, sivae_stream_t stream);
 int sivae_bf16_upsample2_bwd(const void* dy, void* dx, int B, int C, int Hs, int Ws, sivae_stream_t stream);
 int sivae_bf16_add_inplace(void* y, const void* x, size_t nvec, sivae_stream_t stream);

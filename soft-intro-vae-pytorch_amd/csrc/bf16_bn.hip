@@ -147,23 +147,29 @@ __global__ void __launch_bounds__(256) bf16_bn_apply_kernel(const void* __restri
                                                             const float* __restrict__ beta, float slope,
                                                             void* __restrict__ y, void* __restrict__ yp,
                                                             unsigned char* __restrict__ mask, int B, int C, int Cb,
-                                                            int H, int W) {
-  extern __shared__ __attribute__((aligned(16))) float tab[];  // [Cb][2][8]
-  for (int c = threadIdx.x; c < Cb * 8; c += blockDim.x) {
+                                                            int H, int W, int seg_images) {
+  // SEGMENTED batch (seg_images < B: B / seg_images passes laid end to end, mean / invstd [nseg][C], shared gamma / beta):
+  // one table row per (segment, channel block); image b reads row (b / seg_images) * Cb + cb
+  extern __shared__ __attribute__((aligned(16))) float tab[];  // [nseg][Cb][2][8]
+  const int nseg = B / seg_images;
+  for (int i = threadIdx.x; i < nseg * Cb * 8; i += blockDim.x) {
+    const int sg = i / (Cb * 8), c = i - sg * (Cb * 8);
     float sc = 0.f, sh = 0.f;
     if (c < C) {
-      sc = invstd[c] * gamma[c];
-      sh = beta[c] - mean[c] * sc;
+      sc = invstd[sg * C + c] * gamma[c];
+      sh = beta[c] - mean[sg * C + c] * sc;
     }
-    tab[((c >> 3) * 2 + 0) * 8 + (c & 7)] = sc;
-    tab[((c >> 3) * 2 + 1) * 8 + (c & 7)] = sh;
+    tab[((sg * Cb + (c >> 3)) * 2 + 0) * 8 + (c & 7)] = sc;
+    tab[((sg * Cb + (c >> 3)) * 2 + 1) * 8 + (c & 7)] = sh;
   }
   __syncthreads();
   const int HW = H * W;
   if (!QUAD) {
     const size_t n = (size_t)B * Cb * HW;
     for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (size_t)gridDim.x * blockDim.x) {
-      const int cb = (int)((v / HW) % Cb);
+      const unsigned bc = (unsigned)(v / HW);  // b * Cb + cb
+      const unsigned b = bc / (unsigned)Cb;
+      const int cb = (int)(bc - b * (unsigned)Cb + (b / (unsigned)seg_images) * (unsigned)Cb);  // (table row)
       float p[2][8], f[8];
       load_tab<2>(tab, cb, p);
       unpack8(ldv(x, v), f);
@@ -188,7 +194,8 @@ __global__ void __launch_bounds__(256) bf16_bn_apply_kernel(const void* __restri
       const size_t t = qd / Wh;
       const int hq = (int)(t % Hh);
       const size_t bc = t / Hh;  // b * Cb + cb
-      const int cb = (int)(bc % Cb);
+      const unsigned bi = (unsigned)bc / (unsigned)Cb;
+      const int cb = (int)((unsigned)bc - bi * (unsigned)Cb + (bi / (unsigned)seg_images) * (unsigned)Cb);  // (table row)
       float p[2][8];
       load_tab<2>(tab, cb, p);
       float rh[8];
@@ -554,28 +561,41 @@ extern "C" size_t sivae_bf16_bn_signmask_bytes(int B, int C, int H, int W) {
   return (size_t)B * bf16_cblocks(C) * H * W;  // one byte per 8-channel pixel vector
 }
 
-extern "C" int sivae_bf16_bn_apply_act(const void* x, const void* res, int res_up, const float* mean,
-                                       const float* invstd, const float* gamma, const float* beta, float slope,
-                                       void* y, void* y_pool, unsigned char* sign_mask, int B, int C, int H, int W,
-                                       hipStream_t stream) {
+// SEGMENTED batch: B = nseg * seg_images images, mean / invstd [nseg][C] (one set of batch statistics per pass of
+// seg_images images), gamma / beta [C] — the bf16 twin of sivae_bn_apply_act_seg (bn.hip); seg_images == B is the plain form
+extern "C" int sivae_bf16_bn_apply_act_seg(const void* x, const void* res, int res_up, const float* mean,
+                                           const float* invstd, const float* gamma, const float* beta, float slope,
+                                           void* y, void* y_pool, unsigned char* sign_mask, int B, int C, int H, int W,
+                                           int seg_images, hipStream_t stream) {
   if (!x || !mean || !invstd || !gamma || !beta || (!y && !y_pool)) return SIVAE_ERR_NULL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return SIVAE_ERR_SHAPE;
+  if (seg_images <= 0 || B % seg_images != 0) return SIVAE_ERR_SHAPE;
+  if ((size_t)(B / seg_images) * bf16_cblocks(C) * 16 * sizeof(float) > 48 * 1024) return SIVAE_ERR_SHAPE;
   if (res_up && !res) return SIVAE_ERR_NULL;
   const bool quad = y_pool != nullptr || res_up;
   if (quad && ((H & 1) || (W & 1))) return SIVAE_ERR_SHAPE;
   const int Cb = bf16_cblocks(C);
-  const size_t lds = (size_t)Cb * 16 * sizeof(float);
+  if ((unsigned long long)B * Cb >= 0xffffffffull) return SIVAE_ERR_RANGE;
+  const size_t lds = (size_t)(B / seg_images) * Cb * 16 * sizeof(float);
   if (quad) {
     const size_t n = (size_t)B * Cb * (H / 2) * (W / 2);
     hipLaunchKernelGGL(bf16_bn_apply_kernel<true>, dim3(grid_for(n)), dim3(256), lds, stream, x, res, res_up, mean,
-                       invstd, gamma, beta, slope, y, y_pool, sign_mask, B, C, Cb, H, W);
+                       invstd, gamma, beta, slope, y, y_pool, sign_mask, B, C, Cb, H, W, seg_images);
   } else {
     if (!y) return SIVAE_ERR_NULL;
     const size_t n = (size_t)B * Cb * H * W;
     hipLaunchKernelGGL(bf16_bn_apply_kernel<false>, dim3(grid_for(n)), dim3(256), lds, stream, x, res, res_up, mean,
-                       invstd, gamma, beta, slope, y, y_pool, sign_mask, B, C, Cb, H, W);
+                       invstd, gamma, beta, slope, y, y_pool, sign_mask, B, C, Cb, H, W, seg_images);
   }
   return sivae_launch_status();
+}
+
+extern "C" int sivae_bf16_bn_apply_act(const void* x, const void* res, int res_up, const float* mean,
+                                       const float* invstd, const float* gamma, const float* beta, float slope,
+                                       void* y, void* y_pool, unsigned char* sign_mask, int B, int C, int H, int W,
+                                       hipStream_t stream) {
+  return sivae_bf16_bn_apply_act_seg(x, res, res_up, mean, invstd, gamma, beta, slope, y, y_pool, sign_mask, B, C, H, W,
+                                     B, stream);
 }
 
 static int bn_bwd_slices(int B, int C, int H, int W) {

@@ -30,11 +30,13 @@ struct Bf16BnFusedArgs {
   void* dz;
   float* dgamma;
   float* dbeta;
-  double* part;  // [Cb][spc][16]
+  double* part;  // [VCb][spc][16]
+  double* sums;  // [VCb][16]: a (segment, channel block)'s 16 sums, published for the dgamma / dbeta fold (nseg > 1)
   unsigned* bar;
   float inv_n;
   float slope;
-  int C, Cb, H, W, B;
+  int C, Cb, H, W, B;  // B: images of ONE segment (a plane set = one channel block of one segment's images)
+  int nseg, VCb;       // segments of the batch; VCb = nseg * Cb "virtual" channel blocks, segment-major
   int l2_qpp, l2_qw;  // log2(quads per plane), log2(quads per row); a quad = 2 x 2 pixels
   int spc, cpg, ngroups, nx, nsub, local;
   int dzmode;  // 0 none, 1 full resolution, 2 2x2 block sums
@@ -80,6 +82,7 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
   const int sub = (!local && (int)blockIdx.x >= nb_sub) ? 1 : 0;
   const int bid = (int)blockIdx.x - sub * nb_sub;
   unsigned* bar = a.bar + sub * BF_BAR_UINTS;
+  unsigned* chcnt = a.bar + 2 * BF_BAR_UINTS;  // per-channel-block segment-arrival counters (bn_fused.hip's, zero at rest)
   const int xcd = bid % a.nx;
   const unsigned bpx = (unsigned)(nb_sub / a.nx);
   __shared__ int bar_failed;
@@ -111,8 +114,10 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
     const unsigned b = q >> a.l2_qpp, r = q & qpp_m;
     return q < (unsigned)nq ? b * (img_pitch >> 2) + r * 16u : BF_OOB;
   };
-  auto request_x = [&](int cbn) {  // x of channel block cbn (this block's slab) -> LDS, 4 * PFU LDS-direct loads
-    const __amdgpu_buffer_rsrc_t rxn = make_rsrc(reinterpret_cast<const char*>(a.x) + (size_t)cbn * HW * 16, win);
+  auto request_x = [&](int vcbn) {  // x of virtual channel block vcbn (this block's slab) -> LDS, 4 * PFU LDS-direct loads
+    const int segn = vcbn / Cb, cbn = vcbn - segn * Cb;
+    const __amdgpu_buffer_rsrc_t rxn =
+        make_rsrc(reinterpret_cast<const char*>(a.x) + ((size_t)segn * a.B * Cb + cbn) * HW * 16, win);
 #pragma unroll
     for (int j = 0; j < PFU; ++j) {
       const unsigned vo = quad_off(qbase + j * 256);
@@ -123,10 +128,11 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
                                                  16, (int)((v & 1) ? vo1 : vo), (int)((v >> 1) ? row_b : 0u), 0, 0);
     }
   };
-  if (pf && !local && ci < a.cpg && sub * a.cpg + ci < Cb && sub < a.ngroups) request_x(sub * a.cpg + ci);
+  if (pf && !local && ci < a.cpg && sub * a.cpg + ci < a.VCb && sub < a.ngroups) request_x(sub * a.cpg + ci);
   for (int grp = sub; grp < (local ? 1 : a.ngroups); grp += a.nsub) {
-    const int cb = local ? bid : grp * a.cpg + ci;
-    const bool active = local ? true : (ci < a.cpg && cb < Cb);
+    const int vcb = local ? bid : grp * a.cpg + ci;  // (segment, channel block), segment-major
+    const bool active = local ? true : (ci < a.cpg && vcb < a.VCb);
+    const int seg = vcb / Cb, cb = vcb - seg * Cb;
     unsigned sg_bits[NU];  // sign bytes of the quad's 4 vectors (row 0: bytes 0, 1; row 1: bytes 2, 3)
     float mu[8], is[8];
     double tsum = 0.0;  // (threads t < 256: value t & 15 of the channel block's 16 sums)
@@ -135,10 +141,10 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
       for (int e = 0; e < 8; ++e) {
         const int c = cb * 8 + e;
         const bool ok = c < a.C;
-        mu[e] = ok ? a.mean[c] : 0.f;
-        is[e] = ok ? a.invstd[c] : 0.f;
+        mu[e] = ok ? a.mean[seg * a.C + c] : 0.f;
+        is[e] = ok ? a.invstd[seg * a.C + c] : 0.f;
       }
-      const size_t base = (size_t)cb * HW;  // vector index of the channel block's plane in image 0
+      const size_t base = ((size_t)seg * a.B * Cb + cb) * HW;  // vector index of the plane in the segment's first image
       const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(a.x) + base * 16, win);
       const __amdgpu_buffer_rsrc_t rdy =
           POOL ? make_rsrc(reinterpret_cast<const char*>(a.dy) + (base >> 2) * 16, win >> 2)
@@ -276,7 +282,7 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
         if (local)
           tsum = (double)s;
         else
-          __hip_atomic_store(a.part + ((size_t)cb * a.spc + slab) * 16 + t, (double)s, __ATOMIC_RELAXED,
+          __hip_atomic_store(a.part + ((size_t)vcb * a.spc + slab) * 16 + t, (double)s, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
       }
     }
@@ -287,7 +293,7 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
       }
       if (pf) {
         const int cbn = (grp + a.nsub) * a.cpg + ci;
-        if (grp + a.nsub < a.ngroups && ci < a.cpg && cbn < Cb) request_x(cbn);
+        if (grp + a.nsub < a.ngroups && ci < a.cpg && cbn < a.VCb) request_x(cbn);
       }
       if (t == 0) bar_failed = bf_grid_wait(bar, a.bar + BF_POISON_WORD, xcd, target, a.spin_limit) ? 0 : 1;
       __syncthreads();
@@ -297,7 +303,7 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
       // rows folded in order through LDS — the same in every block of the channel block
       const int v = t & 15, r = t >> 4;
       double acc = 0.0;
-      for (int s = r; s < a.spc; s += 16) acc += bf_load_f64(a.part + ((size_t)cb * a.spc + s) * 16 + v);
+      for (int s = r; s < a.spc; s += 16) acc += bf_load_f64(a.part + ((size_t)vcb * a.spc + s) * 16 + v);
       red2[r][v] = acc;
       __syncthreads();
       if (t < 16) {
@@ -309,11 +315,31 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
     }
     if (t < 16) {
       coef[t] = (float)tsum * a.inv_n;
-      if (slab == 0) {
+      if (slab == 0 && (a.dbeta != nullptr || a.dgamma != nullptr)) {
         const int c = cb * 8 + (t & 7);
-        if (c < a.C) {
-          if (t < 8 && a.dbeta) a.dbeta[c] = (float)tsum;
-          if (t >= 8 && a.dgamma) a.dgamma[c] = (float)tsum;
+        if (a.nseg == 1) {
+          if (c < a.C) {
+            if (t < 8 && a.dbeta) a.dbeta[c] = (float)tsum;
+            if (t >= 8 && a.dgamma) a.dgamma[c] = (float)tsum;
+          }
+        } else {
+          // dgamma / dbeta sum over the segments of a channel: publish this segment's 16 sums; the LAST segment leader
+          // of the channel block to arrive adds them in segment order (bn_fused.hip's protocol: the result does not
+          // depend on which one is last) and puts the counter back to zero
+          __hip_atomic_store(a.sums + (size_t)vcb * 16 + t, tsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          unsigned done = 0;
+          if (t == 0) done = __hip_atomic_fetch_add(chcnt + cb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          done = (unsigned)__builtin_amdgcn_readfirstlane((int)done);
+          if (done == (unsigned)a.nseg - 1u) {
+            double u = 0.0;
+            for (int g = 0; g < a.nseg; ++g) u += bf_load_f64(a.sums + ((size_t)g * Cb + cb) * 16 + t);
+            if (c < a.C) {
+              if (t < 8 && a.dbeta) a.dbeta[c] = (float)u;
+              if (t >= 8 && a.dgamma) a.dgamma[c] = (float)u;
+            }
+            if (t == 0) __hip_atomic_store(chcnt + cb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       }
     }
@@ -327,7 +353,7 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
       c1[e] = coef[e];
       c2[e] = coef[8 + e];
     }
-    const size_t base = (size_t)cb * HW;
+    const size_t base = ((size_t)seg * a.B * Cb + cb) * HW;
     const __amdgpu_buffer_rsrc_t rdx = make_rsrc(reinterpret_cast<char*>(a.dx) + base * 16, win);
     const __amdgpu_buffer_rsrc_t rdz =
         a.dzmode == 2 ? make_rsrc(reinterpret_cast<char*>(a.dz) + (base >> 2) * 16, win >> 2)
@@ -448,39 +474,55 @@ static inline bool b16_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 }  // namespace
 
-// power-of-two maps from 2x2 up whose channel-block plane sets fit one group of the grid
-extern "C" int sivae_bf16_bn_bwd_fused_supported(int B, int C, int H, int W) {
+// power-of-two maps from 2x2 up whose (segment, channel block) plane sets fit one group of the grid; B = nseg * seg_images
+extern "C" int sivae_bf16_bn_bwd_fused_seg_supported(int B, int C, int H, int W, int seg_images) {
   if (B <= 0 || C <= 0 || !b16_pow2(H) || !b16_pow2(W) || H < 2 || W < 2) return 0;
+  if (seg_images <= 0 || B % seg_images != 0) return 0;
   const int Cb = bf16_cblocks(C);
-  if ((long long)B * Cb * H * W * 16 >= 0xfffffe00LL) return 0;
+  if (Cb > BF_CH_COUNTERS) return 0;
+  if ((long long)seg_images * Cb * H * W * 16 >= 0xfffffe00LL) return 0;  // (a plane set's window: 32-bit byte offsets)
   B16Plan p;
-  return b16_plan(B, Cb, H * W, &p) ? 1 : 0;
+  return b16_plan(seg_images, (B / seg_images) * Cb, H * W, &p) ? 1 : 0;
+}
+
+extern "C" int sivae_bf16_bn_bwd_fused_supported(int B, int C, int H, int W) {
+  return sivae_bf16_bn_bwd_fused_seg_supported(B, C, H, W, B);
+}
+
+// partial sums [VCb][spc][16] + per-(segment, channel block) sums [VCb][16], doubles
+extern "C" size_t sivae_bf16_bn_bwd_fused_seg_workspace_bytes(int B, int C, int H, int W, int seg_images) {
+  if (!sivae_bf16_bn_bwd_fused_seg_supported(B, C, H, W, seg_images)) return 0;
+  const int VCb = (B / seg_images) * bf16_cblocks(C);
+  B16Plan p;
+  b16_plan(seg_images, VCb, H * W, &p);
+  return ((size_t)VCb * p.spc * 16 + (size_t)VCb * 16) * sizeof(double) + 16;
 }
 
 extern "C" size_t sivae_bf16_bn_bwd_fused_workspace_bytes(int B, int C, int H, int W) {
-  if (!sivae_bf16_bn_bwd_fused_supported(B, C, H, W)) return 0;
-  B16Plan p;
-  b16_plan(B, bf16_cblocks(C), H * W, &p);
-  return (size_t)bf16_cblocks(C) * p.spc * 16 * sizeof(double) + 16;
+  return sivae_bf16_bn_bwd_fused_seg_workspace_bytes(B, C, H, W, B);
 }
 
 // sivae_bf16_bn_bwd (bf16_bn.hip) as one launch; same arguments + `state` (the zero-initialised-once barrier state of
 // sivae_bn_bwd_fused: sivae_bn_bwd_fused_state_uints() unsigned ints, one buffer per stream).  The persistent form needs
 // its whole grid (2 blocks per CU) resident.
-extern "C" int sivae_bf16_bn_bwd_fused(const void* dy, int dy_pooled, const void* y, const unsigned char* sign_mask,
-                                       const void* x, const float* mean, const float* invstd, const float* gamma,
-                                       const float* beta, float slope, void* dx, void* dz, int dz_sum, float* dgamma,
-                                       float* dbeta, int B, int C, int H, int W, unsigned int* state, void* workspace,
-                                       size_t workspace_bytes, hipStream_t stream) {
+//
+// SEGMENTED batch (sivae_bf16_bn_bwd_fused_seg): B = nseg * seg_images images, mean / invstd [nseg][C] (per-pass batch
+// statistics), dgamma / dbeta [C] summed over the segments in segment order — the bf16 twin of sivae_bn_bwd_fused (bn_fused.hip).
+extern "C" int sivae_bf16_bn_bwd_fused_seg(const void* dy, int dy_pooled, const void* y, const unsigned char* sign_mask,
+                                           const void* x, const float* mean, const float* invstd, const float* gamma,
+                                           const float* beta, float slope, void* dx, void* dz, int dz_sum, float* dgamma,
+                                           float* dbeta, int B, int C, int H, int W, int seg_images, unsigned int* state,
+                                           void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!dy || !x || !mean || !invstd || !gamma || !dx || !workspace || !state) return SIVAE_ERR_NULL;
   if (!y && !sign_mask && !beta) return SIVAE_ERR_NULL;
   if (dz_sum && !dz) return SIVAE_ERR_NULL;
   if (dy_pooled && dz_sum) return SIVAE_ERR_MODE;
-  if (!sivae_bf16_bn_bwd_fused_supported(B, C, H, W)) return SIVAE_ERR_SHAPE;
-  if (workspace_bytes < sivae_bf16_bn_bwd_fused_workspace_bytes(B, C, H, W)) return SIVAE_ERR_WORKSPACE;
+  if (!sivae_bf16_bn_bwd_fused_seg_supported(B, C, H, W, seg_images)) return SIVAE_ERR_SHAPE;
+  if (workspace_bytes < sivae_bf16_bn_bwd_fused_seg_workspace_bytes(B, C, H, W, seg_images)) return SIVAE_ERR_WORKSPACE;
   const int Cb = bf16_cblocks(C);
+  const int nseg = B / seg_images, VCb = nseg * Cb;
   B16Plan p;
-  b16_plan(B, Cb, H * W, &p);
+  b16_plan(seg_images, VCb, H * W, &p);
   Bf16BnFusedArgs a;
   a.dy = dy;
   a.y = y;
@@ -495,14 +537,17 @@ extern "C" int sivae_bf16_bn_bwd_fused(const void* dy, int dy_pooled, const void
   a.dgamma = dgamma;
   a.dbeta = dbeta;
   a.part = (double*)workspace;
+  a.sums = a.part + (size_t)VCb * p.spc * 16;
   a.bar = state;
-  a.inv_n = 1.0f / ((float)B * H * W);
+  a.inv_n = 1.0f / ((float)seg_images * H * W);
   a.slope = slope;
   a.C = C;
   a.Cb = Cb;
   a.H = H;
   a.W = W;
-  a.B = B;
+  a.B = seg_images;
+  a.nseg = nseg;
+  a.VCb = VCb;
   a.l2_qpp = ilog2_exact(H * W / 4);
   a.l2_qw = ilog2_exact(W / 2);
   a.spc = p.spc;
@@ -521,7 +566,7 @@ extern "C" int sivae_bf16_bn_bwd_fused(const void* dy, int dy_pooled, const void
   a.pf = (pf_on && !p.local && p.nu == 4 && p.ngroups > p.nsub && b16_occupancy(true) >= 2) ? 1 : 0;
   const size_t lds = a.pf ? (size_t)3 * 4 * 256 * 16 : 0;  // 48 KB
   const int act = sign_mask ? 3 : (y ? 1 : 2);
-  const dim3 grid((unsigned)(p.local ? Cb : p.nsub * p.nb_sub)), block(256);
+  const dim3 grid((unsigned)(p.local ? VCb : p.nsub * p.nb_sub)), block(256);
 #define B16_LAUNCH(A, P, N) hipLaunchKernelGGL((bf16_bn_bwd_fused_kernel<A, P, N>), grid, block, lds, stream, a)
 #define B16_NU(A, P)                       \
   {                                        \
@@ -538,4 +583,13 @@ extern "C" int sivae_bf16_bn_bwd_fused(const void* dy, int dy_pooled, const void
 #undef B16_NU
 #undef B16_LAUNCH
   return sivae_launch_status();
+}
+
+extern "C" int sivae_bf16_bn_bwd_fused(const void* dy, int dy_pooled, const void* y, const unsigned char* sign_mask,
+                                       const void* x, const float* mean, const float* invstd, const float* gamma,
+                                       const float* beta, float slope, void* dx, void* dz, int dz_sum, float* dgamma,
+                                       float* dbeta, int B, int C, int H, int W, unsigned int* state, void* workspace,
+                                       size_t workspace_bytes, hipStream_t stream) {
+  return sivae_bf16_bn_bwd_fused_seg(dy, dy_pooled, y, sign_mask, x, mean, invstd, gamma, beta, slope, dx, dz, dz_sum,
+                                     dgamma, dbeta, B, C, H, W, B, state, workspace, workspace_bytes, stream);
 }

@@ -109,11 +109,22 @@ def from_blocked(xb, C):
 
 class ResBlockFn16(torch.autograd.Function):
     """ResidualBlock.forward (train_soft_intro_vae.py:65-75) on blocked bf16 activations; arguments as
-    functional.ResBlockFn (x_up: x is stored at half resolution and stands for Upsample(2)(x))"""
+    functional.ResBlockFn (x_up: x is stored at half resolution and stands for Upsample(2)(x); nseg > 1: a SEGMENTED
+    batch — nseg passes of the network laid end to end, one set of BatchNorm batch statistics per pass, the running
+    buffers updated once per pass in pass order (seg_rev: last first); replay_update=False: a replay of a `cache_segment`
+    view leaves the running buffers alone).  The bf16 convolutions take a segmented batch as it is: they have no
+    BatchNorm prologue (MATERIALIZE_H), their statistics rows are in image order and never straddle two passes
+    (ops.bn_stats_from_conv checks), and the weight gradients sum over the whole batch like the reference's two
+    backward passes through one parameter do."""
 
     @staticmethod
-    def forward(ctx, x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache=None, x_up=False):
+    def forward(ctx, x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache=None, x_up=False, nseg=1, seg_rev=False,
+                replay_update=True):
         SF._claim(ctx, ((1, w_exp), (2, w1), (3, g1), (4, b1), (5, w2), (6, g2), (7, b2)))
+        if nseg > 1 and not MATERIALIZE_H:
+            raise NotImplementedError("sivae_hip: segmented bf16 batches need SIVAE_BF16_MATERIALIZE_H=1 (the fused "
+                                      "BatchNorm prologue of the bf16 convs has no per-segment form)")
+        ctx.nseg = nseg
         B, Cib, Hs, Ws, _ = x.shape
         H, W = (2 * Hs, 2 * Ws) if x_up else (Hs, Ws)
         Cm, Ci, Co = w1.shape[0], w1.shape[1], w2.shape[0]
@@ -124,10 +135,15 @@ class ResBlockFn16(torch.autograd.Function):
         if cache is not None and cache.get("y") is not None and cache.get("tag") == tag:
             a, h, c, out, mean1, invstd1, mean2, invstd2, y = (cache[k] for k in (
                 "a", "h", "c", "out", "mean1", "invstd1", "mean2", "invstd2", "y"))
-            SF._replay_bn(st1, mean1, invstd1, B * H * W)
-            SF._replay_bn(st2, mean2, invstd2, B * H * W)
+            if replay_update:
+                SF._replay_bn(st1, mean1, invstd1, (B // nseg) * H * W, nseg, seg_rev)
+                SF._replay_bn(st2, mean2, invstd2, (B // nseg) * H * W, nseg, seg_rev)
             ctx.save_for_backward(x, a, h, c, out, mean1, invstd1, mean2, invstd2, w_exp, w1, g1, b1, w2, g2, b2)
             return y.view_as(y)
+        if not replay_update:
+            # (functional.ResBlockFn: a `cache_segment` view that cannot be replayed must not be recomputed with a
+            # running-statistics update the reference never makes)
+            raise RuntimeError("sivae_hip: replay_update=False needs a filled, current replay cache for this block")
         idt = x
         if w_exp is not None:
             idt = ops16.conv2d(x, packed16(w_exp, 0), Ci, Co, 1)  # (at half resolution with x_up: commutes with Upsample)
@@ -135,9 +151,9 @@ class ResBlockFn16(torch.autograd.Function):
             a, p1 = ops16.conv2d(x, packed16(w1, 0), Ci, Cm, 3, want_stats=True, upsample=x_up)
         else:
             a, p1 = ops16.conv2d(x, packed16(w1, 0), Ci, Cm, 3, upsample=x_up), None
-        mean1, invstd1 = SF._stats(p1, B, Cm, H * W, st1)
+        mean1, invstd1 = SF._stats(p1, B, Cm, H * W, st1, nseg, seg_rev)
         if MATERIALIZE_H:
-            h, _ = ops16.bn_apply_act(a, None, mean1, invstd1, g1.detach(), b1.detach(), Cm, SLOPE)
+            h, _ = ops16.bn_apply_act(a, None, mean1, invstd1, g1.detach(), b1.detach(), Cm, SLOPE, nseg=nseg)
             pro1 = None
         else:
             h, pro1 = a, (mean1, invstd1, g1.detach(), b1.detach(), SLOPE)
@@ -145,16 +161,16 @@ class ResBlockFn16(torch.autograd.Function):
             c, p2 = ops16.conv2d(h, packed16(w2, 0), Cm, Co, 3, pro=pro1, want_stats=True)
         else:
             c, p2 = ops16.conv2d(h, packed16(w2, 0), Cm, Co, 3, pro=pro1), None
-        mean2, invstd2 = SF._stats(p2, B, Co, H * W, st2)
+        mean2, invstd2 = SF._stats(p2, B, Co, H * W, st2, nseg, seg_rev)
         pool = post == "pool"
         if ctx.training and SIGNMASK:
             # the backward takes the LeakyReLU sign from a 1-bit-per-element mask written here (`out` below IS that mask),
             # and a pooled block never writes its full-resolution output
             full, yp, out = ops16.bn_apply_act(c, idt, mean2, invstd2, g2.detach(), b2.detach(), Co, SLOPE,
-                                               res_up=x_up, want_full=not pool, pool=pool, want_mask=True)
+                                               res_up=x_up, want_full=not pool, pool=pool, want_mask=True, nseg=nseg)
         else:
             full, yp = ops16.bn_apply_act(c, idt, mean2, invstd2, g2.detach(), b2.detach(), Co, SLOPE, res_up=x_up,
-                                          want_full=True, pool=pool)
+                                          want_full=True, pool=pool, nseg=nseg)
             out = full
         if pool:
             y = yp
@@ -179,7 +195,7 @@ class ResBlockFn16(torch.autograd.Function):
         need_x, need_we, need_w1, need_bn1, need_w2, need_bn2 = need[0], need[1], need[2], need[3] or need[4], \
             need[5], need[6] or need[7]
         Ci, Cm, Co = ctx.dims
-        x_up = ctx.x_up
+        x_up, nseg = ctx.x_up, ctx.nseg
         dy = dy.contiguous()
         pool = ctx.post == "pool"
         d_out = ops16.upsample2_bwd(dy, Co) if ctx.post == "up" else dy
@@ -188,7 +204,7 @@ class ResBlockFn16(torch.autograd.Function):
         pg1 = SF._pg_dst(g1, k_g1, b1, k_b1) if need_bn1 else None
         dc, dz, dg2, db2 = ops16.bn_bwd(d_out, out, c, mean2, invstd2, g2, b2, Co, SLOPE, dy_pooled=pool,
                                         want_dz=need_dz and not x_up, dz_sum=need_dz and x_up,
-                                        want_param_grads=need_bn2, pg_out=pg2)
+                                        want_param_grads=need_bn2, pg_out=pg2, nseg=nseg)
         if pg2 is not None:
             SF._done(g2, b2)
         del d_out
@@ -201,7 +217,7 @@ class ResBlockFn16(torch.autograd.Function):
         # BatchNorm-1 + LeakyReLU: the sign is recomputed from a (x-hat * gamma + beta) even when h was stored — both
         # backward passes then read two tensors (dh, a) instead of three (2 of 7 tensor passes of this BatchNorm)
         da, _, dg1, db1 = ops16.bn_bwd(dh, None, a, mean1, invstd1, g1, b1, Cm, SLOPE, want_param_grads=need_bn1,
-                                       pg_out=pg1)
+                                       pg_out=pg1, nseg=nseg)
         if pg1 is not None:
             SF._done(g1, b1)
         del dh
@@ -232,7 +248,7 @@ class ResBlockFn16(torch.autograd.Function):
                 dg1 if (need[3] and pg1 is None) else None, db1 if (need[4] and pg1 is None) else None,
                 dw2 if k_w2 < 0 else None,
                 dg2 if (need[6] and pg2 is None) else None, db2 if (need[7] and pg2 is None) else None,
-                None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
 class StemFn16(torch.autograd.Function):
@@ -240,8 +256,9 @@ class StemFn16(torch.autograd.Function):
     out: blocked bf16.  With <= 3 image channels the conv runs kw-packed (5 taps over 5C channels)."""
 
     @staticmethod
-    def forward(ctx, x, w, g, b, st):
+    def forward(ctx, x, w, g, b, st, nseg=1, seg_rev=False):
         SF._claim(ctx, ((1, w), (2, g), (3, b)))
+        ctx.nseg = nseg
         B, Ci, H, W = x.shape
         Co = w.shape[0]
         ctx.kw = _kwpack_ok(w, Ci)
@@ -253,9 +270,9 @@ class StemFn16(torch.autograd.Function):
             a, p = ops16.conv2d(xb, wp, ci_eff, Co, ks, want_stats=True)
         else:
             a, p = ops16.conv2d(xb, wp, ci_eff, Co, ks), None
-        mean, invstd = SF._stats(p, B, Co, H * W, st)
+        mean, invstd = SF._stats(p, B, Co, H * W, st, nseg, seg_rev)
         _, out = ops16.bn_apply_act(a, None, mean, invstd, g.detach(), b.detach(), Co, SLOPE, want_full=False,
-                                    pool=True)
+                                    pool=True, nseg=nseg)
         ctx.training = st.training
         ctx.Ci = Ci
         ctx.save_for_backward(xb, a, mean, invstd, w, g, b)
@@ -271,7 +288,7 @@ class StemFn16(torch.autograd.Function):
         Co, Ci, ks = w.shape[0], ctx.Ci, w.shape[2]
         pg = SF._pg_dst(g, k_g, b, k_b) if (need[2] or need[3]) else None
         da, _, dg, db = ops16.bn_bwd(dy.contiguous(), None, a, mean, invstd, g, b, Co, SLOPE, dy_pooled=True,
-                                     want_param_grads=need[2] or need[3], pg_out=pg)
+                                     want_param_grads=need[2] or need[3], pg_out=pg, nseg=ctx.nseg)
         if pg is not None:
             SF._done(g, b)
         dw = dx = None
@@ -290,7 +307,7 @@ class StemFn16(torch.autograd.Function):
         if dst is not None:
             SF._done(w)
         return (dx, dw if k_w < 0 else None, dg if (need[2] and pg is None) else None,
-                db if (need[3] and pg is None) else None, None)
+                db if (need[3] and pg is None) else None, None, None, None)
 
 
 class PredictFn16(torch.autograd.Function):
@@ -341,12 +358,14 @@ class PredictFn16(torch.autograd.Function):
         return dx, dw if k_w < 0 else None, db if k_b < 0 else None, None
 
 
-def residual_block(x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post=None, cache=None, x_up=False):
-    return SF._apply(ResBlockFn16, x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache, x_up)
+def residual_block(x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post=None, cache=None, x_up=False, nseg=1,
+                   seg_rev=False, replay_update=True):
+    return SF._apply(ResBlockFn16, x, w_exp, w1, g1, b1, w2, g2, b2, st1, st2, post, cache, x_up, nseg, seg_rev,
+                     replay_update)
 
 
-def stem(x, w, g, b, st):
-    return SF._apply(StemFn16, x, w, g, b, st)
+def stem(x, w, g, b, st, nseg=1, seg_rev=False):
+    return SF._apply(StemFn16, x, w, g, b, st, nseg, seg_rev)
 
 
 def conv_bias(x, w, bias, cache=None):

@@ -49,9 +49,7 @@ class ResidualBlock(nn.Module):
                 self.bn1.bias, self.conv2.weight, self.bn2.weight, self.bn2.bias, SF.BNState(self.bn1),
                 SF.BNState(self.bn2), post, cache, x_up)
         if x.dtype == torch.bfloat16:
-            if nseg != 1:
-                raise NotImplementedError("sivae_hip: segmented batches run in fp32 mode only")
-            return SF16.residual_block(*args)
+            return SF16.residual_block(*args, nseg, seg_rev, replay_update)
         return SF.residual_block(*args, nseg, seg_rev, replay_update)
 
 
@@ -78,8 +76,13 @@ def _block_weights(m):
 
 
 def segments_supported(image_size, seg_images, compute_dtype="fp32"):
-    """can `nseg` passes of seg_images images each run as ONE segmented batch through these networks?  (fp32 mode,
-    power-of-two maps, and a pass must be a whole number of the 4-image tile blocks of the 4x4 maps)"""
+    """can `nseg` passes of seg_images images each run as ONE segmented batch through these networks?  (power-of-two
+    maps, and no row of conv-epilogue statistics may straddle two passes: fp32 — a pass must be a whole number of the
+    4-image tile blocks of the 4x4 maps; bf16 mode — its pixel tiles hold up to 16 whole images of a 4x4 map, and the
+    BatchNorm prologue must be off, functional16.MATERIALIZE_H)"""
+    if compute_dtype == "bf16":
+        return (SF16.MATERIALIZE_H and image_size >= 32 and (image_size & (image_size - 1)) == 0
+                and seg_images % 16 == 0 and SF.ops.SYNC_BN is None)
     return (compute_dtype == "fp32" and image_size >= 32 and (image_size & (image_size - 1)) == 0
             and seg_images % 4 == 0 and SF.ops.SYNC_BN is None)
 
@@ -126,10 +129,7 @@ def _run_main(main, x, cache=None, bf16=None, nseg=1, seg_rev=False, replay_upda
         elif isinstance(m, nn.Conv2d) and isinstance(nxt, nn.BatchNorm2d):
             # encoder stem: conv5x5 -> BN -> LeakyReLU -> AvgPool2d
             assert isinstance(mods[i + 2], nn.LeakyReLU) and isinstance(mods[i + 3], nn.AvgPool2d)
-            if nseg != 1:
-                x = SF.stem(x, m.weight, nxt.weight, nxt.bias, SF.BNState(nxt), nseg, seg_rev)
-            else:
-                x = F_.stem(x, m.weight, nxt.weight, nxt.bias, SF.BNState(nxt))
+            x = F_.stem(x, m.weight, nxt.weight, nxt.bias, SF.BNState(nxt), nseg, seg_rev)
             i += 4
         elif isinstance(m, nn.Conv2d):
             x = F_.conv_bias(x, m.weight, m.bias, sub)
@@ -195,16 +195,13 @@ class Encoder(nn.Module):
         """nseg > 1: x is nseg independent batches laid end to end (a SEGMENTED batch): one pass of the kernels, per-segment
         BatchNorm statistics, running buffers updated once per segment in order (seg_rev: last first) — numerically the
         reference's nseg separate calls (train_soft_intro_vae.py:567-568, :601-605)."""
-        if nseg != 1:
-            if self.compute_dtype == "bf16":
-                raise NotImplementedError("sivae_hip: segmented batches run in fp32 mode only")
-            y = _run_main(self.main, x, nseg=nseg, seg_rev=seg_rev).reshape(x.size(0), -1)
-        elif self.compute_dtype == "bf16":
+        if self.compute_dtype == "bf16":
             # (the stem takes the fp32 image itself: it chooses the operand layout of the 5x5 conv)
-            y = SF16.from_blocked(_run_main(self.main, x, bf16=True), self.conv_output_size[0])
+            y = SF16.from_blocked(_run_main(self.main, x, bf16=True, nseg=nseg, seg_rev=seg_rev),
+                                  self.conv_output_size[0])
             y = y.reshape(x.size(0), -1)
         else:
-            y = _run_main(self.main, x).reshape(x.size(0), -1)
+            y = _run_main(self.main, x, nseg=nseg, seg_rev=seg_rev).reshape(x.size(0), -1)
         if self.conditional and o_cond is not None:
             y = torch.cat([y, o_cond], dim=1)
         y = SF.linear(y, self.fc.weight, self.fc.bias)
@@ -250,8 +247,6 @@ class Decoder(nn.Module):
         replay_update=False / check_input=False: replay a `functional.cache_segment` view (one pass of a pair that already
         ran as a segmented batch): the running statistics were counted by that pass, and the cache belongs to the pair's
         input tensor, not to this z."""
-        if nseg != 1 and self.compute_dtype == "bf16":
-            raise NotImplementedError("sivae_hip: segmented batches run in fp32 mode only")
         z = z.reshape(z.size(0), -1)
         if self.conditional and y_cond is not None:
             y_cond = y_cond.reshape(y_cond.size(0), -1)

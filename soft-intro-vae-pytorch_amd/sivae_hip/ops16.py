@@ -172,27 +172,38 @@ def conv2d_wgrad(x, dy, Ci, Co, ks, pro=None, upsample=False, out=None):
     return dw
 
 
+def _seg_images(B, C, mean, nseg):
+    """images per segment of a SEGMENTED batch (nseg passes laid end to end, mean / invstd [nseg][C])"""
+    if nseg < 1 or B % nseg or mean.numel() != nseg * C:
+        raise ValueError("sivae_hip: %d images / %d statistics entries do not make %d segments of %d channels"
+                         % (B, mean.numel(), nseg, C))
+    return B // nseg
+
+
 def bn_apply_act(x, res, mean, invstd, gamma, beta, C, slope=LRELU_SLOPE, res_up=False, want_full=True, pool=False,
-                 want_mask=False):
+                 want_mask=False, nseg=1):
     """LeakyReLU(BN(x) + res) -> (y or None, AvgPool2d(2)(y) or None[, sign mask])
-    want_mask: also return the activation's sign bits (uint8, one byte per 8-channel pixel vector) for bn_bwd"""
+    want_mask: also return the activation's sign bits (uint8, one byte per 8-channel pixel vector) for bn_bwd
+    nseg > 1: SEGMENTED batch, mean / invstd [nseg][C] (functional.py)"""
     _req16(x, res)
     ops._require(mean, invstd, gamma, beta)
     B, Cb, H, W, _ = x.shape
+    bs = _seg_images(B, C, mean, nseg)
     assert want_full or pool
     y = torch.empty_like(x) if want_full else None
     yp = torch.empty((B, Cb, H // 2, W // 2, 8), dtype=torch.bfloat16, device=x.device) if pool else None
     mask = torch.empty((B, Cb, H, W), dtype=torch.uint8, device=x.device) if want_mask else None
-    _lib.call("sivae_bf16_bn_apply_act", _p(x), _p(res), int(bool(res_up)), _p(mean), _p(invstd), _p(gamma), _p(beta),
-              float(slope), _p(y), _p(yp), _p(mask), B, C, H, W, _s(x))
+    _lib.call("sivae_bf16_bn_apply_act_seg", _p(x), _p(res), int(bool(res_up)), _p(mean), _p(invstd), _p(gamma),
+              _p(beta), float(slope), _p(y), _p(yp), _p(mask), B, C, H, W, bs, _s(x))
     return (y, yp, mask) if want_mask else (y, yp)
 
 
 def bn_bwd(dy, y, x, mean, invstd, gamma, beta, C, slope=LRELU_SLOPE, dy_pooled=False, want_dz=False, dz_sum=False,
-           want_param_grads=True, pg_out=None):
+           want_param_grads=True, pg_out=None, nseg=1):
     """-> dx, dz (full resolution, its 2x2 block sums with dz_sum, or None), dgamma, dbeta.
     y: the saved block output (bf16) or its sign mask (uint8 from bn_apply_act(want_mask=True)) — the sign of the
-    activation —, or None to recompute the sign from x (needs beta)."""
+    activation —, or None to recompute the sign from x (needs beta).
+    nseg > 1: SEGMENTED batch, mean / invstd [nseg][C]; dgamma / dbeta summed over the segments in segment order."""
     mask = None
     if y is not None and y.dtype == torch.uint8:
         mask, y = y, None
@@ -201,7 +212,7 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, beta, C, slope=LRELU_SLOPE, dy_pooled=
     _req16(dy, y, x)
     ops._require(mean, invstd, gamma, beta)
     B, Cb, H, W, _ = x.shape
-    ws = ops.workspace(_lib.load().sivae_bf16_bn_bwd_workspace_bytes(B, C, H, W), x.device)
+    bs = _seg_images(B, C, mean, nseg)
     dx = torch.empty_like(x)
     dz = None
     if dz_sum:
@@ -211,16 +222,30 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, beta, C, slope=LRELU_SLOPE, dy_pooled=
     dgamma, dbeta = ops._pg(pg_out, C, x.device, want_param_grads)
     L = _lib.load()
     if (ops.BN_FUSED and ops.SYNC_BN is None and os.environ.get("SIVAE_DP_SAME_DEVICE", "0") != "1"
-            and L.sivae_bf16_bn_bwd_fused_supported(B, C, H, W) == 1):
+            and L.sivae_bf16_bn_bwd_fused_seg_supported(B, C, H, W, bs) == 1):
         # one launch, dy and x read once (bf16_bn_fused.hip)
-        ws = ops.workspace(L.sivae_bf16_bn_bwd_fused_workspace_bytes(B, C, H, W), x.device)
-        _lib.call("sivae_bf16_bn_bwd_fused", _p(dy), int(bool(dy_pooled)), _p(y), _p(mask), _p(x), _p(mean), _p(invstd),
-                  _p(gamma), _p(beta), float(slope), _p(dx), _p(dz), int(bool(dz_sum)), _p(dgamma), _p(dbeta), B, C, H, W,
-                  _p(ops.bn_fused_state(x.device)), _p(ws), ws.numel(), _s(x))
+        ws = ops.workspace(L.sivae_bf16_bn_bwd_fused_seg_workspace_bytes(B, C, H, W, bs), x.device)
+        _lib.call("sivae_bf16_bn_bwd_fused_seg", _p(dy), int(bool(dy_pooled)), _p(y), _p(mask), _p(x), _p(mean),
+                  _p(invstd), _p(gamma), _p(beta), float(slope), _p(dx), _p(dz), int(bool(dz_sum)), _p(dgamma),
+                  _p(dbeta), B, C, H, W, bs, _p(ops.bn_fused_state(x.device)), _p(ws), ws.numel(), _s(x))
         return dx, dz, dgamma, dbeta
-    _lib.call("sivae_bf16_bn_bwd", _p(dy), int(bool(dy_pooled)), _p(y), _p(mask), _p(x), _p(mean), _p(invstd), _p(gamma),
-              _p(beta), float(slope), _p(dx), _p(dz), int(bool(dz_sum)), _p(dgamma), _p(dbeta), B, C, H, W, _p(ws),
-              ws.numel(), _s(x))
+    # three-launch form (maps the one-launch form does not take, synchronised BatchNorm, two ranks on one device): a
+    # segment is a contiguous run of images, so a segmented batch is nseg calls on its slices; dgamma / dbeta are the
+    # segments' sums added in segment order
+    ws = ops.workspace(L.sivae_bf16_bn_bwd_workspace_bytes(bs, C, H, W), x.device)
+    for g in range(nseg):
+        sl = slice(g * bs, (g + 1) * bs)
+        pg = nseg > 1 and g > 0 and dgamma is not None
+        dgg = torch.empty_like(dgamma) if pg else dgamma
+        dbg = torch.empty_like(dbeta) if pg else dbeta
+        _lib.call("sivae_bf16_bn_bwd", _p(dy[sl]), int(bool(dy_pooled)), _p(None if y is None else y[sl]),
+                  _p(None if mask is None else mask[sl]), _p(x[sl]), _p(mean[g * C:(g + 1) * C]),
+                  _p(invstd[g * C:(g + 1) * C]), _p(gamma), _p(beta), float(slope), _p(dx[sl]),
+                  _p(None if dz is None else dz[sl]), int(bool(dz_sum)), _p(dgg), _p(dbg), bs, C, H, W, _p(ws),
+                  ws.numel(), _s(x))
+        if pg:
+            dgamma += dgg
+            dbeta += dbg
     return dx, dz, dgamma, dbeta
 
 

@@ -350,6 +350,77 @@ def check_bn_fused16():
     return res
 
 
+def check_bn_seg16():
+    """SEGMENTED batches of the bf16 BatchNorm kernels (sivae_bf16_bn_apply_act_seg / sivae_bf16_bn_bwd_fused_seg and the
+    per-segment calls of the three-launch form): two passes with their own batch statistics laid end to end must give
+    what the two separate calls give — outputs, sign mask, pooled output, dx and dz BIT FOR BIT (the same arithmetic per
+    element, the same partial-sum order per (segment, channel block)); dgamma / dbeta are the two passes' sums added in
+    fp64 before the one rounding (separate calls round twice): 1e-6."""
+    from sivae_hip import ops, ops16
+    res = []
+    for (Bs, C, H, W) in [(4, 64, 16, 16), (8, 520, 4, 4), (16, 64, 64, 64), (3, 40, 8, 8), (32, 16, 128, 128)]:
+        tag = "bn16_seg(2x%d,%d,%d,%d)" % (Bs, C, H, W)
+        xs = [_r16(_rand(Bs, C, H, W, seed=1)), _r16(_rand(Bs, C, H, W, seed=11) * 1.7 + 0.3)]
+        rs = [_r16(_rand(Bs, C, H, W, seed=2)), _r16(_rand(Bs, C, H, W, seed=12))]
+        rh = [_r16(_rand(Bs, C, H // 2, W // 2, seed=5)), _r16(_rand(Bs, C, H // 2, W // 2, seed=15))]
+        prm = [_bn_params(C, x) for x in xs]
+        gamma, beta = prm[0][2].float().to(DEV), prm[0][3].float().to(DEV)
+        mean = [p[0].float().to(DEV) for p in prm]
+        invstd = [p[1].float().to(DEV) for p in prm]
+        mean2, invstd2 = torch.cat(mean), torch.cat(invstd)
+        xb = [to_blocked(x).to(DEV) for x in xs]
+        rb = [to_blocked(r).to(DEV) for r in rs]
+        rhb = [to_blocked(r).to(DEV) for r in rh]
+        x2, r2, rh2 = torch.cat(xb), torch.cat(rb), torch.cat(rhb)
+        dy = [to_blocked(_r16(_rand(Bs, C, H, W, seed=3 + 10 * g))).to(DEV) for g in range(2)]
+        dyh = [to_blocked(_r16(_rand(Bs, C, H // 2, W // 2, seed=4 + 10 * g))).to(DEV) for g in range(2)]
+        dy2, dyh2 = torch.cat(dy), torch.cat(dyh)
+
+        def same(name, got, parts):
+            ok = all(torch.equal(got[g * Bs:(g + 1) * Bs], parts[g]) for g in range(2))
+            res.append(("%s %s" % (tag, name), 0.0 if ok else float("inf"), 0.0))
+
+        # ---- apply: plain / residual + mask / half-resolution residual + pool
+        for name, kw, rr in (("apply", dict(), (None, None, None)),
+                             ("apply res+mask+pool", dict(want_mask=True, pool=True), (rb[0], rb[1], r2)),
+                             ("apply res_up", dict(res_up=True, want_mask=True), (rhb[0], rhb[1], rh2))):
+            sep = [ops16.bn_apply_act(xb[g], rr[g], mean[g], invstd[g], gamma, beta, C, **kw) for g in range(2)]
+            seg = ops16.bn_apply_act(x2, rr[2], mean2, invstd2, gamma, beta, C, nseg=2, **kw)
+            for i, part in enumerate(seg):
+                if part is not None:
+                    same("%s out%d" % (name, i), part, [sep[0][i], sep[1][i]])
+        masks = [ops16.bn_apply_act(xb[g], rb[g], mean[g], invstd[g], gamma, beta, C, want_mask=True) for g in range(2)]
+        y = [m[0] for m in masks]
+        mask = [m[2] for m in masks]
+        y2, mask2 = torch.cat(y), torch.cat(mask)
+        # ---- backward: every sign source, pooled dy, dz full / block sums; one-launch and three-launch forms
+        cases = [("mask", lambda d, sg, yy, mk, xx, mu, iv, n: ops16.bn_bwd(d[0], mk, xx, mu, iv, gamma, beta, C, want_dz=True, nseg=n)),
+                 ("mask dzsum", lambda d, sg, yy, mk, xx, mu, iv, n: ops16.bn_bwd(d[0], mk, xx, mu, iv, gamma, beta, C, want_dz=True, dz_sum=True, nseg=n)),
+                 ("mask pooled", lambda d, sg, yy, mk, xx, mu, iv, n: ops16.bn_bwd(d[1], mk, xx, mu, iv, gamma, beta, C, dy_pooled=True, want_dz=True, nseg=n)),
+                 ("output", lambda d, sg, yy, mk, xx, mu, iv, n: ops16.bn_bwd(d[0], yy, xx, mu, iv, gamma, beta, C, want_dz=True, nseg=n)),
+                 ("recomputed", lambda d, sg, yy, mk, xx, mu, iv, n: ops16.bn_bwd(d[0], None, xx, mu, iv, gamma, beta, C, nseg=n)),
+                 ("recomputed pooled", lambda d, sg, yy, mk, xx, mu, iv, n: ops16.bn_bwd(d[1], None, xx, mu, iv, gamma, beta, C, dy_pooled=True, nseg=n))]
+        for fused in (True, False):
+            ops.BN_FUSED = fused
+            try:
+                for name, fn in cases:
+                    sep = [fn((dy[g], dyh[g]), g, y[g], mask[g], xb[g], mean[g], invstd[g], 1) for g in range(2)]
+                    seg = fn((dy2, dyh2), None, y2, mask2, x2, mean2, invstd2, 2)
+                    nm = "%s %s" % ("fused" if fused else "3-launch", name)
+                    same(nm + " dx", seg[0], [sep[0][0], sep[1][0]])
+                    if seg[1] is not None:
+                        same(nm + " dz", seg[1], [sep[0][1], sep[1][1]])
+                    res.append(("%s %s dgamma" % (tag, nm), _err(seg[2], sep[0][2].double() + sep[1][2].double()), 1e-6))
+                    res.append(("%s %s dbeta" % (tag, nm), _err(seg[3], sep[0][3].double() + sep[1][3].double()), 1e-6))
+            finally:
+                ops.BN_FUSED = True
+        # the per-channel arrival counters are back at zero: a second segmented call gives the same parameter gradients
+        a1 = ops16.bn_bwd(dy2, mask2, x2, mean2, invstd2, gamma, beta, C, nseg=2)
+        a2 = ops16.bn_bwd(dy2, mask2, x2, mean2, invstd2, gamma, beta, C, nseg=2)
+        res.append((tag + " repeat dgamma/dbeta", 0.0 if (torch.equal(a1[2], a2[2]) and torch.equal(a1[3], a2[3])) else float("inf"), 0.0))
+    return res
+
+
 def check_eltwise16():
     from sivae_hip import ops16
     res = []
@@ -470,6 +541,7 @@ def all_checks():
         for rm in (0, 1, 2):
             checks.append(("bn16%s res%d" % (s, rm), lambda s=s, rm=rm: check_bn(s, rm, pool=rm != 2)))
     checks.append(("bn16_fused", check_bn_fused16))
+    checks.append(("bn16_seg", check_bn_seg16))
     checks.append(("eltwise16", check_eltwise16))
     checks.append(("splitk16", check_splitk16))
     return checks

@@ -358,7 +358,17 @@ def test_round4_entry_points_validate_arguments():
     # bf16 form
     assert [L.sivae_bf16_bn_bwd_fused_supported(*a) for a in ((128, 64, 128, 128), (8, 512, 4, 4), (2, 24, 8, 12),
                                                              (128, 64, 256, 256))] == [1, 1, 0, 0]
-    assert L.sivae_bf16_bn_bwd_fused_workspace_bytes(8, 512, 4, 4) == 64 * 1 * 16 * 8 + 16
+    assert L.sivae_bf16_bn_bwd_fused_workspace_bytes(8, 512, 4, 4) == (64 * 1 * 16 + 64 * 16) * 8 + 16  # partials + sums
+    # segmented form: B = nseg * seg_images, one plane set per (segment, channel block); a 128-image pass at 256 x 256 does
+    # not fit the grid, its two 64-image halves do not make it fit either (the plane set is per segment)
+    assert [L.sivae_bf16_bn_bwd_fused_seg_supported(*a) for a in ((256, 64, 128, 128, 128), (16, 512, 4, 4, 8),
+                                                                 (16, 512, 4, 4, 5), (16, 512, 4, 4, 0),
+                                                                 (256, 64, 256, 256, 128))] == [1, 1, 0, 0, 0]
+    assert L.sivae_bf16_bn_bwd_fused_seg_workspace_bytes(16, 512, 4, 4, 8) == (128 * 1 * 16 + 128 * 16) * 8 + 16
+    assert L.sivae_bf16_bn_bwd_fused_seg(one, 0, null, null, one, one, one, one, one, 0.2, one, null, 0, null, null, 16, 16, 8,
+                                         8, 5, one, one, 1 << 20, null) == -2  # 16 images are not passes of 5
+    assert L.sivae_bf16_bn_apply_act_seg(one, null, 0, one, one, one, one, 0.2, one, null, null, 16, 16, 8, 8, 5, null) == -2
+    assert L.sivae_bf16_bn_apply_act_seg(one, null, 0, one, one, one, one, 0.2, null, null, null, 16, 16, 8, 8, 8, null) == -1
     assert L.sivae_bf16_bn_bwd_fused(one, 0, null, null, one, one, one, one, one, 0.2, one, null, 0, null, null, 8, 16, 8, 8,
                                      null, one, 1 << 20, null) == -1
     assert L.sivae_bf16_bn_bwd_fused(one, 0, null, null, one, one, one, one, null, 0.2, one, null, 0, null, null, 8, 16, 8, 8,
