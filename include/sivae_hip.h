@@ -457,6 +457,12 @@ int sivae_bf16_conv2d_fwd_splitk(const void* x, const void* wp, void* y, const f
                                  const float* pro_invstd, const float* pro_gamma, const float* pro_beta, float pro_slope,
                                  float* stats_partial, int B, int Ci, int Co, int H, int W, int ks, int upsample,
                                  int accumulate, void* workspace, size_t workspace_bytes, sivae_stream_t stream);
+/* y_half [B][Co][H/2][W/2] (blocked bf16) (+)= the 2x2 block sums of conv3x3(x): the data gradient of a 3x3 conv that read
+ * its input through nearest-2x upsample addressing, the adjoint of the nn.Upsample (train_soft_intro_vae.py:155) folded
+ * into the epilogue (four fp32 accumulators summed, one rounding; the full-resolution gradient is never written).  wp: the
+ * mode-1 pack; H, W even; never split-K (the caller keeps the two-launch form where sivae_bf16_conv2d_splitk(...) > 1). */
+int sivae_bf16_conv2d_fwd_pool(const void* x, const void* wp, void* y_half, int B, int Ci, int Co, int H, int W,
+                               int accumulate, sivae_stream_t stream);
 /* dw [Co][Ci][ks][ks] fp32 = weight gradient (aten::convolution_backward, weight half); x' as above (prologue 3x3
  * only, upsample addressing); deterministic two-pass reduction over pixel slices */
 size_t sivae_bf16_conv2d_wgrad_workspace_bytes(int B, int Ci, int Co, int H, int W, int ks);

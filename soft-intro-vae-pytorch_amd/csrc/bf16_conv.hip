@@ -48,6 +48,10 @@ struct Bf16ConvArgs {
   // (vector -> channel block, image, row, column) decompositions — as run-time integer divisions they were 400 of the
   // kernel's 820 set-up instructions (set by launch_cfg)
   unsigned magic_plane, magic_lw, magic_lh;
+  // 1: y is [B][Cob][H/2][W/2][8] and receives the 2x2 BLOCK SUMS of the conv's outputs (3x3 kernels, H and W even) —
+  // the data gradient of a conv whose input is read through nearest-2x upsample addressing (adjoint of nn.Upsample,
+  // train_soft_intro_vae.py:155) without the full-resolution tensor ever being written
+  int poolsum = 0;
 };
 
 // KS x KW taps (KW = KS except for the kw-packed 5x1 form of the RGB-side layers, ks code 51)
@@ -293,6 +297,74 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
     return;
   }
 
+  if constexpr (KS == 3 && KW == 3 && !PRO) {
+    if (a.poolsum) {
+      // 2x2 block sums of the fp32 accumulators, rounded once.  A 32-pixel MFMA tile is one image row when the tile is 32
+      // pixels wide (the vertical neighbour is then tile n ^ 1 of the same lane), else 32 / TW rows of TW pixels (the
+      // vertical neighbour is lane ^ TW); the horizontal neighbour is lane ^ 1.  Tiles start on even rows / columns and H, W
+      // are even: a block never leaves its tile or the image.  The lane of the block's top-left pixel stores.
+      const int Hh = H >> 1, Wh = W >> 1, HWh = Hh * Wh;
+      const __amdgpu_buffer_rsrc_t prs = make_rsrc(reinterpret_cast<unsigned char*>(a.y) + (size_t)b0 * a.Cob * HWh * 16,
+                                                   (unsigned long long)nb_here * a.Cob * HWh * 16ull);
+      const bool row_tiles = a.tw_log2 >= 5;
+      bool own[WN];
+      unsigned p_off[WN];
+#pragma unroll
+      for (int n = 0; n < WN; ++n) {
+        const int m_pix = (wvn * WN + n) * 32 + l31;
+        const int cc = m_pix & (TW - 1);
+        const int rr = (m_pix >> a.tw_log2) & (TH - 1);
+        const int tb = m_pix >> (a.tw_log2 + a.th_log2);
+        const int r = r0 + rr, c = c0 + cc;
+        own[n] = px_ok[n] && !(r & 1) && !(c & 1);
+        p_off[n] = (unsigned)((tb * a.Cob * Hh + (r >> 1)) * Wh + (c >> 1)) * 16u + (unsigned)hh * 8u;
+      }
+      auto pool_epilogue = [&](auto ACC_) {
+        constexpr bool ACC = decltype(ACC_)::value;
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int cb = (co0 >> 3) + (wvm * WM + m) * 4 + g;
+            const bool cb_ok = cb < a.Cob;
+            const unsigned cboff = (unsigned)cb * (unsigned)HWh * 16u;
+#pragma unroll
+            for (int n = 0; n < WN; ++n) {
+              if (row_tiles && (n & 1)) continue;
+              float v[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float t = acc[m][n][4 * g + e];
+                if (row_tiles)
+                  t += acc[m][n ^ 1][4 * g + e];
+                else
+                  t += __shfl_xor(t, TW, 64);
+                t += dpp_mov_f32<0xB1, 0xf>(t);  // lane ^ 1
+                v[e] = t;
+              }
+              const unsigned off = (cb_ok && own[n]) ? p_off[n] + cboff : SIVAE_OOB;
+              if constexpr (ACC) {
+                const u32x2_t old = __builtin_amdgcn_raw_buffer_load_b64(prs, (int)off, 0, 0);
+                v[0] += bf16_lo(old[0]);
+                v[1] += bf16_hi(old[0]);
+                v[2] += bf16_lo(old[1]);
+                v[3] += bf16_hi(old[1]);
+              }
+              u32x2_t o;
+              o[0] = pack_bf16(v[0], v[1]);
+              o[1] = pack_bf16(v[2], v[3]);
+              __builtin_amdgcn_raw_buffer_store_b64(o, prs, (int)off, 0, 0);
+            }
+          }
+        }
+      };
+      if (a.accumulate)
+        pool_epilogue(std::true_type{});
+      else
+        pool_epilogue(std::false_type{});
+      return;
+    }
+  }
   const __amdgpu_buffer_rsrc_t yrsrc = make_rsrc(reinterpret_cast<unsigned char*>(a.y) + (size_t)b0 * a.Cob * HW * 16,
                                                  (unsigned long long)nb_here * a.Cob * HW * 16ull);
   // The run-time switches of the epilogue are block-uniform: one copy of the loop per (accumulate, statistics, whole tile)
@@ -633,6 +705,42 @@ extern "C" int sivae_bf16_conv2d_fwd(const void* x, const void* wp, void* y, con
   }
   if (out_f32_nchw) return launch_by_co<5, 1, 4, false, true>(a, c.TCO, stream);
   return launch_by_co<5, 1, 4, false, false>(a, c.TCO, stream);
+}
+
+// y_half[b][co][h/2][w/2] (+)= the 2x2 block sums of conv3x3(x)[b][co][h][w] (H, W even; y_half blocked bf16 at half
+// resolution): the data gradient of a 3x3 conv whose input was read through nearest-2x upsample addressing, with the
+// adjoint of the nn.Upsample (train_soft_intro_vae.py:155) folded into the epilogue — the four fp32 accumulators are
+// summed before the one rounding, and the full-resolution gradient is never written.  wp: the data-gradient pack
+// (mode 1; Ci / Co are this launch's inputs / outputs).
+extern "C" int sivae_bf16_conv2d_fwd_pool(const void* x, const void* wp, void* y_half, int B, int Ci, int Co, int H, int W,
+                                          int accumulate, hipStream_t stream) {
+  if (!x || !wp || !y_half) return SIVAE_ERR_NULL;
+  if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return SIVAE_ERR_SHAPE;
+  const long long hw = (long long)H * W;
+  const int Cib = bf16_cblocks(Ci), Cob = bf16_cblocks(Co);
+  if ((long long)Cib * hw * 16 >= 0x7fffffffLL || (long long)Cob * hw * 16 >= 0x3fffffffLL) return SIVAE_ERR_RANGE;
+  Bf16ConvArgs a;
+  a.x = x;
+  a.wp = wp;
+  a.y = y_half;
+  a.bias = nullptr;
+  a.pro_mean = a.pro_invstd = a.pro_gamma = a.pro_beta = nullptr;
+  a.pro_slope = 1.f;
+  a.stats = nullptr;
+  a.B = B;
+  a.Ci = Ci;
+  a.Co = Co;
+  a.H = H;
+  a.W = W;
+  a.Cib = Cib;
+  a.Cob = Cob;
+  a.accumulate = accumulate;
+  a.upsample = 0;
+  a.chunks_per_split = 0;
+  a.split_stride = 0;
+  a.poolsum = 1;
+  const Bf16Cfg c = bf16_cfg(3, Co, Ci);
+  return launch_by_co<3, 1, 5, false, false>(a, c.TCO, stream);
 }
 
 // ---- split-K form (3x3, small grids) ------------------------------------------------------------------------------

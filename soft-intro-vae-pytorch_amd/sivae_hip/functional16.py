@@ -232,6 +232,15 @@ class ResBlockFn16(torch.autograd.Function):
                 # skip gradient (one read-modify-write in the conv epilogue instead of a separate 3-pass add)
                 dx = dz
                 ops16.conv2d(da, packed16(w1, 1), Cm, Ci, 3, out=dx, accumulate=True)
+            elif x_up and ops16.conv2d_pool_supported(da.shape[0], Cm, Ci, da.shape[2], da.shape[3], 3):
+                # conv1 read x through upsample addressing: its data gradient is needed as 2x2 block sums only (the adjoint
+                # of the deferred nn.Upsample) — summed in the conv's epilogue, and for an identity skip straight onto
+                # the skip gradient (dz already holds ITS block sums: bn_bwd(dz_sum=True))
+                if ctx.has_exp:
+                    dx = ops16.conv2d_pool(da, packed16(w1, 1), Cm, Ci)
+                    ops16.conv2d(dz, packed16(w_exp, 1), Co, Ci, 1, out=dx, accumulate=True)
+                else:
+                    dx = ops16.conv2d_pool(da, packed16(w1, 1), Cm, Ci, out=dz, accumulate=True)
             else:
                 dx = ops16.conv2d(da, packed16(w1, 1), Cm, Ci, 3)
                 if x_up:

@@ -18,6 +18,9 @@ LRELU_SLOPE = ops.LRELU_SLOPE
 TIMER_KEYS = True
 
 
+# SIVAE_BF16_POOL_DGRAD=0: the data gradient of a conv of an upsampled input is written at full resolution and summed by
+# a second launch (A/B measurements)
+POOL_DGRAD = os.environ.get("SIVAE_BF16_POOL_DGRAD", "1") != "0"
 KS51 = 51  # ks code of the 5-row x 1-column conv (kw-packed RGB-side layers, include/sivae_hip.h)
 
 
@@ -149,6 +152,30 @@ def conv2d(x, wp, Ci, Co, ks, bias=None, pro=None, upsample=False, want_stats=Fa
         ops.TIMER.end("bf16_conv_kernel<%d,%s>" % (ks, "co32" if Co <= 32 else ("co64" if Co <= 64 else "co128")),
                       2.0 * B * H * W * Co * Ci * _taps(ks), t0)
     return (y, stats) if want_stats else y
+
+
+def conv2d_pool_supported(B, Ci, Co, H, W, ks):
+    """can conv2d_pool take this layer?  (3x3, even maps, and the grid fills the chip without a K split: the small
+    512-channel maps keep conv2d + upsample2_bwd, whose split-K form has no pooled epilogue)"""
+    return (POOL_DGRAD and ks == 3 and H % 2 == 0 and W % 2 == 0
+            and _lib.load().sivae_bf16_conv2d_splitk(B, Ci, Co, H, W, ks) <= 1)
+
+
+def conv2d_pool(x, wp, Ci, Co, out=None, accumulate=False):
+    """x blocked [B, Cib, H, W, 8] -> the 2x2 BLOCK SUMS of conv3x3(x), blocked [B, Cob, H/2, W/2, 8] (written into /
+    accumulated onto `out`): the data gradient of a conv that read its input through upsample addressing, the adjoint
+    of the nn.Upsample folded into the conv's epilogue (bf16_conv.hip `poolsum`).  wp: the mode-1 pack."""
+    _req16(x, out)
+    B, Cib, H, W, _ = x.shape
+    assert Cib == cblocks(Ci), (Cib, Ci)
+    y = out if out is not None else empty_blocked(B, Co, H // 2, W // 2, x.device)
+    assert tuple(y.shape) == (B, cblocks(Co), H // 2, W // 2, 8)
+    t0 = ops.TIMER.begin() if ops.TIMER is not None else None
+    _lib.call("sivae_bf16_conv2d_fwd_pool", _p(x), _p(wp.data), _p(y), B, Ci, Co, H, W, int(bool(accumulate)), _s(x))
+    if t0 is not None:
+        ops.TIMER.end("bf16_conv_kernel<3,%s>" % ("co32" if Co <= 32 else ("co64" if Co <= 64 else "co128")),
+                      2.0 * B * H * W * Co * Ci * 9, t0)
+    return y
 
 
 def conv2d_wgrad(x, dy, Ci, Co, ks, pro=None, upsample=False, out=None):

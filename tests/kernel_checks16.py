@@ -159,6 +159,31 @@ def check_conv_dgrad(shape):
     return [("dgrad16%s" % (shape,), _err16(from_blocked(dx, Ci), ref), TOL_BF16)]
 
 
+def check_conv_dgrad_pool(shape):
+    """sivae_bf16_conv2d_fwd_pool: the data gradient of a 3x3 conv of an UPSAMPLED input = the 2x2 block sums of the
+    transposed conv of dy (the adjoint of nn.Upsample folded into the epilogue), fresh and accumulated onto a
+    half-resolution tensor; against fp64 on the same bf16 operands, ONE rounding of the block sum"""
+    from sivae_hip import ops16
+    B, Ci, Co, H, W, _ = shape
+    dy = _r16(_rand(B, Co, H, W, seed=4))
+    w = _rand(Co, Ci, 3, 3, seed=2, scale=1.0 / (Ci * 9) ** 0.5)
+    ref = F.avg_pool2d(F.conv_transpose2d(dy, _r16(w), padding=1), 2) * 4
+    wp = ops16.PackedW16(w.float().to(DEV), 1)
+    dyb = to_blocked(dy).to(DEV)
+    dx = ops16.conv2d_pool(dyb, wp, Co, Ci)
+    res = [("dgrad16_pool%s" % (shape,), _err16(from_blocked(dx, Ci), ref), TOL_BF16),
+           ("dgrad16_pool%s pad" % (shape,), _padded_zero(dx, Ci), 0.0)]
+    old = _r16(_rand(B, Ci, H // 2, W // 2, seed=6))
+    acc = to_blocked(old).to(DEV)
+    ops16.conv2d_pool(dyb, wp, Co, Ci, out=acc, accumulate=True)
+    res.append(("dgrad16_pool%s accumulate" % (shape,), _err16(from_blocked(acc, Ci), ref + old), TOL_BF16))
+    # and against the two-launch form it replaces (full-resolution bf16 gradient, then the block sum): two roundings there
+    two = ops16.upsample2_bwd(ops16.conv2d(dyb, wp, Co, Ci, 3), Ci)
+    res.append(("dgrad16_pool%s vs conv + upsample2_bwd" % (shape,), _err(from_blocked(dx, Ci), from_blocked(two, Ci)),
+                2 * TOL_BF16))
+    return res
+
+
 def check_conv_wgrad(shape, pro=False, upsample=False):
     from sivae_hip import ops16
     B, Ci, Co, H, W, ks = shape
@@ -526,6 +551,11 @@ def all_checks():
         checks.append(("conv16%s" % (s,), lambda s=s: check_conv(s)))
         checks.append(("dgrad16%s" % (s,), lambda s=s: check_conv_dgrad(s)))
         checks.append(("wgrad16%s" % (s,), lambda s=s: check_conv_wgrad(s)))
+    # pooled data gradient: 32-wide tiles (row pairs = accumulator tiles), 16- and 8-wide maps (row pairs = lanes), the
+    # 32 / 64 / 128-channel tile configurations, big pixel tiles (B = 16 at 64x64), ragged tiles, padded channels
+    for sh in [(2, 64, 64, 64, 64, 3), (16, 64, 64, 64, 64, 3), (2, 128, 64, 32, 32, 3), (3, 256, 128, 16, 16, 3),
+               (4, 160, 136, 8, 8, 3), (2, 24, 16, 12, 20, 3), (2, 64, 128, 48, 40, 3), (8, 128, 128, 32, 32, 3)]:
+        checks.append(("dgrad16_pool%s" % (sh,), lambda sh=sh: check_conv_dgrad_pool(sh)))
     checks.append(("conv16_bias_f32out", lambda: check_conv((2, 64, 3, 32, 32, 5), bias=True, out_f32=True)
                    + check_conv((2, 64, 15, 32, 32, 51), out_f32=True)
                    + check_conv((2, 64, 3, 16, 16, 5), bias=True)))
