@@ -594,13 +594,7 @@ int px_tile_3x3(int TCO, int B, int H, int W, int n_out) {
   TileGeom g = make_tile_geom(B, H, W, big);
   const long long nblk = (long long)g.ntb * g.nth * g.ntw * cdiv(n_out, TCO);
   const int plane = (1 << g.tb_log2) * ((1 << g.th_log2) + 2) * ((1 << g.tw_log2) + 2);
-  // (SIVAE_BF16_BIG_TILE_MIN_BLOCKS: the smallest grid of big tiles taken, default 512 = two blocks per CU; A/B switch)
-  static int min_blocks = -1;
-  if (min_blocks < 0) {
-    const char* e = getenv("SIVAE_BF16_BIG_TILE_MIN_BLOCKS");
-    min_blocks = (e && atoi(e) > 0) ? atoi(e) : 512;
-  }
-  if (nblk < min_blocks || 2 * plane > 5 * 256) return small;
+  if (nblk < 512 || 2 * plane > 5 * 256) return small;
   return big;
 }
 
