@@ -42,7 +42,16 @@ struct Bf16BnFusedArgs {
   int dzmode;  // 0 none, 1 full resolution, 2 2x2 block sums
   int pf;      // 1: the NEXT group's x is requested into LDS between the barrier's arrival and its wait (as bn_fused.hip)
   unsigned spin_limit;  // polls of the barrier wait before the launch is abandoned (bn_fused_common.h)
+#ifdef B16_TIMING
+  unsigned long long* ts;  // [block][group][8] s_memrealtime stamps of thread 0 (tools/b16_bn_timing.py; not a product build)
+#endif
 };
+#ifdef B16_TIMING
+#define B16_STAMP(K) \
+  if (t == 0 && a.ts) a.ts[((size_t)blockIdx.x * a.ngroups + grp) * 8 + (K)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define B16_STAMP(K)
+#endif
 
 // 16-byte buffer stores and the lifetime of their data registers.  Measured on gfx950 / ROCm 7.2 (this kernel, memory pipe
 // saturated, round 4): when the VALU instructions that follow a buffer_store_dwordx4 rewrite its data registers within a
@@ -136,6 +145,7 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
     unsigned sg_bits[NU];  // sign bytes of the quad's 4 vectors (row 0: bytes 0, 1; row 1: bytes 2, 3)
     float mu[8], is[8];
     double tsum = 0.0;  // (threads t < 256: value t & 15 of the channel block's 16 sums)
+    B16_STAMP(0)
     if (active) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -216,6 +226,10 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
         }
       }
       float sg[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sgx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#ifdef B16_TIMING
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (stamp 1: every raw vector has landed)
+#endif
+      B16_STAMP(1)
 #pragma unroll
       for (int j = 0; j < NU; ++j) {
         float dp[8];
@@ -286,24 +300,40 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
                              __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    B16_STAMP(2)
     if (!local) {
       if (t == 0) {
         ++target;
         bf_grid_arrive(bar, xcd, a.nx, bpx, nbar++);
       }
+      B16_STAMP(3)
       if (pf) {
         const int cbn = (grp + a.nsub) * a.cpg + ci;
         if (grp + a.nsub < a.ngroups && ci < a.cpg && cbn < a.VCb) request_x(cbn);
       }
       if (t == 0) bar_failed = bf_grid_wait(bar, a.bar + BF_POISON_WORD, xcd, target, a.spin_limit) ? 0 : 1;
+      B16_STAMP(4)
       __syncthreads();
       if (bar_failed) return;  // abandoned launch (poison word set; the host raises)
       if (!active) continue;
       // the channel block's 16 sums over its slabs: thread (value v = t & 15, row r = t >> 4) strides over the slabs,
       // rows folded in order through LDS — the same in every block of the channel block
       const int v = t & 15, r = t >> 4;
+      // (eight loads in flight per thread, added in slab order: one dependent agent-scope load per step made this fold 32
+      // memory round trips = 8.8 of a 37-us group on the 128 x 128 layers — tools/b16_bn_timing.py)
       double acc = 0.0;
-      for (int s = r; s < a.spc; s += 16) acc += bf_load_f64(a.part + ((size_t)vcb * a.spc + s) * 16 + v);
+      const double* prow = a.part + (size_t)vcb * a.spc * 16 + v;
+      for (int s0 = r; s0 < a.spc; s0 += 16 * 8) {
+        double tmp[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int sk = s0 + 16 * k;
+          tmp[k] = bf_load_f64(prow + (size_t)(sk < a.spc ? sk : r) * 16);  // (past the end: a valid row, not added)
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (s0 + 16 * k < a.spc) acc += tmp[k];
+      }
       red2[r][v] = acc;
       __syncthreads();
       if (t < 16) {
@@ -344,6 +374,7 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
       }
     }
     __syncthreads();
+    B16_STAMP(5)
     // ---- phase 2
     float gi[8], c1[8], c2[8];
 #pragma unroll
@@ -406,7 +437,9 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
         bf_store_u32x4(rdz, dq[j][0], half_off(qbase + j * 256), 0);
       }
     }
+    B16_STAMP(6)
     __syncthreads();  // (coef / red are reused by the next group)
+    B16_STAMP(7)
   }
   // the arrival counters of this half-grid back to zero (bn_fused_common.h: they run on through a launch's barriers)
   if (t == 0 && bid == 0 && nbar != 0u) bf_grid_reset(bar, a.nx);
@@ -472,7 +505,22 @@ static bool b16_plan(int B, int Cb, int HW, B16Plan* out) {
 
 static inline bool b16_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+#ifdef B16_TIMING
+static unsigned long long* b16_timing_buffer = nullptr;
+#endif
+
 }  // namespace
+
+#ifdef B16_TIMING
+// timing build only (tools/b16_bn_timing.py): device buffer of blocks * groups * 8 stamps, or null; returns the launch plan
+extern "C" void sivae_debug_b16_timing(unsigned long long* buf) { b16_timing_buffer = buf; }
+extern "C" int sivae_debug_b16_plan(int B, int C, int H, int W, int seg_images, int* out6) {
+  B16Plan p;
+  if (!b16_plan(seg_images, (B / seg_images) * bf16_cblocks(C), H * W, &p)) return -1;
+  out6[0] = p.nu; out6[1] = p.spc; out6[2] = p.cpg; out6[3] = p.ngroups; out6[4] = p.nb_sub; out6[5] = p.nsub;
+  return 0;
+}
+#endif
 
 // power-of-two maps from 2x2 up whose (segment, channel block) plane sets fit one group of the grid; B = nseg * seg_images
 extern "C" int sivae_bf16_bn_bwd_fused_seg_supported(int B, int C, int H, int W, int seg_images) {
@@ -558,6 +606,9 @@ extern "C" int sivae_bf16_bn_bwd_fused_seg(const void* dy, int dy_pooled, const 
   a.local = p.local;
   a.dzmode = !dz ? 0 : (dz_sum ? 2 : 1);
   a.spin_limit = bf_spin_limit();
+#ifdef B16_TIMING
+  a.ts = b16_timing_buffer;
+#endif
   static int pf_on = -1;
   if (pf_on < 0) {
     const char* e = getenv("SIVAE_BN_FUSED_PREFETCH");
