@@ -55,7 +55,16 @@ struct BnFusedArgs {
   int dzmode;  // 0: none, 1: dz at full resolution, 2: 2x2 block sums [.][H/2][W/2]
   int pf;      // 1: the NEXT group's x is requested into LDS (LDS-direct loads) between the barrier's arrival and its wait
   unsigned spin_limit;  // polls of the barrier wait before the launch is abandoned (poison word set)
+#ifdef BF_TIMING
+  unsigned long long* ts;  // [block][group][8] s_memrealtime stamps of thread 0 (tools/bn_fused_timing.py; not a product build)
+#endif
 };
+#ifdef BF_TIMING
+#define BF_STAMP(K) \
+  if (t == 0 && a.ts) a.ts[((size_t)blockIdx.x * a.ngroups + grp) * 8 + (K)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define BF_STAMP(K)
+#endif
 
 __device__ __forceinline__ void bf_sign_nibble(float4& g, unsigned nib, float slope) {
   g.x = (nib & 1u) ? g.x : g.x * slope;
@@ -98,7 +107,7 @@ __device__ __forceinline__ void bf_store4(__amdgpu_buffer_rsrc_t r, const float4
 // carries an out-of-range offset: its loads return 0 (dz = 0: no contribution to the sums) and its stores are skipped.
 template <int ACT, bool POOL, int NQ>
 __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
-  __shared__ double red[4];
+  __shared__ double red[8];
   // x of the NEXT group, requested while this block waits at the grid barrier (a.pf): [PFQ][2 rows][256 threads] float4 —
   // a wave's 64 lanes are 1 KB contiguous, the layout an LDS-direct load writes (M0 base + lane * 16)
   extern __shared__ __attribute__((aligned(16))) float4 bf_pfx[];
@@ -171,6 +180,7 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
     float m = 0.f, is = 0.f, gs = 0.f;
     int c = 0;
     size_t base = 0;  // element index of the plane (segment's first image, channel c)
+    BF_STAMP(0)
     if (active) {
       const int seg = vc / C;
       c = vc - seg * C;
@@ -225,6 +235,10 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
         }
       }
       double s1 = 0.0, s2 = 0.0;
+#ifdef BF_TIMING
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (stamp 1: every raw vector has landed)
+#endif
+      BF_STAMP(1)
 #pragma unroll
       for (int j = 0; j < NQ; ++j) {
         if (ACT == 3) {
@@ -250,8 +264,7 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
         s1 += (double)q1;
         s2 += (double)q2;
       }
-      s1 = block_sum<256>(s1, red);
-      s2 = block_sum<256>(s2, red);
+      block_sum2<256>(s1, s2, red);
       if (local) {
         t1 = s1;
         t2 = s2;
@@ -260,30 +273,43 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
         __hip_atomic_store(a.part + ((size_t)vc * a.spc + slab) * 2 + 1, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    BF_STAMP(2)
     if (!local) {
       // ---- barrier: every slab of every channel of this group is published
       if (t == 0) {
         ++target;
         bf_grid_arrive(bar, xcd, a.nx, bpx, nbar++);
       }
+      BF_STAMP(3)
       if (pf) {
         const int vcn = (grp + a.nsub) * a.cpg + ci;
         if (grp + a.nsub < a.ngroups && ci < a.cpg && vcn < VC) request_x(vcn);
       }
       if (t == 0) bar_failed = bf_grid_wait(bar, a.bar + BF_POISON_WORD, xcd, target, a.spin_limit) ? 0 : 1;
+      BF_STAMP(4)
       __syncthreads();
       if (bar_failed) return;  // abandoned launch (poison word set): no trap, no hang; the host raises
       if (!active) continue;
       // ---- phase 2: coefficients of this channel (fixed order: thread-strided slabs, then the block tree — the same
       // in every block of the channel), then dx straight from the registers
-      for (int s = t; s < a.spc; s += 256) {
-        t1 += bf_load_f64(a.part + ((size_t)vc * a.spc + s) * 2 + 0);
-        t2 += bf_load_f64(a.part + ((size_t)vc * a.spc + s) * 2 + 1);
+      // (a thread's slabs — two at most 512 — are requested together and added in slab order; one reduction for both sums)
+      for (int s = t; s < a.spc; s += 512) {
+        const int sb = s + 256 < a.spc ? s + 256 : s;
+        const double p1 = bf_load_f64(a.part + ((size_t)vc * a.spc + s) * 2 + 0);
+        const double p2 = bf_load_f64(a.part + ((size_t)vc * a.spc + s) * 2 + 1);
+        const double q1 = bf_load_f64(a.part + ((size_t)vc * a.spc + sb) * 2 + 0);
+        const double q2 = bf_load_f64(a.part + ((size_t)vc * a.spc + sb) * 2 + 1);
+        t1 += p1;
+        t2 += p2;
+        if (s + 256 < a.spc) {
+          t1 += q1;
+          t2 += q2;
+        }
       }
-      t1 = block_sum<256>(t1, red);
-      t2 = block_sum<256>(t2, red);
+      block_sum2<256>(t1, t2, red);
     }
     const float c1 = (float)(t1 / a.count), c2 = (float)(t2 / a.count);
+    BF_STAMP(5)
     if (slab == 0 && t == 0 && (a.dgamma != nullptr || a.dbeta != nullptr)) {
       if (a.nseg == 1) {
         if (a.dbeta) a.dbeta[c] = (float)t1;
@@ -337,6 +363,11 @@ __global__ void __launch_bounds__(256, 2) bn_bwd_fused_kernel(BnFusedArgs a) {
         buf_store_f32x2(rdz, sa, sb, half_off(qbase + j * 256), 0);
       }
     }
+    BF_STAMP(6)
+#ifdef BF_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BF_STAMP(7)
+#endif
   }
   // the arrival counters of this half-grid back to zero (bn_fused_common.h: they run on through a launch's barriers)
   if (t == 0 && bid == 0 && nbar != 0u) bf_grid_reset(bar, a.nx);
@@ -434,7 +465,22 @@ static bool bf_plan(int Bs, int VC, int HW, int max_nq, BfPlan* out) {
 
 static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+#ifdef BF_TIMING
+static unsigned long long* bf_timing_buffer = nullptr;
+#endif
+
 }  // namespace
+
+#ifdef BF_TIMING
+// timing build only (tools/bn_fused_timing.py)
+extern "C" void sivae_debug_bf_timing(unsigned long long* buf) { bf_timing_buffer = buf; }
+extern "C" int sivae_debug_bf_plan(int B, int C, int H, int W, int seg_images, int max_nq, int* out6) {
+  BfPlan p;
+  if (!bf_plan(seg_images, (B / seg_images) * C, H * W, max_nq, &p)) return -1;
+  out6[0] = p.nq_per_thread; out6[1] = p.spc; out6[2] = p.cpg; out6[3] = p.ngroups; out6[4] = p.nb_sub; out6[5] = p.nsub;
+  return 0;
+}
+#endif
 
 // shapes the one-pass backward takes: power-of-two maps from 4x4 up (H even, W % 4 == 0 by construction), per-(segment,
 // channel) plane sets that fit one group of a half-grid, at most 8192 channels
@@ -531,6 +577,9 @@ extern "C" int sivae_bn_bwd_fused(const float* dy, const float* y, const unsigne
   a.local = p.local;
   a.dzmode = !dz_out ? 0 : (dz_sum ? 2 : 1);
   a.spin_limit = bf_spin_limit();
+#ifdef BF_TIMING
+  a.ts = bf_timing_buffer;
+#endif
   // the next group's x requested into LDS across the barrier (up to 6 quads per thread = 48 KB per block): persistent
   // forms with up to 8 quads per thread and more than one group per (half-)grid
   static int pf_on = -1;

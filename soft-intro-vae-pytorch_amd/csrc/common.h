@@ -220,6 +220,34 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return t;
 }
 
+// Two block-wide sums at once: the same per-value order as two block_sum calls (butterfly inside a wave, waves in index
+// order) — bit-identical results —, but the cross-lane steps of the two values overlap and one barrier pair serves both.
+// `red` must hold 2 * NT/64 doubles.
+template <int NT>
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ta = __shfl_xor(a, o, 64), tb = __shfl_xor(b, o, 64);
+    a += ta;
+    b += tb;
+  }
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    red[wave] = a;
+    red[NT / 64 + wave] = b;
+  }
+  __syncthreads();
+  double ua = 0.0, ub = 0.0;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) {
+    ua += red[i];
+    ub += red[NT / 64 + i];
+  }
+  a = ua;
+  b = ub;
+}
+
 // ---- out[e] = sum_s part[s][e] for split-K style workspaces ([n_slices][numel] floats) ----
 // A block owns 64 consecutive elements; its YL wave-rows each walk every YL-th slice with four independent
 // accumulators (so 4*YL loads per element are in flight instead of one), then the rows are folded through LDS in
