@@ -54,8 +54,24 @@ struct Bf16ConvArgs {
   int poolsum = 0;
 };
 
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N)
+template <int I0, int N, typename F>
+__device__ __forceinline__ void ad_steps(F&& f) {
+  if constexpr (I0 < N) {
+    f(std::integral_constant<int, I0>{});
+    ad_steps<I0 + 1, N>(f);
+  }
+}
+
 // KS x KW taps (KW = KS except for the kw-packed 5x1 form of the RGB-side layers, ks code 51)
-template <int KS, int WM, int WN, int WVM, int WVN, int CKS, int MAXV, bool PRO, bool OUTF32, int MINW, int KW = KS>
+// AD ("A direct"): the weight operands do not pass through LDS.  The pack is in operand order, so a lane's A vector of
+// (chunk, tap, k-step, m) is ONE 16-byte load at a lane-constant offset + a scalar offset; every block of a co tile reads
+// the same slab (L2-resident).  A ring of AD_RING k-steps per wave keeps those loads in flight behind the MFMAs, the B
+// operands of the next k-step are read from LDS before the current k-step's MFMAs, and LDS carries the halo tile only:
+// per chunk and block 36 KB of ds_write_b128 (13 LDS cycles each) and a third of the operand reads are gone.
+template <int KS, int WM, int WN, int WVM, int WVN, int CKS, int MAXV, bool PRO, bool OUTF32, int MINW, int KW = KS,
+          bool AD = false>
 __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16ConvArgs a) {
   constexpr int P = KS / 2, PW = KW / 2;
   constexpr int NT = WVM * WVN * 64;
@@ -67,7 +83,7 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4_t* ws = reinterpret_cast<u32x4_t*>(smem_raw);
-  u32x4_t* xs = ws + NW;
+  u32x4_t* xs = AD ? ws : ws + NW;  // (AD: no weight slab in LDS)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
@@ -165,8 +181,83 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  u32x4_t wr[NWQ];
   u32x4_t xr[MAXV];
+  if constexpr (AD) {
+    constexpr int NS = TAPS * CKS;  // k-steps (MFMA groups) per chunk, in the order (ks, kh, kw)
+    constexpr int RD = 3;           // ring depth in k-steps
+    static_assert(NS % RD == 0, "the ring slots are compile-time indices of the unrolled chunk body");
+    const __amdgpu_buffer_rsrc_t wr_t = make_rsrc(wbase + (size_t)co_tile * a.nchunks * (size_t)NW * 16,
+                                                  (unsigned long long)a.nchunks * NW * 16ull);
+    const __amdgpu_buffer_rsrc_t xnull = make_rsrc(a.x, 0ull);  // (every offset out of range: zeros, no traffic)
+    const unsigned a_voff = (unsigned)a_base * 16u;
+    u32x4_t ar[RD][WM];
+    u32x4_t bq[2][WN];
+#define SIVAE_AD_LOAD_A(SLOT, CH, S)                                                                      \
+  {                                                                                                       \
+    const unsigned so_ = ((unsigned)(CH) * (unsigned)NW + (unsigned)(S) * (unsigned)(2 * TCO)) * 16u;     \
+    _Pragma("unroll") for (int m = 0; m < WM; ++m) ar[SLOT][m] = buf_load_u32x4(wr_t, a_voff + m * 512, so_); \
+  }
+#define SIVAE_AD_LOAD_X(RS, CH)                                                                           \
+  {                                                                                                       \
+    const unsigned xsoff = (unsigned)(CH) * (unsigned)(NCB * 16) * (unsigned)HWs;                         \
+    _Pragma("unroll") for (int p = 0; p < MAXV; ++p) xr[p] = buf_load_u32x4(RS, xo[p], xsoff);            \
+  }
+#define SIVAE_AD_READ_B(BUF, S)                                                                           \
+  {                                                                                                       \
+    constexpr int ks_ = (S) / TAPS, tap_ = (S) % TAPS, kh_ = tap_ / KW, kw_ = tap_ % KW;                  \
+    const int soff_ = ks_ * 2 * plane + kh_ * LW + kw_;                                                   \
+    _Pragma("unroll") for (int n = 0; n < WN; ++n) bq[BUF][n] = xs[b_base[n] + soff_];                    \
+  }
+    SIVAE_AD_LOAD_X(xrsrc, kc0)
+#pragma unroll
+    for (int s = 0; s < RD; ++s) SIVAE_AD_LOAD_A(s, kc0, s)
+    if (PRO) __syncthreads();
+    for (int ch = kc0; ch < kc1; ++ch) {
+#pragma unroll
+      for (int p = 0; p < MAXV; ++p) {
+        const int v = tid + p * NT;
+        u32x4_t q = xr[p];
+        if (PRO) {
+          float f[8];
+          unpack8(q, f);
+          const float* pp = ps + (ch * NCB + xcb[p]) * 16;
+          const bool in = xo[p] != SIVAE_OOB;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = in ? lrelu01(f[e] * pp[e] + pp[8 + e], a.pro_slope) : 0.f;
+          q = pack8(f);
+        }
+        if (v < nvec) xs[v] = q;
+      }
+      __syncthreads();
+      // the next chunk's halo tile: always issued (a conditional load would make every later wait a full drain); behind
+      // the last chunk it goes through the empty window
+      SIVAE_AD_LOAD_X((ch + 1 < kc1 ? xrsrc : xnull), ch + 1)
+      const int chn = ch + 1 < a.nchunks ? ch + 1 : ch;  // (the ring runs RD k-steps ahead, past the slice's end too)
+      SIVAE_AD_READ_B(0, 0)
+      ad_steps<0, NS>([&](auto S_) {
+        constexpr int S = decltype(S_)::value;
+        if constexpr (S + 1 < NS) SIVAE_AD_READ_B((S + 1) & 1, S + 1)
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+          for (int n = 0; n < WN; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ar[S % RD][m]),
+                                                                __builtin_bit_cast(bf16x8_t, bq[S & 1][n]), acc[m][n], 0, 0, 0);
+        if constexpr (S + RD < NS)
+          SIVAE_AD_LOAD_A(S % RD, ch, S + RD)
+        else
+          SIVAE_AD_LOAD_A(S % RD, chn, S + RD - NS)
+        // (without the fence hipcc sinks the refill to just in front of its use — the slot is dead in between, so that is
+        // "free" for register pressure — and the L2 round trip is exposed)
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      __syncthreads();
+    }
+#undef SIVAE_AD_LOAD_A
+#undef SIVAE_AD_LOAD_X
+#undef SIVAE_AD_READ_B
+  } else {
+  u32x4_t wr[NWQ];
 
 #define SIVAE_LOAD_CHUNK(CH)                                                                                   \
   {                                                                                                            \
@@ -229,6 +320,7 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
     __syncthreads();
   }
 #undef SIVAE_LOAD_CHUNK
+  }  // (!AD)
 
   // ---- epilogue
   int px_ok[WN];
@@ -534,7 +626,8 @@ Bf16Cfg bf16_cfg(int ks, int n_out, int n_in) {
   return c;
 }
 
-template <int KS, int WM, int WN, int WVM, int WVN, int CKS, int MAXV, bool PRO, bool OUTF32, int MINW, int KW = KS>
+template <int KS, int WM, int WN, int WVM, int WVN, int CKS, int MAXV, bool PRO, bool OUTF32, int MINW, int KW = KS,
+          bool AD = false>
 int launch_cfg(Bf16ConvArgs& a, hipStream_t stream) {
   constexpr int TCO = WVM * WM * 32;
   constexpr int TPX = WVN * WN * 32;
@@ -556,7 +649,7 @@ int launch_cfg(Bf16ConvArgs& a, hipStream_t stream) {
   a.magic_plane = make_magic((unsigned)plane);
   a.magic_lw = make_magic((unsigned)((1 << g.tw_log2) + 2 * PW));
   a.magic_lh = make_magic((unsigned)((1 << g.th_log2) + 2 * P));
-  size_t lds = (size_t)(NW + 2 * CKS * plane) * 16 + (PRO ? (size_t)a.Cib * 64 : 0);
+  size_t lds = (size_t)((AD ? 0 : NW) + 2 * CKS * plane) * 16 + (PRO ? (size_t)a.Cib * 64 : 0);
   const size_t red = (size_t)WVN * TCO * 2 * sizeof(float);
   if (lds < red) lds = red;
   const long long nbase = (long long)a.n_co_tiles * g.ntb * g.nth * g.ntw;
@@ -564,7 +657,7 @@ int launch_cfg(Bf16ConvArgs& a, hipStream_t stream) {
   const long long nblk = nbase * cdiv(a.nchunks, a.chunks_per_split);
   if (nblk > 0x7fffffffLL) return SIVAE_ERR_RANGE;
   a.nblk_base = (int)nbase;
-  auto kern = bf16_conv_kernel<KS, WM, WN, WVM, WVN, CKS, MAXV, PRO, OUTF32, MINW, KW>;
+  auto kern = bf16_conv_kernel<KS, WM, WN, WVM, WVN, CKS, MAXV, PRO, OUTF32, MINW, KW, AD>;
   static size_t lds_hwm = 0;
   const int rc_lds = sivae_ensure_lds(reinterpret_cast<const void*>(kern), lds, &lds_hwm);
   if (rc_lds != SIVAE_OK) return rc_lds;
@@ -577,6 +670,16 @@ int big_tiles_enabled() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("SIVAE_BF16_CONV_TILE");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
+// SIVAE_BF16_CONV_AD=0: the 3x3 kernels stage their weight slabs through LDS again (A/B switch)
+int a_direct_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SIVAE_BF16_CONV_AD");
     v = (e && e[0] == '0') ? 0 : 1;
   }
   return v;
@@ -609,6 +712,12 @@ int launch_by_co(Bf16ConvArgs& a, int TCO, hipStream_t stream) {
   if constexpr (!OUTF32) {
     if constexpr (KS == 3) {
       const int tpx = px_tile_3x3(TCO, a.B, a.H, a.W, a.Co);
+      if (a_direct_enabled()) {  // weights straight from L2 (see the kernel's AD note)
+        if (TCO == 64 && tpx == 512) return launch_cfg<KS, 2, 4, 1, 4, CKS, MAXV, PRO, false, 2, KS, true>(a, stream);
+        if (TCO == 128 && tpx == 256) return launch_cfg<KS, 2, 4, 2, 2, CKS, MAXV, PRO, false, 2, KS, true>(a, stream);
+        if (TCO == 64) return launch_cfg<KS, 2, 2, 1, 4, CKS, MAXV, PRO, false, 2, KS, true>(a, stream);
+        if (TCO == 128) return launch_cfg<KS, 2, 2, 2, 2, CKS, MAXV, PRO, false, 2, KS, true>(a, stream);
+      }
       if (TCO == 64 && tpx == 512) return launch_cfg<KS, 2, 4, 1, 4, CKS, MAXV, PRO, false, 2>(a, stream);
       if (TCO == 128 && tpx == 256) return launch_cfg<KS, 2, 4, 2, 2, CKS, MAXV, PRO, false, 2>(a, stream);
     }
