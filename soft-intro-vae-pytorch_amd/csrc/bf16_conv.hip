@@ -65,11 +65,20 @@ __device__ __forceinline__ void ad_steps(F&& f) {
 }
 
 // KS x KW taps (KW = KS except for the kw-packed 5x1 form of the RGB-side layers, ks code 51)
-// AD ("A direct"): the weight operands do not pass through LDS.  The pack is in operand order, so a lane's A vector of
-// (chunk, tap, k-step, m) is ONE 16-byte load at a lane-constant offset + a scalar offset; every block of a co tile reads
-// the same slab (L2-resident).  A ring of AD_RING k-steps per wave keeps those loads in flight behind the MFMAs, the B
-// operands of the next k-step are read from LDS before the current k-step's MFMAs, and LDS carries the halo tile only:
-// per chunk and block 36 KB of ds_write_b128 (13 LDS cycles each) and a third of the operand reads are gone.
+// AD ("A direct", the 3x3 kernels): the weight operands do not pass through LDS.  The pack is in operand order, so a
+// lane's A vector of (chunk, tap, k-step, m) is ONE 16-byte load at a lane-constant offset + a scalar offset, and every
+// block of a co tile reads the same slab (L2-resident).  Per wave a ring of RD = 3 k-steps keeps those loads in flight
+// behind the MFMAs (refilled right after the slot's MFMAs; hipcc must be fenced or it sinks the refill to its use); the
+// MFMAs of a k-step run pixel-tile-major, and each B fragment is re-read for the next k-step as soon as its WM MFMAs are
+// issued (one register set, (WN - 1) * WM MFMAs of slack).  LDS carries the halo tile only, in TWO buffers: chunk ch + 1
+// is written in front of the last k-step's MFMAs of chunk ch — one barrier per chunk.  Against the staged form: 36 KB of
+// ds_write_b128 (13 LDS cycles each) per chunk and block and a third of the operand reads gone; 3x3 layers 6-13 % faster.
+// VMEM returns in order: every load (the next chunk's halo tile too) has to land within RD k-steps of the ring's next
+// wait, and the halo loads are therefore issued unconditionally (through an empty window behind the last chunk) — a load
+// under a branch turns every later wait into vmcnt(0).
+// Timing-only ablations (wrong results): -DAD_ABL_NOA / NOB / NOX / NOSTAGE / NOBAR, tools/build_ad_ablations.sh.  With
+// ALL of them (a bare MFMA loop) the 512 -> 512 @ 16x16 layer runs at 1.58 PF/s (the sustained clock under dense bf16 MFMA
+// work, not issue, bounds it); the full kernel reaches 1.34 (profiles/r6_bf16_conv_ad_ablations.txt).
 template <int KS, int WM, int WN, int WVM, int WVN, int CKS, int MAXV, bool PRO, bool OUTF32, int MINW, int KW = KS,
           bool AD = false>
 __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16ConvArgs a) {
@@ -96,7 +105,7 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
   const int H = a.H, W = a.W, HW = H * W;
   const int Hs = a.upsample ? (H >> 1) : H, Ws = a.upsample ? (W >> 1) : W;
   const int HWs = Hs * Ws;
-  float* ps = reinterpret_cast<float*>(xs + nvec);  // [Cib][16]: 8 scales, 8 shifts per channel block (PRO)
+  float* ps = reinterpret_cast<float*>(xs + (AD ? 2 : 1) * nvec);  // [Cib][16]: 8 scales, 8 shifts per channel block (PRO); AD: two halo buffers
 
   const int slice = (int)blockIdx.x / a.nblk_base;
   const int bid = (int)blockIdx.x - slice * a.nblk_base;
@@ -191,7 +200,7 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
     const __amdgpu_buffer_rsrc_t xnull = make_rsrc(a.x, 0ull);  // (every offset out of range: zeros, no traffic)
     const unsigned a_voff = (unsigned)a_base * 16u;
     u32x4_t ar[RD][WM];
-    u32x4_t bq[2][WN];
+    u32x4_t bq[WN];
 #define SIVAE_AD_LOAD_A(SLOT, CH, S)                                                                      \
   {                                                                                                       \
     const unsigned so_ = ((unsigned)(CH) * (unsigned)NW + (unsigned)(S) * (unsigned)(2 * TCO)) * 16u;     \
@@ -202,57 +211,89 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
     const unsigned xsoff = (unsigned)(CH) * (unsigned)(NCB * 16) * (unsigned)HWs;                         \
     _Pragma("unroll") for (int p = 0; p < MAXV; ++p) xr[p] = buf_load_u32x4(RS, xo[p], xsoff);            \
   }
-#define SIVAE_AD_READ_B(BUF, S)                                                                           \
+#define SIVAE_AD_READ_B(N, S)                                                                             \
   {                                                                                                       \
     constexpr int ks_ = (S) / TAPS, tap_ = (S) % TAPS, kh_ = tap_ / KW, kw_ = tap_ % KW;                  \
-    const int soff_ = ks_ * 2 * plane + kh_ * LW + kw_;                                                   \
-    _Pragma("unroll") for (int n = 0; n < WN; ++n) bq[BUF][n] = xs[b_base[n] + soff_];                    \
+    bq[N] = xs[xb + b_base[N] + ks_ * 2 * plane + kh_ * LW + kw_];                                        \
   }
+    // halo tile of chunk CH (in xr) -> LDS buffer DST, the producer's BatchNorm + LeakyReLU applied on the way (PRO)
+#define SIVAE_AD_STAGE_X(DST, CH)                                                                         \
+  {                                                                                                       \
+    _Pragma("unroll") for (int p = 0; p < MAXV; ++p) {                                                    \
+      const int v = tid + p * NT;                                                                         \
+      u32x4_t q = xr[p];                                                                                  \
+      if (PRO) {                                                                                          \
+        float f[8];                                                                                       \
+        unpack8(q, f);                                                                                    \
+        const float* pp = ps + ((CH) * NCB + xcb[p]) * 16;                                                \
+        const bool in = xo[p] != SIVAE_OOB;                                                               \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                     \
+            f[e] = in ? lrelu01(f[e] * pp[e] + pp[8 + e], a.pro_slope) : 0.f;                             \
+        q = pack8(f);                                                                                     \
+      }                                                                                                   \
+      if (v < nvec) xs[(DST) + v] = q;                                                                    \
+    }                                                                                                     \
+  }
+    // Two halo buffers: chunk ch + 1 is written (in front of the last k-step's MFMAs, by then its loads have had the whole
+    // chunk to land) while chunk ch is still being read — ONE barrier per chunk, and the ds_write_b128s sit in the shadow of
+    // the queued MFMAs instead of between two barriers.
     SIVAE_AD_LOAD_X(xrsrc, kc0)
 #pragma unroll
     for (int s = 0; s < RD; ++s) SIVAE_AD_LOAD_A(s, kc0, s)
     if (PRO) __syncthreads();
+    SIVAE_AD_STAGE_X(0, kc0)
+    __syncthreads();
     for (int ch = kc0; ch < kc1; ++ch) {
-#pragma unroll
-      for (int p = 0; p < MAXV; ++p) {
-        const int v = tid + p * NT;
-        u32x4_t q = xr[p];
-        if (PRO) {
-          float f[8];
-          unpack8(q, f);
-          const float* pp = ps + (ch * NCB + xcb[p]) * 16;
-          const bool in = xo[p] != SIVAE_OOB;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] = in ? lrelu01(f[e] * pp[e] + pp[8 + e], a.pro_slope) : 0.f;
-          q = pack8(f);
-        }
-        if (v < nvec) xs[v] = q;
-      }
-      __syncthreads();
+      const int xb = ((ch - kc0) & 1) ? nvec : 0, xbn = nvec - xb;
       // the next chunk's halo tile: always issued (a conditional load would make every later wait a full drain); behind
       // the last chunk it goes through the empty window
+#ifndef AD_ABL_NOX
       SIVAE_AD_LOAD_X((ch + 1 < kc1 ? xrsrc : xnull), ch + 1)
+#endif
       const int chn = ch + 1 < a.nchunks ? ch + 1 : ch;  // (the ring runs RD k-steps ahead, past the slice's end too)
-      SIVAE_AD_READ_B(0, 0)
+#pragma unroll
+      for (int n = 0; n < WN; ++n) SIVAE_AD_READ_B(n, 0)
       ad_steps<0, NS>([&](auto S_) {
         constexpr int S = decltype(S_)::value;
-        if constexpr (S + 1 < NS) SIVAE_AD_READ_B((S + 1) & 1, S + 1)
+#ifndef AD_ABL_NOSTAGE
+        if constexpr (S == NS - 1) {
+          if (ch + 1 < kc1) SIVAE_AD_STAGE_X(xbn, ch + 1)
+        }
+#endif
+        // pixel-tile-major: a B fragment is dead after its WM MFMAs and is re-read for the next k-step at once — one
+        // register set, and (WN - 1) * WM MFMAs between the read and its first use
 #pragma unroll
-        for (int m = 0; m < WM; ++m)
+        for (int n = 0; n < WN; ++n) {
 #pragma unroll
-          for (int n = 0; n < WN; ++n)
+          for (int m = 0; m < WM; ++m)
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ar[S % RD][m]),
-                                                                __builtin_bit_cast(bf16x8_t, bq[S & 1][n]), acc[m][n], 0, 0, 0);
+                                                                __builtin_bit_cast(bf16x8_t, bq[n]), acc[m][n], 0, 0, 0);
+#ifndef AD_ABL_NOB
+          if constexpr (S + 1 < NS) SIVAE_AD_READ_B(n, S + 1)
+#endif
+        }
+#ifndef AD_ABL_NOA
         if constexpr (S + RD < NS)
           SIVAE_AD_LOAD_A(S % RD, ch, S + RD)
         else
           SIVAE_AD_LOAD_A(S % RD, chn, S + RD - NS)
-        // (without the fence hipcc sinks the refill to just in front of its use — the slot is dead in between, so that is
-        // "free" for register pressure — and the L2 round trip is exposed)
+#endif
+        // the order above is the order wanted: WM MFMAs, one LDS read, ..., then the WM refill loads (without the fences hipcc
+        // sinks the refill to just in front of its use — the slot is dead in between, so that is "free" for register
+        // pressure — and the L2 round trip is exposed)
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+          __builtin_amdgcn_sched_group_barrier(0x008, WM, 0);
+          if constexpr (S + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, WM, 0);
         __builtin_amdgcn_sched_barrier(0);
       });
+#ifndef AD_ABL_NOBAR
       __syncthreads();
+#endif
     }
+#undef SIVAE_AD_STAGE_X
 #undef SIVAE_AD_LOAD_A
 #undef SIVAE_AD_LOAD_X
 #undef SIVAE_AD_READ_B
@@ -649,7 +690,7 @@ int launch_cfg(Bf16ConvArgs& a, hipStream_t stream) {
   a.magic_plane = make_magic((unsigned)plane);
   a.magic_lw = make_magic((unsigned)((1 << g.tw_log2) + 2 * PW));
   a.magic_lh = make_magic((unsigned)((1 << g.th_log2) + 2 * P));
-  size_t lds = (size_t)((AD ? 0 : NW) + 2 * CKS * plane) * 16 + (PRO ? (size_t)a.Cib * 64 : 0);
+  size_t lds = (size_t)(AD ? 2 * (2 * CKS * plane) : NW + 2 * CKS * plane) * 16 + (PRO ? (size_t)a.Cib * 64 : 0);
   const size_t red = (size_t)WVN * TCO * 2 * sizeof(float);
   if (lds < red) lds = red;
   const long long nbase = (long long)a.n_co_tiles * g.ntb * g.nth * g.ntw;
@@ -705,6 +746,10 @@ template <int KS, int CKS, int MAXV, bool PRO, bool OUTF32, int KW = KS>
 int launch_by_co(Bf16ConvArgs& a, int TCO, hipStream_t stream) {
   if (TCO == 32) return launch_cfg<KS, 1, 2, 1, 4, CKS, MAXV, PRO, OUTF32, 2, KW>(a, stream);
   if constexpr (OUTF32 && KS == 3) {  // split-K partials of the 3x3 kernels (small pixel tiles)
+    if (a_direct_enabled()) {
+      if (TCO == 64) return launch_cfg<KS, 2, 2, 1, 4, CKS, MAXV, PRO, true, 2, KS, true>(a, stream);
+      return launch_cfg<KS, 2, 2, 2, 2, CKS, MAXV, PRO, true, 2, KS, true>(a, stream);
+    }
     if (TCO == 64) return launch_cfg<KS, 2, 2, 1, 4, CKS, MAXV, PRO, true, 2>(a, stream);
     return launch_cfg<KS, 2, 2, 2, 2, CKS, MAXV, PRO, true, 2>(a, stream);
   }
