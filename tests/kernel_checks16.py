@@ -247,6 +247,22 @@ def check_conv_fused(shape):
     return res
 
 
+def check_conv_big_tiles():
+    """the 64 co x 512 px and 128 co x 256 px tiles of the 3x3 kernels (128 accumulators per wave) are taken only where the
+    grid gives every CU two blocks — the shapes of the headline's large maps, which the small check shapes never reach:
+    grids of exactly 512 blocks with an ODD number of 16-channel chunks (3 / 5: both halo buffers of the AD form end a
+    K loop), statistics rows, upsampled input, accumulation, prologue, and the pooled data gradient on 32-pixel-wide tiles"""
+    from sivae_hip import lib
+    L = lib.load()
+    res = []
+    for (B, Ci, Co, H, W, ks), tpx in (((16, 48, 64, 128, 128, 3), 512), ((16, 80, 256, 64, 64, 3), 256)):
+        assert L.sivae_bf16_conv2d_num_px_tiles(B, Co, H, W, ks) == B * H * W // tpx, "not the big pixel tile"
+    res += check_conv((16, 48, 64, 128, 128, 3), stats=True)
+    res += check_conv_fused((16, 80, 256, 64, 64, 3))
+    res += check_conv_dgrad_pool((16, 64, 48, 128, 128, 3))
+    return res
+
+
 BN16_SHAPES = [(4, 64, 16, 16), (2, 24, 8, 12), (8, 512, 4, 4), (3, 128, 32, 32)]
 
 
@@ -564,6 +580,7 @@ def all_checks():
                    + check_conv((5, 32, 96, 4, 4, 3), stats=True)))
     for s in [(2, 64, 128, 32, 32, 3), (2, 128, 64, 16, 16, 1), (3, 64, 64, 8, 8, 3), (2, 24, 40, 12, 20, 3)]:
         checks.append(("conv16_fused%s" % (s,), lambda s=s: check_conv_fused(s)))
+    checks.append(("conv16_big_tiles", check_conv_big_tiles))
     for s in [(2, 64, 128, 32, 32, 3), (3, 24, 40, 12, 20, 3), (4, 64, 64, 8, 8, 3)]:
         checks.append(("wgrad16_fused%s" % (s,), lambda s=s: check_conv_wgrad(s, pro=True)
                        + check_conv_wgrad(s, upsample=True)))
