@@ -77,8 +77,12 @@ __device__ __forceinline__ void bf_store_u32x4_padded(__amdgpu_buffer_rsrc_t r, 
 template <int ACT, bool POOL, int NU>
 __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedArgs a) {
   __shared__ float red[4][16];
-  __shared__ double red2[16][16];
+  __shared__ double red2[32][16];
   __shared__ float coef[16];  // c1[8] = sg / N, c2[8] = sgx / N of this block's channel block
+  // LeakyReLU-derivative factors of four sign bits at a time: entry n = {bit0 ? 1 : slope, ..., bit3 ? 1 : slope}.  One
+  // ds_read_b128 per nibble (16 entries x 16 bytes = one bank row: distinct entries never conflict, equal ones broadcast)
+  // instead of and + compare + select per element — the sign handling was 37 % of phase 2's vector instructions
+  __shared__ float4 sel_lut[16];
   // x of the NEXT group for up to 3 of the 4 units per thread (48 KB per block — the bound of bn_fused.hip's request
   // buffer, for the same reasons): [unit][vector][256 threads] 16-byte vectors, a wave's 64 lanes 1 KB contiguous
   extern __shared__ __attribute__((aligned(16))) u32x4_t b16_pfx[];
@@ -97,6 +101,8 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
   __shared__ int bar_failed;
   unsigned target = 0, nbar = 0;  // (thread 0) generation to wait for; barriers of this launch passed so far
   if (t == 0 && !local) target = bf_load_u32(bar + (9 + xcd) * 32);
+  if (t < 16) sel_lut[t] = float4{(t & 1) ? 1.f : a.slope, (t & 2) ? 1.f : a.slope, (t & 4) ? 1.f : a.slope, (t & 8) ? 1.f : a.slope};
+  __syncthreads();
   const int W = a.W, HW = a.H * a.W, Cb = a.Cb;
   const int nq = a.B << a.l2_qpp;
   const unsigned qpp_m = (1u << a.l2_qpp) - 1u, qw_m = (1u << a.l2_qw) - 1u;
@@ -250,17 +256,23 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
           }
           unpack8(xq[j][v], xv);
           unsigned m = 0;
+          float sl[8];
+          if (ACT != 2) {
+            const float4 s0 = sel_lut[(bits >> (8 * v)) & 15u], s1 = sel_lut[(bits >> (8 * v + 4)) & 15u];
+            sl[0] = s0.x; sl[1] = s0.y; sl[2] = s0.z; sl[3] = s0.w;
+            sl[4] = s1.x; sl[5] = s1.y; sl[6] = s1.z; sl[7] = s1.w;
+          }
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float xh = (xv[e] - mu[e]) * is[e];
-            bool pos;
+            float g;
             if (ACT == 2) {
-              pos = xh * gm[e] + bt[e] > 0.f;
+              const bool pos = xh * gm[e] + bt[e] > 0.f;
               m |= (pos ? 1u : 0u) << e;
+              g = d[e] * (pos ? 1.f : slope);
             } else {
-              pos = (bits >> (8 * v + e)) & 1u;
+              g = d[e] * sl[e];
             }
-            const float g = d[e] * (pos ? 1.f : slope);
             sg[e] += g;
             sgx[e] += g * xh;
           }
@@ -318,28 +330,34 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
       if (!active) continue;
       // the channel block's 16 sums over its slabs: thread (value v = t & 15, row r = t >> 4) strides over the slabs,
       // rows folded in order through LDS — the same in every block of the channel block
-      const int v = t & 15, r = t >> 4;
-      // (eight loads in flight per thread, added in slab order: one dependent agent-scope load per step made this fold 32
-      // memory round trips = 8.8 of a 37-us group on the 128 x 128 layers — tools/b16_bn_timing.py)
-      double acc = 0.0;
-      const double* prow = a.part + (size_t)vcb * a.spc * 16 + v;
-      for (int s0 = r; s0 < a.spc; s0 += 16 * 8) {
-        double tmp[8];
+      // (16-byte agent-scope loads: thread = (value pair p = t & 7, row r = t >> 3), eight in flight per thread, added in
+      // slab order — 512 slabs are two memory round trips; with 8-byte loads, 16 rows and one dependent load per step this
+      // fold was 32 round trips = 8.8 of a 37-us group on the 128 x 128 layers, tools/b16_bn_timing.py)
+      const int pr = t & 7, r = t >> 3;
+      double acc0 = 0.0, acc1 = 0.0;
+      const __amdgpu_buffer_rsrc_t rpart = make_rsrc(a.part + (size_t)vcb * a.spc * 16, (unsigned long long)a.spc * 128ull);
+      for (int s0 = r; s0 < a.spc; s0 += 32 * 8) {
+        u32x4_t tmp[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const int sk = s0 + 16 * k;
-          tmp[k] = bf_load_f64(prow + (size_t)(sk < a.spc ? sk : r) * 16);  // (past the end: a valid row, not added)
+          const int sk = s0 + 32 * k;
+          // (cache policy 16 = sc1: agent scope, like bf_load_f64; past the end: out of the window, zeros, not added)
+          tmp[k] = __builtin_amdgcn_raw_buffer_load_b128(rpart, sk < a.spc ? (sk * 128 + pr * 16) : (int)BF_OOB, 0, 16);
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-          if (s0 + 16 * k < a.spc) acc += tmp[k];
+          if (s0 + 32 * k < a.spc) {
+            acc0 += __builtin_bit_cast(double, ((unsigned long long)tmp[k][1] << 32) | tmp[k][0]);
+            acc1 += __builtin_bit_cast(double, ((unsigned long long)tmp[k][3] << 32) | tmp[k][2]);
+          }
       }
-      red2[r][v] = acc;
+      red2[r][2 * pr] = acc0;
+      red2[r][2 * pr + 1] = acc1;
       __syncthreads();
       if (t < 16) {
         double u = 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) u += red2[k][t];
+        for (int k = 0; k < 32; ++k) u += red2[k][t];
         tsum = u;
       }
     }
@@ -376,13 +394,16 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
     __syncthreads();
     B16_STAMP(5)
     // ---- phase 2
-    float gi[8], c1[8], c2[8];
+    // dx = gi (g - c1 - xhat c2) with xhat = (x - mu) is, as two fused multiply-adds per element on the raw x:
+    // dx = g gi + (x bc + cc), bc = -gi c2 is, cc = gi (c2 is mu - c1)  (24 per-channel scalars instead of 40)
+    float gi[8], bc[8], cc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = cb * 8 + e;
       gi[e] = (c < a.C ? a.gamma[c] : 0.f) * is[e];
-      c1[e] = coef[e];
-      c2[e] = coef[8 + e];
+      const float c2i = coef[8 + e] * is[e];
+      bc[e] = -gi[e] * c2i;
+      cc[e] = gi[e] * (c2i * mu[e] - coef[e]);
     }
     const size_t base = ((size_t)seg * a.B * Cb + cb) * HW;
     const __amdgpu_buffer_rsrc_t rdx = make_rsrc(reinterpret_cast<char*>(a.dx) + base * 16, win);
@@ -411,13 +432,13 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
           unpack8(dq[j][v], d);
         }
         unpack8(xq[j][v], xv);
+        const float4 s0 = sel_lut[(bits >> (8 * v)) & 15u], s1 = sel_lut[(bits >> (8 * v + 4)) & 15u];
+        const float sl[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float xh = (xv[e] - mu[e]) * is[e];
-          const bool pos = (bits >> (8 * v + e)) & 1u;
-          g[e] = d[e] * (pos ? 1.f : slope);
+          g[e] = d[e] * sl[e];
           zs[e] += g[e];
-          xv[e] = gi[e] * (g[e] - c1[e] - xh * c2[e]);
+          xv[e] = fmaf(g[e], gi[e], fmaf(xv[e], bc[e], cc[e]));
         }
         const unsigned vv = vo + (v & 1) * 16u, so = (v >> 1) ? row_b : 0u;
         // store data in place of the raw vectors it was computed from (dead from here on)
