@@ -52,7 +52,8 @@ int sivae_pack_conv_weight(const float* w /*[Co][Ci][ks][ks]*/, float* wp, int C
  *   sivae_pack_job_fill   writes job `index` of a HOST table (sivae_pack_job_bytes() bytes per job) for operand form
  *                         0 direct (ks, mode) / 1 Winograd F(2x2,3x3) (mode) / 2 Winograd F(4x4,3x3) (mode) /
  *                         3 upsample-phase forward / 4 upsample-phase data gradient / 5 Winograd F(4x4,3x3) pre-split
- *                         into three bf16 pieces (mode; sivae_pack_wino4_b6_weight); dst = the buffer the per-weight
+ *                         into three bf16 pieces (mode; sivae_pack_wino4_b6_weight) / 6 bf16 operand slabs of the bf16
+ *                         mode (ks incl. the code 51, mode; sivae_bf16_pack_conv_weight); dst = the buffer the per-weight
  *                         sivae_pack_* call of that form writes; returns the job's block count (its blocks are
  *                         [first_block, first_block + count) of the launch) or an error code (< 0)
  *   sivae_pack_batch      the launch: jobs_dev = the uploaded table, block_job_dev[b] = job index of block b (uint16) */

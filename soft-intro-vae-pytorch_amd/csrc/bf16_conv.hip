@@ -19,6 +19,7 @@
 // nearest-2x upsample addressing of x, bias, y += result, per-channel {sum, sumsq} partials of the ROUNDED output for
 // the consumer BatchNorm, fp32 NCHW output (OUTF32: Decoder.predict feeds the fp32 loss kernels).
 #include "bf16_common.h"
+#include "pack_batch.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -613,11 +614,8 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
 //   wp[co_tile][chunk][tap][ks][hh][TCO][8]   (input channel = (chunk*CKS + ks)*16 + hh*8 + e)
 // mode 0: forward operand; mode 1: data-gradient operand (output channels = the conv's input channels, taps flipped)
 // ------------------------------------------------------------------------------------------------
-__global__ void bf16_pack_conv_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Co,
-                                             int Ci, int KS, int KW, int mode, int TCO, int CKS, int nchunks,
-                                             size_t total) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
+__device__ __forceinline__ void bf16_pack_element(const float* __restrict__ w, unsigned short* __restrict__ wp, int Co,
+                                                  int Ci, int KS, int KW, int mode, int TCO, int CKS, int nchunks, size_t i) {
   // outputs / inputs of the GEMM this pack feeds
   const int N_out = mode == 0 ? Co : Ci, N_in = mode == 0 ? Ci : Co;
   const int TAPS = KS * KW;
@@ -646,6 +644,25 @@ __global__ void bf16_pack_conv_weight_kernel(const float* __restrict__ w, unsign
   }
   const unsigned u = pack_bf16(v, 0.f);
   wp[i] = (unsigned short)(u & 0xffffu);
+}
+
+__global__ void bf16_pack_conv_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Co,
+                                             int Ci, int KS, int KW, int mode, int TCO, int CKS, int nchunks,
+                                             size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  bf16_pack_element(w, wp, Co, Ci, KS, KW, mode, TCO, CKS, nchunks, i);
+}
+
+// batched form (pack_batch.h, form SIVAE_PACK_BF16): block -> job through the uint16 map, a job's blocks stride over its
+// elements — ONE launch rebuilds the operand slabs of every conv weight of a network after its optimizer step (the bf16
+// mode's ~65 per-weight launches of 7 us per step were 1 % of the celeb128 iteration, 2 % of the 16-image shard's)
+__global__ void __launch_bounds__(256) bf16_pack_conv_weight_batch_kernel(const SivaePackJob* __restrict__ jobs,
+                                                                          const unsigned short* __restrict__ block_job) {
+  const SivaePackJob j = jobs[block_job[blockIdx.x]];
+  unsigned short* wp = reinterpret_cast<unsigned short*>(j.dst);
+  for (size_t i = (size_t)(blockIdx.x - j.blk0) * 256 + threadIdx.x; i < (size_t)j.total; i += (size_t)j.nblk * 256)
+    bf16_pack_element(j.w, wp, j.Co, j.Ci, j.kdim, j.ndim, j.mode, j.kpad, j.npad, j.aux, i);
 }
 
 namespace {
@@ -797,6 +814,26 @@ extern "C" int sivae_bf16_pack_conv_weight(const float* w, void* wp, int Co, int
                      reinterpret_cast<unsigned short*>(wp), Co, Ci, ks_h(ks), ks_w(ks), mode, c.TCO, c.CKS, nchunks,
                      total);
   return sivae_launch_status();
+}
+
+// job shape of the batched pack (pack_batch.h): kdim / ndim = kernel rows / columns, kpad = TCO, npad = CKS, aux = chunks
+int sivae_packjob_bf16(SivaePackJob* j, int Co, int Ci, int ks, int mode) {
+  if (!ks_ok(ks)) return SIVAE_ERR_KSIZE;
+  const size_t bytes = sivae_bf16_pack_conv_weight_bytes(Co, Ci, ks, mode);
+  if (bytes == 0) return SIVAE_ERR_SHAPE;
+  const int n_out = mode == 0 ? Co : Ci, n_in = mode == 0 ? Ci : Co;
+  const Bf16Cfg c = bf16_cfg(ks, n_out, n_in);
+  j->taps = ks_h(ks) * ks_w(ks);
+  j->kdim = ks_h(ks);
+  j->ndim = ks_w(ks);
+  j->kpad = c.TCO;
+  j->npad = c.CKS;
+  j->aux = bf16_cblocks(n_in) / (2 * c.CKS);
+  j->total = bytes / 2;
+  return SIVAE_OK;
+}
+void sivae_packbatch_bf16(const SivaePackJob* jobs, const unsigned short* block_job, int nblocks, hipStream_t s) {
+  hipLaunchKernelGGL(bf16_pack_conv_weight_batch_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, jobs, block_job);
 }
 
 extern "C" int sivae_bf16_conv2d_num_px_tiles(int B, int Co, int H, int W, int ks) {

@@ -86,7 +86,8 @@ extern "C" int sivae_pack_job_bytes() { return (int)sizeof(SivaePackJob); }
 
 // Fill job `index` of a HOST job table (sivae_pack_job_bytes() bytes per job) for operand form `form` (0 direct [ks, mode],
 // 1 Winograd F(2x2,3x3) [mode], 2 Winograd F(4x4,3x3) [mode], 3 upsample-phase forward, 4 upsample-phase data gradient,
-// 5 Winograd F(4x4,3x3) pre-split into three bf16 pieces [mode] (conv_wino4_b6.hip))
+// 5 Winograd F(4x4,3x3) pre-split into three bf16 pieces [mode] (conv_wino4_b6.hip), 6 bf16 operand slabs of the bf16 mode
+// [ks incl. the code 51, mode] (bf16_conv.hip; dst is the bf16 buffer of sivae_bf16_pack_conv_weight))
 // of the weight w [Co][Ci][ks][ks] -> dst (the buffer the per-weight sivae_pack_* call of that form writes);
 // first_block: the job's first block in the batch launch.  Returns the number of blocks the job takes, or < 0.
 extern "C" int sivae_pack_job_fill(void* jobs_host, int index, int form, const float* w, float* dst, int Co, int Ci,
@@ -109,6 +110,7 @@ extern "C" int sivae_pack_job_fill(void* jobs_host, int index, int form, const f
     case SIVAE_PACK_WINO4_B6: rc = ks == 3 ? sivae_packjob_wino4_b6(j, Co, Ci, mode) : SIVAE_ERR_KSIZE; break;
     case SIVAE_PACK_WINO_UP: rc = ks == 3 ? sivae_packjob_wino_up(j, Co, Ci) : SIVAE_ERR_KSIZE; break;
     case SIVAE_PACK_WINO_UP_DGRAD: rc = ks == 3 ? sivae_packjob_wino_up_dgrad(j, Co, Ci) : SIVAE_ERR_KSIZE; break;
+    case SIVAE_PACK_BF16: rc = sivae_packjob_bf16(j, Co, Ci, ks, mode); break;
     default: rc = SIVAE_ERR_MODE;
   }
   if (rc != SIVAE_OK) return rc;
@@ -130,6 +132,7 @@ extern "C" int sivae_pack_batch(int form, const void* jobs_dev, const unsigned s
     case SIVAE_PACK_WINO4_B6: sivae_packbatch_wino4_b6(jobs, block_job_dev, n_blocks, stream); break;
     case SIVAE_PACK_WINO_UP: sivae_packbatch_wino_up(jobs, block_job_dev, n_blocks, stream); break;
     case SIVAE_PACK_WINO_UP_DGRAD: sivae_packbatch_wino_up_dgrad(jobs, block_job_dev, n_blocks, stream); break;
+    case SIVAE_PACK_BF16: sivae_packbatch_bf16(jobs, block_job_dev, n_blocks, stream); break;
     default: return SIVAE_ERR_MODE;
   }
   return sivae_launch_status();

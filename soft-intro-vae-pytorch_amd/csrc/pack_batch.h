@@ -13,6 +13,7 @@ struct SivaePackJob {
   int kdim, ndim, kpad, npad;
   unsigned blk0, nblk;  // this job's blocks are [blk0, blk0 + nblk) of the batch launch
   unsigned long long total;
+  int aux;  // form-specific (bf16 operand slabs: number of input-channel chunks)
 };
 
 #define SIVAE_PACK_DIRECT 0
@@ -21,7 +22,8 @@ struct SivaePackJob {
 #define SIVAE_PACK_WINO_UP 3
 #define SIVAE_PACK_WINO_UP_DGRAD 4
 #define SIVAE_PACK_WINO4_B6 5
-#define SIVAE_PACK_NTYPES 6
+#define SIVAE_PACK_BF16 6  // bf16 MFMA-operand slabs of the bf16 mode (bf16_conv.hip; dst is bf16, ks may be the code 51)
+#define SIVAE_PACK_NTYPES 7
 
 static inline unsigned sivae_pack_job_blocks(unsigned long long total) {
   unsigned long long nb = (total + 511) / 512;  // ~2 elements (weight pairs: 9 loads, 16-48 stores each) per thread
@@ -37,9 +39,11 @@ int sivae_packjob_wino4(SivaePackJob* j, int Co, int Ci, int mode);
 int sivae_packjob_wino4_b6(SivaePackJob* j, int Co, int Ci, int mode);
 int sivae_packjob_wino_up(SivaePackJob* j, int Co, int Ci);
 int sivae_packjob_wino_up_dgrad(SivaePackJob* j, int Co, int Ci);
+int sivae_packjob_bf16(SivaePackJob* j, int Co, int Ci, int ks, int mode);
 void sivae_packbatch_direct(const SivaePackJob* jobs, const unsigned short* block_job, int nblocks, hipStream_t s);
 void sivae_packbatch_wino(const SivaePackJob* jobs, const unsigned short* block_job, int nblocks, hipStream_t s);
 void sivae_packbatch_wino4(const SivaePackJob* jobs, const unsigned short* block_job, int nblocks, hipStream_t s);
 void sivae_packbatch_wino4_b6(const SivaePackJob* jobs, const unsigned short* block_job, int nblocks, hipStream_t s);
 void sivae_packbatch_wino_up(const SivaePackJob* jobs, const unsigned short* block_job, int nblocks, hipStream_t s);
 void sivae_packbatch_wino_up_dgrad(const SivaePackJob* jobs, const unsigned short* block_job, int nblocks, hipStream_t s);
+void sivae_packbatch_bf16(const SivaePackJob* jobs, const unsigned short* block_job, int nblocks, hipStream_t s);

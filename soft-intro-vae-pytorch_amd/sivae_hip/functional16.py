@@ -74,6 +74,61 @@ def packed16(w, mode, virt=None):
     return wp
 
 
+PACK_FORM_BF16 = 6  # (include/sivae_hip.h: operand form 6 of sivae_pack_job_fill / sivae_pack_batch)
+
+
+def repack16(params, owner):
+    """The bf16 mode's part of `functional.repack`: after `params` were updated in place (FlatAdam.step, generation already
+    bumped) every bf16 operand slab cached on them is rebuilt IN PLACE by ONE launch (sivae_pack_batch, form 6) and its
+    cache entry re-validated.  Slabs of the virtual [*, *, 5, 1] weights (permuted copies of the RGB-side 5x5 layers) and
+    slabs whose source alias no longer is the parameter's storage are dropped and rebuilt on demand.  The job table lives
+    on `owner` and is rebuilt only when the set of cached slabs changes (the first iterations)."""
+    import ctypes
+    if not SF.PACK_BATCH:
+        return
+    L = ops._lib.load()
+    entries = []
+    for p in params:
+        store = p.__dict__.get("_sivae_pack16")
+        if not store:
+            continue
+        for slot, (tag, obj) in list(store.items()):
+            if slot[1] is not None or obj.w.data_ptr() != p.data_ptr() or obj.w.shape != p.shape or tag[2] != p.data_ptr():
+                del store[slot]
+                continue
+            entries.append((p, store, slot, obj))
+    if not entries:
+        return
+    key = tuple((obj.w.data_ptr(), obj.data.data_ptr(), obj.mode) for _, _, _, obj in entries)
+    plan = owner.__dict__.get("_sivae_pack16_plan")
+    if plan is None or plan["key"] != key:
+        if torch.cuda.is_current_stream_capturing() or len(entries) > 32767:
+            return  # (uploading a job table is not capturable: the slabs stay invalid and are rebuilt one by one on use)
+        jb = L.sivae_pack_job_bytes()
+        host = ctypes.create_string_buffer(jb * len(entries))
+        block_job, nblocks = [], 0
+        for i, (_, _, _, obj) in enumerate(entries):
+            nb = L.sivae_pack_job_fill(host, i, PACK_FORM_BF16, ctypes.c_void_p(obj.w.data_ptr()),
+                                       ctypes.c_void_p(obj.data.data_ptr()), obj.Co, obj.Ci, obj.ks, obj.mode, nblocks)
+            if nb <= 0:
+                raise ops._lib.SivaeError("sivae_pack_job_fill", nb)
+            block_job.extend([i] * nb)
+            nblocks += nb
+        dev = entries[0][0].device
+        jt = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(dev)
+        bj = torch.tensor(block_job, dtype=torch.int16).to(dev)
+        prev = owner.__dict__.get("_sivae_pack16_plan")
+        if prev is not None:  # (a HIP graph captured while an earlier table was current still launches with it)
+            old = owner.__dict__.setdefault("_sivae_pack16_plan_old", [])
+            old.append(prev)
+            del old[:-4]
+        plan = {"key": key, "jt": jt, "bj": bj, "nblocks": nblocks, "keep": [obj.data for _, _, _, obj in entries]}
+        owner.__dict__["_sivae_pack16_plan"] = plan
+    ops._lib.call("sivae_pack_batch", PACK_FORM_BF16, ops._p(plan["jt"]), ops._p(plan["bj"]), plan["nblocks"], ops._s(plan["jt"]))
+    for p, store, slot, obj in entries:
+        store[slot] = ((p._version, getattr(p, "_sivae_gen", 0), p.data_ptr(), SF.cache_epoch()), obj)
+
+
 def _kwpack_ok(w, narrow):
     return KWPACK and w.dim() == 4 and tuple(w.shape[2:]) == (5, 5) and 5 * narrow <= 16
 

@@ -102,6 +102,7 @@ class PackedW16:
                     raise _lib.SivaeError("sivae_bf16_pack_conv_weight", -4)
                 ks = KS51
         self.Co, self.Ci, self.ks, self.mode = Co, Ci, ks, mode
+        self.w = w  # (the batched repack rebuilds `data` in place from here: functional16.repack16)
         nbytes = _lib.load().sivae_bf16_pack_conv_weight_bytes(Co, Ci, ks, mode)
         if nbytes == 0:
             raise _lib.SivaeError("sivae_bf16_pack_conv_weight_bytes", -3)

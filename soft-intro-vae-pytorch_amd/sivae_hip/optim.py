@@ -128,6 +128,8 @@ class FlatAdam:
         self._reset_uses()
         SF.bump_generation(self.params)
         SF.repack(self.params, self)  # every cached operand form of every weight, one launch per form
+        from . import functional16 as SF16
+        SF16.repack16(self.params, self)  # (bf16 mode: the bf16 operand slabs, one launch)
 
     def use_device_state(self):
         """Move the step counter and learning rate into a device tensor {t, lr, ., .} (float64).  Needed before the

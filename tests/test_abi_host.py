@@ -398,6 +398,10 @@ def test_round4_entry_points_validate_arguments():
     assert L.sivae_pack_job_fill(host, 2, 1, one, one, 64, 64, 3, 0, nb + nb2) >= 1
     assert L.sivae_pack_job_fill(host, 3, 3, one, one, 64, 64, 5, 0, 0) == -3  # the Winograd forms are 3x3 only
     assert L.sivae_pack_job_fill(host, 3, 9, one, one, 64, 64, 3, 0, 0) == -6
+    # form 6: the bf16 operand slabs of the bf16 mode (one launch per optimizer step); ks may be the 5 x 1 code 51
+    assert L.sivae_pack_job_fill(host, 3, 6, one, one, 64, 64, 3, 1, 0) >= 1
+    assert L.sivae_pack_job_fill(host, 3, 6, one, one, 64, 15, 51, 0, 0) >= 1
+    assert L.sivae_pack_job_fill(host, 3, 6, one, one, 64, 64, 4, 0, 0) == -3
     assert L.sivae_pack_job_fill(host, 3, 0, one, one, 64, 64, 4, 0, 0) == -3
     assert L.sivae_pack_job_fill(null, 0, 0, one, one, 64, 64, 3, 0, 0) == -1
     assert L.sivae_pack_job_fill(host, 0, 0, one, one, 0, 64, 3, 0, 0) == -2
@@ -446,7 +450,7 @@ def test_round5_entry_points_validate_arguments():
     host = ctypes.create_string_buffer(jb)
     assert L.sivae_pack_job_fill(host, 0, 5, one, one, 64, 64, 3, 0, 0) > 0
     assert L.sivae_pack_job_fill(host, 0, 5, one, one, 64, 64, 1, 0, 0) == -3   # 3x3 only
-    assert L.sivae_pack_job_fill(host, 0, 6, one, one, 64, 64, 3, 0, 0) == -6   # unknown form
+    assert L.sivae_pack_job_fill(host, 0, 7, one, one, 64, 64, 3, 0, 0) == -6   # unknown form (6: the bf16 slabs)
     # the grid-barrier timeout word lies inside the barrier state, on its own 128-byte line behind the 17 used lines
     w = L.sivae_bn_bwd_fused_poison_word()
     assert 17 * 32 <= w < 1024 and w % 32 == 0 and w < L.sivae_bn_bwd_fused_state_uints()

@@ -287,3 +287,58 @@ def test_bf16_iteration_vs_reference_fixture_celeb128_narrow():
     for k, err, tol in table:
         print("  E/%-16s %.3e  (tol %.1e)" % (k, err, tol))
     assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_batched_repack16_rebuilds_every_bf16_slab_in_place():
+    """bf16 mode: FlatAdam.step() rebuilds every cached bf16 operand slab of a network with ONE launch (sivae_pack_batch,
+    form 6).  After three iterations every slab must equal a fresh per-weight pack of the CURRENT weight bit for bit, its
+    cache entry must be valid for the current weight (no lazy rebuild left; the slabs of the virtual 5 x 1 weights — permuted
+    copies — are dropped by the step and rebuilt on demand), and training must agree bit for bit with the unbatched path."""
+    import train_soft_intro_vae as T
+    from sivae_hip import functional as SF
+    from sivae_hip import functional16 as SF16
+    from sivae_hip import ops16
+    from sivae_hip.engine import SoftIntroEngine
+    from sivae_hip.optim import FlatAdam
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    real = torch.rand(8, 3, 64, 64, generator=g).to(dev)
+    noise = torch.randn(8, 32, generator=g).to(dev)
+    eps = [torch.randn(8, 32, generator=g).to(dev) for _ in range(5)]
+    finals = {}
+    for batch in (True, False):
+        SF.PACK_BATCH = batch
+        try:
+            torch.manual_seed(11)
+            model = T.SoftIntroVAE(cdim=3, zdim=32, channels=[32, 64, 64], image_size=64).to(dev).train()
+            oe, od = FlatAdam(model.encoder.parameters(), lr=2e-4), FlatAdam(model.decoder.parameters(), lr=2e-4)
+            eng = SoftIntroEngine(model, oe, od, beta_kl=1.0, beta_rec=0.5, beta_neg=256.0, compute_dtype="bf16")
+            for _ in range(3):
+                out = eng.soft_intro_step(real, noise, eps)
+            torch.cuda.synchronize()
+            finals[batch] = ({k: v.detach().clone() for k, v in model.state_dict().items()}, out["stats"].clone())
+            if not batch:
+                continue
+            assert "_sivae_pack16_plan" in oe.__dict__ and "_sivae_pack16_plan" in od.__dict__
+            n = 0
+            for p in list(model.encoder.parameters()) + list(model.decoder.parameters()):
+                for (mode, virt), (tag, obj) in p.__dict__.get("_sivae_pack16", {}).items():
+                    assert tag == (p._version, getattr(p, "_sivae_gen", 0), p.data_ptr(), SF.cache_epoch()), \
+                        "cache entry not re-validated by the batched repack"
+                    if virt is not None:
+                        # (a virtual-weight slab is dropped by its optimizer's step and rebuilt on demand: the encoder's is
+                        # back, with a current tag, because the decoder step runs the encoder after the encoder's update)
+                        fresh = ops16.PackedW16(SF16._virtual(p.detach(), virt), mode)
+                        assert torch.equal(obj.data.view(torch.int16), fresh.data.view(torch.int16)), (mode, virt)
+                        continue
+                    fresh = ops16.PackedW16(p.detach(), mode)
+                    assert torch.equal(obj.data.view(torch.int16), fresh.data.view(torch.int16)), (mode, tuple(p.shape))
+                    assert SF16.packed16(p, mode) is obj  # (a hit: no lazy rebuild)
+                    n += 1
+            assert n >= 20, n
+        finally:
+            SF.PACK_BATCH = True
+    for k, v in finals[True][0].items():
+        assert torch.equal(v, finals[False][0][k]), k  # same kernels, same operands: bit-identical training
+    assert torch.equal(finals[True][1], finals[False][1])
