@@ -83,6 +83,8 @@ __global__ void __launch_bounds__(256, 2) bf16_bn_bwd_fused_kernel(Bf16BnFusedAr
   // ds_read_b128 per nibble (16 entries x 16 bytes = one bank row: distinct entries never conflict, equal ones broadcast)
   // instead of and + compare + select per element — the sign handling was 37 % of phase 2's vector instructions
   __shared__ float4 sel_lut[16];
+  static_assert(sizeof(red) + sizeof(red2) + sizeof(coef) + sizeof(sel_lut) + 16 + 48 * 1024 <= 160 * 1024 / 3,
+                "static LDS + the 48-KB request buffer must stay under a third of the CU's LDS (co-residency, see b16_occupancy)");
   // x of the NEXT group for up to 3 of the 4 units per thread (48 KB per block — the bound of bn_fused.hip's request
   // buffer, for the same reasons): [unit][vector][256 threads] 16-byte vectors, a wave's 64 lanes 1 KB contiguous
   extern __shared__ __attribute__((aligned(16))) u32x4_t b16_pfx[];
@@ -480,10 +482,11 @@ struct B16Plan {
 
 // how many blocks of the heaviest instantiation (4 units per thread) does the runtime place on one CU, with and without
 // the 48-KB request buffer?  (bn_fused.hip's bf_occupancy_ok for this kernel.  Two by construction —
-// __launch_bounds__(256, 2), 2.4 KB of static LDS + 48 KB —; the query guards against a runtime that disagrees: fewer
+// __launch_bounds__(256, 2), 4.6 KB of static LDS + 48 KB —; the query guards against a runtime that disagrees: fewer
 // than two without the buffer -> no persistent form; fewer than two with it -> the buffer is switched off.  Margin next
-// to a co-tenant: two blocks hold 2 x 50.4 KB, i.e. they fit beside up to 59 KB of somebody else's LDS, and no block is
-// larger than 160 / 3 KB, so a co-tenant that leaves cannot fragment the CU against the second block.)
+// to a co-tenant: two blocks hold 2 x 52.6 KB, i.e. they fit beside up to 54 KB of somebody else's LDS, and no block is
+// larger than 160 / 3 KB (the kernel asserts it: 0.7 KB to spare since the fold's 32-row table and the sign-factor table
+// of round 6), so a co-tenant that leaves cannot fragment the CU against the second block.)
 static int b16_occupancy(bool with_buffer) {
   static int occ[2] = {-1, -1};
   int& o = occ[with_buffer ? 1 : 0];
