@@ -184,12 +184,14 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
   }
 
   f32x16 acc[WM][WN];
+  if constexpr (!AD) {  // (AD: the first k-step's MFMAs take C = 0 and define the accumulators)
 #pragma unroll
-  for (int m = 0; m < WM; ++m)
+    for (int m = 0; m < WM; ++m)
 #pragma unroll
-    for (int n = 0; n < WN; ++n)
+      for (int n = 0; n < WN; ++n)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  }
 
   u32x4_t xr[MAXV];
   if constexpr (AD) {
@@ -244,7 +246,11 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
     if (PRO) __syncthreads();
     SIVAE_AD_STAGE_X(0, kc0)
     __syncthreads();
-    for (int ch = kc0; ch < kc1; ++ch) {
+    // One chunk.  FIRST: the slice's first chunk (every slice has one), peeled: its first k-step's MFMAs take the inline
+    // constant 0 as C — hipcc otherwise zeroes the 128 accumulators TWICE in front of the loop (254 v_movs, once for the
+    // initial value and once for the loop-carried copy: ~1 000 cycles of a 4-chunk block's ~9 000-cycle K loop).
+    auto chunk_body = [&](const int ch, auto FIRST_) {
+      constexpr bool FIRST = decltype(FIRST_)::value;
       const int xb = ((ch - kc0) & 1) ? nvec : 0, xbn = nvec - xb;
       // the next chunk's halo tile: always issued (a conditional load would make every later wait a full drain); behind
       // the last chunk it goes through the empty window
@@ -266,9 +272,16 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
 #pragma unroll
         for (int n = 0; n < WN; ++n) {
 #pragma unroll
-          for (int m = 0; m < WM; ++m)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ar[S % RD][m]),
-                                                                __builtin_bit_cast(bf16x8_t, bq[n]), acc[m][n], 0, 0, 0);
+          for (int m = 0; m < WM; ++m) {
+            if constexpr (FIRST && S == 0) {
+              const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ar[S % RD][m]),
+                                                                  __builtin_bit_cast(bf16x8_t, bq[n]), zero, 0, 0, 0);
+            } else {
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ar[S % RD][m]),
+                                                                  __builtin_bit_cast(bf16x8_t, bq[n]), acc[m][n], 0, 0, 0);
+            }
+          }
 #ifndef AD_ABL_NOB
           if constexpr (S + 1 < NS) SIVAE_AD_READ_B(n, S + 1)
 #endif
@@ -293,7 +306,9 @@ __global__ void __launch_bounds__(WVM* WVN * 64, MINW) bf16_conv_kernel(Bf16Conv
 #ifndef AD_ABL_NOBAR
       __syncthreads();
 #endif
-    }
+    };
+    chunk_body(kc0, std::true_type{});
+    for (int ch = kc0 + 1; ch < kc1; ++ch) chunk_body(ch, std::false_type{});
 #undef SIVAE_AD_STAGE_X
 #undef SIVAE_AD_LOAD_A
 #undef SIVAE_AD_LOAD_X
